@@ -1,0 +1,188 @@
+"""ctypes mirror of include/align3d_hip.h: POD structs, status codes and the loader of
+libalign3d_hip.so.  The product path has no CPU fallback: if the HIP library is missing or a call
+fails, an exception is raised (never a silent detour)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+A3D_OK = 0
+A3D_INVALID_PARAMETER = 1
+A3D_MISSING_FIELD = 2
+A3D_SOLVE_FAILED = 3
+A3D_HIP_ERROR = 4
+A3D_NAN_IN_INPUT = 5
+A3D_CAST_OVERFLOW = 6
+
+STATUS_NAMES = {
+    0: "A3D_OK",
+    1: "A3D_INVALID_PARAMETER",
+    2: "A3D_MISSING_FIELD",
+    3: "A3D_SOLVE_FAILED",
+    4: "A3D_HIP_ERROR",
+    5: "A3D_NAN_IN_INPUT",
+    6: "A3D_CAST_OVERFLOW",
+}
+
+
+class A3dError(Exception):
+    """Mirror of A3dError (src/error.rs:3-9) plus the status codes that stand in for the
+    reference's panics."""
+
+    def __init__(self, status, message=""):
+        self.status = status
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+
+
+class InvalidParameter(A3dError):
+    def __init__(self, message):
+        super().__init__(A3D_INVALID_PARAMETER, message)
+
+
+class IcpParamsC(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_uint64),
+        ("weight", C.c_float),
+        ("color_weight", C.c_float),
+        ("max_point_to_plane_distance", C.c_float),
+        ("max_distance", C.c_float),
+        ("max_normal_angle", C.c_float),
+        ("max_color_distance", C.c_float),
+    ]
+
+
+class PoseC(C.Structure):
+    _fields_ = [("t", C.c_float * 3), ("q", C.c_float * 4)]
+
+
+class RangeImageViewC(C.Structure):
+    _fields_ = [
+        ("points", C.c_void_p),
+        ("mask", C.c_void_p),
+        ("normals", C.c_void_p),
+        ("intensities", C.c_void_p),
+        ("intensity_map", C.c_void_p),
+        ("fx", C.c_double),
+        ("fy", C.c_double),
+        ("cx", C.c_double),
+        ("cy", C.c_double),
+        ("width", C.c_uint64),
+        ("height", C.c_uint64),
+    ]
+
+
+class PointCloudViewC(C.Structure):
+    _fields_ = [("points", C.c_void_p), ("normals", C.c_void_p), ("len", C.c_uint64)]
+
+
+class GnStateC(C.Structure):
+    _fields_ = [
+        ("hessian", C.c_float * 36),
+        ("gradient", C.c_float * 6),
+        ("squared_residual_sum", C.c_float),
+        ("count", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {
+            "H": np.array(self.hessian[:], dtype=np.float32).reshape(6, 6),
+            "g": np.array(self.gradient[:], dtype=np.float32),
+            "ssq": np.float32(self.squared_residual_sum),
+            "count": int(self.count),
+        }
+
+
+def ptr(arr):
+    """Raw address of a C-contiguous numpy array (None -> NULL)."""
+    if arr is None:
+        return None
+    assert arr.flags["C_CONTIGUOUS"], "arrays cross the ABI in standard layout"
+    return arr.ctypes.data
+
+
+# Every symbol include/align3d_hip.h declares, with (restype, argtypes).
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_ST = C.c_int
+SIGNATURES = {
+    "a3d_abi_version": (C.c_uint32, []),
+    "a3d_last_error": (C.c_char_p, []),
+    "a3d_status_string": (C.c_char_p, [C.c_int]),
+    "a3d_context_create": (_ST, [C.c_int32, _PP]),
+    "a3d_context_destroy": (_ST, [_P]),
+    "a3d_context_synchronize": (_ST, [_P]),
+    "a3d_context_stream": (_P, [_P]),
+    "a3d_timer_start": (_ST, [_P]),
+    "a3d_timer_stop": (_ST, [_P, C.POINTER(C.c_float)]),
+    "a3d_malloc": (_ST, [_P, C.c_size_t, _PP]),
+    "a3d_free": (_ST, [_P, _P]),
+    "a3d_memcpy_h2d": (_ST, [_P, _P, _P, C.c_size_t]),
+    "a3d_memcpy_d2h": (_ST, [_P, _P, _P, C.c_size_t]),
+    "a3d_memcpy_d2d": (_ST, [_P, _P, _P, C.c_size_t]),
+    "a3d_icp_params_default": (None, [C.POINTER(IcpParamsC)]),
+    "a3d_ms_icp_params_default": (None, [C.POINTER(IcpParamsC)]),
+    "a3d_range_image_upload": (_ST, [_P, C.POINTER(RangeImageViewC), _PP]),
+    "a3d_range_image_free": (_ST, [_P]),
+    "a3d_range_image_compute_normals": (_ST, [_P]),
+    "a3d_range_image_download_normals": (_ST, [_P, _P]),
+    "a3d_compute_normals": (_ST, [_P, _P, _P, C.c_uint64, C.c_uint64, _P]),
+    "a3d_image_icp_align": (_ST, [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(PoseC)]),
+    "a3d_image_icp_accumulate": (
+        _ST,
+        [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC), C.POINTER(GnStateC)],
+    ),
+    "a3d_multiscale_new": (_ST, [_P, C.POINTER(IcpParamsC), C.c_uint64, _PP, C.c_uint64, _PP]),
+    "a3d_multiscale_align": (_ST, [_P, _PP, C.c_uint64, C.POINTER(PoseC)]),
+    "a3d_multiscale_free": (_ST, [_P]),
+    "a3d_multiscale_batch_new": (
+        _ST,
+        [_P, C.POINTER(IcpParamsC), C.c_uint64, C.c_uint64, C.c_uint64, _PP, _PP, _PP],
+    ),
+    "a3d_multiscale_batch_align": (_ST, [_P, C.POINTER(PoseC), _P, C.POINTER(C.c_int32)]),
+    "a3d_multiscale_batch_free": (_ST, [_P]),
+    "a3d_multiscale_batch_last_timing": (_ST, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
+    "a3d_kdtree_new": (_ST, [_P, _P, C.c_uint64, _PP]),
+    "a3d_kdtree_nearest": (_ST, [_P, _P, C.c_uint64, _P, _P]),
+    "a3d_kdtree_nearest_device": (_ST, [_P, _P, C.c_uint64, _P, _P]),
+    "a3d_kdtree_free": (_ST, [_P]),
+    "a3d_pcl_icp_new": (_ST, [_P, C.POINTER(IcpParamsC), C.POINTER(PointCloudViewC), _PP]),
+    "a3d_pcl_icp_align": (_ST, [_P, C.POINTER(PointCloudViewC), C.POINTER(PoseC)]),
+    "a3d_pcl_icp_accumulate": (_ST, [_P, C.POINTER(PointCloudViewC), C.POINTER(PoseC), C.POINTER(GnStateC)]),
+    "a3d_pcl_icp_free": (_ST, [_P]),
+    "a3d_bilateral_default_sigmas": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "a3d_bilateral_filter_u16": (
+        _ST,
+        [_P, _P, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _P, C.POINTER(C.c_uint64)],
+    ),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libalign3d_hip.so")
+_lib = None
+
+
+def load_library():
+    """Loads libalign3d_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if it is
+    missing: there is deliberately no other implementation to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C align3d_amd/csrc)"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.a3d_abi_version() != 1:
+        raise RuntimeError("libalign3d_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != A3D_OK:
+        msg = load_library().a3d_last_error().decode("utf-8", "replace")
+        raise A3dError(status, f"{what}: {msg}" if what else msg)

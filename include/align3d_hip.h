@@ -1,0 +1,239 @@
+/*
+ * align3d_hip.h — C ABI of the MI355X (gfx950) implementation of align3d's ICP hot path.
+ *
+ * The reference (otaviog/align3d, Rust) has no FFI of its own: the hot path sits behind ordinary
+ * public Rust API.  Every entry point below names the Rust item it stands in for (file:line under
+ * the reference checkout).  A Rust shim that keeps `MultiscaleAlign::new/align` and `MsIcpParams`
+ * binds exactly these symbols (INTEGRATION.md shows the `extern "C"` block).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all structs are POD with fixed-width members;
+ *  - every function returns an a3d_status; nothing throws or aborts across the boundary.  Where the
+ *    reference panics (`expect`, `unwrap`) the status says why and the shim re-raises;
+ *  - "host" pointers are ordinary process memory, "device" pointers are HIP device memory of the
+ *    context's GPU;
+ *  - a context owns one HIP stream; calls on one context are serialised on that stream and the
+ *    functions that return results to host memory synchronise it before returning.
+ *  - poses are nalgebra `Isometry3<f32>` storage: translation xyz + unit quaternion (i, j, k, w)
+ *    (src/transform.rs:18).
+ */
+#ifndef ALIGN3D_HIP_H
+#define ALIGN3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3D_ABI_VERSION 1
+
+typedef enum a3d_status {
+  A3D_OK = 0,
+  /* MultiscaleAlign::new length mismatch (src/icp/multiscale.rs:30-34) and any malformed argument. */
+  A3D_INVALID_PARAMETER = 1,
+  /* target without intensity map / normals, source without intensities (src/icp/image_icp.rs:44-57),
+     point cloud without normals (src/icp/pcl_icp.rs:50-58): the reference `expect`s. */
+  A3D_MISSING_FIELD = 2,
+  /* GaussNewton::solve() == None (count == 0 or Cholesky failed; src/optim/gaussnewton.rs:84-93):
+     the reference `unwrap`s (src/icp/image_icp.rs:152, src/icp/pcl_icp.rs:96). */
+  A3D_SOLVE_FAILED = 3,
+  /* any HIP runtime failure, including "no device"; a3d_last_error() has the text. */
+  A3D_HIP_ERROR = 4,
+  /* NaN coordinate while building the kd-tree (partial_cmp().unwrap(), src/kdtree.rs:43). */
+  A3D_NAN_IN_INPUT = 5,
+  /* bilateral slice result not representable as u16 (num::cast().unwrap(), src/bilateral/grid.rs:129). */
+  A3D_CAST_OVERFLOW = 6
+} a3d_status;
+
+/* IcpParams (src/icp/icp_params.rs:8-23), field for field. */
+typedef struct a3d_icp_params {
+  uint64_t max_iterations;
+  float weight;
+  float color_weight;
+  float max_point_to_plane_distance; /* never read by the reference either */
+  float max_distance;
+  float max_normal_angle;
+  float max_color_distance;
+} a3d_icp_params;
+
+/* Transform = Isometry3<f32> (src/transform.rs:18). */
+typedef struct a3d_pose {
+  float t[3];
+  float q[4]; /* i, j, k, w */
+} a3d_pose;
+
+/* Borrowed view of a RangeImage (src/range_image/structure.rs:20-36) exactly as the Rust struct
+ * holds it in standard layout, so a shim passes `as_ptr()` with no copies.  Host pointers. */
+typedef struct a3d_range_image_view {
+  const float* points;        /* [height][width][3], 12-byte stride (Array2<Vector3<f32>>) */
+  const uint8_t* mask;        /* [height][width] */
+  const float* normals;       /* [height][width][3] or NULL (Option) */
+  const uint8_t* intensities; /* [height*width] or NULL (Option) */
+  const float* intensity_map; /* [(height+2)][(width+2)] or NULL (IntensityMap.map, src/intensity_map.rs:8) */
+  double fx, fy, cx, cy;      /* CameraIntrinsics (src/camera.rs:7-20); cast to f32 at use */
+  uint64_t width, height;     /* array dims (the reference never reads intrinsics.width/height on this path) */
+} a3d_range_image_view;
+
+/* Borrowed view of a PointCloud (src/pointcloud.rs:8-12). Host pointers. */
+typedef struct a3d_point_cloud_view {
+  const float* points;  /* [len][3] */
+  const float* normals; /* [len][3] or NULL */
+  uint64_t len;
+} a3d_point_cloud_view;
+
+/* One GaussNewton<6> accumulator as read back for tests (src/optim/gaussnewton.rs:9-14). */
+typedef struct a3d_gn_state {
+  float hessian[36]; /* row-major 6x6, both triangles filled */
+  float gradient[6];
+  float squared_residual_sum;
+  uint64_t count;
+} a3d_gn_state;
+
+typedef struct a3d_context a3d_context;
+typedef struct a3d_device_image a3d_device_image;       /* one RangeImage resident in HBM */
+typedef struct a3d_multiscale a3d_multiscale;           /* MultiscaleAlign */
+typedef struct a3d_multiscale_batch a3d_multiscale_batch; /* P independent MultiscaleAlign jobs */
+typedef struct a3d_kdtree a3d_kdtree;                   /* R3dTree */
+typedef struct a3d_pcl_icp a3d_pcl_icp;                 /* Icp */
+
+/* ---- library / context ------------------------------------------------------------------- */
+
+uint32_t a3d_abi_version(void);
+/* Text of the most recent failure on the calling thread ("" if none). */
+const char* a3d_last_error(void);
+const char* a3d_status_string(a3d_status s);
+
+/* Binds HIP device `device_index`, creates the context's stream. A3D_HIP_ERROR if there is no GPU. */
+a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx);
+a3d_status a3d_context_destroy(a3d_context* ctx);
+a3d_status a3d_context_synchronize(a3d_context* ctx);
+/* The context's hipStream_t, for callers that want to order their own work after ours. */
+void* a3d_context_stream(a3d_context* ctx);
+
+/* hipEvent pair on the context stream: start, ..., stop -> elapsed milliseconds (stop synchronises). */
+a3d_status a3d_timer_start(a3d_context* ctx);
+a3d_status a3d_timer_stop(a3d_context* ctx, float* out_ms);
+
+/* Raw device memory on the context's GPU (bench / tests keep inputs resident with these). */
+a3d_status a3d_malloc(a3d_context* ctx, size_t bytes, void** out_device_ptr);
+a3d_status a3d_free(a3d_context* ctx, void* device_ptr);
+a3d_status a3d_memcpy_h2d(a3d_context* ctx, void* dst_device, const void* src_host, size_t bytes);
+a3d_status a3d_memcpy_d2h(a3d_context* ctx, void* dst_host, const void* src_device, size_t bytes);
+a3d_status a3d_memcpy_d2d(a3d_context* ctx, void* dst_device, const void* src_device, size_t bytes);
+
+/* ---- parameters (host only, no GPU needed) ---------------------------------------------- */
+
+/* IcpParams::default() (src/icp/icp_params.rs:33-43). */
+void a3d_icp_params_default(a3d_icp_params* out);
+/* MsIcpParams::default() (src/icp/icp_params.rs:112-133): writes 3 entries, index 0 = finest level. */
+void a3d_ms_icp_params_default(a3d_icp_params out[3]);
+
+/* ---- range images resident on the device ------------------------------------------------- */
+
+/* Copies a RangeImage into HBM in the kernels' layout.  `view->normals`, `intensities`,
+ * `intensity_map` may be NULL; what is missing only matters to the call that needs it. */
+a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* view,
+                                  a3d_device_image** out_image);
+a3d_status a3d_range_image_free(a3d_device_image* image);
+
+/* RangeImage::compute_normals (src/range_image/structure.rs:184-262) on a resident image;
+ * afterwards the image "has normals". */
+a3d_status a3d_range_image_compute_normals(a3d_device_image* image);
+/* Reads the resident normals back: [height][width][3] f32. */
+a3d_status a3d_range_image_download_normals(a3d_device_image* image, float* out_normals);
+
+/* RangeImage::compute_normals, host in / host out convenience form. */
+a3d_status a3d_compute_normals(a3d_context* ctx, const float* points, const uint8_t* mask,
+                               uint64_t width, uint64_t height, float* out_normals);
+
+/* ---- ImageIcp (src/icp/image_icp.rs:19-165) ---------------------------------------------- */
+
+/* ImageIcp::new(params, target) + initial_transform + align(source): all iterations run on the
+ * device; returns best_transform.  init_pose NULL = Transform::eye(). */
+a3d_status a3d_image_icp_align(a3d_context* ctx, const a3d_icp_params* params,
+                               const a3d_device_image* target, const a3d_device_image* source,
+                               const a3d_pose* init_pose, a3d_pose* out_pose);
+
+/* One pass of the per-pixel body (src/icp/image_icp.rs:101-139) from `pose`, returning the two
+ * merged accumulators before add_weighted.  Test hook for per-iteration parity. */
+a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* params,
+                                    const a3d_device_image* target, const a3d_device_image* source,
+                                    const a3d_pose* pose, a3d_gn_state* out_geom,
+                                    a3d_gn_state* out_color);
+
+/* ---- MultiscaleAlign (src/icp/multiscale.rs:7-68) ---------------------------------------- */
+
+/* MultiscaleAlign::new(params, &target_pyramid): A3D_INVALID_PARAMETER unless
+ * n_params == n_levels (multiscale.rs:30-34).  Index 0 = finest level.  Borrows the images. */
+a3d_status a3d_multiscale_new(a3d_context* ctx, const a3d_icp_params* params, uint64_t n_params,
+                              const a3d_device_image* const* target_pyramid, uint64_t n_levels,
+                              a3d_multiscale** out);
+/* MultiscaleAlign::align(&source_pyramid): coarsest level first, each level starts from the
+ * previous level's result; a shorter source pyramid truncates like izip! (multiscale.rs:54-64). */
+a3d_status a3d_multiscale_align(a3d_multiscale* ms, const a3d_device_image* const* source_pyramid,
+                                uint64_t n_source_levels, a3d_pose* out_pose);
+a3d_status a3d_multiscale_free(a3d_multiscale* ms);
+
+/* P independent MultiscaleAlign::new(params, target_p).align(source_p) jobs run as one launch
+ * sequence (grid = pairs x tiles).  target/source are [n_pairs][n_levels] row-major handle tables. */
+a3d_status a3d_multiscale_batch_new(a3d_context* ctx, const a3d_icp_params* params,
+                                    uint64_t n_params, uint64_t n_pairs, uint64_t n_levels,
+                                    const a3d_device_image* const* target_pyramids,
+                                    const a3d_device_image* const* source_pyramids,
+                                    a3d_multiscale_batch** out);
+/* Runs every pair.  out_poses_host: [n_pairs] or NULL.  out_matrices_device: [n_pairs][16] f32
+ * row-major 4x4 in device memory (the buffer the RCCL gather sends) or NULL.
+ * out_status_host: per-pair A3D_OK / A3D_SOLVE_FAILED, [n_pairs] or NULL.  With
+ * out_poses_host == NULL and out_status_host == NULL the call only enqueues (no host sync). */
+a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* batch, a3d_pose* out_poses_host,
+                                      float* out_matrices_device, int32_t* out_status_host);
+a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* batch);
+/* Time of the most recent batch_align on the device, between hipEvents recorded on the context
+ * stream around its launches, and the share of it spent in the per-pixel kernel (sum of that
+ * kernel's launches / number of launches). */
+a3d_status a3d_multiscale_batch_last_timing(a3d_multiscale_batch* batch, float* out_total_ms,
+                                            uint64_t* out_pixel_kernel_launches);
+
+/* ---- R3dTree (src/kdtree.rs:19-106) ------------------------------------------------------- */
+
+/* R3dTree::new(&points): host build (stable sort, leaf <= 16, mid = len/2), uploaded to HBM. */
+a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d_kdtree** out);
+/* R3dTree::nearest for m queries (leaf-only search, no backtracking).  Host pointers.
+ * out_indices are indices into the `points` given to a3d_kdtree_new. */
+a3d_status a3d_kdtree_nearest(a3d_kdtree* tree, const float* queries, uint64_t m,
+                              uint64_t* out_indices, float* out_sqr_distances);
+/* Same with queries and results resident: d_queries [m][3] f32, d_indices [m] u32, d_sqr [m] f32. */
+a3d_status a3d_kdtree_nearest_device(a3d_kdtree* tree, const void* d_queries, uint64_t m,
+                                     void* d_indices, void* d_sqr_distances);
+a3d_status a3d_kdtree_free(a3d_kdtree* tree);
+
+/* ---- Icp (src/icp/pcl_icp.rs:15-108) ------------------------------------------------------ */
+
+/* Icp::new(params, &target): builds the kd-tree over target.points; A3D_MISSING_FIELD is
+ * deferred to align like the reference. */
+a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params,
+                           const a3d_point_cloud_view* target, a3d_pcl_icp** out);
+/* Icp::align(&source): starts from Transform::eye() (initial_transform is ignored, pcl_icp.rs:59). */
+a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* source,
+                             a3d_pose* out_pose);
+/* One pass of the per-point body (pcl_icp.rs:68-92) from `pose`: test hook. */
+a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* source,
+                                  const a3d_pose* pose, a3d_gn_state* out_state);
+a3d_status a3d_pcl_icp_free(a3d_pcl_icp* icp);
+
+/* ---- BilateralFilter<u16> (src/bilateral/edge_aware_filter.rs:30-135, grid.rs:32-162) ----- */
+
+/* BilateralFilter::default() sigmas (edge_aware_filter.rs:30-36). */
+void a3d_bilateral_default_sigmas(double* out_sigma_space, double* out_sigma_color);
+/* BilateralFilter::new(sigma_space, sigma_color).filter(&image): u16 [height][width] in and out,
+ * host pointers.  out_grid_dims (nullable) receives GH, GW, GD. */
+a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t* image, uint64_t width,
+                                    uint64_t height, double sigma_space, double sigma_color,
+                                    uint16_t* out_image, uint64_t out_grid_dims[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGN3D_HIP_H */
