@@ -1,1 +1,14 @@
-"""align3d_amd — MI355X-native ICP hot path of align3d (host-side mirror of the reference API)."""
+"""align3d_amd — MI355X-native implementation of align3d's ICP hot path.
+
+Host-side mirror of the reference's public API for that path (same names and argument meaning:
+IcpParams, MsIcpParams, ImageIcp, MultiscaleAlign, Icp, R3dTree, RangeImage, BilateralFilter,
+Transform) over the C ABI of libalign3d_hip.so (include/align3d_hip.h).  All compute runs in
+hand-written HIP kernels for gfx950; there is no CPU fallback."""
+from ._abi import A3dError, InvalidParameter, load_library  # noqa: F401
+from .bilateral import BilateralFilter  # noqa: F401
+from .context import Context  # noqa: F401
+from .icp import Icp, ImageIcp, MultiscaleAlign, MultiscaleAlignBatch, PointCloud  # noqa: F401
+from .icp_params import IcpParams, MsIcpParams  # noqa: F401
+from .kdtree import R3dTree  # noqa: F401
+from .range_image import CameraIntrinsics, DeviceRangeImage, RangeImage, RangeImageBuilder  # noqa: F401
+from .transform import Transform  # noqa: F401

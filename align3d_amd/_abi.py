@@ -131,6 +131,10 @@ SIGNATURES = {
         _ST,
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC), C.POINTER(GnStateC)],
     ),
+    "a3d_image_icp_align_trace": (
+        _ST,
+        [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(PoseC), _P],
+    ),
     "a3d_multiscale_new": (_ST, [_P, C.POINTER(IcpParamsC), C.c_uint64, _PP, C.c_uint64, _PP]),
     "a3d_multiscale_align": (_ST, [_P, _PP, C.c_uint64, C.POINTER(PoseC)]),
     "a3d_multiscale_free": (_ST, [_P]),
@@ -141,6 +145,9 @@ SIGNATURES = {
     "a3d_multiscale_batch_align": (_ST, [_P, C.POINTER(PoseC), _P, C.POINTER(C.c_int32)]),
     "a3d_multiscale_batch_free": (_ST, [_P]),
     "a3d_multiscale_batch_last_timing": (_ST, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
+    "a3d_multiscale_batch_set_profiling": (_ST, [_P, C.c_int32]),
+    "a3d_multiscale_batch_last_kernel_ms": (_ST, [_P, C.POINTER(C.c_float)]),
+    "a3d_kdtree_stats": (_ST, [_P, C.POINTER(C.c_uint64)]),
     "a3d_kdtree_new": (_ST, [_P, _P, C.c_uint64, _PP]),
     "a3d_kdtree_nearest": (_ST, [_P, _P, C.c_uint64, _P, _P]),
     "a3d_kdtree_nearest_device": (_ST, [_P, _P, C.c_uint64, _P, _P]),

@@ -1,0 +1,51 @@
+"""Device context: one GPU, one HIP stream (a3d_context)."""
+import ctypes as C
+
+from . import _abi
+
+
+class Context:
+    def __init__(self, device_index=0):
+        self.lib = _abi.load_library()
+        self.handle = C.c_void_p()
+        _abi.check(self.lib.a3d_context_create(int(device_index), C.byref(self.handle)), "a3d_context_create")
+        self.device_index = int(device_index)
+
+    def synchronize(self):
+        _abi.check(self.lib.a3d_context_synchronize(self.handle))
+
+    def timer_start(self):
+        _abi.check(self.lib.a3d_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _abi.check(self.lib.a3d_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        _abi.check(self.lib.a3d_malloc(self.handle, int(nbytes), C.byref(p)))
+        return p
+
+    def free(self, p):
+        _abi.check(self.lib.a3d_free(self.handle, p))
+
+    def to_device(self, arr):
+        p = self.malloc(arr.nbytes)
+        _abi.check(self.lib.a3d_memcpy_h2d(self.handle, p, _abi.ptr(arr), arr.nbytes))
+        return p
+
+    def to_host(self, p, arr):
+        _abi.check(self.lib.a3d_memcpy_d2h(self.handle, _abi.ptr(arr), p, arr.nbytes))
+        return arr
+
+    def close(self):
+        if self.handle:
+            self.lib.a3d_context_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

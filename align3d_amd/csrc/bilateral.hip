@@ -1,0 +1,208 @@
+// BilateralFilter<u16>::filter (src/bilateral/edge_aware_filter.rs:126-135): bilateral-grid splat,
+// 3 axes x 2 passes of the [1 2 1]/4 blur, normalise, trilinear slice — all in f64 like the reference,
+// compiled without contraction, so the u16 result is bit-identical to the CPU path.
+//
+// Why the splat may use atomics: every summand is an integer (a depth value, or 1.0) and the totals
+// stay far below 2^53, so f64 addition is exact and the order of the adds cannot matter.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+using namespace a3d;
+
+namespace {
+
+struct GridDims {
+  uint32_t gh, gw, gd;
+};
+
+// `x as usize` for a non-negative finite f64
+__device__ __forceinline__ uint32_t f64_as_usize(double x) { return x > 0.0 ? (uint32_t)x : 0u; }
+
+// min / max over ALL pixels, zeros included (src/bilateral/grid.rs:41-49)
+__global__ void __launch_bounds__(256)
+    minmax_u16_kernel(const uint16_t* __restrict__ img, uint32_t n, uint32_t* __restrict__ out_minmax) {
+  uint32_t mi = 0xFFFFu, ma = 0u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t v = img[i];
+    mi = min(mi, v);
+    ma = max(ma, v);
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    mi = min(mi, (uint32_t)__shfl_xor((int)mi, off, 64));
+    ma = max(ma, (uint32_t)__shfl_xor((int)ma, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&out_minmax[0], mi);
+    atomicMax(&out_minmax[1], ma);
+  }
+}
+
+// BilateralGrid::from_image splat (src/bilateral/grid.rs:60-78); grid cell = {value sum, count}
+__global__ void __launch_bounds__(256)
+    splat_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
+                 uint32_t color_min, GridDims g, double* __restrict__ grid) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const uint32_t color = img[i];
+  if (color == 0) return;  // `color <= I::min_value()` (:67)
+  const uint32_t row = i / w, col = i % w;
+  const uint32_t grow = f64_as_usize((double)row * inv_ss + 0.5) + 2;
+  const uint32_t gcol = f64_as_usize((double)col * inv_ss + 0.5) + 2;
+  const uint32_t ch = f64_as_usize((double)(color - color_min) * inv_sc + 0.5) + 2;
+  const size_t cell = (((size_t)grow * g.gw + gcol) * g.gd + ch) * 2;
+  atomicAdd(&grid[cell], (double)color);
+  atomicAdd(&grid[cell + 1], 1.0);
+}
+
+// One pass of BilateralFilter::convolution (src/bilateral/edge_aware_filter.rs:68-114) along `axis`
+// (0 = row, 1 = col, 2 = channel): out = (prev + next + 2 cur) * 0.25 on value and weight, written for
+// rows 1..gh-2, cols 1..gw-2, channels 0..gd-2; every other cell is never written and stays zero in both
+// buffers.  The reference's channel loop starts at an un-offset pointer, so at channel 0 its "previous"
+// read aliases cell (row, col-1, gd-1), which is always zero: read as 0.0 here.
+__global__ void __launch_bounds__(256)
+    blur_axis_kernel(const double2* __restrict__ in, double2* __restrict__ out, GridDims g, int axis) {
+  const uint32_t zc = g.gd - 1;  // channels per (row, col) that are written
+  const uint64_t interior = (uint64_t)(g.gh - 2) * (g.gw - 2) * zc;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= interior) return;
+  const uint32_t z = (uint32_t)(t % zc);
+  const uint64_t rc = t / zc;
+  const uint32_t col = 1 + (uint32_t)(rc % (g.gw - 2));
+  const uint32_t row = 1 + (uint32_t)(rc / (g.gw - 2));
+  const size_t cell = ((size_t)row * g.gw + col) * g.gd + z;
+  const size_t stride = axis == 0 ? (size_t)g.gw * g.gd : (axis == 1 ? (size_t)g.gd : 1);
+  const double2 cur = in[cell];
+  const double2 next = in[cell + stride];
+  double2 prev = make_double2(0.0, 0.0);
+  if (!(axis == 2 && z == 0)) prev = in[cell - stride];
+  double2 o;
+  o.x = (prev.x + next.x + 2.0 * cur.x) * 0.25;
+  o.y = (prev.y + next.y + 2.0 * cur.y) * 0.25;
+  out[cell] = o;
+}
+
+__device__ __forceinline__ uint32_t clampu(uint32_t v, uint32_t hi) { return v > hi ? hi : v; }
+
+// BilateralGrid::normalize (grid.rs:90-104) folded into the read, then trilinear (grid.rs:132-162)
+__device__ __forceinline__ double cell_value(const double2* __restrict__ grid, GridDims g, uint32_t r, uint32_t c,
+                                             uint32_t z) {
+  const double2 v = grid[((size_t)r * g.gw + c) * g.gd + z];
+  return v.y > 0.0 ? v.x / v.y : v.x;
+}
+
+// BilateralGrid::slice (grid.rs:106-130): every pixel, zeros included; num::cast::<f64,u16>
+__global__ void __launch_bounds__(256)
+    slice_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
+                 uint32_t color_min, GridDims g, const double2* __restrict__ grid, uint16_t* __restrict__ out,
+                 uint32_t* __restrict__ overflow_flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const uint32_t r = i / w, c = i % w;
+  const double row = (double)r * inv_ss + 2.0;
+  const double col = (double)c * inv_ss + 2.0;
+  const double channel = (double)((uint32_t)img[i] - color_min) * inv_sc + 2.0;
+  const uint32_t z = clampu(f64_as_usize(channel), g.gd - 1), zz = clampu(f64_as_usize(channel + 1.0), g.gd - 1);
+  const double za = channel - (double)z;
+  const uint32_t y = clampu(f64_as_usize(row), g.gh - 1), yy = clampu(f64_as_usize(row + 1.0), g.gh - 1);
+  const double ya = row - (double)y;
+  const uint32_t x = clampu(f64_as_usize(col), g.gw - 1), xx = clampu(f64_as_usize(col + 1.0), g.gw - 1);
+  const double xa = col - (double)x;
+  const double value = (1.0 - ya) * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, y, x, z) +
+                       (1.0 - ya) * xa * (1.0 - za) * cell_value(grid, g, y, xx, z) +
+                       ya * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, yy, x, z) +
+                       ya * xa * (1.0 - za) * cell_value(grid, g, yy, xx, z) +
+                       (1.0 - ya) * (1.0 - xa) * za * cell_value(grid, g, y, x, zz) +
+                       (1.0 - ya) * xa * za * cell_value(grid, g, y, xx, zz) +
+                       ya * (1.0 - xa) * za * cell_value(grid, g, yy, x, zz) +
+                       ya * xa * za * cell_value(grid, g, yy, xx, zz);
+  if (value > -1.0 && value < 65536.0) {
+    out[i] = (uint16_t)value;  // truncation toward zero
+  } else {
+    out[i] = 0;
+    atomicOr(overflow_flag, 1u);  // the reference's .unwrap() would panic
+  }
+}
+
+}  // namespace
+
+extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t* image, uint64_t width,
+                                               uint64_t height, double sigma_space, double sigma_color,
+                                               uint16_t* out_image, uint64_t out_grid_dims[3]) {
+  A3D_REQUIRE(ctx && image && out_image, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(width > 0 && height > 0 && width * height < (1ull << 30), A3D_INVALID_PARAMETER, "bad image size");
+  A3D_REQUIRE(sigma_space > 0.0 && sigma_color > 0.0, A3D_INVALID_PARAMETER, "sigmas must be positive");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint32_t w = (uint32_t)width, h = (uint32_t)height, n = w * h;
+  uint16_t *d_img = nullptr, *d_out = nullptr;
+  uint32_t* d_scal = nullptr;  // [0] min, [1] max, [2] overflow flag
+  double2 *d_a = nullptr, *d_b = nullptr;
+  a3d_status st = A3D_OK;
+  auto fail = [&](const char* what) {
+    set_error("a3d_bilateral_filter_u16: %s: %s", what, hipGetErrorString(hipGetLastError()));
+    st = A3D_HIP_ERROR;
+  };
+  uint32_t h_scal[3] = {0xFFFFu, 0u, 0u};
+  if (hipMalloc((void**)&d_img, n * 2) != hipSuccess || hipMalloc((void**)&d_out, n * 2) != hipSuccess ||
+      hipMalloc((void**)&d_scal, 12) != hipSuccess)
+    fail("hipMalloc");
+  if (st == A3D_OK && (hipMemcpyAsync(d_img, image, n * 2, hipMemcpyHostToDevice, s) != hipSuccess ||
+                       hipMemcpyAsync(d_scal, h_scal, 12, hipMemcpyHostToDevice, s) != hipSuccess))
+    fail("upload");
+  if (st == A3D_OK) {
+    hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, s, d_img, n,
+                       d_scal);
+    if (hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      fail("min/max");
+  }
+  GridDims g{0, 0, 0};
+  if (st == A3D_OK) {
+    // grid.rs:37-56 (host arithmetic: the grid size is needed to allocate)
+    const uint32_t cmin = h_scal[0], cmax = h_scal[1];
+    g.gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4;
+    g.gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
+    g.gd = (uint32_t)((double)(cmax - cmin) / sigma_color) + 1 + 4;
+    if (out_grid_dims) out_grid_dims[0] = g.gh, out_grid_dims[1] = g.gw, out_grid_dims[2] = g.gd;
+    const size_t cells = (size_t)g.gh * g.gw * g.gd;
+    if (hipMalloc((void**)&d_a, cells * sizeof(double2)) != hipSuccess ||
+        hipMalloc((void**)&d_b, cells * sizeof(double2)) != hipSuccess ||
+        hipMemsetAsync(d_a, 0, cells * sizeof(double2), s) != hipSuccess ||
+        hipMemsetAsync(d_b, 0, cells * sizeof(double2), s) != hipSuccess)
+      fail("grid allocation");
+    if (st == A3D_OK) {
+      const double inv_ss = 1.0 / sigma_space, inv_sc = 1.0 / sigma_color;
+      hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
+                         (double*)d_a);
+      const uint64_t interior = (uint64_t)(g.gh - 2) * (g.gw - 2) * (g.gd - 1);
+      const uint32_t blocks = (uint32_t)((interior + 255) / 256);
+      double2 *src = d_a, *dst = d_b;
+      for (int axis = 0; axis < 3; ++axis)
+        for (int rep = 0; rep < 2; ++rep) {
+          hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, s, src, dst, g, axis);
+          std::swap(src, dst);
+        }
+      // six passes: the result is back in d_a (== src after the final swap)
+      hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
+                         src, d_out, d_scal + 2);
+      if (hipGetLastError() != hipSuccess) fail("kernel launch");
+    }
+    if (st == A3D_OK && (hipMemcpyAsync(out_image, d_out, n * 2, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                         hipMemcpyAsync(h_scal + 2, d_scal + 2, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                         hipStreamSynchronize(s) != hipSuccess))
+      fail("download");
+  }
+  hipFree(d_img);
+  hipFree(d_out);
+  hipFree(d_scal);
+  hipFree(d_a);
+  hipFree(d_b);
+  if (st != A3D_OK) return st;
+  if (h_scal[2]) {
+    set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
+    return A3D_CAST_OVERFLOW;
+  }
+  return A3D_OK;
+}

@@ -1,0 +1,85 @@
+// Internal definitions shared by the translation units of libalign3d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/align3d_hip.h"
+#include "devmath.hpp"
+
+namespace a3d {
+
+void set_error(const char* fmt, ...);
+
+#define A3D_HIP_TRY(expr)                                                                 \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      a3d::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return A3D_HIP_ERROR;                                                               \
+    }                                                                                     \
+  } while (0)
+
+#define A3D_TRY(expr)                  \
+  do {                                 \
+    a3d_status _s = (expr);            \
+    if (_s != A3D_OK) return _s;       \
+  } while (0)
+
+#define A3D_REQUIRE(cond, status, msg) \
+  do {                                 \
+    if (!(cond)) {                     \
+      a3d::set_error("%s", msg);       \
+      return status;                   \
+    }                                  \
+  } while (0)
+
+inline Pose pose_from_c(const a3d_pose* p) {
+  return Pose{{p->t[0], p->t[1], p->t[2]}, {p->q[0], p->q[1], p->q[2], p->q[3]}};
+}
+inline void pose_to_c(const Pose& p, a3d_pose* o) {
+  o->t[0] = p.t.x, o->t[1] = p.t.y, o->t[2] = p.t.z;
+  o->q[0] = p.q.i, o->q[1] = p.q.j, o->q[2] = p.q.k, o->q[3] = p.q.w;
+}
+
+// Largest f32 d in [-1, 1] with  acosf(d) >= thr  (strict = false)  or  acosf(d) > thr  (strict =
+// true), found by bisection over the f32 ordering with the host libm (the libm the reference's
+// f32::acos resolves to).  Returns -2.0f when no d qualifies.  The kernels then test
+// "d >= -1 && d <= d_star" instead of calling a device acosf: the same decisions, one compare.
+float acos_gate_threshold(float thr, bool strict);
+
+}  // namespace a3d
+
+struct a3d_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  int num_cus = 0;
+};
+
+// One RangeImage in HBM.  Raw arrays keep the reference layout; the packed arrays are what the ICP
+// kernel reads (DESIGN.md "Data layout in HBM").
+struct a3d_device_image {
+  a3d_context* ctx = nullptr;
+  uint32_t width = 0, height = 0;
+  float fx = 0, fy = 0, cx = 0, cy = 0;  // cast f64 -> f32 once, as the reference does at each use
+  float* points = nullptr;               // [h][w][3]
+  uint8_t* mask = nullptr;               // [h][w]
+  float* normals = nullptr;              // [h][w][3] or null
+  uint8_t* intensities = nullptr;        // [h*w] or null
+  float* imap = nullptr;                 // [(h+2)][(w+2)] or null
+  float4* src_pack = nullptr;            // [h*w]   {x, y, z, intensity or -1 when mask == 0}
+  float4* tgt_pack = nullptr;            // [h*w][2] {x, y, z, mask == 1}, {nx, ny, nz, 0}
+  bool has_normals = false, has_intensities = false, has_imap = false;
+  bool src_pack_valid = false, tgt_pack_valid = false;
+};
+
+namespace a3d {
+// Builds (or refreshes) the packed arrays an image needs to act as ICP source / target.
+a3d_status ensure_source_pack(a3d_device_image* im);
+a3d_status ensure_target_pack(a3d_device_image* im);
+}  // namespace a3d

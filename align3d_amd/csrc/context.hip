@@ -1,0 +1,191 @@
+// Context, error text, raw device memory, timers and the host-only parameter helpers of the C ABI.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace a3d {
+
+static thread_local char g_last_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+}
+
+static inline uint32_t f32_bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+static inline float bits_f32(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// Monotone map f32 -> u32 (total order of finite floats).
+static inline uint32_t ordered(float f) {
+  uint32_t u = f32_bits(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float unordered(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return bits_f32(u);
+}
+
+float acos_gate_threshold(float thr, bool strict) {
+  auto rejects = [&](float d) {
+    float a = fabsf(acosf(d));
+    return strict ? (a > thr) : (a >= thr);
+  };
+  if (!rejects(-1.0f)) return -2.0f;  // acos is largest at -1: nothing is rejected (also thr = NaN)
+  if (rejects(1.0f)) return 1.0f;
+  // invariant: rejects(lo) && !rejects(hi); acosf is non-increasing
+  uint32_t lo = ordered(-1.0f), hi = ordered(1.0f);
+  while (hi - lo > 1) {
+    uint32_t mid = lo + (hi - lo) / 2;
+    if (rejects(unordered(mid)))
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return unordered(lo);
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" {
+
+uint32_t a3d_abi_version(void) { return A3D_ABI_VERSION; }
+const char* a3d_last_error(void) { return a3d::g_last_error; }
+const char* a3d_status_string(a3d_status s) {
+  switch (s) {
+    case A3D_OK: return "A3D_OK";
+    case A3D_INVALID_PARAMETER: return "A3D_INVALID_PARAMETER";
+    case A3D_MISSING_FIELD: return "A3D_MISSING_FIELD";
+    case A3D_SOLVE_FAILED: return "A3D_SOLVE_FAILED";
+    case A3D_HIP_ERROR: return "A3D_HIP_ERROR";
+    case A3D_NAN_IN_INPUT: return "A3D_NAN_IN_INPUT";
+    case A3D_CAST_OVERFLOW: return "A3D_CAST_OVERFLOW";
+  }
+  return "A3D_UNKNOWN";
+}
+
+a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx) {
+  A3D_REQUIRE(out_ctx, A3D_INVALID_PARAMETER, "out_ctx is null");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    set_error("no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return A3D_HIP_ERROR;
+  }
+  A3D_REQUIRE(device_index >= 0 && device_index < count, A3D_INVALID_PARAMETER, "device index out of range");
+  A3D_HIP_TRY(hipSetDevice(device_index));
+  a3d_context* ctx = new a3d_context();
+  ctx->device = device_index;
+  hipDeviceProp_t prop;
+  A3D_HIP_TRY(hipGetDeviceProperties(&prop, device_index));
+  ctx->num_cus = prop.multiProcessorCount;
+  A3D_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  A3D_HIP_TRY(hipEventCreate(&ctx->ev_start));
+  A3D_HIP_TRY(hipEventCreate(&ctx->ev_stop));
+  *out_ctx = ctx;
+  return A3D_OK;
+}
+
+a3d_status a3d_context_destroy(a3d_context* ctx) {
+  if (!ctx) return A3D_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  hipEventDestroy(ctx->ev_start);
+  hipEventDestroy(ctx->ev_stop);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return A3D_OK;
+}
+
+a3d_status a3d_context_synchronize(a3d_context* ctx) {
+  A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
+  A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return A3D_OK;
+}
+
+void* a3d_context_stream(a3d_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+a3d_status a3d_timer_start(a3d_context* ctx) {
+  A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
+  A3D_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+  return A3D_OK;
+}
+a3d_status a3d_timer_stop(a3d_context* ctx, float* out_ms) {
+  A3D_REQUIRE(ctx && out_ms, A3D_INVALID_PARAMETER, "null argument");
+  A3D_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+  A3D_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+  A3D_HIP_TRY(hipEventElapsedTime(out_ms, ctx->ev_start, ctx->ev_stop));
+  return A3D_OK;
+}
+
+a3d_status a3d_malloc(a3d_context* ctx, size_t bytes, void** out) {
+  A3D_REQUIRE(ctx && out, A3D_INVALID_PARAMETER, "null argument");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  A3D_HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+  return A3D_OK;
+}
+a3d_status a3d_free(a3d_context* ctx, void* p) {
+  A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
+  if (p) A3D_HIP_TRY(hipFree(p));
+  return A3D_OK;
+}
+a3d_status a3d_memcpy_h2d(a3d_context* ctx, void* dst, const void* src, size_t bytes) {
+  A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
+  A3D_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return A3D_OK;
+}
+a3d_status a3d_memcpy_d2h(a3d_context* ctx, void* dst, const void* src, size_t bytes) {
+  A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
+  A3D_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return A3D_OK;
+}
+a3d_status a3d_memcpy_d2d(a3d_context* ctx, void* dst, const void* src, size_t bytes) {
+  A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
+  A3D_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return A3D_OK;
+}
+
+// IcpParams::default() (src/icp/icp_params.rs:33-43)
+void a3d_icp_params_default(a3d_icp_params* out) {
+  out->max_iterations = 15;
+  out->weight = 1.0f;
+  out->color_weight = 1.0e-1f;
+  out->max_point_to_plane_distance = 0.1f;
+  out->max_distance = 0.5f;
+  out->max_normal_angle = 18.0f * (3.14159265358979323846f / 180.0f);  // f32::to_radians
+  out->max_color_distance = 0.25f;
+}
+
+// MsIcpParams::default() (src/icp/icp_params.rs:112-133)
+void a3d_ms_icp_params_default(a3d_icp_params out[3]) {
+  const uint64_t iters[3] = {20, 20, 30};
+  for (int l = 0; l < 3; ++l) {
+    a3d_icp_params_default(&out[l]);
+    out[l].weight = 1.0f;
+    out[l].color_weight = 1.0f;
+    out[l].max_normal_angle = 3.14159265358979323846f / 10.0f;
+    out[l].max_color_distance = 2.75f;
+    out[l].max_distance = 0.5f;
+    out[l].max_iterations = iters[l];
+  }
+}
+
+// BilateralFilter::default() (src/bilateral/edge_aware_filter.rs:30-36)
+void a3d_bilateral_default_sigmas(double* ss, double* sc) {
+  if (ss) *ss = 4.50000000225;
+  if (sc) *sc = 29.9999880000072;
+}
+
+}  // extern "C"

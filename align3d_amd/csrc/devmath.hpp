@@ -1,0 +1,182 @@
+// Scalar math shared by the HIP kernels and the host-side pose code of libalign3d_hip.so.
+// Every expression keeps the reference's evaluation order (Rust/nalgebra never contract a*b+c), and
+// the library is compiled with -ffp-contract=off, so a per-sample value computed here is the
+// bit-identical f32 the reference computes; only sums over samples are re-associated.
+//
+//   Transform::transform_vector / transform_normal   src/transform.rs:138-153
+//   Isometry3 * Isometry3                            src/transform.rs:205-220
+//   Transform::exp(Se3)                              src/transform.rs:44-108
+//   CameraIntrinsics::project / project_grad         src/camera.rs:64-89
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define A3D_HD __host__ __device__ __forceinline__
+
+namespace a3d {
+
+struct V3 {
+  float x, y, z;
+};
+A3D_HD V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+A3D_HD V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+A3D_HD V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+A3D_HD V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+// nalgebra 3-vector dot: (a0 b0 + a1 b1) + a2 b2
+A3D_HD float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+A3D_HD float norm_squared(V3 a) { return dot(a, a); }
+A3D_HD V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+struct Quat {
+  float i, j, k, w;
+};
+struct Pose {
+  V3 t;
+  Quat q;
+};
+A3D_HD Pose pose_eye() { return {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 1.f}}; }
+
+// UnitQuaternion * Vector3: t = 2 (q_v x v); v' = (t w + q_v x t) + v
+A3D_HD V3 rotate(const Quat& q, V3 v) {
+  V3 qv{q.i, q.j, q.k};
+  V3 t = cross(qv, v) * 2.0f;
+  V3 c = cross(qv, t);
+  return (t * q.w + c) + v;
+}
+A3D_HD V3 transform_vector(const Pose& p, V3 v) { return rotate(p.q, v) + p.t; }
+A3D_HD V3 transform_normal(const Pose& p, V3 v) { return rotate(p.q, v); }
+
+A3D_HD Quat qmul(const Quat& a, const Quat& b) {
+  Quat r;
+  r.w = a.w * b.w - a.i * b.i - a.j * b.j - a.k * b.k;
+  r.i = a.w * b.i + a.i * b.w + a.j * b.k - a.k * b.j;
+  r.j = a.w * b.j - a.i * b.k + a.j * b.w + a.k * b.i;
+  r.k = a.w * b.k + a.i * b.j - a.j * b.i + a.k * b.w;
+  return r;
+}
+A3D_HD Pose compose(const Pose& a, const Pose& b) {
+  Pose r;
+  r.t = a.t + rotate(a.q, b.t);
+  r.q = qmul(a.q, b.q);
+  return r;
+}
+
+// Unit::new_normalize on the 4-vector (i, j, k, w): norm^2 = (i^2 + k^2) + (j^2 + w^2)
+A3D_HD Quat qnormalize(Quat q) {
+  float a = q.i * q.i, b = q.j * q.j, c = q.k * q.k, d = q.w * q.w;
+  a += c;
+  b += d;
+  float n = sqrtf(a + b);
+  return {q.i / n, q.j / n, q.k / n, q.w / n};
+}
+
+// sin/cos of an f32 argument, evaluated in f64 and rounded once: agrees with a correctly rounded
+// sinf/cosf (what glibc delivers in practice) and is the same on host and device.
+A3D_HD float sin_f32(float x) { return (float)sin((double)x); }
+A3D_HD float cos_f32(float x) { return (float)cos((double)x); }
+
+// Transform::exp(&LieGroup::Se3(u)), u = [rho, omega]
+A3D_HD Pose exp_se3(const float u[6]) {
+  const float EPS = 1e-8f;
+  V3 omega{u[3], u[4], u[5]};
+  float theta_sq0 = norm_squared(omega);
+  float theta, imag, real;
+  if (theta_sq0 < EPS * EPS) {
+    float po4 = theta_sq0 * theta_sq0;
+    theta = 0.0f;
+    imag = 0.5f - (1.0f / 48.0f) * theta_sq0 + (1.0f / 3840.0f) * po4;
+    real = 1.0f - (1.0f / 8.0f) * theta_sq0 + (1.0f / 384.0f) * po4;
+  } else {
+    theta = sqrtf(theta_sq0);
+    float half = 0.5f * theta;
+    imag = sin_f32(half) / theta;
+    real = cos_f32(half);
+  }
+  Quat q = qnormalize(Quat{imag * omega.x, imag * omega.y, imag * omega.z, real});
+  float theta_sq = theta * theta;
+  // V = I + a W + b W^2, W = [omega]x ; translation = V rho (column-axpy order)
+  float W[3][3] = {{0.f, -omega.z, omega.y}, {omega.z, 0.f, -omega.x}, {-omega.y, omega.x, 0.f}};
+  float V[3][3];
+  if (theta_sq < EPS) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) V[r][c] = (r == c ? 1.0f : 0.0f) + W[r][c] * 0.5f;
+  } else {
+    float W2[3][3];
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) {
+        float acc = W[r][0] * W[0][c];
+        acc = W[r][1] * W[1][c] + acc;
+        acc = W[r][2] * W[2][c] + acc;
+        W2[r][c] = acc;
+      }
+    float a = (1.0f - cos_f32(theta)) / theta_sq;
+    float b = (theta - sin_f32(theta)) / (theta_sq * theta);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) V[r][c] = ((r == c ? 1.0f : 0.0f) + W[r][c] * a) + W2[r][c] * b;
+  }
+  Pose p;
+  float rho[3] = {u[0], u[1], u[2]}, t[3];
+  for (int r = 0; r < 3; ++r) {
+    float acc = V[r][0] * rho[0];
+    acc = V[r][1] * rho[1] + acc;
+    acc = V[r][2] * rho[2] + acc;
+    t[r] = acc;
+  }
+  p.t = {t[0], t[1], t[2]};
+  p.q = q;
+  return p;
+}
+
+// Isometry3 -> Matrix4 (row-major), UnitQuaternion::to_rotation_matrix
+A3D_HD void pose_to_matrix(const Pose& p, float m[16]) {
+  const float i = p.q.i, j = p.q.j, k = p.q.k, w = p.q.w;
+  float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+  float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f, ik = i * k * 2.0f;
+  float jk = j * k * 2.0f, wi = w * i * 2.0f;
+  m[0] = ww + ii - jj - kk, m[1] = ij - wk, m[2] = wj + ik, m[3] = p.t.x;
+  m[4] = wk + ij, m[5] = ww - ii + jj - kk, m[6] = jk - wi, m[7] = p.t.y;
+  m[8] = ik - wj, m[9] = wi + jk, m[10] = ww - ii - jj + kk, m[11] = p.t.z;
+  m[12] = 0.f, m[13] = 0.f, m[14] = 0.f, m[15] = 1.f;
+}
+
+// GaussNewton::solve (src/optim/gaussnewton.rs:84-93): f64 Cholesky (nalgebra's left-looking
+// column form) + forward / adjoint substitution.  H is the full symmetric 6x6.  false == None.
+A3D_HD bool gn_solve6(const float H[36], const float g[6], float out[6]) {
+  double L[6][6], b[6];
+  for (int r = 0; r < 6; ++r) {
+    for (int c = 0; c < 6; ++c) L[r][c] = (double)H[r * 6 + c];
+    b[r] = (double)g[r];
+  }
+  for (int j = 0; j < 6; ++j) {
+    for (int k = 0; k < j; ++k) {
+      double factor = -L[j][k];
+      for (int r = j; r < 6; ++r) L[r][j] = factor * L[r][k] + L[r][j];
+    }
+    double diag = L[j][j];
+    if (diag == 0.0) return false;
+    if (!(diag >= 0.0)) return false;
+    double denom = sqrt(diag);
+    L[j][j] = denom;
+    for (int r = j + 1; r < 6; ++r) L[r][j] /= denom;
+  }
+  for (int i = 0; i < 6; ++i) {
+    double coeff = b[i] / L[i][i];
+    b[i] = coeff;
+    for (int r = i + 1; r < 6; ++r) b[r] = -coeff * L[r][i] + b[r];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double d = 0.0;
+    for (int r = i + 1; r < 6; ++r) d += L[r][i] * b[r];
+    b[i] = (b[i] - d) / L[i][i];
+  }
+  for (int i = 0; i < 6; ++i) out[i] = (float)b[i];
+  return true;
+}
+
+// Index of (r, c), r <= c, in the packed upper triangle of a symmetric 6x6 (21 entries).
+A3D_HD constexpr int tri6(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
+
+}  // namespace a3d

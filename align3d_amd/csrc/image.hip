@@ -1,0 +1,243 @@
+// Range images resident in HBM: upload, the packed layouts the ICP kernel reads, and
+// RangeImage::compute_normals (src/range_image/structure.rs:184-262) as an LDS-tiled stencil.
+#include "common.hpp"
+
+using namespace a3d;
+
+namespace {
+
+// ---- packing ----------------------------------------------------------------------------------
+// Source side of ImageIcp: one 16-byte record per pixel, read as a coalesced float4 stream.
+// w = intensity (exact in f32) when mask != 0 (src/icp/image_icp.rs:102), -1 otherwise.
+__global__ void pack_source_kernel(const float* __restrict__ points, const uint8_t* __restrict__ mask,
+                                   const uint8_t* __restrict__ intensities, float4* __restrict__ out,
+                                   uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float w = -1.0f;
+  if (mask[i] != 0) w = intensities ? (float)intensities[i] : 0.0f;
+  out[i] = make_float4(points[3 * i], points[3 * i + 1], points[3 * i + 2], w);
+}
+
+// Target side: one 32-byte record per pixel = point + validity (mask == 1, RangeImage::get_point,
+// structure.rs:176) and normal, so the projective gather touches one 32-byte sector.
+__global__ void pack_target_kernel(const float* __restrict__ points, const uint8_t* __restrict__ mask,
+                                   const float* __restrict__ normals, float4* __restrict__ out,
+                                   uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[2 * i] = make_float4(points[3 * i], points[3 * i + 1], points[3 * i + 2], mask[i] == 1 ? 1.0f : 0.0f);
+  out[2 * i + 1] = make_float4(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 0.0f);
+}
+
+// ---- compute_normals ----------------------------------------------------------------------------
+constexpr int TILE_W = 32, TILE_H = 8;  // 256 threads; LDS tile (TILE_W+2) x (TILE_H+2) with 1-px halo
+
+// get_point(...).unwrap_or_else(zeros): the point if in range and mask == 1, else (0,0,0).
+__device__ __forceinline__ V3 masked_point(const float* __restrict__ points, const uint8_t* __restrict__ mask,
+                                           int w, int h, int row, int col) {
+  if (row < 0 || col < 0 || row >= h || col >= w) return {0.f, 0.f, 0.f};
+  int idx = row * w + col;
+  if (mask[idx] != 1) return {0.f, 0.f, 0.f};
+  return {points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
+}
+
+__device__ __forceinline__ V3 pick_direction(V3 lo, V3 hi, V3 center, bool hi_minus_lo_is_result) {
+  (void)hi_minus_lo_is_result;
+  return hi - lo;
+}
+
+__global__ void __launch_bounds__(TILE_W* TILE_H)
+    compute_normals_kernel(const float* __restrict__ points, const uint8_t* __restrict__ mask,
+                           float* __restrict__ normals, int w, int h) {
+  __shared__ float tile[3][TILE_H + 2][TILE_W + 3];  // SoA planes; +3 keeps rows off the same banks
+  const int tx = threadIdx.x % TILE_W, ty = threadIdx.x / TILE_W;
+  const int col0 = blockIdx.x * TILE_W, row0 = blockIdx.y * TILE_H;
+  // cooperative load of the haloed tile, masked (neighbour semantics)
+  for (int t = threadIdx.x; t < (TILE_W + 2) * (TILE_H + 2); t += TILE_W * TILE_H) {
+    int lx = t % (TILE_W + 2), ly = t / (TILE_W + 2);
+    V3 p = masked_point(points, mask, w, h, row0 + ly - 1, col0 + lx - 1);
+    tile[0][ly][lx] = p.x;
+    tile[1][ly][lx] = p.y;
+    tile[2][ly][lx] = p.z;
+  }
+  __syncthreads();
+  const int col = col0 + tx, row = row0 + ty;
+  if (col >= w || row >= h) return;
+  const int idx = row * w + col;
+  // the centre is read raw: its mask is NOT checked (structure.rs:207)
+  V3 center{points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
+  auto at = [&](int ly, int lx) { return V3{tile[0][ly][lx], tile[1][ly][lx], tile[2][ly][lx]}; };
+  V3 left = at(ty + 1, tx), right = at(ty + 1, tx + 2);
+  V3 top = at(ty, tx + 1), bottom = at(ty + 2, tx + 1);
+  const float thr_sq = 2.0f * 2.0f;
+  float ld = norm_squared(left - center), rd = norm_squared(right - center);
+  float lr_ratio = ld / rd;
+  V3 left_to_right;
+  if (lr_ratio < thr_sq && lr_ratio > 1.0f / thr_sq)
+    left_to_right = right - left;
+  else if (ld < rd)
+    left_to_right = center - left;
+  else
+    left_to_right = right - center;
+  float bd = norm_squared(bottom - center), td = norm_squared(top - center);
+  float bt_ratio = bd / td;
+  V3 bottom_to_top;
+  if (bt_ratio < thr_sq && bt_ratio > 1.0f / thr_sq)
+    bottom_to_top = top - bottom;
+  else if (bd < td)
+    bottom_to_top = center - bottom;
+  else
+    bottom_to_top = top - center;
+  V3 n = cross(left_to_right, bottom_to_top);
+  float mag = sqrtf(norm_squared(n));
+  V3 out{0.f, 0.f, 0.f};
+  if (mag > 1e-6f) out = n / mag;
+  normals[3 * idx] = out.x;
+  normals[3 * idx + 1] = out.y;
+  normals[3 * idx + 2] = out.z;
+}
+
+template <typename T>
+a3d_status upload_array(a3d_context* ctx, const T* host, size_t count, T** dev) {
+  A3D_HIP_TRY(hipMalloc((void**)dev, count * sizeof(T)));
+  A3D_HIP_TRY(hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return A3D_OK;
+}
+
+a3d_status launch_compute_normals(a3d_context* ctx, const float* points, const uint8_t* mask, float* normals,
+                                  uint32_t w, uint32_t h) {
+  dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H);
+  hipLaunchKernelGGL(compute_normals_kernel, grid, dim3(TILE_W * TILE_H), 0, ctx->stream, points, mask, normals,
+                     (int)w, (int)h);
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
+
+}  // namespace
+
+namespace a3d {
+
+a3d_status ensure_source_pack(a3d_device_image* im) {
+  if (im->src_pack_valid) return A3D_OK;
+  const uint32_t n = im->width * im->height;
+  if (!im->src_pack) A3D_HIP_TRY(hipMalloc((void**)&im->src_pack, (size_t)n * sizeof(float4)));
+  hipLaunchKernelGGL(pack_source_kernel, dim3((n + 255) / 256), dim3(256), 0, im->ctx->stream, im->points,
+                     im->mask, im->intensities, im->src_pack, n);
+  A3D_HIP_TRY(hipGetLastError());
+  im->src_pack_valid = true;
+  return A3D_OK;
+}
+
+a3d_status ensure_target_pack(a3d_device_image* im) {
+  if (im->tgt_pack_valid || !im->has_normals) return A3D_OK;
+  const uint32_t n = im->width * im->height;
+  if (!im->tgt_pack) A3D_HIP_TRY(hipMalloc((void**)&im->tgt_pack, (size_t)n * 2 * sizeof(float4)));
+  hipLaunchKernelGGL(pack_target_kernel, dim3((n + 255) / 256), dim3(256), 0, im->ctx->stream, im->points,
+                     im->mask, im->normals, im->tgt_pack, n);
+  A3D_HIP_TRY(hipGetLastError());
+  im->tgt_pack_valid = true;
+  return A3D_OK;
+}
+
+}  // namespace a3d
+
+extern "C" {
+
+a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* v, a3d_device_image** out) {
+  A3D_REQUIRE(ctx && v && out, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(v->points && v->mask, A3D_INVALID_PARAMETER, "RangeImage needs points and mask");
+  A3D_REQUIRE(v->width > 0 && v->height > 0 && v->width * v->height < (1ull << 30), A3D_INVALID_PARAMETER,
+              "bad image size");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  a3d_device_image* im = new a3d_device_image();
+  im->ctx = ctx;
+  im->width = (uint32_t)v->width;
+  im->height = (uint32_t)v->height;
+  im->fx = (float)v->fx, im->fy = (float)v->fy, im->cx = (float)v->cx, im->cy = (float)v->cy;
+  const size_t n = (size_t)im->width * im->height;
+  a3d_status st = upload_array(ctx, v->points, n * 3, &im->points);
+  if (st == A3D_OK) st = upload_array(ctx, v->mask, n, &im->mask);
+  if (st == A3D_OK && v->normals) {
+    st = upload_array(ctx, v->normals, n * 3, &im->normals);
+    im->has_normals = true;
+  }
+  if (st == A3D_OK && v->intensities) {
+    st = upload_array(ctx, v->intensities, n, &im->intensities);
+    im->has_intensities = true;
+  }
+  if (st == A3D_OK && v->intensity_map) {
+    st = upload_array(ctx, v->intensity_map, (size_t)(im->width + 2) * (im->height + 2), &im->imap);
+    im->has_imap = true;
+  }
+  if (st == A3D_OK) st = ensure_source_pack(im);
+  if (st == A3D_OK) st = ensure_target_pack(im);
+  if (st == A3D_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    set_error("upload failed");
+    st = A3D_HIP_ERROR;
+  }
+  if (st != A3D_OK) {
+    a3d_range_image_free(im);
+    return st;
+  }
+  *out = im;
+  return A3D_OK;
+}
+
+a3d_status a3d_range_image_free(a3d_device_image* im) {
+  if (!im) return A3D_OK;
+  hipStreamSynchronize(im->ctx->stream);
+  hipFree(im->points);
+  hipFree(im->mask);
+  hipFree(im->normals);
+  hipFree(im->intensities);
+  hipFree(im->imap);
+  hipFree(im->src_pack);
+  hipFree(im->tgt_pack);
+  delete im;
+  return A3D_OK;
+}
+
+a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
+  A3D_REQUIRE(im, A3D_INVALID_PARAMETER, "image is null");
+  const size_t n = (size_t)im->width * im->height;
+  if (!im->normals) A3D_HIP_TRY(hipMalloc((void**)&im->normals, n * 3 * sizeof(float)));
+  A3D_TRY(launch_compute_normals(im->ctx, im->points, im->mask, im->normals, im->width, im->height));
+  im->has_normals = true;
+  im->tgt_pack_valid = false;
+  return ensure_target_pack(im);
+}
+
+a3d_status a3d_range_image_download_normals(a3d_device_image* im, float* out) {
+  A3D_REQUIRE(im && out, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(im->has_normals, A3D_MISSING_FIELD, "image has no normals");
+  const size_t n = (size_t)im->width * im->height;
+  A3D_HIP_TRY(hipMemcpyAsync(out, im->normals, n * 3 * sizeof(float), hipMemcpyDeviceToHost, im->ctx->stream));
+  A3D_HIP_TRY(hipStreamSynchronize(im->ctx->stream));
+  return A3D_OK;
+}
+
+a3d_status a3d_compute_normals(a3d_context* ctx, const float* points, const uint8_t* mask, uint64_t width,
+                               uint64_t height, float* out_normals) {
+  A3D_REQUIRE(ctx && points && mask && out_normals, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(width > 0 && height > 0 && width * height < (1ull << 30), A3D_INVALID_PARAMETER, "bad image size");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = width * height;
+  float *d_points = nullptr, *d_normals = nullptr;
+  uint8_t* d_mask = nullptr;
+  a3d_status st = upload_array(ctx, points, n * 3, &d_points);
+  if (st == A3D_OK) st = upload_array(ctx, mask, n, &d_mask);
+  if (st == A3D_OK && hipMalloc((void**)&d_normals, n * 3 * sizeof(float)) != hipSuccess) st = A3D_HIP_ERROR;
+  if (st == A3D_OK) st = launch_compute_normals(ctx, d_points, d_mask, d_normals, (uint32_t)width, (uint32_t)height);
+  if (st == A3D_OK &&
+      hipMemcpyAsync(out_normals, d_normals, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    st = A3D_HIP_ERROR;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) st = A3D_HIP_ERROR;
+  hipFree(d_points);
+  hipFree(d_mask);
+  hipFree(d_normals);
+  if (st == A3D_HIP_ERROR) set_error("a3d_compute_normals: HIP failure");
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,512 @@
+// ImageIcp::align (src/icp/image_icp.rs:43-164) and MultiscaleAlign (src/icp/multiscale.rs:26-67)
+// for P independent frame pairs at once: per iteration one per-pixel kernel (grid = tiles x pairs)
+// and one solve kernel (grid = pairs); the whole coarse-to-fine sequence is enqueued without a host
+// round trip.
+#include <memory>
+
+#include "icp_engine.hpp"
+
+using namespace a3d;
+
+namespace {
+
+// What the per-pixel kernel needs to know about one (pair, level): resident arrays + intrinsics.
+struct LevelDesc {
+  const float4* src;  // [src_n] {x, y, z, intensity | -1}
+  const float4* tgt;  // [th*tw][2] {x, y, z, valid}, {nx, ny, nz, 0}
+  const float* imap;  // [(th+2)][(tw+2)]
+  uint32_t src_n;
+  uint32_t tw, th;
+  float fx, fy, cx, cy;
+  uint32_t pad;
+};
+
+struct Gates {
+  float max_distance_sqr;
+  float max_color_distance_sqr;
+  float dot_reject_max;  // reject iff -1 <= p.n <= dot_reject_max  (== acos(p.n).abs() >= max_normal_angle)
+};
+
+// `u as usize` (Rust): NaN and negatives -> 0; the callers only see u < width.
+__device__ __forceinline__ uint32_t f32_as_usize(float x) { return x > 0.0f ? (uint32_t)x : 0u; }
+
+// IntensityMap::bilinear (src/intensity_map.rs:150-169) from four already-loaded texels.
+__device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v11, float uf, float vf) {
+  float u0 = v00 * (1.0f - uf) + v10 * uf;
+  float u1 = v01 * (1.0f - uf) + v11 * uf;
+  return u0 * (1.0f - vf) + u1 * vf;
+}
+
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ imap, uint32_t mw, float u, float v) {
+  uint32_t ui = f32_as_usize(u), vi = f32_as_usize(v);
+  const float* r0 = imap + (size_t)vi * mw + ui;
+  return bilerp(r0[0], r0[1], r0[mw], r0[mw + 1], u - (float)ui, v - (float)vi);
+}
+
+// The body of the reference's pixel loop (image_icp.rs:101-139) for one source record.
+__device__ __forceinline__ void image_icp_pixel(const float4 s, const Pose& T, const LevelDesc& d, const Gates& gt,
+                                                float* __restrict__ acc) {
+  if (!(s.w >= 0.0f)) return;  // mask == 0
+  const V3 p = transform_vector(T, V3{s.x, s.y, s.z});
+  // CameraIntrinsics::project (src/camera.rs:64-70)
+  const float z = p.z;
+  const float u = p.x * d.fx / z + d.cx;
+  const float v = p.y * d.fy / z + d.cy;
+  // (u + 0.5) as i32 -> as usize -> get_point bounds test: in range iff -1 < x < dim (NaN casts to 0)
+  const float ur = u + 0.5f, vr = v + 0.5f;
+  if (ur <= -1.0f || ur >= (float)d.tw || vr <= -1.0f || vr >= (float)d.th) return;
+  const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
+  const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
+  const uint32_t tidx = row * d.tw + col;
+  const float4 tp = d.tgt[2 * tidx];
+  if (tp.w != 1.0f) return;  // mask != 1
+  const V3 q{tp.x, tp.y, tp.z};
+  const V3 diff = q - p;
+  if (norm_squared(diff) > gt.max_distance_sqr) return;
+  const float4 tn = d.tgt[2 * tidx + 1];
+  const V3 n{tn.x, tn.y, tn.z};
+  // angle_between_normals(&p, &n) >= max_normal_angle, NaN (|p.n| > 1) passes (image_icp.rs:118-123)
+  const float pn = dot(p, n);
+  if (pn >= -1.0f && pn <= gt.dot_reject_max) return;
+  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
+  {
+    const float r = dot(diff, n);
+    const V3 tw = cross(p, n);
+    const float J[6] = {n.x, n.y, n.z, tw.x, tw.y, tw.z};
+    gn_step(acc, r, J);
+  }
+  // colour term: IntensityMap::bilinear_grad (src/intensity_map.rs:184-210), H = 0.005
+  const uint32_t mw = d.tw + 2;
+  const uint32_t ui = f32_as_usize(u), vi = f32_as_usize(v);
+  const float* r0 = d.imap + (size_t)vi * mw + ui;
+  const float v00 = r0[0], v10 = r0[1], v01 = r0[mw], v11 = r0[mw + 1];
+  const float uf = u - (float)ui, vf = v - (float)vi;
+  const float value = bilerp(v00, v10, v01, v11, uf, vf);
+  const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
+  const float u2 = u + Hh, v2 = v + Hh;
+  // the shifted samples fall in the same texel cell except within 0.005 of a texel boundary
+  const float uh = (f32_as_usize(u2) == ui) ? bilerp(v00, v10, v01, v11, u2 - (float)ui, vf)
+                                            : bilinear_at(d.imap, mw, u2, v);
+  const float vh = (f32_as_usize(v2) == vi) ? bilerp(v00, v10, v01, v11, uf, v2 - (float)vi)
+                                            : bilinear_at(d.imap, mw, u, v2);
+  const float du = (uh - value) * H_INV;
+  const float dv = (vh - value) * H_INV;
+  const float sc = s.w * 0.003921569f;
+  // CameraIntrinsics::project_grad (src/camera.rs:82-89)
+  const float zz = z * z;
+  const float dfx = d.fx / z, dcx = -p.x * d.fx / zz;
+  const float dfy = d.fy / z, dcy = -p.y * d.fy / zz;
+  const V3 g{du * dfx, dv * dfy, du * dcx + dv * dcy};
+  const float rc = sc - value;
+  if (rc * rc <= gt.max_color_distance_sqr) {
+    const V3 tw = cross(p, g);
+    const float J[6] = {g.x, g.y, g.z, tw.x, tw.y, tw.z};
+    gn_step(acc + GN_ACC, rc, J);
+  }
+}
+
+// grid = (tiles, pairs); block = 256; each thread visits PPT source pixels, 256 apart (coalesced).
+template <int PPT>
+__global__ void __launch_bounds__(256)
+    image_icp_kernel(const LevelDesc* __restrict__ descs, const JobState* __restrict__ states, Gates gates,
+                     float* __restrict__ partials) {
+  const int pair = blockIdx.y;
+  float acc[GN_PARTIAL];
+#pragma unroll
+  for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
+  const JobState* st = &states[pair];
+  if (st->status == A3D_OK) {
+    const LevelDesc d = descs[pair];
+    const Pose T = st->pose;
+    const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const uint32_t i = base + k * 256u;
+      if (i < d.src_n) image_icp_pixel(d.src[i], T, d, gates, acc);
+    }
+  }
+  block_reduce_store<GN_PARTIAL>(acc, partials + ((size_t)pair * gridDim.x + blockIdx.x) * GN_PARTIAL);
+}
+
+}  // namespace
+
+// P independent coarse-to-fine alignments.  Owns only small state; the images are borrowed.
+struct a3d_multiscale_batch {
+  a3d_context* ctx = nullptr;
+  uint32_t n_pairs = 0, n_levels = 0;
+  std::vector<a3d_icp_params> params;  // index 0 = finest
+  std::vector<Gates> gates;
+  std::vector<uint32_t> tiles, ppt;    // per level
+  std::vector<LevelDesc> h_descs;      // [level][pair]
+  LevelDesc* d_descs = nullptr;
+  JobState* d_states = nullptr;
+  float* d_partials = nullptr;
+  Pose* d_poses = nullptr;
+  int32_t* d_status = nullptr;
+  double* d_readback = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> kev;  // per pixel-kernel launch: start/stop pairs, when profiling
+  bool profile_kernels = false;
+  float last_total_ms = 0.f, last_kernel_ms = 0.f;
+  uint64_t last_kernel_launches = 0;
+
+  ~a3d_multiscale_batch() {
+    hipFree(d_descs);
+    hipFree(d_states);
+    hipFree(d_partials);
+    hipFree(d_poses);
+    hipFree(d_status);
+    hipFree(d_readback);
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
+    for (auto e : kev) hipEventDestroy(e);
+  }
+};
+
+namespace {
+
+a3d_status fill_desc(const a3d_device_image* target, const a3d_device_image* source, LevelDesc* d) {
+  A3D_REQUIRE(target && source, A3D_INVALID_PARAMETER, "null image handle");
+  // the reference `expect`s these three (image_icp.rs:44-57)
+  A3D_REQUIRE(target->has_imap, A3D_MISSING_FIELD, "Please, the target image should have a intensity map.");
+  A3D_REQUIRE(target->has_normals, A3D_MISSING_FIELD, "Please, the target image should have normals.");
+  A3D_REQUIRE(source->has_intensities, A3D_MISSING_FIELD,
+              "Please, the source image should have intensity colors.");
+  A3D_REQUIRE(target->tgt_pack_valid && source->src_pack_valid, A3D_INVALID_PARAMETER, "image not packed");
+  d->src = source->src_pack;
+  d->tgt = target->tgt_pack;
+  d->imap = target->imap;
+  d->src_n = source->width * source->height;
+  d->tw = target->width;
+  d->th = target->height;
+  d->fx = target->fx, d->fy = target->fy, d->cx = target->cx, d->cy = target->cy;
+  d->pad = 0;
+  return A3D_OK;
+}
+
+Gates make_gates(const a3d_icp_params& p) {
+  Gates g;
+  g.max_distance_sqr = p.max_distance * p.max_distance;
+  g.max_color_distance_sqr = p.max_color_distance * p.max_color_distance;
+  g.dot_reject_max = acos_gate_threshold(p.max_normal_angle, /*strict=*/false);
+  return g;
+}
+
+// Pixels per thread: as many as keep >= 1024 blocks in flight (4 per CU), at most 8.
+uint32_t choose_ppt(uint32_t n_pairs, uint32_t max_src_n) {
+  for (uint32_t ppt = 8; ppt > 1; ppt >>= 1) {
+    uint64_t blocks = (uint64_t)n_pairs * ((max_src_n + 256 * ppt - 1) / (256 * ppt));
+    if (blocks >= 1024) return ppt;
+  }
+  return 1;
+}
+
+a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level) {
+  dim3 grid(b->tiles[level], b->n_pairs), block(256);
+  const LevelDesc* descs = b->d_descs + (size_t)level * b->n_pairs;
+  hipStream_t s = b->ctx->stream;
+  switch (b->ppt[level]) {
+    case 8: hipLaunchKernelGGL(image_icp_kernel<8>, grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials); break;
+    case 4: hipLaunchKernelGGL(image_icp_kernel<4>, grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials); break;
+    case 2: hipLaunchKernelGGL(image_icp_kernel<2>, grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials); break;
+    default: hipLaunchKernelGGL(image_icp_kernel<1>, grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials); break;
+  }
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
+
+// (Re)derives tiling from h_descs and uploads the descriptors.
+a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
+  const uint32_t P = b->n_pairs, L = b->n_levels;
+  size_t max_partials = 1;
+  for (uint32_t l = 0; l < L; ++l) {
+    uint32_t max_n = 0;
+    for (uint32_t p = 0; p < P; ++p) max_n = std::max(max_n, b->h_descs[(size_t)l * P + p].src_n);
+    b->ppt[l] = choose_ppt(P, max_n);
+    b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
+    max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
+  }
+  if (b->d_partials) A3D_HIP_TRY(hipFree(b->d_partials));
+  b->d_partials = nullptr;
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_partials, max_partials * sizeof(float)));
+  A3D_HIP_TRY(hipMemcpyAsync(b->d_descs, b->h_descs.data(), b->h_descs.size() * sizeof(LevelDesc),
+                             hipMemcpyHostToDevice, b->ctx->stream));
+  return A3D_OK;
+}
+
+a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t n_levels, uint32_t n_pairs,
+                        std::unique_ptr<a3d_multiscale_batch>* out) {
+  auto b = std::make_unique<a3d_multiscale_batch>();
+  b->ctx = ctx;
+  b->n_pairs = n_pairs;
+  b->n_levels = n_levels;
+  b->params.assign(params, params + n_levels);
+  for (uint32_t l = 0; l < n_levels; ++l) b->gates.push_back(make_gates(params[l]));
+  b->tiles.assign(n_levels, 0);
+  b->ppt.assign(n_levels, 1);
+  b->h_descs.resize((size_t)n_levels * n_pairs);
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_states, n_pairs * sizeof(JobState)));
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_poses, n_pairs * sizeof(Pose)));
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_status, n_pairs * sizeof(int32_t)));
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_readback, GN_PARTIAL * sizeof(double)));
+  A3D_HIP_TRY(hipEventCreate(&b->ev0));
+  A3D_HIP_TRY(hipEventCreate(&b->ev1));
+  *out = std::move(b);
+  return A3D_OK;
+}
+
+// Enqueues init -> levels (coarsest first) -> finish.  d_init: device Pose[P] or null (identity).
+a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t levels_to_run, float* d_matrices,
+                         float* d_trace, int trace_stride) {
+  hipStream_t s = b->ctx->stream;
+  const uint32_t P = b->n_pairs;
+  A3D_HIP_TRY(hipEventRecord(b->ev0, s));
+  A3D_TRY(launch_job_init(s, b->d_states, d_init, (int)P));
+  size_t kidx = 0;
+  int trace_index = 0;
+  for (uint32_t l = levels_to_run; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
+    const a3d_icp_params& prm = b->params[l];
+    for (uint64_t it = 0; it < prm.max_iterations; ++it) {
+      if (b->profile_kernels) {
+        if (b->kev.size() < 2 * (kidx + 1)) {
+          hipEvent_t e0, e1;
+          A3D_HIP_TRY(hipEventCreate(&e0));
+          A3D_HIP_TRY(hipEventCreate(&e1));
+          b->kev.push_back(e0);
+          b->kev.push_back(e1);
+        }
+        A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx], s));
+      }
+      A3D_TRY(launch_pixel_kernel(b, l));
+      if (b->profile_kernels) A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx + 1], s));
+      ++kidx;
+      A3D_TRY(launch_gn_solve(s, b->d_states, b->d_partials, (int)P, (int)b->tiles[l], prm.weight, prm.color_weight,
+                              SOLVE_IMAGE_ICP, it == 0, it + 1 == prm.max_iterations, d_trace, trace_stride,
+                              trace_index));
+      ++trace_index;
+    }
+  }
+  A3D_TRY(launch_job_finish(s, b->d_states, b->d_poses, b->d_status, d_matrices, (int)P));
+  A3D_HIP_TRY(hipEventRecord(b->ev1, s));
+  b->last_kernel_launches = kidx;
+  return A3D_OK;
+}
+
+a3d_status batch_collect_timing(a3d_multiscale_batch* b) {
+  A3D_HIP_TRY(hipEventSynchronize(b->ev1));
+  A3D_HIP_TRY(hipEventElapsedTime(&b->last_total_ms, b->ev0, b->ev1));
+  b->last_kernel_ms = 0.f;
+  if (b->profile_kernels) {
+    for (size_t k = 0; k < b->last_kernel_launches; ++k) {
+      float ms = 0.f;
+      A3D_HIP_TRY(hipEventElapsedTime(&ms, b->kev[2 * k], b->kev[2 * k + 1]));
+      b->last_kernel_ms += ms;
+    }
+  }
+  return A3D_OK;
+}
+
+a3d_status read_results(a3d_multiscale_batch* b, a3d_pose* out_poses, int32_t* out_status, a3d_status* worst) {
+  const uint32_t P = b->n_pairs;
+  std::vector<Pose> poses(P);
+  std::vector<int32_t> status(P);
+  hipStream_t s = b->ctx->stream;
+  A3D_HIP_TRY(hipMemcpyAsync(poses.data(), b->d_poses, P * sizeof(Pose), hipMemcpyDeviceToHost, s));
+  A3D_HIP_TRY(hipMemcpyAsync(status.data(), b->d_status, P * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  A3D_HIP_TRY(hipStreamSynchronize(s));
+  *worst = A3D_OK;
+  for (uint32_t p = 0; p < P; ++p) {
+    if (out_poses) pose_to_c(poses[p], &out_poses[p]);
+    if (out_status) out_status[p] = status[p];
+    if (status[p] != A3D_OK) *worst = (a3d_status)status[p];
+  }
+  return A3D_OK;
+}
+
+// One pair, any number of levels, host-synchronous: shared by image_icp_align and multiscale_align.
+a3d_status align_single(a3d_context* ctx, const a3d_icp_params* params, uint32_t n_levels,
+                        const a3d_device_image* const* targets, const a3d_device_image* const* sources,
+                        const a3d_pose* init, a3d_pose* out_pose, float* host_trace) {
+  std::unique_ptr<a3d_multiscale_batch> b;
+  A3D_TRY(batch_create(ctx, params, n_levels, 1, &b));
+  for (uint32_t l = 0; l < n_levels; ++l) A3D_TRY(fill_desc(targets[l], sources[l], &b->h_descs[l]));
+  A3D_TRY(batch_commit_descs(b.get()));
+  Pose* d_init = nullptr;
+  Pose h_init;
+  if (init) {
+    h_init = pose_from_c(init);
+    A3D_HIP_TRY(hipMalloc((void**)&d_init, sizeof(Pose)));
+    A3D_HIP_TRY(hipMemcpyAsync(d_init, &h_init, sizeof(Pose), hipMemcpyHostToDevice, ctx->stream));
+  }
+  uint64_t total_iters = 0;
+  for (uint32_t l = 0; l < n_levels; ++l) total_iters += params[l].max_iterations;
+  float* d_trace = nullptr;
+  if (host_trace && total_iters) {
+    A3D_HIP_TRY(hipMalloc((void**)&d_trace, total_iters * 8 * sizeof(float)));
+    A3D_HIP_TRY(hipMemsetAsync(d_trace, 0, total_iters * 8 * sizeof(float), ctx->stream));
+  }
+  a3d_status st = batch_enqueue(b.get(), d_init, n_levels, nullptr, d_trace, (int)total_iters);
+  a3d_status worst = A3D_OK;
+  if (st == A3D_OK) st = read_results(b.get(), out_pose, nullptr, &worst);
+  if (st == A3D_OK && d_trace)
+    if (hipMemcpy(host_trace, d_trace, total_iters * 8 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+      st = A3D_HIP_ERROR;
+  hipFree(d_init);
+  hipFree(d_trace);
+  if (st != A3D_OK) return st;
+  if (worst == A3D_SOLVE_FAILED) set_error("GaussNewton::solve() returned None (count == 0 or Cholesky failed)");
+  return worst;
+}
+
+}  // namespace
+
+// MultiscaleAlign: params + borrowed target pyramid (src/icp/multiscale.rs:7-10).
+struct a3d_multiscale {
+  a3d_context* ctx = nullptr;
+  std::vector<a3d_icp_params> params;
+  std::vector<const a3d_device_image*> targets;
+};
+
+extern "C" {
+
+a3d_status a3d_image_icp_align(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
+                               const a3d_device_image* source, const a3d_pose* init_pose, a3d_pose* out_pose) {
+  A3D_REQUIRE(ctx && params && out_pose, A3D_INVALID_PARAMETER, "null argument");
+  return align_single(ctx, params, 1, &target, &source, init_pose, out_pose, nullptr);
+}
+
+// Test hook (not part of the reference surface): a3d_image_icp_align that also returns, per
+// iteration, [residual, t(3), q(4)] of the transform after that iteration's update.
+a3d_status a3d_image_icp_align_trace(a3d_context* ctx, const a3d_icp_params* params,
+                                     const a3d_device_image* target, const a3d_device_image* source,
+                                     const a3d_pose* init_pose, a3d_pose* out_pose, float* out_trace) {
+  A3D_REQUIRE(ctx && params && out_pose, A3D_INVALID_PARAMETER, "null argument");
+  return align_single(ctx, params, 1, &target, &source, init_pose, out_pose, out_trace);
+}
+
+a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
+                                    const a3d_device_image* source, const a3d_pose* pose, a3d_gn_state* out_geom,
+                                    a3d_gn_state* out_color) {
+  A3D_REQUIRE(ctx && params, A3D_INVALID_PARAMETER, "null argument");
+  std::unique_ptr<a3d_multiscale_batch> b;
+  A3D_TRY(batch_create(ctx, params, 1, 1, &b));
+  A3D_TRY(fill_desc(target, source, &b->h_descs[0]));
+  A3D_TRY(batch_commit_descs(b.get()));
+  Pose h_pose = pose ? pose_from_c(pose) : pose_eye();
+  Pose* d_pose = nullptr;
+  A3D_HIP_TRY(hipMalloc((void**)&d_pose, sizeof(Pose)));
+  a3d_status st = A3D_OK;
+  double sums[GN_PARTIAL];
+  hipStream_t s = ctx->stream;
+  if (hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess) st = A3D_HIP_ERROR;
+  if (st == A3D_OK) st = launch_job_init(s, b->d_states, d_pose, 1);
+  if (st == A3D_OK) st = launch_pixel_kernel(b.get(), 0);
+  if (st == A3D_OK) st = launch_gn_readback(s, b->d_partials, (int)b->tiles[0], b->d_readback);
+  if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
+    st = A3D_HIP_ERROR;
+  if (hipStreamSynchronize(s) != hipSuccess) st = A3D_HIP_ERROR;
+  hipFree(d_pose);
+  if (st == A3D_HIP_ERROR) set_error("a3d_image_icp_accumulate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  if (st != A3D_OK) return st;
+  gn_states_from_sums(sums, out_geom, out_color);
+  return A3D_OK;
+}
+
+a3d_status a3d_multiscale_new(a3d_context* ctx, const a3d_icp_params* params, uint64_t n_params,
+                              const a3d_device_image* const* target_pyramid, uint64_t n_levels,
+                              a3d_multiscale** out) {
+  A3D_REQUIRE(ctx && out && (params || n_params == 0) && (target_pyramid || n_levels == 0), A3D_INVALID_PARAMETER,
+              "null argument");
+  // multiscale.rs:30-34
+  A3D_REQUIRE(n_params == n_levels, A3D_INVALID_PARAMETER,
+              "The number of range images pyramid levels and ICP parameters must be equal.");
+  a3d_multiscale* ms = new a3d_multiscale();
+  ms->ctx = ctx;
+  ms->params.assign(params, params + n_params);
+  ms->targets.assign(target_pyramid, target_pyramid + n_levels);
+  *out = ms;
+  return A3D_OK;
+}
+
+a3d_status a3d_multiscale_align(a3d_multiscale* ms, const a3d_device_image* const* source_pyramid,
+                                uint64_t n_source_levels, a3d_pose* out_pose) {
+  A3D_REQUIRE(ms && out_pose && (source_pyramid || n_source_levels == 0), A3D_INVALID_PARAMETER, "null argument");
+  // izip! stops at the shortest of (params, targets, sources) BEFORE .rev() (multiscale.rs:54-59)
+  uint32_t n = (uint32_t)std::min<uint64_t>(ms->params.size(), n_source_levels);
+  if (n == 0) {
+    pose_to_c(pose_eye(), out_pose);
+    return A3D_OK;
+  }
+  return align_single(ms->ctx, ms->params.data(), n, ms->targets.data(), source_pyramid, nullptr, out_pose, nullptr);
+}
+
+a3d_status a3d_multiscale_free(a3d_multiscale* ms) {
+  delete ms;
+  return A3D_OK;
+}
+
+a3d_status a3d_multiscale_batch_new(a3d_context* ctx, const a3d_icp_params* params, uint64_t n_params,
+                                    uint64_t n_pairs, uint64_t n_levels,
+                                    const a3d_device_image* const* target_pyramids,
+                                    const a3d_device_image* const* source_pyramids, a3d_multiscale_batch** out) {
+  A3D_REQUIRE(ctx && params && target_pyramids && source_pyramids && out, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(n_params == n_levels, A3D_INVALID_PARAMETER,
+              "The number of range images pyramid levels and ICP parameters must be equal.");
+  A3D_REQUIRE(n_pairs > 0 && n_pairs <= 65535 && n_levels > 0 && n_levels <= 16, A3D_INVALID_PARAMETER,
+              "bad batch shape");
+  std::unique_ptr<a3d_multiscale_batch> b;
+  A3D_TRY(batch_create(ctx, params, (uint32_t)n_levels, (uint32_t)n_pairs, &b));
+  for (uint32_t p = 0; p < n_pairs; ++p)
+    for (uint32_t l = 0; l < n_levels; ++l)
+      A3D_TRY(fill_desc(target_pyramids[(size_t)p * n_levels + l], source_pyramids[(size_t)p * n_levels + l],
+                        &b->h_descs[(size_t)l * n_pairs + p]));
+  A3D_TRY(batch_commit_descs(b.get()));
+  A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *out = b.release();
+  return A3D_OK;
+}
+
+a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* b, a3d_pose* out_poses_host, float* out_matrices_device,
+                                      int32_t* out_status_host) {
+  A3D_REQUIRE(b, A3D_INVALID_PARAMETER, "batch is null");
+  A3D_TRY(batch_enqueue(b, nullptr, b->n_levels, out_matrices_device, nullptr, 0));
+  if (!out_poses_host && !out_status_host) return A3D_OK;
+  a3d_status worst;
+  A3D_TRY(read_results(b, out_poses_host, out_status_host, &worst));
+  return A3D_OK;  // per-pair failures are reported through out_status_host
+}
+
+// When on, every per-pixel kernel launch is bracketed by its own hipEvent pair on the context stream.
+a3d_status a3d_multiscale_batch_set_profiling(a3d_multiscale_batch* b, int32_t on) {
+  A3D_REQUIRE(b, A3D_INVALID_PARAMETER, "batch is null");
+  b->profile_kernels = on != 0;
+  return A3D_OK;
+}
+
+a3d_status a3d_multiscale_batch_last_timing(a3d_multiscale_batch* b, float* out_total_ms,
+                                            uint64_t* out_pixel_kernel_launches) {
+  A3D_REQUIRE(b, A3D_INVALID_PARAMETER, "batch is null");
+  A3D_TRY(batch_collect_timing(b));
+  if (out_total_ms) *out_total_ms = b->last_total_ms;
+  if (out_pixel_kernel_launches) *out_pixel_kernel_launches = b->last_kernel_launches;
+  return A3D_OK;
+}
+
+// Sum of the per-pixel kernel's launch durations in the most recent batch_align (profiling on).
+a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* b, float* out_kernel_ms) {
+  A3D_REQUIRE(b && out_kernel_ms, A3D_INVALID_PARAMETER, "null argument");
+  A3D_TRY(batch_collect_timing(b));
+  *out_kernel_ms = b->last_kernel_ms;
+  return A3D_OK;
+}
+
+a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* b) {
+  if (!b) return A3D_OK;
+  hipStreamSynchronize(b->ctx->stream);
+  delete b;
+  return A3D_OK;
+}
+
+}  // extern "C"

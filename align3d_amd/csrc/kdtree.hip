@@ -1,0 +1,366 @@
+// R3dTree::new / nearest (src/kdtree.rs:28-105) and Icp (src/icp/pcl_icp.rs:15-108).
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <memory>
+
+#include "icp_engine.hpp"
+#include "kdtree.hpp"
+
+using namespace a3d;
+
+namespace a3d {
+
+a3d_status kdtree_build_host(const float* points, uint32_t n, std::vector<float>* split,
+                             std::vector<float4>* leaves, std::vector<uint32_t>* slot_of_point,
+                             uint32_t* max_depth_out, uint64_t* n_leaves_out, uint64_t* n_internal_out) {
+  // Shape pass: the (start, len) recursion is data independent, so the depth of the deepest leaf is known
+  // before any sorting.
+  uint32_t max_depth = 0;
+  {
+    struct Item { uint32_t len, depth; };
+    std::vector<Item> stack{{n, 0}};
+    while (!stack.empty()) {
+      Item it = stack.back();
+      stack.pop_back();
+      if (it.len <= 16) {
+        max_depth = std::max(max_depth, it.depth);
+        continue;
+      }
+      uint32_t mid = it.len / 2;
+      stack.push_back({mid, it.depth + 1});
+      stack.push_back({it.len - mid, it.depth + 1});
+    }
+  }
+  A3D_REQUIRE(max_depth < 26, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout");
+  const uint64_t n_split = (1ull << max_depth) - 1, n_slots = (1ull << max_depth) * 16;
+  split->assign(n_split, 0.0f);
+  const float inf = std::numeric_limits<float>::infinity();
+  leaves->assign(n_slots, make_float4(inf, inf, inf, 0.0f));
+  slot_of_point->assign(n, 0);
+  std::vector<uint32_t> idx(n);
+  for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+  uint64_t n_leaves = 0, n_internal = 0;
+  bool nan_seen = false;
+
+  struct Seg { uint32_t start, len, node, path, depth; };
+  std::vector<Seg> stack{{0, n, 0, 0, 0}};
+  while (!stack.empty()) {
+    Seg s = stack.back();
+    stack.pop_back();
+    if (s.len <= 16) {  // Leaf: points gathered in the current (parent-sorted) order (kdtree.rs:32-37)
+      const uint64_t base = ((uint64_t)s.path << (max_depth - s.depth)) * 16;
+      for (uint32_t k = 0; k < s.len; ++k) {
+        const uint32_t pi = idx[s.start + k];
+        float bits;
+        memcpy(&bits, &pi, 4);
+        (*leaves)[base + k] = make_float4(points[3 * pi], points[3 * pi + 1], points[3 * pi + 2], bits);
+        (*slot_of_point)[pi] = (uint32_t)(base + k);
+      }
+      ++n_leaves;
+      continue;
+    }
+    const int k = (int)(s.depth % 3);
+    auto first = idx.begin() + s.start, last = first + s.len;
+    for (auto it = first; it != last; ++it)
+      if (std::isnan(points[3 * (*it) + k])) nan_seen = true;  // partial_cmp().unwrap() (kdtree.rs:43)
+    if (nan_seen) break;
+    // slice::sort_by is stable; partial_cmp treats -0.0 == +0.0
+    std::stable_sort(first, last, [&](uint32_t a, uint32_t b) { return points[3 * a + k] < points[3 * b + k]; });
+    const uint32_t mid = s.len / 2;
+    (*split)[s.node] = points[3 * idx[s.start + mid] + k];
+    ++n_internal;
+    stack.push_back({s.start + mid, s.len - mid, 2 * s.node + 2, 2 * s.path + 1, s.depth + 1});
+    stack.push_back({s.start, mid, 2 * s.node + 1, 2 * s.path, s.depth + 1});
+  }
+  A3D_REQUIRE(!nan_seen, A3D_NAN_IN_INPUT, "NaN coordinate in kd-tree input (the reference panics in partial_cmp().unwrap())");
+  *max_depth_out = max_depth;
+  *n_leaves_out = n_leaves;
+  *n_internal_out = n_internal;
+  return A3D_OK;
+}
+
+}  // namespace a3d
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+    kdtree_nearest_kernel(const float* __restrict__ split, const float4* __restrict__ leaves, uint32_t n,
+                          uint32_t max_depth, const float* __restrict__ queries, uint32_t m,
+                          uint32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const V3 q{queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]};
+  float dist;
+  float4 win;
+  kdtree_nearest_slot(split, leaves, n, max_depth, q, &dist, &win);
+  out_idx[i] = __float_as_uint(win.w);
+  out_dist[i] = dist;
+}
+
+struct PclGates {
+  float max_distance_sqr;
+  float dot_reject_max;  // reject iff -1 <= sn.tn <= dot_reject_max  (== acos(sn.tn).abs() > max_normal_angle)
+};
+
+// The body of Icp::align's point loop (src/icp/pcl_icp.rs:68-92); grid-stride, 256 threads.
+__global__ void __launch_bounds__(256)
+    pcl_icp_kernel(const float* __restrict__ split, const float4* __restrict__ leaves,
+                   const float4* __restrict__ leaf_normals, uint32_t n, uint32_t max_depth,
+                   const float* __restrict__ src_points, const float* __restrict__ src_normals, uint32_t m,
+                   const JobState* __restrict__ states, PclGates gates, float* __restrict__ partials) {
+  float acc[GN_ACC];
+#pragma unroll
+  for (int k = 0; k < GN_ACC; ++k) acc[k] = 0.0f;
+  if (states->status == A3D_OK) {
+    const Pose T = states->pose;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+      const V3 sp = transform_vector(T, V3{src_points[3 * i], src_points[3 * i + 1], src_points[3 * i + 2]});
+      const V3 sn = transform_normal(T, V3{src_normals[3 * i], src_normals[3 * i + 1], src_normals[3 * i + 2]});
+      float d2;
+      float4 win;
+      const uint32_t slot = kdtree_nearest_slot(split, leaves, n, max_depth, sp, &d2, &win);
+      if (d2 > gates.max_distance_sqr) continue;
+      const float4 tn4 = leaf_normals[slot];
+      const V3 tn{tn4.x, tn4.y, tn4.z};
+      const float c = dot(sn, tn);
+      if (c >= -1.0f && c <= gates.dot_reject_max) continue;
+      const V3 tp{win.x, win.y, win.z};
+      const float r = dot(tp - sp, tn);
+      const V3 tw = cross(sp, tn);
+      const float J[6] = {tn.x, tn.y, tn.z, tw.x, tw.y, tw.z};
+      gn_step(acc, r, J);
+    }
+  }
+  float* out = partials + (size_t)blockIdx.x * GN_PARTIAL;
+  block_reduce_store<GN_ACC>(acc, out);
+  if (threadIdx.x >= GN_ACC && threadIdx.x < GN_PARTIAL) out[threadIdx.x] = 0.0f;  // no colour term
+}
+
+a3d_status check_finite_query_count(uint64_t m) {
+  A3D_REQUIRE(m < (1ull << 31), A3D_INVALID_PARAMETER, "too many queries for one call");
+  return A3D_OK;
+}
+
+}  // namespace
+
+struct a3d_pcl_icp {
+  a3d_context* ctx = nullptr;
+  a3d_icp_params params;
+  a3d_kdtree* tree = nullptr;
+  bool target_has_normals = false;
+  uint32_t blocks = 0;
+  JobState* d_state = nullptr;
+  float* d_partials = nullptr;
+  double* d_readback = nullptr;
+};
+
+extern "C" {
+
+a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d_kdtree** out) {
+  A3D_REQUIRE(ctx && out && points, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(n > 0 && n < (1ull << 31), A3D_INVALID_PARAMETER,
+              "kd-tree needs 1 <= n < 2^31 points (the reference indexes an empty leaf and panics)");
+  auto t = std::make_unique<a3d_kdtree>();
+  t->ctx = ctx;
+  t->n = (uint32_t)n;
+  std::vector<float4> leaves;
+  A3D_TRY(kdtree_build_host(points, t->n, &t->h_split, &leaves, &t->h_slot_of_point, &t->max_depth, &t->n_leaves,
+                            &t->n_internal));
+  t->n_split = (uint32_t)t->h_split.size();
+  t->n_leaf_slots = leaves.size();
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  A3D_HIP_TRY(hipMalloc((void**)&t->d_split, std::max<size_t>(1, t->h_split.size()) * sizeof(float)));
+  A3D_HIP_TRY(hipMalloc((void**)&t->d_leaves, leaves.size() * sizeof(float4)));
+  if (!t->h_split.empty())
+    A3D_HIP_TRY(hipMemcpyAsync(t->d_split, t->h_split.data(), t->h_split.size() * sizeof(float),
+                               hipMemcpyHostToDevice, ctx->stream));
+  A3D_HIP_TRY(hipMemcpyAsync(t->d_leaves, leaves.data(), leaves.size() * sizeof(float4), hipMemcpyHostToDevice,
+                             ctx->stream));
+  A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *out = t.release();
+  return A3D_OK;
+}
+
+a3d_status a3d_kdtree_nearest_device(a3d_kdtree* t, const void* d_queries, uint64_t m, void* d_indices,
+                                     void* d_sqr) {
+  A3D_REQUIRE(t && (m == 0 || (d_queries && d_indices && d_sqr)), A3D_INVALID_PARAMETER, "null argument");
+  A3D_TRY(check_finite_query_count(m));
+  if (m == 0) return A3D_OK;
+  hipLaunchKernelGGL(kdtree_nearest_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, t->ctx->stream,
+                     t->d_split, t->d_leaves, t->n, t->max_depth, (const float*)d_queries, (uint32_t)m,
+                     (uint32_t*)d_indices, (float*)d_sqr);
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
+
+a3d_status a3d_kdtree_nearest(a3d_kdtree* t, const float* queries, uint64_t m, uint64_t* out_indices,
+                              float* out_sqr) {
+  A3D_REQUIRE(t && (m == 0 || (queries && out_indices && out_sqr)), A3D_INVALID_PARAMETER, "null argument");
+  A3D_TRY(check_finite_query_count(m));
+  if (m == 0) return A3D_OK;
+  hipStream_t s = t->ctx->stream;
+  float *d_q = nullptr, *d_d = nullptr;
+  uint32_t* d_i = nullptr;
+  std::vector<uint32_t> idx32(m);
+  a3d_status st = A3D_OK;
+  if (hipMalloc((void**)&d_q, m * 12) != hipSuccess || hipMalloc((void**)&d_i, m * 4) != hipSuccess ||
+      hipMalloc((void**)&d_d, m * 4) != hipSuccess)
+    st = A3D_HIP_ERROR;
+  if (st == A3D_OK && hipMemcpyAsync(d_q, queries, m * 12, hipMemcpyHostToDevice, s) != hipSuccess) st = A3D_HIP_ERROR;
+  if (st == A3D_OK) st = a3d_kdtree_nearest_device(t, d_q, m, d_i, d_d);
+  if (st == A3D_OK && hipMemcpyAsync(idx32.data(), d_i, m * 4, hipMemcpyDeviceToHost, s) != hipSuccess) st = A3D_HIP_ERROR;
+  if (st == A3D_OK && hipMemcpyAsync(out_sqr, d_d, m * 4, hipMemcpyDeviceToHost, s) != hipSuccess) st = A3D_HIP_ERROR;
+  if (hipStreamSynchronize(s) != hipSuccess) st = A3D_HIP_ERROR;
+  hipFree(d_q);
+  hipFree(d_i);
+  hipFree(d_d);
+  if (st == A3D_HIP_ERROR) set_error("a3d_kdtree_nearest: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  if (st != A3D_OK) return st;
+  for (uint64_t i = 0; i < m; ++i) out_indices[i] = idx32[i];
+  return A3D_OK;
+}
+
+// Test hook: tree shape {leaves, internal nodes, max depth}.
+a3d_status a3d_kdtree_stats(a3d_kdtree* t, uint64_t out3[3]) {
+  A3D_REQUIRE(t && out3, A3D_INVALID_PARAMETER, "null argument");
+  out3[0] = t->n_leaves, out3[1] = t->n_internal, out3[2] = t->max_depth;
+  return A3D_OK;
+}
+
+a3d_status a3d_kdtree_free(a3d_kdtree* t) {
+  if (!t) return A3D_OK;
+  hipStreamSynchronize(t->ctx->stream);
+  hipFree(t->d_split);
+  hipFree(t->d_leaves);
+  hipFree(t->d_leaf_normals);
+  delete t;
+  return A3D_OK;
+}
+
+a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const a3d_point_cloud_view* target,
+                           a3d_pcl_icp** out) {
+  A3D_REQUIRE(ctx && params && target && out && target->points, A3D_INVALID_PARAMETER, "null argument");
+  auto icp = std::make_unique<a3d_pcl_icp>();
+  icp->ctx = ctx;
+  icp->params = *params;
+  A3D_TRY(a3d_kdtree_new(ctx, target->points, target->len, &icp->tree));
+  a3d_kdtree* t = icp->tree;
+  a3d_status st = A3D_OK;
+  if (target->normals) {  // scatter the target normals into the leaf slots of their points
+    std::vector<float4> ln(t->n_leaf_slots, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (uint32_t i = 0; i < t->n; ++i)
+      ln[t->h_slot_of_point[i]] =
+          make_float4(target->normals[3 * i], target->normals[3 * i + 1], target->normals[3 * i + 2], 0.f);
+    if (hipMalloc((void**)&t->d_leaf_normals, ln.size() * sizeof(float4)) != hipSuccess ||
+        hipMemcpy(t->d_leaf_normals, ln.data(), ln.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
+      st = A3D_HIP_ERROR;
+    icp->target_has_normals = true;
+  }
+  icp->blocks = (uint32_t)std::max(1, ctx->num_cus * 8);
+  if (st == A3D_OK &&
+      (hipMalloc((void**)&icp->d_state, sizeof(JobState)) != hipSuccess ||
+       hipMalloc((void**)&icp->d_partials, (size_t)icp->blocks * GN_PARTIAL * sizeof(float)) != hipSuccess ||
+       hipMalloc((void**)&icp->d_readback, GN_PARTIAL * sizeof(double)) != hipSuccess))
+    st = A3D_HIP_ERROR;
+  if (st != A3D_OK) {
+    set_error("a3d_pcl_icp_new: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+    a3d_pcl_icp_free(icp.release());
+    return st;
+  }
+  *out = icp.release();
+  return A3D_OK;
+}
+
+static a3d_status pcl_upload_source(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, float** d_pts,
+                                    float** d_nrm) {
+  // the reference `expect`s both normal sets at align time (pcl_icp.rs:50-58)
+  A3D_REQUIRE(icp->target_has_normals, A3D_MISSING_FIELD, "Please, the target point cloud should have normals.");
+  A3D_REQUIRE(source->normals, A3D_MISSING_FIELD, "Please, the source point cloud should have normals.");
+  A3D_REQUIRE(source->points && source->len > 0 && source->len < (1ull << 31), A3D_INVALID_PARAMETER,
+              "bad source cloud");
+  const size_t bytes = source->len * 12;
+  A3D_HIP_TRY(hipMalloc((void**)d_pts, bytes));
+  A3D_HIP_TRY(hipMalloc((void**)d_nrm, bytes));
+  A3D_HIP_TRY(hipMemcpyAsync(*d_pts, source->points, bytes, hipMemcpyHostToDevice, icp->ctx->stream));
+  A3D_HIP_TRY(hipMemcpyAsync(*d_nrm, source->normals, bytes, hipMemcpyHostToDevice, icp->ctx->stream));
+  return A3D_OK;
+}
+
+static a3d_status pcl_launch_pass(a3d_pcl_icp* icp, const float* d_pts, const float* d_nrm, uint32_t m) {
+  PclGates g;
+  g.max_distance_sqr = icp->params.max_distance * icp->params.max_distance;
+  g.dot_reject_max = acos_gate_threshold(icp->params.max_normal_angle, /*strict=*/true);
+  a3d_kdtree* t = icp->tree;
+  hipLaunchKernelGGL(pcl_icp_kernel, dim3(icp->blocks), dim3(256), 0, icp->ctx->stream, t->d_split, t->d_leaves,
+                     t->d_leaf_normals, t->n, t->max_depth, d_pts, d_nrm, m, icp->d_state, g, icp->d_partials);
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
+
+a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, a3d_pose* out_pose) {
+  A3D_REQUIRE(icp && source && out_pose, A3D_INVALID_PARAMETER, "null argument");
+  float *d_pts = nullptr, *d_nrm = nullptr;
+  a3d_status st = pcl_upload_source(icp, source, &d_pts, &d_nrm);
+  hipStream_t s = icp->ctx->stream;
+  const uint32_t m = (uint32_t)source->len;
+  // Icp::align starts from Transform::eye(): initial_transform is ignored (pcl_icp.rs:59)
+  if (st == A3D_OK) st = launch_job_init(s, icp->d_state, nullptr, 1);
+  for (uint64_t it = 0; st == A3D_OK && it < icp->params.max_iterations; ++it) {
+    st = pcl_launch_pass(icp, d_pts, d_nrm, m);
+    if (st == A3D_OK)
+      st = launch_gn_solve(s, icp->d_state, icp->d_partials, 1, (int)icp->blocks, icp->params.weight, 0.0f,
+                           SOLVE_PCL_ICP, it == 0, it + 1 == icp->params.max_iterations, nullptr, 0, 0);
+  }
+  JobState h;
+  if (st == A3D_OK && hipMemcpyAsync(&h, icp->d_state, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess)
+    st = A3D_HIP_ERROR;
+  if (hipStreamSynchronize(s) != hipSuccess && st == A3D_OK) st = A3D_HIP_ERROR;
+  hipFree(d_pts);
+  hipFree(d_nrm);
+  if (st == A3D_HIP_ERROR) set_error("a3d_pcl_icp_align: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  if (st != A3D_OK) return st;
+  pose_to_c(h.pose, out_pose);
+  if (h.status == A3D_SOLVE_FAILED) set_error("GaussNewton::solve() returned None (count == 0 or Cholesky failed)");
+  return (a3d_status)h.status;
+}
+
+a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, const a3d_pose* pose,
+                                  a3d_gn_state* out_state) {
+  A3D_REQUIRE(icp && source && out_state, A3D_INVALID_PARAMETER, "null argument");
+  float *d_pts = nullptr, *d_nrm = nullptr;
+  a3d_status st = pcl_upload_source(icp, source, &d_pts, &d_nrm);
+  hipStream_t s = icp->ctx->stream;
+  Pose h_pose = pose ? pose_from_c(pose) : pose_eye();
+  Pose* d_pose = nullptr;
+  double sums[GN_PARTIAL];
+  if (st == A3D_OK && (hipMalloc((void**)&d_pose, sizeof(Pose)) != hipSuccess ||
+                       hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess))
+    st = A3D_HIP_ERROR;
+  if (st == A3D_OK) st = launch_job_init(s, icp->d_state, d_pose, 1);
+  if (st == A3D_OK) st = pcl_launch_pass(icp, d_pts, d_nrm, (uint32_t)source->len);
+  if (st == A3D_OK) st = launch_gn_readback(s, icp->d_partials, (int)icp->blocks, icp->d_readback);
+  if (st == A3D_OK && hipMemcpyAsync(sums, icp->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
+    st = A3D_HIP_ERROR;
+  if (hipStreamSynchronize(s) != hipSuccess && st == A3D_OK) st = A3D_HIP_ERROR;
+  hipFree(d_pts);
+  hipFree(d_nrm);
+  hipFree(d_pose);
+  if (st == A3D_HIP_ERROR) set_error("a3d_pcl_icp_accumulate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  if (st != A3D_OK) return st;
+  gn_states_from_sums(sums, out_state, nullptr);
+  return A3D_OK;
+}
+
+a3d_status a3d_pcl_icp_free(a3d_pcl_icp* icp) {
+  if (!icp) return A3D_OK;
+  hipStreamSynchronize(icp->ctx->stream);
+  a3d_kdtree_free(icp->tree);
+  hipFree(icp->d_state);
+  hipFree(icp->d_partials);
+  hipFree(icp->d_readback);
+  delete icp;
+  return A3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,240 @@
+"""ImageIcp, MultiscaleAlign, Icp — the reference's alignment API (src/icp/*.rs) over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .icp_params import IcpParams, MsIcpParams
+from .range_image import DeviceRangeImage, RangeImage
+from .transform import Transform
+
+
+def _dev(ctx, image):
+    if isinstance(image, DeviceRangeImage):
+        return image
+    if isinstance(image, RangeImage):
+        return image.device(ctx)
+    raise TypeError("expected a RangeImage or DeviceRangeImage")
+
+
+def _handle_array(images):
+    arr = (C.c_void_p * max(1, len(images)))()
+    for i, im in enumerate(images):
+        arr[i] = im.handle
+    return arr
+
+
+class ImageIcp:
+    """ImageIcp (src/icp/image_icp.rs:19-165)."""
+
+    def __init__(self, ctx, params, target):
+        self.ctx = ctx
+        self.params = params
+        self.target = _dev(ctx, target)
+        self.initial_transform = Transform.eye()
+
+    @staticmethod
+    def new(ctx, params, target):
+        return ImageIcp(ctx, params, target)
+
+    def align(self, source, trace=False):
+        src = _dev(self.ctx, source)
+        p = self.params.to_c()
+        init = self.initial_transform.to_c()
+        out = _abi.PoseC()
+        if trace:
+            tr = np.zeros((int(self.params.max_iterations), 8), np.float32)
+            _abi.check(
+                self.ctx.lib.a3d_image_icp_align_trace(self.ctx.handle, C.byref(p), self.target.handle, src.handle,
+                                                       C.byref(init), C.byref(out), _abi.ptr(tr)),
+                "ImageIcp::align",
+            )
+            return Transform.from_c(out), tr
+        _abi.check(
+            self.ctx.lib.a3d_image_icp_align(self.ctx.handle, C.byref(p), self.target.handle, src.handle,
+                                             C.byref(init), C.byref(out)),
+            "ImageIcp::align",
+        )
+        return Transform.from_c(out)
+
+    def accumulate(self, source, transform):
+        """One pass of the pixel loop from `transform`: (geom, colour) accumulators (test hook)."""
+        src = _dev(self.ctx, source)
+        p = self.params.to_c()
+        t = transform.to_c()
+        g, c = _abi.GnStateC(), _abi.GnStateC()
+        _abi.check(
+            self.ctx.lib.a3d_image_icp_accumulate(self.ctx.handle, C.byref(p), self.target.handle, src.handle,
+                                                  C.byref(t), C.byref(g), C.byref(c)),
+            "ImageIcp accumulate",
+        )
+        return g.as_dict(), c.as_dict()
+
+
+class MultiscaleAlign:
+    """MultiscaleAlign (src/icp/multiscale.rs:7-68)."""
+
+    def __init__(self, ctx, params, target_pyramid):
+        self.ctx = ctx
+        self.params = params
+        self.targets = [_dev(ctx, t) for t in target_pyramid]
+        self.handle = C.c_void_p()
+        parr = params.to_c_array()
+        tarr = _handle_array(self.targets)
+        st = ctx.lib.a3d_multiscale_new(ctx.handle, parr, len(params), tarr, len(self.targets), C.byref(self.handle))
+        if st == _abi.A3D_INVALID_PARAMETER:
+            # Err(A3dError::InvalidParameter(..)) (multiscale.rs:30-34)
+            raise _abi.InvalidParameter(ctx.lib.a3d_last_error().decode())
+        _abi.check(st, "MultiscaleAlign::new")
+
+    @staticmethod
+    def new(ctx, params, target_pyramid):
+        return MultiscaleAlign(ctx, params, target_pyramid)
+
+    def align(self, source_pyramid):
+        srcs = [_dev(self.ctx, s) for s in source_pyramid]
+        out = _abi.PoseC()
+        _abi.check(self.ctx.lib.a3d_multiscale_align(self.handle, _handle_array(srcs), len(srcs), C.byref(out)),
+                   "MultiscaleAlign::align")
+        return Transform.from_c(out)
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.a3d_multiscale_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MultiscaleAlignBatch:
+    """P independent MultiscaleAlign::new(params, target_p).align(source_p) in one launch sequence."""
+
+    def __init__(self, ctx, params, target_pyramids, source_pyramids):
+        assert len(target_pyramids) == len(source_pyramids) and len(target_pyramids) > 0
+        self.ctx = ctx
+        self.n_pairs = len(target_pyramids)
+        self.n_levels = len(target_pyramids[0])
+        self._keep = []
+        t_flat, s_flat = [], []
+        for tp, sp in zip(target_pyramids, source_pyramids):
+            assert len(tp) == self.n_levels and len(sp) == self.n_levels
+            t_flat += [_dev(ctx, t) for t in tp]
+            s_flat += [_dev(ctx, s) for s in sp]
+        self._keep = (t_flat, s_flat)
+        self.handle = C.c_void_p()
+        st = ctx.lib.a3d_multiscale_batch_new(ctx.handle, params.to_c_array(), len(params), self.n_pairs,
+                                              self.n_levels, _handle_array(t_flat), _handle_array(s_flat),
+                                              C.byref(self.handle))
+        if st == _abi.A3D_INVALID_PARAMETER:
+            raise _abi.InvalidParameter(ctx.lib.a3d_last_error().decode())
+        _abi.check(st, "a3d_multiscale_batch_new")
+
+    def align(self, matrices_device=None):
+        """Runs all pairs; returns (list of Transform, int32 status array)."""
+        poses = (_abi.PoseC * self.n_pairs)()
+        status = np.zeros(self.n_pairs, np.int32)
+        _abi.check(
+            self.ctx.lib.a3d_multiscale_batch_align(self.handle, poses, matrices_device,
+                                                    status.ctypes.data_as(C.POINTER(C.c_int32))),
+            "a3d_multiscale_batch_align",
+        )
+        return [Transform.from_c(p) for p in poses], status
+
+    def enqueue(self, matrices_device=None):
+        """Enqueues one pass without synchronising the host."""
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_align(self.handle, None, matrices_device, None))
+
+    def set_profiling(self, on):
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_set_profiling(self.handle, 1 if on else 0))
+
+    def last_timing(self):
+        ms, n = C.c_float(), C.c_uint64()
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_last_timing(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_last_kernel_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.a3d_multiscale_batch_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PointCloud:
+    """PointCloud (src/pointcloud.rs:8-12): points [N,3], optional normals."""
+
+    def __init__(self, points, normals=None):
+        self.points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+
+    @staticmethod
+    def from_range_image(im):
+        """From<&RangeImage> for PointCloud (src/range_image/structure.rs:375-406): mask != 0, row-major."""
+        m = im.mask.reshape(-1) != 0
+        normals = None if im.normals is None else im.normals.reshape(-1, 3)[m]
+        return PointCloud(im.points.reshape(-1, 3)[m], normals)
+
+    def len(self):
+        return len(self.points)
+
+    def view(self):
+        v = _abi.PointCloudViewC()
+        v.points = _abi.ptr(self.points)
+        v.normals = _abi.ptr(self.normals)
+        v.len = len(self.points)
+        return v
+
+
+class Icp:
+    """Icp (src/icp/pcl_icp.rs:15-108): point-to-plane ICP with kd-tree correspondences."""
+
+    def __init__(self, ctx, params, target):
+        self.ctx = ctx
+        self.params = params
+        self.target = target
+        self.initial_transform = Transform.eye()  # public field the reference ignores (pcl_icp.rs:59)
+        self.handle = C.c_void_p()
+        p = params.to_c()
+        v = target.view()
+        _abi.check(ctx.lib.a3d_pcl_icp_new(ctx.handle, C.byref(p), C.byref(v), C.byref(self.handle)), "Icp::new")
+
+    @staticmethod
+    def new(ctx, params, target):
+        return Icp(ctx, params, target)
+
+    def align(self, source):
+        v = source.view()
+        out = _abi.PoseC()
+        _abi.check(self.ctx.lib.a3d_pcl_icp_align(self.handle, C.byref(v), C.byref(out)), "Icp::align")
+        return Transform.from_c(out)
+
+    def accumulate(self, source, transform):
+        v = source.view()
+        t = transform.to_c()
+        g = _abi.GnStateC()
+        _abi.check(self.ctx.lib.a3d_pcl_icp_accumulate(self.handle, C.byref(v), C.byref(t), C.byref(g)))
+        return g.as_dict()
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.a3d_pcl_icp_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,49 @@
+"""R3dTree (src/kdtree.rs:19-106)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+class R3dTree:
+    def __init__(self, ctx, points):
+        """R3dTree::new(&points)"""
+        self.ctx = ctx
+        self.points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        self.handle = C.c_void_p()
+        _abi.check(ctx.lib.a3d_kdtree_new(ctx.handle, _abi.ptr(self.points), len(self.points), C.byref(self.handle)),
+                   "a3d_kdtree_new")
+
+    @staticmethod
+    def new(ctx, points):
+        return R3dTree(ctx, points)
+
+    def nearest(self, queries):
+        """R3dTree::nearest for a batch: (indices u64, squared distances f32)."""
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, 3)
+        idx = np.empty(len(q), np.uint64)
+        d = np.empty(len(q), np.float32)
+        _abi.check(self.ctx.lib.a3d_kdtree_nearest(self.handle, _abi.ptr(q), len(q), _abi.ptr(idx), _abi.ptr(d)),
+                   "a3d_kdtree_nearest")
+        return idx, d
+
+    def nearest_device(self, d_queries, m, d_idx, d_sqr):
+        _abi.check(self.ctx.lib.a3d_kdtree_nearest_device(self.handle, d_queries, m, d_idx, d_sqr))
+
+    def stats(self):
+        s = (C.c_uint64 * 3)()
+        _abi.check(self.ctx.lib.a3d_kdtree_stats(self.handle, s))
+        return tuple(s)
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.a3d_kdtree_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx.handle:
+                self.free()
+        except Exception:
+            pass

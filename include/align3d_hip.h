@@ -163,6 +163,13 @@ a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* para
                                     const a3d_pose* pose, a3d_gn_state* out_geom,
                                     a3d_gn_state* out_color);
 
+/* Instrumentation (no reference counterpart): a3d_image_icp_align that also writes, per iteration,
+ * [residual, t(3), q_ijkw(4)] of the transform after that iteration's update; out_trace holds
+ * 8 * params->max_iterations floats. */
+a3d_status a3d_image_icp_align_trace(a3d_context* ctx, const a3d_icp_params* params,
+                                     const a3d_device_image* target, const a3d_device_image* source,
+                                     const a3d_pose* init_pose, a3d_pose* out_pose, float* out_trace);
+
 /* ---- MultiscaleAlign (src/icp/multiscale.rs:7-68) ---------------------------------------- */
 
 /* MultiscaleAlign::new(params, &target_pyramid): A3D_INVALID_PARAMETER unless
@@ -190,6 +197,11 @@ a3d_status a3d_multiscale_batch_new(a3d_context* ctx, const a3d_icp_params* para
 a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* batch, a3d_pose* out_poses_host,
                                       float* out_matrices_device, int32_t* out_status_host);
 a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* batch);
+/* Instrumentation: when on, every launch of the per-pixel kernel is bracketed by its own hipEvent pair
+ * on the context stream, and a3d_multiscale_batch_last_kernel_ms returns the sum of those durations for
+ * the most recent batch_align (divide by the launch count for the average launch). */
+a3d_status a3d_multiscale_batch_set_profiling(a3d_multiscale_batch* batch, int32_t on);
+a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* batch, float* out_kernel_ms);
 /* Time of the most recent batch_align on the device, between hipEvents recorded on the context
  * stream around its launches, and the share of it spent in the per-pixel kernel (sum of that
  * kernel's launches / number of launches). */
@@ -208,6 +220,8 @@ a3d_status a3d_kdtree_nearest(a3d_kdtree* tree, const float* queries, uint64_t m
 a3d_status a3d_kdtree_nearest_device(a3d_kdtree* tree, const void* d_queries, uint64_t m,
                                      void* d_indices, void* d_sqr_distances);
 a3d_status a3d_kdtree_free(a3d_kdtree* tree);
+/* Instrumentation: tree shape {leaves, internal nodes, depth of the deepest leaf}. */
+a3d_status a3d_kdtree_stats(a3d_kdtree* tree, uint64_t out3[3]);
 
 /* ---- Icp (src/icp/pcl_icp.rs:15-108) ------------------------------------------------------ */
 
