@@ -2,6 +2,7 @@
 // for P independent frame pairs at once: per iteration one per-pixel kernel (grid = tiles x pairs)
 // and one solve kernel (grid = pairs); the whole coarse-to-fine sequence is enqueued without a host
 // round trip.
+#include <cstdlib>
 #include <memory>
 
 #include "icp_engine.hpp"
@@ -30,6 +31,12 @@ struct Gates {
 // `u as usize` (Rust): NaN and negatives -> 0; the callers only see u < width.
 __device__ __forceinline__ uint32_t f32_as_usize(float x) { return x > 0.0f ? (uint32_t)x : 0u; }
 
+// Pointers read out of a descriptor are generic; the arrays live in global memory, and saying so
+// gives global_load instead of flat_load (one counter to wait on, free scheduling).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* gptr_f4;
+typedef const float __attribute__((address_space(1)))* gptr_f;
+
 // IntensityMap::bilinear (src/intensity_map.rs:150-169) from four already-loaded texels.
 __device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v11, float uf, float vf) {
   float u0 = v00 * (1.0f - uf) + v10 * uf;
@@ -37,79 +44,22 @@ __device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v
   return u0 * (1.0f - vf) + u1 * vf;
 }
 
-__device__ __forceinline__ float bilinear_at(const float* __restrict__ imap, uint32_t mw, float u, float v) {
+__device__ __forceinline__ float bilinear_at(gptr_f imap, uint32_t mw, float u, float v) {
   uint32_t ui = f32_as_usize(u), vi = f32_as_usize(v);
-  const float* r0 = imap + (size_t)vi * mw + ui;
+  gptr_f r0 = imap + (size_t)vi * mw + ui;
   return bilerp(r0[0], r0[1], r0[mw], r0[mw + 1], u - (float)ui, v - (float)vi);
 }
 
-// The body of the reference's pixel loop (image_icp.rs:101-139) for one source record.
-__device__ __forceinline__ void image_icp_pixel(const float4 s, const Pose& T, const LevelDesc& d, const Gates& gt,
-                                                float* __restrict__ acc) {
-  if (!(s.w >= 0.0f)) return;  // mask == 0
-  const V3 p = transform_vector(T, V3{s.x, s.y, s.z});
-  // CameraIntrinsics::project (src/camera.rs:64-70)
-  const float z = p.z;
-  const float u = p.x * d.fx / z + d.cx;
-  const float v = p.y * d.fy / z + d.cy;
-  // (u + 0.5) as i32 -> as usize -> get_point bounds test: in range iff -1 < x < dim (NaN casts to 0)
-  const float ur = u + 0.5f, vr = v + 0.5f;
-  if (ur <= -1.0f || ur >= (float)d.tw || vr <= -1.0f || vr >= (float)d.th) return;
-  const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
-  const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
-  const uint32_t tidx = row * d.tw + col;
-  const float4 tp = d.tgt[2 * tidx];
-  if (tp.w != 1.0f) return;  // mask != 1
-  const V3 q{tp.x, tp.y, tp.z};
-  const V3 diff = q - p;
-  if (norm_squared(diff) > gt.max_distance_sqr) return;
-  const float4 tn = d.tgt[2 * tidx + 1];
-  const V3 n{tn.x, tn.y, tn.z};
-  // angle_between_normals(&p, &n) >= max_normal_angle, NaN (|p.n| > 1) passes (image_icp.rs:118-123)
-  const float pn = dot(p, n);
-  if (pn >= -1.0f && pn <= gt.dot_reject_max) return;
-  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
-  {
-    const float r = dot(diff, n);
-    const V3 tw = cross(p, n);
-    const float J[6] = {n.x, n.y, n.z, tw.x, tw.y, tw.z};
-    gn_step(acc, r, J);
-  }
-  // colour term: IntensityMap::bilinear_grad (src/intensity_map.rs:184-210), H = 0.005
-  const uint32_t mw = d.tw + 2;
-  const uint32_t ui = f32_as_usize(u), vi = f32_as_usize(v);
-  const float* r0 = d.imap + (size_t)vi * mw + ui;
-  const float v00 = r0[0], v10 = r0[1], v01 = r0[mw], v11 = r0[mw + 1];
-  const float uf = u - (float)ui, vf = v - (float)vi;
-  const float value = bilerp(v00, v10, v01, v11, uf, vf);
-  const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
-  const float u2 = u + Hh, v2 = v + Hh;
-  // the shifted samples fall in the same texel cell except within 0.005 of a texel boundary
-  const float uh = (f32_as_usize(u2) == ui) ? bilerp(v00, v10, v01, v11, u2 - (float)ui, vf)
-                                            : bilinear_at(d.imap, mw, u2, v);
-  const float vh = (f32_as_usize(v2) == vi) ? bilerp(v00, v10, v01, v11, uf, v2 - (float)vi)
-                                            : bilinear_at(d.imap, mw, u, v2);
-  const float du = (uh - value) * H_INV;
-  const float dv = (vh - value) * H_INV;
-  const float sc = s.w * 0.003921569f;
-  // CameraIntrinsics::project_grad (src/camera.rs:82-89)
-  const float zz = z * z;
-  const float dfx = d.fx / z, dcx = -p.x * d.fx / zz;
-  const float dfy = d.fy / z, dcy = -p.y * d.fy / zz;
-  const V3 g{du * dfx, dv * dfy, du * dcx + dv * dcy};
-  const float rc = sc - value;
-  if (rc * rc <= gt.max_color_distance_sqr) {
-    const V3 tw = cross(p, g);
-    const float J[6] = {g.x, g.y, g.z, tw.x, tw.y, tw.z};
-    gn_step(acc + GN_ACC, rc, J);
-  }
-}
-
-// grid = (tiles, pairs); block = 256; each thread visits PPT source pixels, 256 apart (coalesced).
-template <int PPT>
+// The reference's pixel loop (image_icp.rs:101-139).  grid = (tiles, pairs); block = 256.  A thread
+// visits PPT source pixels, 256 apart (coalesced), G at a time: the G source records are loaded
+// together, then the G projective gathers of the target record, then the G intensity-map cells, so
+// that each dependent memory round trip is paid once per G pixels; only the accumulation is under
+// the per-pixel gates.
+template <int PPT, int G>
 __global__ void __launch_bounds__(256)
-    image_icp_kernel(const LevelDesc* __restrict__ descs, const JobState* __restrict__ states, Gates gates,
+    image_icp_kernel(const LevelDesc* __restrict__ descs, const JobState* __restrict__ states, Gates gt,
                      float* __restrict__ partials) {
+  static_assert(PPT % G == 0, "PPT must be a multiple of G");
   const int pair = blockIdx.y;
   float acc[GN_PARTIAL];
 #pragma unroll
@@ -118,11 +68,97 @@ __global__ void __launch_bounds__(256)
   if (st->status == A3D_OK) {
     const LevelDesc d = descs[pair];
     const Pose T = st->pose;
+    const gptr_f4 src = (gptr_f4)d.src;
+    const gptr_f4 tgt = (gptr_f4)d.tgt;
+    const gptr_f imap = (gptr_f)d.imap;
+    const uint32_t mw = d.tw + 2;
+    const float twf = (float)d.tw, thf = (float)d.th;
     const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
+#pragma unroll 1
+    for (int k0 = 0; k0 < PPT; k0 += G) {
+      // ---- stage A: source records -----------------------------------------------------------
+      f32x4 s[G];
+      bool live[G];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const uint32_t i = base + k * 256u;
-      if (i < d.src_n) image_icp_pixel(d.src[i], T, d, gates, acc);
+      for (int g = 0; g < G; ++g) {
+        const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
+        const bool inb = i < d.src_n;
+        s[g] = src[inb ? i : 0u];
+        live[g] = inb && (s[g].w >= 0.0f);  // mask != 0 (image_icp.rs:102)
+      }
+      // ---- stage B: transform, project, gather the target record -------------------------------
+      V3 p[G];
+      float u[G], v[G];
+      f32x4 tp[G], tn[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        p[g] = transform_vector(T, V3{s[g].x, s[g].y, s[g].z});
+        // CameraIntrinsics::project (src/camera.rs:64-70)
+        u[g] = p[g].x * d.fx / p[g].z + d.cx;
+        v[g] = p[g].y * d.fy / p[g].z + d.cy;
+        // (u + 0.5) as i32 -> as usize -> get_point bounds test: in range iff -1 < x < dim (NaN casts to 0)
+        const float ur = u[g] + 0.5f, vr = v[g] + 0.5f;
+        live[g] = live[g] && !(ur <= -1.0f || ur >= twf || vr <= -1.0f || vr >= thf);
+        const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
+        const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
+        const uint32_t tidx = live[g] ? row * d.tw + col : 0u;
+        tp[g] = tgt[2 * tidx];
+        tn[g] = tgt[2 * tidx + 1];
+      }
+      // ---- stage C: gates, intensity-map cell -----------------------------------------------------
+      float t00[G], t10[G], t01[G], t11[G];
+      uint32_t ui[G], vi[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const V3 diff = V3{tp[g].x, tp[g].y, tp[g].z} - p[g];
+        // angle_between_normals(&p, &n) >= max_normal_angle with NaN (|p.n| > 1) passing (image_icp.rs:118-123)
+        const float pn = dot(p[g], V3{tn[g].x, tn[g].y, tn[g].z});
+        live[g] = live[g] && (tp[g].w == 1.0f)                            // mask == 1 (structure.rs:176)
+                  && !(norm_squared(diff) > gt.max_distance_sqr)         // image_icp.rs:114
+                  && !(pn >= -1.0f && pn <= gt.dot_reject_max);
+        ui[g] = live[g] ? f32_as_usize(u[g]) : 0u;
+        vi[g] = live[g] ? f32_as_usize(v[g]) : 0u;
+        const gptr_f r0 = imap + (size_t)vi[g] * mw + ui[g];
+        t00[g] = r0[0], t10[g] = r0[1], t01[g] = r0[mw], t11[g] = r0[mw + 1];
+      }
+      // ---- stage D: residuals, Jacobians, accumulate -----------------------------------------------
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (!live[g]) continue;
+        const V3 P = p[g];
+        const V3 n{tn[g].x, tn[g].y, tn[g].z};
+        {  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
+          const V3 diff = V3{tp[g].x, tp[g].y, tp[g].z} - P;
+          const float r = dot(diff, n);
+          const V3 tw = cross(P, n);
+          const float J[6] = {n.x, n.y, n.z, tw.x, tw.y, tw.z};
+          gn_step(acc, r, J);
+        }
+        // IntensityMap::bilinear_grad (src/intensity_map.rs:184-210), H = 0.005
+        const float uf = u[g] - (float)ui[g], vf = v[g] - (float)vi[g];
+        const float value = bilerp(t00[g], t10[g], t01[g], t11[g], uf, vf);
+        const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
+        const float u2 = u[g] + Hh, v2 = v[g] + Hh;
+        // the shifted samples share the cell except within 0.005 of a texel boundary
+        const float uh = (f32_as_usize(u2) == ui[g]) ? bilerp(t00[g], t10[g], t01[g], t11[g], u2 - (float)ui[g], vf)
+                                                     : bilinear_at(imap, mw, u2, v[g]);
+        const float vh = (f32_as_usize(v2) == vi[g]) ? bilerp(t00[g], t10[g], t01[g], t11[g], uf, v2 - (float)vi[g])
+                                                     : bilinear_at(imap, mw, u[g], v2);
+        const float du = (uh - value) * H_INV;
+        const float dv = (vh - value) * H_INV;
+        const float sc = s[g].w * 0.003921569f;  // image_icp.rs:131
+        // CameraIntrinsics::project_grad (src/camera.rs:82-89)
+        const float z = P.z, zz = z * z;
+        const float dfx = d.fx / z, dcx = -P.x * d.fx / zz;
+        const float dfy = d.fy / z, dcy = -P.y * d.fy / zz;
+        const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
+        const float rc = sc - value;
+        if (rc * rc <= gt.max_color_distance_sqr) {  // image_icp.rs:136
+          const V3 tw = cross(P, gr);
+          const float J[6] = {gr.x, gr.y, gr.z, tw.x, tw.y, tw.z};
+          gn_step(acc + GN_ACC, rc, J);
+        }
+      }
     }
   }
   block_reduce_store<GN_PARTIAL>(acc, partials + ((size_t)pair * gridDim.x + blockIdx.x) * GN_PARTIAL);
@@ -136,7 +172,7 @@ struct a3d_multiscale_batch {
   uint32_t n_pairs = 0, n_levels = 0;
   std::vector<a3d_icp_params> params;  // index 0 = finest
   std::vector<Gates> gates;
-  std::vector<uint32_t> tiles, ppt;    // per level
+  std::vector<uint32_t> tiles, ppt, group;  // per level: tiles per pair, pixels per thread, pixels in flight
   std::vector<LevelDesc> h_descs;      // [level][pair]
   LevelDesc* d_descs = nullptr;
   JobState* d_states = nullptr;
@@ -205,12 +241,25 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level) {
   dim3 grid(b->tiles[level], b->n_pairs), block(256);
   const LevelDesc* descs = b->d_descs + (size_t)level * b->n_pairs;
   hipStream_t s = b->ctx->stream;
-  switch (b->ppt[level]) {
-    case 8: hipLaunchKernelGGL(image_icp_kernel<8>, grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials); break;
-    case 4: hipLaunchKernelGGL(image_icp_kernel<4>, grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials); break;
-    case 2: hipLaunchKernelGGL(image_icp_kernel<2>, grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials); break;
-    default: hipLaunchKernelGGL(image_icp_kernel<1>, grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials); break;
+#define A3D_LAUNCH(PPT, G)                                                                               \
+  hipLaunchKernelGGL((image_icp_kernel<PPT, G>), grid, block, 0, s, descs, b->d_states, b->gates[level], \
+                     b->d_partials)
+  const uint32_t g = b->group[level];
+  switch (b->ppt[level] * 16 + g) {
+    case 8 * 16 + 4: A3D_LAUNCH(8, 4); break;
+    case 8 * 16 + 2: A3D_LAUNCH(8, 2); break;
+    case 8 * 16 + 1: A3D_LAUNCH(8, 1); break;
+    case 4 * 16 + 4: A3D_LAUNCH(4, 4); break;
+    case 4 * 16 + 2: A3D_LAUNCH(4, 2); break;
+    case 4 * 16 + 1: A3D_LAUNCH(4, 1); break;
+    case 2 * 16 + 2: A3D_LAUNCH(2, 2); break;
+    case 2 * 16 + 1: A3D_LAUNCH(2, 1); break;
+    case 1 * 16 + 1: A3D_LAUNCH(1, 1); break;
+    default:
+      set_error("unsupported kernel variant ppt=%u g=%u", b->ppt[level], g);
+      return A3D_INVALID_PARAMETER;
   }
+#undef A3D_LAUNCH
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }
@@ -223,6 +272,11 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     uint32_t max_n = 0;
     for (uint32_t p = 0; p < P; ++p) max_n = std::max(max_n, b->h_descs[(size_t)l * P + p].src_n);
     b->ppt[l] = choose_ppt(P, max_n);
+    b->group[l] = std::min<uint32_t>(b->ppt[l], 2);  // measured best on MI355X (kernel variants)
+    if (const char* env = getenv("A3D_ICP_VARIANT")) {  // tuning knob: "ppt,g"
+      unsigned ep = 0, eg = 0;
+      if (sscanf(env, "%u,%u", &ep, &eg) == 2 && ep && eg) b->ppt[l] = ep, b->group[l] = eg;
+    }
     b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
     max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
   }
@@ -244,6 +298,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   for (uint32_t l = 0; l < n_levels; ++l) b->gates.push_back(make_gates(params[l]));
   b->tiles.assign(n_levels, 0);
   b->ppt.assign(n_levels, 1);
+  b->group.assign(n_levels, 1);
   b->h_descs.resize((size_t)n_levels * n_pairs);
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));

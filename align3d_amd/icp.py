@@ -99,7 +99,7 @@ class MultiscaleAlign:
         return Transform.from_c(out)
 
     def free(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             self.ctx.lib.a3d_multiscale_free(self.handle)
             self.handle = C.c_void_p()
 
@@ -162,7 +162,7 @@ class MultiscaleAlignBatch:
         return ms.value
 
     def free(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:  # a handle must not outlive its context
             self.ctx.lib.a3d_multiscale_batch_free(self.handle)
             self.handle = C.c_void_p()
 
@@ -229,7 +229,7 @@ class Icp:
         return g.as_dict()
 
     def free(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             self.ctx.lib.a3d_pcl_icp_free(self.handle)
             self.handle = C.c_void_p()
 

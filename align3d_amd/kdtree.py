@@ -37,7 +37,7 @@ class R3dTree:
         return tuple(s)
 
     def free(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             self.ctx.lib.a3d_kdtree_free(self.handle)
             self.handle = C.c_void_p()
 

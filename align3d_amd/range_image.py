@@ -250,7 +250,7 @@ class DeviceRangeImage:
         return out
 
     def free(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             self.ctx.lib.a3d_range_image_free(self.handle)
             self.handle = C.c_void_p()
 

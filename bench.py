@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Benchmark of the ICP hot path on MI355X.
+
+One "step" = one pass of MultiscaleAlign over a batch of independent synthetic 640x480 frame pairs
+that are already resident in HBM (`ms3x15`: 3 pyramid levels, IcpParams::default() = 15 iterations
+per level — the shape BASELINE.json's metric is quoted on).  Per GPU the batch is 64 pairs (the
+per-GPU shard of configs[4]: 512 pairs over 8 GPUs); with N > 1 ranks every rank aligns its own
+pairs and one RCCL all-gather collects the 4x4 poses (weak scaling).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the round instructions) with `roofline` for the dominant
+kernel (the per-pixel kernel) and `cpu_baseline` (the CPU oracle timed on a bounded sample)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from align3d_amd import (BilateralFilter, Context, IcpParams, MsIcpParams, MultiscaleAlign,  # noqa: E402
+                         MultiscaleAlignBatch, R3dTree, RangeImageBuilder, synth)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+# algorithmic bytes of one ImageIcp iteration at each level of a 640x480 pyramid:
+# source 14 B/px + target 25 B/px + the (H+2)(W+2) f32 intensity map.
+def level_bytes(w, h):
+    return 39 * w * h + 4 * (w + 2) * (h + 2)
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def build_stream_pyramids(ctx, seed, n_frames, width, height):
+    frames, poses = synth.frame_stream(seed, n_frames, width, height)
+    builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+    cam = synth.camera(width, height)
+    pyramids = [builder.build(cam, d, rgb, synth.DEPTH_SCALE) for d, rgb in frames]
+    return pyramids, poses
+
+
+def kdtree_bench(ctx, n=500_000, reps=20):
+    db = synth.uniform01_f32(10, 3 * n).reshape(n, 3)
+    q = synth.uniform01_f32(11, 3 * n).reshape(n, 3)
+    t0 = time.time()
+    tree = R3dTree.new(ctx, db)
+    build_s = time.time() - t0
+    d_q = ctx.to_device(q)
+    d_i, d_d = ctx.malloc(4 * n), ctx.malloc(4 * n)
+    for _ in range(3):
+        tree.nearest_device(d_q, n, d_i, d_d)
+    ctx.timer_start()
+    for _ in range(reps):
+        tree.nearest_device(d_q, n, d_i, d_d)
+    ms = ctx.timer_stop() / reps
+    for p in (d_q, d_i, d_d):
+        ctx.free(p)
+    leaves, internal, depth = tree.stats()
+    tree.free()
+    alg_bytes = 216 * n + 4 * internal  # 216 B/query + the split table once
+    return {
+        "metric": "kdtree 500k queries/s (500k database, uniform [0,1)^3)",
+        "value": n / (ms * 1e-3),
+        "unit": "queries/s",
+        "ms_per_500k_queries": ms,
+        "host_build_s": build_s,
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+    }
+
+
+def cpu_baseline(host_pyramids, params, n_pairs, gpu_poses):
+    """The CPU oracle ("port": a restatement, not the Rust reference) on the first n_pairs pairs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    cores = os.cpu_count() or 1
+
+    def frame(ri):
+        k = ri.intrinsics
+        return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
+
+    parr = params.to_c_array()
+    worst_ang = worst_tr = 0.0
+    t0 = time.time()
+    done = 0
+    for p in range(n_pairs):
+        tp = [frame(r) for r in host_pyramids[p]]
+        sp = [frame(r) for r in host_pyramids[p + 1]]
+        st, T = O.multiscale_align(parr, len(params), tp, sp, threads=cores)
+        done += 1
+        if st == 0 and gpu_poses is not None:
+            ang, tr = O.transform_metrics(gpu_poses[p].to_c(), T)
+            worst_ang, worst_tr = max(worst_ang, abs(ang)), max(worst_tr, tr)
+        if time.time() - t0 > 30.0:
+            break
+    dt = time.time() - t0
+    return {
+        "value": done / dt,
+        "unit": "frame-pairs/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{done} of the batch's frame pairs, same ms3x15 workload, oracle threaded over {cores} host threads "
+                  f"(4096-pixel chunks like the reference's rayon loop)",
+        "max_gpu_vs_cpu_angle_rad": worst_ang,
+        "max_gpu_vs_cpu_translation_m": worst_tr,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-gpu", type=int, default=64)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the kd-tree / single-pair secondary numbers")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+
+    ctx = Context(local_rank)
+    P, W, H = args.pairs_per_gpu, args.width, args.height
+    params = MsIcpParams.repeat(3, IcpParams.default())  # ms3x15
+    t0 = time.time()
+    host_pyramids, poses_gt = build_stream_pyramids(ctx, seed=1000 + rank, n_frames=P + 1, width=W, height=H)
+    if rank == 0:
+        log(f"built {P + 1} synthetic frame pyramids in {time.time() - t0:.1f}s (bilateral + normals on device)")
+    # pair p: target = frame p, source = frame p + 1; every pyramid level uploaded once, resident in HBM
+    targets = [host_pyramids[p] for p in range(P)]
+    sources = [host_pyramids[p + 1] for p in range(P)]
+    batch = MultiscaleAlignBatch(ctx, params, targets, sources)
+
+    d_mats = gathered = ext_stream = None
+    if world > 1:
+        mats = torch.zeros((P, 16), dtype=torch.float32, device="cuda")
+        gathered = torch.zeros((world * P, 16), dtype=torch.float32, device="cuda")
+        d_mats = C.c_void_p(mats.data_ptr())
+        ext_stream = torch.cuda.ExternalStream(ctx.lib.a3d_context_stream(ctx.handle))
+
+    def step():
+        batch.enqueue(matrices_device=d_mats)
+        if world > 1:
+            with torch.cuda.stream(ext_stream):  # ordered after the kernels on the context stream
+                dist.all_gather_into_tensor(gathered, mats)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * P * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (image_icp_kernel), HIP events on the launch stream ----
+        batch.set_profiling(True)
+        kernel_ms, launches = [], 0
+        for _ in range(max(3, args.steps)):
+            batch.enqueue()
+            ctx.synchronize()
+            kernel_ms.append(batch.last_kernel_ms())
+            launches = batch.last_timing()[1]
+        batch.set_profiling(False)
+        kms = float(np.median(kernel_ms))
+        iters = [int(p.max_iterations) for p in params]
+        step_alg_bytes = P * sum(iters[l] * level_bytes(W >> l, H >> l) for l in range(3))
+        achieved = step_alg_bytes / (kms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "image_icp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "launches_per_step": int(launches), "avg_launch_us": kms * 1e3 / max(1, launches),
+            "algorithmic_bytes_per_launch": step_alg_bytes / max(1, launches),
+            "kernel_share_of_step": kms / ms_per_step,
+        }
+        poses, status = batch.align()
+        extra = {"failed_pairs": int(np.count_nonzero(status))}
+        # accuracy against the synthetic ground truth (reported, not a parity claim)
+        errs = []
+        for p in range(P):
+            gt = synth.relative_pose(poses_gt[p], poses_gt[p + 1])
+            d = np.linalg.inv(gt) @ poses[p].matrix().astype(np.float64)
+            errs.append((np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)), np.linalg.norm(d[:3, 3])))
+        extra["mean_error_vs_synthetic_gt"] = {"angle_rad": float(np.mean([e[0] for e in errs])),
+                                               "translation_m": float(np.mean([e[1] for e in errs]))}
+        if not args.no_extras and world == 1:
+            # configs[1]: one pair alone on the GPU (latency-bound: 45 dependent iterations)
+            ms1 = MultiscaleAlign.new(ctx, params, targets[0])
+            for _ in range(2):
+                ms1.align(sources[0])
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ms1.align(sources[0])
+            extra["single_pair_ms3x15_latency_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+            extra["kdtree"] = kdtree_bench(ctx)
+        cpu = None
+        if world == 1 and args.cpu_pairs > 0:
+            cpu = cpu_baseline(host_pyramids, params, min(args.cpu_pairs, P), poses)
+        out = {
+            "metric": "ICP frame-pairs/sec (640x480, 3-lvl, 15 iters)",
+            "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ms3x15: {P} independent {W}x{H} frame pairs per GPU resident in HBM, "
+                                   "MsIcpParams::repeat(3, IcpParams::default()) = 3 levels x 15 iterations "
+                                   "(configs[1] pair shape, batched as the per-GPU shard of configs[4])",
+                       "pairs_per_gpu": P, "levels": 3, "iterations_per_level": iters,
+                       "collective": "one RCCL all-gather of 16 f32 per pair per step" if world > 1 else "none"},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        }
+    sync_all()
+    batch.free()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

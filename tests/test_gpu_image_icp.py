@@ -38,6 +38,19 @@ def _check_accumulators(ctx, prm, ft, fs, T):
     assert eh < 1e-4 and eg < 1e-3 and es < 1e-4
 
 
+def _oracle_step(prm, ft, fs, T, accum_f64):
+    """One reference iteration (image_icp.rs:145-153) from T with the oracle: (residual, new transform)."""
+    st, g, c = O.image_icp_accumulate(prm.to_c(), ft, fs, T.to_c(), accum_f64=accum_f64)
+    assert st == 0
+    lib = O.load()
+    lib.orc_gn_add_weighted(C.byref(g), C.byref(c), prm.weight, prm.color_weight)
+    residual = lib.orc_gn_mean_squared_residual(C.byref(g))
+    upd = (C.c_float * 6)()
+    assert lib.orc_gn_solve(C.byref(g), upd) == 1
+    new = O.compose(O.exp_se3(np.array(upd[:], np.float32)), T.to_c())
+    return residual, Transform.from_c(new)
+
+
 @pytest.mark.parametrize("sample,tgt,src,bilateral", [("sample1", 0, 5, False), ("sample2", 0, 1, True)])
 @pytest.mark.parametrize("which", ["default", "ms"])
 def test_per_iteration_accumulators(ctx, sample, tgt, src, bilateral, which):
@@ -60,8 +73,13 @@ def test_teacher_forced_along_oracle_trajectory(ctx):
     T_gpu, tr_gpu = ImageIcp.new(ctx, prm, to_range_image(ft)).align(to_range_image(fs), trace=True)
     ang, tr = transform_diff(T_gpu, T_ref)
     print(f"[bench10 end-to-end, non-contractive] d_angle={ang:.3e} rad d_trans={tr:.3e} m")
-    # the first update comes from identical inputs and must agree tightly
-    assert np.allclose(tr_gpu[0], trace[0], rtol=2e-5, atol=2e-7)
+    # The first update comes from identical inputs.  Against the oracle's f64-summed accumulators it
+    # agrees tightly; against the reference-order f32 sums only as well as those sums are accurate
+    # (H is ill-conditioned, so 1e-6 relative noise in H moves the update by ~1e-5).
+    res64, T64 = _oracle_step(prm, ft, fs, Transform.eye(), accum_f64=True)
+    assert abs(tr_gpu[0, 0] - res64) <= 1e-6 * abs(res64)
+    assert np.allclose(tr_gpu[0, 1:], np.concatenate([T64.t, T64.q]), rtol=0, atol=2e-6)
+    assert np.allclose(tr_gpu[0], trace[0], rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("sample,tgt,src", [("sample1", 0, 5), ("sample2", 0, 1)])
@@ -162,7 +180,9 @@ def test_batch_matches_single_pairs(ctx):
     mats = ctx.to_host(d_mats, np.zeros((len(pairs), 4, 4), np.float32))
     for k in range(len(pairs)):
         single = MultiscaleAlign.new(ctx, prm, tps[k]).align(sps[k])
-        assert np.array_equal(single.t, poses[k].t) and np.array_equal(single.q, poses[k].q)
+        # same kernels, but the tiling (pixels per thread) depends on the batch size, so the f32 sums
+        # are associated differently: equal to rounding, not bit for bit
+        assert np.allclose(single.t, poses[k].t, atol=2e-6) and np.allclose(single.q, poses[k].q, atol=2e-6)
         assert np.allclose(mats[k], poses[k].matrix(), atol=1e-6)
         s, a, b = pairs[k]
         st, T_ref = O.multiscale_align(prm.to_c_array(), 3, oracle_pyramid(s, a), oracle_pyramid(s, b), threads=4)
