@@ -23,14 +23,20 @@ struct JobState {
 
 enum SolveMode : int {
   SOLVE_IMAGE_ICP = 0,  // geom.add_weighted(color, w, cw); residual = weighted mean (image_icp.rs:150-151)
-  SOLVE_PCL_ICP = 1     // residual = mean, then weight(w)  (pcl_icp.rs:94-95)
+  SOLVE_PCL_ICP = 1,    // residual = mean, then weight(w)  (pcl_icp.rs:94-95)
+  SOLVE_NONE = 2        // leave the block partials alone (test hook: read the accumulators back)
+};
+
+// What the last block of a job needs in order to finish the iteration on the device.
+struct SolveArgs {
+  float weight, color_weight;
+  int mode;
+  int first_in_level, last_in_level;
+  int trace_stride, trace_index;
+  float* trace;  // nullable: [job][trace_stride][8] = residual, t, q
 };
 
 // Host launchers (kernels live in icp_engine.hip); all enqueue on `stream` and return immediately.
-// partials: [job][tiles][GN_PARTIAL].  trace (nullable): [job][trace_stride][8] = residual, t, q.
-a3d_status launch_gn_solve(hipStream_t stream, JobState* states, const float* partials, int n_jobs, int tiles,
-                           float weight, float color_weight, SolveMode mode, bool first_in_level,
-                           bool last_in_level, float* trace, int trace_stride, int trace_index);
 // Sums the block partials of job 0 in f64 (test hook): out58 is device memory, GN_PARTIAL doubles.
 a3d_status launch_gn_readback(hipStream_t stream, const float* partials, int tiles, double* out58);
 // states[j] = {init_poses[j] (identity when null), same, +inf, A3D_OK}
@@ -95,7 +101,7 @@ __device__ __forceinline__ float wave_reduce_scatter(const float (&acc)[N]) {
 }
 
 // Wave reduce-scatter + LDS across the block's 4 waves -> one block partial of N floats.
-template <int N>
+template <int N, bool WRITE_THROUGH = false>
 __device__ __forceinline__ void block_reduce_store(const float (&acc)[N], float* __restrict__ out) {
   constexpr int WAVES = 4;  // 256-thread blocks
   __shared__ float red[WAVES][64];
@@ -106,8 +112,157 @@ __device__ __forceinline__ void block_reduce_store(const float (&acc)[N], float*
     float s = red[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) s += red[w][threadIdx.x];
-    out[threadIdx.x] = s;
+    if (WRITE_THROUGH)  // global_store_dword sc1: leaves this CU's L1 and the XCD's L2 right away
+      __hip_atomic_store((unsigned*)out + threadIdx.x, __float_as_uint(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      out[threadIdx.x] = s;
   }
+}
+
+// ---- finishing an iteration on the device ---------------------------------------------------------
+// Called by every thread of the job's last block.  sums = GN_PARTIAL f64 totals in LDS.
+//   GaussNewton::add_weighted / weight / mean_squared_residual   src/optim/gaussnewton.rs:115-133
+//   GaussNewton::solve (f64 Cholesky, nalgebra's update order)    src/optim/gaussnewton.rs:84-93
+//   optim_transform = exp(update) * optim_transform, best tracking   src/icp/image_icp.rs:150-161,
+//                                                                   src/icp/pcl_icp.rs:94-103
+// The 6x6 factorisation runs one matrix element per thread out of LDS (column k: sqrt, scale the
+// column, rank-1 update of the trailing columns — the same operations on the same operands, in the
+// same order per element, as nalgebra's left-looking loop), which keeps the solve out of the
+// accumulate kernel's register budget; the substitutions and the pose update are one lane.
+__device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums, const SolveArgs& a, int job) {
+  __shared__ double L[36];
+  __shared__ double bvec[6];
+  __shared__ float s_residual;
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  const int r = tid / 6, c = tid % 6;
+  const bool image_mode = a.mode == SOLVE_IMAGE_ICP;
+  if (tid < 36) {
+    const int t = tri6(r < c ? r : c, r < c ? c : r);
+    const float hg = (float)sums[t], hc = (float)sums[GN_ACC + t];
+    // add_weighted: H = Hg w1^2 + Hc w2^2 ; weight(): H *= w^2   (all f32)
+    const float h = image_mode ? hg * (a.weight * a.weight) + hc * (a.color_weight * a.color_weight)
+                               : hg * (a.weight * a.weight);
+    L[tid] = (double)h;
+  } else if (tid >= 64 && tid < 70) {
+    const int k = tid - 64;
+    const float gg = (float)sums[21 + k], gc = (float)sums[GN_ACC + 21 + k];
+    bvec[k] = (double)(image_mode ? gg * a.weight + gc * a.color_weight : gg * a.weight);
+  } else if (tid == 128) {
+    const float ssq_g = (float)sums[27], ssq_c = (float)sums[GN_ACC + 27];
+    const double cnt_g = sums[28], cnt_c = sums[GN_ACC + 28];
+    // ImageIcp: weighted sum / combined count ; Icp: plain mean taken before weight()
+    const double count = image_mode ? cnt_g + cnt_c : cnt_g;
+    const float ssq = image_mode ? ssq_g * a.weight + ssq_c * a.color_weight : ssq_g;
+    s_residual = ssq / (float)count;
+    s_ok = count != 0.0;  // solve(): None if count == 0
+  }
+  __syncthreads();
+  for (int k = 0; k < 6; ++k) {
+    if (tid == 0 && s_ok) {
+      const double diag = L[k * 6 + k];
+      if (diag == 0.0 || !(diag >= 0.0))
+        s_ok = 0;  // zero, negative or NaN pivot: Cholesky::new() == None
+      else
+        L[k * 6 + k] = sqrt(diag);
+    }
+    __syncthreads();
+    if (tid < 36 && s_ok && c == k && r > k) L[tid] /= L[k * 6 + k];
+    __syncthreads();
+    if (tid < 36 && s_ok && c > k && r >= c) L[tid] = (-L[c * 6 + k]) * L[r * 6 + k] + L[tid];
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  const float residual = s_residual;
+  if (!s_ok) {  // the reference's unwrap() panics here
+    st->status = A3D_SOLVE_FAILED;
+    st->last_residual = residual;
+    return;
+  }
+  double b[6];
+  for (int i = 0; i < 6; ++i) b[i] = bvec[i];
+  for (int i = 0; i < 6; ++i) {  // solve_lower_triangular (column oriented)
+    const double coeff = b[i] / L[i * 6 + i];
+    b[i] = coeff;
+    for (int rr = i + 1; rr < 6; ++rr) b[rr] = -coeff * L[rr * 6 + i] + b[rr];
+  }
+  for (int i = 5; i >= 0; --i) {  // ad_solve_lower_triangular: L^T x = b
+    double d = 0.0;
+    for (int rr = i + 1; rr < 6; ++rr) d += L[rr * 6 + i] * b[rr];
+    b[i] = (b[i] - d) / L[i * 6 + i];
+  }
+  float update[6];
+  for (int i = 0; i < 6; ++i) update[i] = (float)b[i];
+  Pose pose = st->pose;
+  float best_residual = st->best_residual;
+  Pose best = st->best;
+  if (a.first_in_level) {  // ImageIcp::align starts every level with best = initial, +inf
+    best_residual = __builtin_inff();
+    best = pose;
+  }
+  pose = compose(exp_se3(update), pose);  // Transform::exp(Se3(update)) * optim_transform
+  if (residual < best_residual) {         // stores the transform AFTER the update (image_icp.rs:158-161)
+    best_residual = residual;
+    best = pose;
+  }
+  if (a.trace) {
+    float* tr = a.trace + ((size_t)job * a.trace_stride + a.trace_index) * 8;
+    tr[0] = residual;
+    tr[1] = pose.t.x, tr[2] = pose.t.y, tr[3] = pose.t.z;
+    tr[4] = pose.q.i, tr[5] = pose.q.j, tr[6] = pose.q.k, tr[7] = pose.q.w;
+  }
+  if (a.last_in_level) pose = best;  // align() returns best_transform; the next level starts from it
+  st->pose = pose;
+  st->best = best;
+  st->best_residual = best_residual;
+  st->last_residual = residual;
+}
+
+// Tail of an accumulate kernel (all 256 threads call it): reduce the block's accumulators to one
+// partial, publish it, take a ticket on the job's counter; the block that arrives last sums all the
+// job's partials in f64 and runs the solve, while blocks of other jobs are still accumulating.
+// Hand-off (CDNA guide, Guideline 16, form R1): the partial is stored write-through (sc1), the storing
+// wave drains its stores, a barrier, then ONE lane adds to the counter (agent-scope atomic) — no
+// release fence, which would write back the whole L2 once per block.  The last block does one agent
+// acquire, a barrier, and reads the partials with sc1 loads.  `job_partials` = [tiles][GN_PARTIAL].
+template <int N>
+__device__ __forceinline__ void block_finish(const float (&acc)[N], float* __restrict__ job_partials, uint32_t tile,
+                                             uint32_t tiles, unsigned* __restrict__ counter, JobState* st,
+                                             const SolveArgs& args, int job) {
+  float* out = job_partials + (size_t)tile * GN_PARTIAL;
+  block_reduce_store<N, true>(acc, out);
+  if (N < GN_PARTIAL && threadIdx.x >= N && threadIdx.x < GN_PARTIAL)
+    __hip_atomic_store((unsigned*)out + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (args.mode == SOLVE_NONE) return;
+  __shared__ unsigned s_is_last;
+  __shared__ double s_sums[4][64];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = ticket == tiles - 1 ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_is_last = last;
+  }
+  __syncthreads();
+  if (!s_is_last) return;
+  // ---- last block of this job ----
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  double sum = 0.0;
+  if (c < GN_PARTIAL)
+    for (uint32_t t = slice; t < tiles; t += 4)
+      sum += (double)__uint_as_float(__hip_atomic_load((const unsigned*)job_partials + (size_t)t * GN_PARTIAL + c,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  s_sums[slice][c] = sum;
+  __syncthreads();
+  if (threadIdx.x < 64) s_sums[0][c] = (s_sums[0][c] + s_sums[1][c]) + (s_sums[2][c] + s_sums[3][c]);
+  __syncthreads();
+  if (threadIdx.x == 0)  // ready for the next launch (ordered by the kernel boundary)
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  gn_finish_block(st, s_sums[0], args, job);
 }
 
 // acc[0..21) += J J^T (upper triangle), acc[21..27) += J r, acc[27] += r^2, acc[28] += 1

@@ -57,14 +57,14 @@ __device__ __forceinline__ float bilinear_at(gptr_f imap, uint32_t mw, float u, 
 // the per-pixel gates.
 template <int PPT, int G>
 __global__ void __launch_bounds__(256)
-    image_icp_kernel(const LevelDesc* __restrict__ descs, const JobState* __restrict__ states, Gates gt,
-                     float* __restrict__ partials) {
+    image_icp_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
+                     float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve) {
   static_assert(PPT % G == 0, "PPT must be a multiple of G");
   const int pair = blockIdx.y;
   float acc[GN_PARTIAL];
 #pragma unroll
   for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
-  const JobState* st = &states[pair];
+  JobState* st = &states[pair];
   if (st->status == A3D_OK) {
     const LevelDesc d = descs[pair];
     const Pose T = st->pose;
@@ -161,7 +161,11 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
-  block_reduce_store<GN_PARTIAL>(acc, partials + ((size_t)pair * gridDim.x + blockIdx.x) * GN_PARTIAL);
+  // a failed job stays frozen: its blocks contribute nothing and nobody runs its solve
+  SolveArgs sa = solve;
+  if (st->status != A3D_OK) sa.mode = SOLVE_NONE;
+  block_finish<GN_PARTIAL>(acc, partials + (size_t)pair * gridDim.x * GN_PARTIAL, blockIdx.x, gridDim.x,
+                           counters + pair, st, sa, pair);
 }
 
 }  // namespace
@@ -177,6 +181,7 @@ struct a3d_multiscale_batch {
   LevelDesc* d_descs = nullptr;
   JobState* d_states = nullptr;
   float* d_partials = nullptr;
+  unsigned* d_counters = nullptr;  // per pair: blocks that have published their partial in this launch
   Pose* d_poses = nullptr;
   int32_t* d_status = nullptr;
   double* d_readback = nullptr;
@@ -190,6 +195,7 @@ struct a3d_multiscale_batch {
     hipFree(d_descs);
     hipFree(d_states);
     hipFree(d_partials);
+    hipFree(d_counters);
     hipFree(d_poses);
     hipFree(d_status);
     hipFree(d_readback);
@@ -237,13 +243,13 @@ uint32_t choose_ppt(uint32_t n_pairs, uint32_t max_src_n) {
   return 1;
 }
 
-a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level) {
+a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const SolveArgs& solve) {
   dim3 grid(b->tiles[level], b->n_pairs), block(256);
   const LevelDesc* descs = b->d_descs + (size_t)level * b->n_pairs;
   hipStream_t s = b->ctx->stream;
 #define A3D_LAUNCH(PPT, G)                                                                               \
   hipLaunchKernelGGL((image_icp_kernel<PPT, G>), grid, block, 0, s, descs, b->d_states, b->gates[level], \
-                     b->d_partials)
+                     b->d_partials, b->d_counters, solve)
   const uint32_t g = b->group[level];
   switch (b->ppt[level] * 16 + g) {
     case 8 * 16 + 4: A3D_LAUNCH(8, 4); break;
@@ -303,6 +309,8 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_states, n_pairs * sizeof(JobState)));
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_counters, n_pairs * sizeof(unsigned)));
+  A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_poses, n_pairs * sizeof(Pose)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_status, n_pairs * sizeof(int32_t)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_readback, GN_PARTIAL * sizeof(double)));
@@ -334,12 +342,14 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
         }
         A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx], s));
       }
-      A3D_TRY(launch_pixel_kernel(b, l));
+      SolveArgs sa;
+      sa.weight = prm.weight, sa.color_weight = prm.color_weight;
+      sa.mode = SOLVE_IMAGE_ICP;
+      sa.first_in_level = it == 0, sa.last_in_level = it + 1 == prm.max_iterations;
+      sa.trace = d_trace, sa.trace_stride = trace_stride, sa.trace_index = trace_index;
+      A3D_TRY(launch_pixel_kernel(b, l, sa));
       if (b->profile_kernels) A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx + 1], s));
       ++kidx;
-      A3D_TRY(launch_gn_solve(s, b->d_states, b->d_partials, (int)P, (int)b->tiles[l], prm.weight, prm.color_weight,
-                              SOLVE_IMAGE_ICP, it == 0, it + 1 == prm.max_iterations, d_trace, trace_stride,
-                              trace_index));
       ++trace_index;
     }
   }
@@ -457,7 +467,9 @@ a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* para
   hipStream_t s = ctx->stream;
   if (hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess) st = A3D_HIP_ERROR;
   if (st == A3D_OK) st = launch_job_init(s, b->d_states, d_pose, 1);
-  if (st == A3D_OK) st = launch_pixel_kernel(b.get(), 0);
+  SolveArgs none{};
+  none.mode = SOLVE_NONE;
+  if (st == A3D_OK) st = launch_pixel_kernel(b.get(), 0, none);
   if (st == A3D_OK) st = launch_gn_readback(s, b->d_partials, (int)b->tiles[0], b->d_readback);
   if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
     st = A3D_HIP_ERROR;

@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(256)
     pcl_icp_kernel(const float* __restrict__ split, const float4* __restrict__ leaves,
                    const float4* __restrict__ leaf_normals, uint32_t n, uint32_t max_depth,
                    const float* __restrict__ src_points, const float* __restrict__ src_normals, uint32_t m,
-                   const JobState* __restrict__ states, PclGates gates, float* __restrict__ partials) {
+                   JobState* __restrict__ states, PclGates gates, float* __restrict__ partials,
+                   unsigned* __restrict__ counter, SolveArgs solve) {
   float acc[GN_ACC];
 #pragma unroll
   for (int k = 0; k < GN_ACC; ++k) acc[k] = 0.0f;
@@ -132,9 +133,9 @@ __global__ void __launch_bounds__(256)
       gn_step(acc, r, J);
     }
   }
-  float* out = partials + (size_t)blockIdx.x * GN_PARTIAL;
-  block_reduce_store<GN_ACC>(acc, out);
-  if (threadIdx.x >= GN_ACC && threadIdx.x < GN_PARTIAL) out[threadIdx.x] = 0.0f;  // no colour term
+  SolveArgs sa = solve;
+  if (states->status != A3D_OK) sa.mode = SOLVE_NONE;
+  block_finish<GN_ACC>(acc, partials, blockIdx.x, gridDim.x, counter, states, sa, 0);  // no colour term
 }
 
 a3d_status check_finite_query_count(uint64_t m) {
@@ -152,6 +153,7 @@ struct a3d_pcl_icp {
   uint32_t blocks = 0;
   JobState* d_state = nullptr;
   float* d_partials = nullptr;
+  unsigned* d_counter = nullptr;
   double* d_readback = nullptr;
 };
 
@@ -261,7 +263,9 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
   if (st == A3D_OK &&
       (hipMalloc((void**)&icp->d_state, sizeof(JobState)) != hipSuccess ||
        hipMalloc((void**)&icp->d_partials, (size_t)icp->blocks * GN_PARTIAL * sizeof(float)) != hipSuccess ||
-       hipMalloc((void**)&icp->d_readback, GN_PARTIAL * sizeof(double)) != hipSuccess))
+       hipMalloc((void**)&icp->d_readback, GN_PARTIAL * sizeof(double)) != hipSuccess ||
+       hipMalloc((void**)&icp->d_counter, sizeof(unsigned)) != hipSuccess ||
+       hipMemset(icp->d_counter, 0, sizeof(unsigned)) != hipSuccess))
     st = A3D_HIP_ERROR;
   if (st != A3D_OK) {
     set_error("a3d_pcl_icp_new: HIP failure: %s", hipGetErrorString(hipGetLastError()));
@@ -287,13 +291,15 @@ static a3d_status pcl_upload_source(a3d_pcl_icp* icp, const a3d_point_cloud_view
   return A3D_OK;
 }
 
-static a3d_status pcl_launch_pass(a3d_pcl_icp* icp, const float* d_pts, const float* d_nrm, uint32_t m) {
+static a3d_status pcl_launch_pass(a3d_pcl_icp* icp, const float* d_pts, const float* d_nrm, uint32_t m,
+                                  const SolveArgs& solve) {
   PclGates g;
   g.max_distance_sqr = icp->params.max_distance * icp->params.max_distance;
   g.dot_reject_max = acos_gate_threshold(icp->params.max_normal_angle, /*strict=*/true);
   a3d_kdtree* t = icp->tree;
   hipLaunchKernelGGL(pcl_icp_kernel, dim3(icp->blocks), dim3(256), 0, icp->ctx->stream, t->d_split, t->d_leaves,
-                     t->d_leaf_normals, t->n, t->max_depth, d_pts, d_nrm, m, icp->d_state, g, icp->d_partials);
+                     t->d_leaf_normals, t->n, t->max_depth, d_pts, d_nrm, m, icp->d_state, g, icp->d_partials,
+                     icp->d_counter, solve);
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }
@@ -307,10 +313,11 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
   // Icp::align starts from Transform::eye(): initial_transform is ignored (pcl_icp.rs:59)
   if (st == A3D_OK) st = launch_job_init(s, icp->d_state, nullptr, 1);
   for (uint64_t it = 0; st == A3D_OK && it < icp->params.max_iterations; ++it) {
-    st = pcl_launch_pass(icp, d_pts, d_nrm, m);
-    if (st == A3D_OK)
-      st = launch_gn_solve(s, icp->d_state, icp->d_partials, 1, (int)icp->blocks, icp->params.weight, 0.0f,
-                           SOLVE_PCL_ICP, it == 0, it + 1 == icp->params.max_iterations, nullptr, 0, 0);
+    SolveArgs sa{};
+    sa.weight = icp->params.weight, sa.color_weight = 0.0f;
+    sa.mode = SOLVE_PCL_ICP;
+    sa.first_in_level = it == 0, sa.last_in_level = it + 1 == icp->params.max_iterations;
+    st = pcl_launch_pass(icp, d_pts, d_nrm, m, sa);
   }
   JobState h;
   if (st == A3D_OK && hipMemcpyAsync(&h, icp->d_state, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess)
@@ -338,7 +345,9 @@ a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* 
                        hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess))
     st = A3D_HIP_ERROR;
   if (st == A3D_OK) st = launch_job_init(s, icp->d_state, d_pose, 1);
-  if (st == A3D_OK) st = pcl_launch_pass(icp, d_pts, d_nrm, (uint32_t)source->len);
+  SolveArgs none{};
+  none.mode = SOLVE_NONE;
+  if (st == A3D_OK) st = pcl_launch_pass(icp, d_pts, d_nrm, (uint32_t)source->len, none);
   if (st == A3D_OK) st = launch_gn_readback(s, icp->d_partials, (int)icp->blocks, icp->d_readback);
   if (st == A3D_OK && hipMemcpyAsync(sums, icp->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
     st = A3D_HIP_ERROR;
@@ -358,6 +367,7 @@ a3d_status a3d_pcl_icp_free(a3d_pcl_icp* icp) {
   a3d_kdtree_free(icp->tree);
   hipFree(icp->d_state);
   hipFree(icp->d_partials);
+  hipFree(icp->d_counter);
   hipFree(icp->d_readback);
   delete icp;
   return A3D_OK;
