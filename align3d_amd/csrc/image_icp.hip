@@ -16,6 +16,13 @@ struct LevelDesc {
   const float4* src;  // [src_n] {x, y, z, intensity | -1}
   const float4* tgt;  // [th*tw][2] {x, y, z, valid}, {nx, ny, nz, 0}
   const float* imap;  // [(th+2)][(tw+2)]
+  // the same data in the reference's own layout (RAW kernels): 14 B per source pixel, 25 B per target pixel
+  const float* src_points;         // [src_n][3]
+  const uint8_t* src_mask;         // [src_n]
+  const uint8_t* src_intensities;  // [src_n]
+  const float* tgt_points;         // [th*tw][3]
+  const float* tgt_normals;        // [th*tw][3]
+  const uint8_t* tgt_mask;         // [th*tw]
   uint32_t src_n;
   uint32_t tw, th;
   float fx, fy, cx, cy;
@@ -36,6 +43,7 @@ __device__ __forceinline__ uint32_t f32_as_usize(float x) { return x > 0.0f ? (u
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gptr_f4;
 typedef const float __attribute__((address_space(1)))* gptr_f;
+typedef const uint8_t __attribute__((address_space(1)))* gptr_u8;
 
 // IntensityMap::bilinear (src/intensity_map.rs:150-169) from four already-loaded texels.
 __device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v11, float uf, float vf) {
@@ -55,7 +63,7 @@ __device__ __forceinline__ float bilinear_at(gptr_f imap, uint32_t mw, float u, 
 // together, then the G projective gathers of the target record, then the G intensity-map cells, so
 // that each dependent memory round trip is paid once per G pixels; only the accumulation is under
 // the per-pixel gates.
-template <int PPT, int G>
+template <int PPT, int G, bool RAW>
 __global__ void __launch_bounds__(256)
     image_icp_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
                      float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve) {
@@ -71,6 +79,10 @@ __global__ void __launch_bounds__(256)
     const gptr_f4 src = (gptr_f4)d.src;
     const gptr_f4 tgt = (gptr_f4)d.tgt;
     const gptr_f imap = (gptr_f)d.imap;
+    const gptr_f src_points = (gptr_f)d.src_points, tgt_points = (gptr_f)d.tgt_points,
+                 tgt_normals = (gptr_f)d.tgt_normals;
+    const gptr_u8 src_mask = (gptr_u8)d.src_mask, src_int = (gptr_u8)d.src_intensities,
+                  tgt_mask = (gptr_u8)d.tgt_mask;
     const uint32_t mw = d.tw + 2;
     const float twf = (float)d.tw, thf = (float)d.th;
     const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
@@ -83,8 +95,15 @@ __global__ void __launch_bounds__(256)
       for (int g = 0; g < G; ++g) {
         const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
         const bool inb = i < d.src_n;
-        s[g] = src[inb ? i : 0u];
-        live[g] = inb && (s[g].w >= 0.0f);  // mask != 0 (image_icp.rs:102)
+        const uint32_t ii = inb ? i : 0u;
+        if constexpr (RAW) {
+          s[g].x = src_points[3 * ii], s[g].y = src_points[3 * ii + 1], s[g].z = src_points[3 * ii + 2];
+          s[g].w = (float)src_int[ii];
+          live[g] = inb && (src_mask[ii] != 0);  // mask != 0 (image_icp.rs:102)
+        } else {
+          s[g] = src[ii];
+          live[g] = inb && (s[g].w >= 0.0f);
+        }
       }
       // ---- stage B: transform, project, gather the target record -------------------------------
       V3 p[G];
@@ -102,8 +121,15 @@ __global__ void __launch_bounds__(256)
         const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
         const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
         const uint32_t tidx = live[g] ? row * d.tw + col : 0u;
-        tp[g] = tgt[2 * tidx];
-        tn[g] = tgt[2 * tidx + 1];
+        if constexpr (RAW) {
+          tp[g].x = tgt_points[3 * tidx], tp[g].y = tgt_points[3 * tidx + 1], tp[g].z = tgt_points[3 * tidx + 2];
+          tp[g].w = tgt_mask[tidx] == 1 ? 1.0f : 0.0f;
+          tn[g].x = tgt_normals[3 * tidx], tn[g].y = tgt_normals[3 * tidx + 1], tn[g].z = tgt_normals[3 * tidx + 2];
+          tn[g].w = 0.0f;
+        } else {
+          tp[g] = tgt[2 * tidx];
+          tn[g] = tgt[2 * tidx + 1];
+        }
       }
       // ---- stage C: gates, intensity-map cell -----------------------------------------------------
       float t00[G], t10[G], t01[G], t11[G];
@@ -188,6 +214,7 @@ struct a3d_multiscale_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;  // per pixel-kernel launch: start/stop pairs, when profiling
   bool profile_kernels = false;
+  bool raw_layout = true;
   float last_total_ms = 0.f, last_kernel_ms = 0.f;
   uint64_t last_kernel_launches = 0;
 
@@ -218,6 +245,8 @@ a3d_status fill_desc(const a3d_device_image* target, const a3d_device_image* sou
   d->src = source->src_pack;
   d->tgt = target->tgt_pack;
   d->imap = target->imap;
+  d->src_points = source->points, d->src_mask = source->mask, d->src_intensities = source->intensities;
+  d->tgt_points = target->points, d->tgt_normals = target->normals, d->tgt_mask = target->mask;
   d->src_n = source->width * source->height;
   d->tw = target->width;
   d->th = target->height;
@@ -248,8 +277,14 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
   const LevelDesc* descs = b->d_descs + (size_t)level * b->n_pairs;
   hipStream_t s = b->ctx->stream;
 #define A3D_LAUNCH(PPT, G)                                                                               \
-  hipLaunchKernelGGL((image_icp_kernel<PPT, G>), grid, block, 0, s, descs, b->d_states, b->gates[level], \
-                     b->d_partials, b->d_counters, solve)
+  do {                                                                                                      \
+    if (b->raw_layout)                                                                                      \
+      hipLaunchKernelGGL((image_icp_kernel<PPT, G, true>), grid, block, 0, s, descs, b->d_states,           \
+                         b->gates[level], b->d_partials, b->d_counters, solve);                             \
+    else                                                                                                    \
+      hipLaunchKernelGGL((image_icp_kernel<PPT, G, false>), grid, block, 0, s, descs, b->d_states,          \
+                         b->gates[level], b->d_partials, b->d_counters, solve);                             \
+  } while (0)
   const uint32_t g = b->group[level];
   switch (b->ppt[level] * 16 + g) {
     case 8 * 16 + 4: A3D_LAUNCH(8, 4); break;
@@ -306,6 +341,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   b->ppt.assign(n_levels, 1);
   b->group.assign(n_levels, 1);
   b->h_descs.resize((size_t)n_levels * n_pairs);
+  if (const char* env = getenv("A3D_ICP_LAYOUT")) b->raw_layout = strcmp(env, "packed") != 0;  // tuning knob
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_states, n_pairs * sizeof(JobState)));
