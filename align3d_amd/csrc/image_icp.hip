@@ -33,7 +33,6 @@ struct Gates {
   float max_distance_sqr;
   float max_color_distance_sqr;
   float dot_reject_max;  // reject iff -1 <= p.n <= dot_reject_max  (== acos(p.n).abs() >= max_normal_angle)
-  int ablate;            // diagnostics only (A3D_ICP_ABLATE): 1 = no colour term, 2 = no accumulation at all
 };
 
 // `u as usize` (Rust): NaN and negatives -> 0; the callers only see u < width.
@@ -152,7 +151,6 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         if (!live[g]) continue;
-        if (gt.ablate == 2) { acc[28] += 1.0f; continue; }
         const V3 P = p[g];
         const V3 n{tn[g].x, tn[g].y, tn[g].z};
         {  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
@@ -162,7 +160,6 @@ __global__ void __launch_bounds__(256)
           const float J[6] = {n.x, n.y, n.z, tw.x, tw.y, tw.z};
           gn_step(acc, r, J);
         }
-        if (gt.ablate == 1) continue;
         // IntensityMap::bilinear_grad (src/intensity_map.rs:184-210), H = 0.005
         const float uf = u[g] - (float)ui[g], vf = v[g] - (float)vi[g];
         const float value = bilerp(t00[g], t10[g], t01[g], t11[g], uf, vf);
@@ -263,7 +260,6 @@ Gates make_gates(const a3d_icp_params& p) {
   g.max_distance_sqr = p.max_distance * p.max_distance;
   g.max_color_distance_sqr = p.max_color_distance * p.max_color_distance;
   g.dot_reject_max = acos_gate_threshold(p.max_normal_angle, /*strict=*/false);
-  g.ablate = getenv("A3D_ICP_ABLATE") ? atoi(getenv("A3D_ICP_ABLATE")) : 0;
   return g;
 }
 
