@@ -179,20 +179,25 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
     st->last_residual = residual;
     return;
   }
-  double b[6];
-  for (int i = 0; i < 6; ++i) b[i] = bvec[i];
+  // The substitutions work in place on the LDS vector, loops kept rolled: this single-lane code must
+  // not set the register budget of the accumulate kernel it is inlined into.
+#pragma unroll 1
   for (int i = 0; i < 6; ++i) {  // solve_lower_triangular (column oriented)
-    const double coeff = b[i] / L[i * 6 + i];
-    b[i] = coeff;
-    for (int rr = i + 1; rr < 6; ++rr) b[rr] = -coeff * L[rr * 6 + i] + b[rr];
+    const double coeff = bvec[i] / L[i * 6 + i];
+    bvec[i] = coeff;
+#pragma unroll 1
+    for (int rr = i + 1; rr < 6; ++rr) bvec[rr] = -coeff * L[rr * 6 + i] + bvec[rr];
   }
+#pragma unroll 1
   for (int i = 5; i >= 0; --i) {  // ad_solve_lower_triangular: L^T x = b
     double d = 0.0;
-    for (int rr = i + 1; rr < 6; ++rr) d += L[rr * 6 + i] * b[rr];
-    b[i] = (b[i] - d) / L[i * 6 + i];
+#pragma unroll 1
+    for (int rr = i + 1; rr < 6; ++rr) d += L[rr * 6 + i] * bvec[rr];
+    bvec[i] = (bvec[i] - d) / L[i * 6 + i];
   }
   float update[6];
-  for (int i = 0; i < 6; ++i) update[i] = (float)b[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) update[i] = (float)bvec[i];
   Pose pose = st->pose;
   float best_residual = st->best_residual;
   Pose best = st->best;
@@ -225,6 +230,11 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
 // wave drains its stores, a barrier, then ONE lane adds to the counter (agent-scope atomic) — no
 // release fence, which would write back the whole L2 once per block.  The last block does one agent
 // acquire, a barrier, and reads the partials with sc1 loads.  `job_partials` = [tiles][GN_PARTIAL].
+// Second half of the tail: the block's partial has been stored write-through by its wave 0.
+__device__ __forceinline__ void block_publish_and_finish(float* __restrict__ job_partials, uint32_t tiles,
+                                                         unsigned* __restrict__ counter, JobState* st,
+                                                         const SolveArgs& args, int job);
+
 template <int N>
 __device__ __forceinline__ void block_finish(const float (&acc)[N], float* __restrict__ job_partials, uint32_t tile,
                                              uint32_t tiles, unsigned* __restrict__ counter, JobState* st,
@@ -233,6 +243,12 @@ __device__ __forceinline__ void block_finish(const float (&acc)[N], float* __res
   block_reduce_store<N, true>(acc, out);
   if (N < GN_PARTIAL && threadIdx.x >= N && threadIdx.x < GN_PARTIAL)
     __hip_atomic_store((unsigned*)out + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  block_publish_and_finish(job_partials, tiles, counter, st, args, job);
+}
+
+__device__ __forceinline__ void block_publish_and_finish(float* __restrict__ job_partials, uint32_t tiles,
+                                                         unsigned* __restrict__ counter, JobState* st,
+                                                         const SolveArgs& args, int job) {
   if (args.mode == SOLVE_NONE) return;
   __shared__ unsigned s_is_last;
   __shared__ double s_sums[4][64];

@@ -194,6 +194,201 @@ __global__ void __launch_bounds__(256)
                            counters + pair, st, sa, pair);
 }
 
+
+// ---- MFMA accumulation -----------------------------------------------------------------------------
+// The per-pixel sums  H += J J^T, g += J r, ssq += r^2, count += 1  for the geometric and the colour
+// term are all entries of X^T X, where row p of X holds pixel p's 16 "features"
+//   [ Jg(6) | rg | Jc(6) | rc | live_g | live_c ].
+// v_mfma_f32_16x16x4_f32 computes a 16x16 f32 tile of A B with K = 4, exact f32 fma chains; with
+// A = X^T and B = X both operands are the SAME register: lane l supplies X[pixel l>>4][feature l&15]
+// (CDNA guide §3).  A wave's 64 pixels therefore take 16 MFMAs, fed by a transpose through a 4 KiB LDS
+// slab per wave: lane p writes its 16 features as one row, then reads X[4m + (l>>4)][l&15] for MFMA m.
+// What it buys: the 58 per-thread accumulators (58 VGPRs) become one 16x16 tile = 8 VGPRs (two
+// interleaved tiles), occupancy doubles, and the 54 accumulate FMAs per pixel leave the VALU for the
+// matrix pipe, which runs beside it.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// Row p of the slab is 16 floats; the four 16-byte chunks of a row are XOR-swizzled by (p >> 1) & 3 so
+// that the b128 row writes of 8 neighbouring lanes and the b32 transposed reads are both conflict-free.
+__device__ __forceinline__ int feat_chunk(int row, int chunk) { return row * 16 + ((chunk ^ ((row >> 1) & 3)) << 2); }
+
+// Index into the 16x16 tile of partial entry k (0..57): geometric then colour accumulator, each
+// 21 upper-triangle H, 6 g, ssq, count.
+__device__ __forceinline__ int tile_index_of_partial(int k) {
+  const int a = k >= GN_ACC ? 1 : 0, kk = k - a * GN_ACC, base = a * 7;
+  int row, col;
+  if (kk < 21) {
+    int i = 0, rem = kk;
+    while (rem >= 6 - i) { rem -= 6 - i; ++i; }
+    row = base + i, col = base + i + rem;
+  } else if (kk < 27) {
+    row = base + (kk - 21), col = base + 6;
+  } else if (kk == 27) {
+    row = col = base + 6;
+  } else {
+    row = col = 14 + a;
+  }
+  return row * 16 + col;
+}
+
+template <int PPT, int G, bool RAW>
+__global__ void __launch_bounds__(256)
+    image_icp_mfma_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
+                          float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve) {
+  static_assert(PPT % G == 0, "PPT must be a multiple of G");
+  __shared__ __attribute__((aligned(16))) float slab[4][64 * 16];  // per wave: 64 pixels x 16 features
+  const int pair = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* const my_slab = slab[wave];
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  JobState* st = &states[pair];
+  if (st->status == A3D_OK) {
+    const LevelDesc d = descs[pair];
+    const Pose T = st->pose;
+    const gptr_f4 src = (gptr_f4)d.src;
+    const gptr_f4 tgt = (gptr_f4)d.tgt;
+    const gptr_f imap = (gptr_f)d.imap;
+    const gptr_f src_points = (gptr_f)d.src_points, tgt_points = (gptr_f)d.tgt_points,
+                 tgt_normals = (gptr_f)d.tgt_normals;
+    const gptr_u8 src_mask = (gptr_u8)d.src_mask, src_int = (gptr_u8)d.src_intensities,
+                  tgt_mask = (gptr_u8)d.tgt_mask;
+    const uint32_t mw = d.tw + 2;
+    const float twf = (float)d.tw, thf = (float)d.th;
+    const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
+    // transposed-read offsets of this lane: row 4m + (lane >> 4), feature lane & 15
+    const int rd_row0 = lane >> 4, rd_chunk = (lane & 15) >> 2, rd_word = lane & 3;
+#pragma unroll 1
+    for (int k0 = 0; k0 < PPT; k0 += G) {
+      f32x4 s[G];
+      bool live[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
+        const bool inb = i < d.src_n;
+        const uint32_t ii = inb ? i : 0u;
+        if constexpr (RAW) {
+          s[g].x = src_points[3 * ii], s[g].y = src_points[3 * ii + 1], s[g].z = src_points[3 * ii + 2];
+          s[g].w = (float)src_int[ii];
+          live[g] = inb && (src_mask[ii] != 0);
+        } else {
+          s[g] = src[ii];
+          live[g] = inb && (s[g].w >= 0.0f);
+        }
+      }
+      V3 p[G];
+      float u[G], v[G];
+      f32x4 tp[G], tn[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        p[g] = transform_vector(T, V3{s[g].x, s[g].y, s[g].z});
+        u[g] = p[g].x * d.fx / p[g].z + d.cx;
+        v[g] = p[g].y * d.fy / p[g].z + d.cy;
+        const float ur = u[g] + 0.5f, vr = v[g] + 0.5f;
+        live[g] = live[g] && !(ur <= -1.0f || ur >= twf || vr <= -1.0f || vr >= thf);
+        const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
+        const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
+        const uint32_t tidx = live[g] ? row * d.tw + col : 0u;
+        if constexpr (RAW) {
+          tp[g].x = tgt_points[3 * tidx], tp[g].y = tgt_points[3 * tidx + 1], tp[g].z = tgt_points[3 * tidx + 2];
+          tp[g].w = tgt_mask[tidx] == 1 ? 1.0f : 0.0f;
+          tn[g].x = tgt_normals[3 * tidx], tn[g].y = tgt_normals[3 * tidx + 1], tn[g].z = tgt_normals[3 * tidx + 2];
+          tn[g].w = 0.0f;
+        } else {
+          tp[g] = tgt[2 * tidx];
+          tn[g] = tgt[2 * tidx + 1];
+        }
+      }
+      float t00[G], t10[G], t01[G], t11[G];
+      uint32_t ui[G], vi[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const V3 diff = V3{tp[g].x, tp[g].y, tp[g].z} - p[g];
+        const float pn = dot(p[g], V3{tn[g].x, tn[g].y, tn[g].z});
+        live[g] = live[g] && (tp[g].w == 1.0f) && !(norm_squared(diff) > gt.max_distance_sqr) &&
+                  !(pn >= -1.0f && pn <= gt.dot_reject_max);
+        ui[g] = live[g] ? f32_as_usize(u[g]) : 0u;
+        vi[g] = live[g] ? f32_as_usize(v[g]) : 0u;
+        const gptr_f r0 = imap + (size_t)vi[g] * mw + ui[g];
+        t00[g] = r0[0], t10[g] = r0[1], t01[g] = r0[mw], t11[g] = r0[mw + 1];
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        // ---- features of this lane's pixel (all zero when it is gated out) ----------------------
+        f32x4_t f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0, f2 = f0, f3 = f0;
+        if (live[g]) {
+          const V3 P = p[g];
+          const V3 n{tn[g].x, tn[g].y, tn[g].z};
+          const V3 diff = V3{tp[g].x, tp[g].y, tp[g].z} - P;
+          const float r = dot(diff, n);
+          const V3 tw = cross(P, n);
+          f0 = f32x4_t{n.x, n.y, n.z, tw.x};
+          f1.x = tw.y, f1.y = tw.z, f1.z = r;
+          f3.z = 1.0f;
+          const float uf = u[g] - (float)ui[g], vf = v[g] - (float)vi[g];
+          const float value = bilerp(t00[g], t10[g], t01[g], t11[g], uf, vf);
+          const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
+          const float u2 = u[g] + Hh, v2 = v[g] + Hh;
+          const float uh = (f32_as_usize(u2) == ui[g])
+                               ? bilerp(t00[g], t10[g], t01[g], t11[g], u2 - (float)ui[g], vf)
+                               : bilinear_at(imap, mw, u2, v[g]);
+          const float vh = (f32_as_usize(v2) == vi[g])
+                               ? bilerp(t00[g], t10[g], t01[g], t11[g], uf, v2 - (float)vi[g])
+                               : bilinear_at(imap, mw, u[g], v2);
+          const float du = (uh - value) * H_INV;
+          const float dv = (vh - value) * H_INV;
+          const float sc = s[g].w * 0.003921569f;
+          const float z = P.z, zz = z * z;
+          const float dfx = d.fx / z, dcx = -P.x * d.fx / zz;
+          const float dfy = d.fy / z, dcy = -P.y * d.fy / zz;
+          const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
+          const float rc = sc - value;
+          if (rc * rc <= gt.max_color_distance_sqr) {
+            const V3 twc = cross(P, gr);
+            f1.w = gr.x;
+            f2 = f32x4_t{gr.y, gr.z, twc.x, twc.y};
+            f3.x = twc.z, f3.y = rc, f3.w = 1.0f;
+          }
+        }
+        // ---- transpose through the wave's LDS slab, 16 MFMAs --------------------------------------
+        *(f32x4_t*)(my_slab + feat_chunk(lane, 0)) = f0;
+        *(f32x4_t*)(my_slab + feat_chunk(lane, 1)) = f1;
+        *(f32x4_t*)(my_slab + feat_chunk(lane, 2)) = f2;
+        *(f32x4_t*)(my_slab + feat_chunk(lane, 3)) = f3;
+        float x[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) x[m] = my_slab[feat_chunk(4 * m + rd_row0, rd_chunk) + rd_word];
+#pragma unroll
+        for (int m = 0; m < 16; m += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[m], x[m], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[m + 1], x[m + 1], acc1, 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- block partial: sum the four waves' tiles, pick the 58 entries, store write-through ----------
+  __syncthreads();  // every wave is done with its slab; reuse the first 4 KiB as [wave][256]
+  float* tiles_lds = &slab[0][0];
+  {
+    const f32x4_t t = acc0 + acc1;  // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+    const int colx = lane & 15, row4 = (lane >> 4) * 4;
+    tiles_lds[wave * 256 + (row4 + 0) * 16 + colx] = t.x;
+    tiles_lds[wave * 256 + (row4 + 1) * 16 + colx] = t.y;
+    tiles_lds[wave * 256 + (row4 + 2) * 16 + colx] = t.z;
+    tiles_lds[wave * 256 + (row4 + 3) * 16 + colx] = t.w;
+  }
+  __syncthreads();
+  float* job_partials = partials + (size_t)pair * gridDim.x * GN_PARTIAL;
+  if (threadIdx.x < GN_PARTIAL) {
+    const int e = tile_index_of_partial(threadIdx.x);
+    const float v = (tiles_lds[e] + tiles_lds[256 + e]) + (tiles_lds[512 + e] + tiles_lds[768 + e]);
+    __hip_atomic_store((unsigned*)(job_partials + (size_t)blockIdx.x * GN_PARTIAL) + threadIdx.x, __float_as_uint(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  SolveArgs sa = solve;
+  if (st->status != A3D_OK) sa.mode = SOLVE_NONE;
+  block_publish_and_finish(job_partials, gridDim.x, counters + pair, st, sa, pair);
+}
+
 }  // namespace
 
 // P independent coarse-to-fine alignments.  Owns only small state; the images are borrowed.
@@ -215,6 +410,7 @@ struct a3d_multiscale_batch {
   std::vector<hipEvent_t> kev;  // per pixel-kernel launch: start/stop pairs, when profiling
   bool profile_kernels = false;
   bool raw_layout = true;
+  bool use_mfma = true;
   float last_total_ms = 0.f, last_kernel_ms = 0.f;
   uint64_t last_kernel_launches = 0;
 
@@ -278,7 +474,13 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
   hipStream_t s = b->ctx->stream;
 #define A3D_LAUNCH(PPT, G)                                                                               \
   do {                                                                                                      \
-    if (b->raw_layout)                                                                                      \
+    if (b->use_mfma && b->raw_layout)                                                                       \
+      hipLaunchKernelGGL((image_icp_mfma_kernel<PPT, G, true>), grid, block, 0, s, descs, b->d_states,      \
+                         b->gates[level], b->d_partials, b->d_counters, solve);                             \
+    else if (b->use_mfma)                                                                                   \
+      hipLaunchKernelGGL((image_icp_mfma_kernel<PPT, G, false>), grid, block, 0, s, descs, b->d_states,     \
+                         b->gates[level], b->d_partials, b->d_counters, solve);                             \
+    else if (b->raw_layout)                                                                                 \
       hipLaunchKernelGGL((image_icp_kernel<PPT, G, true>), grid, block, 0, s, descs, b->d_states,           \
                          b->gates[level], b->d_partials, b->d_counters, solve);                             \
     else                                                                                                    \
@@ -342,6 +544,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   b->group.assign(n_levels, 1);
   b->h_descs.resize((size_t)n_levels * n_pairs);
   if (const char* env = getenv("A3D_ICP_LAYOUT")) b->raw_layout = strcmp(env, "packed") != 0;  // tuning knob
+  if (const char* env = getenv("A3D_ICP_ACCUM")) b->use_mfma = strcmp(env, "valu") != 0;        // tuning knob
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_states, n_pairs * sizeof(JobState)));
