@@ -268,10 +268,23 @@ __device__ __forceinline__ void block_publish_and_finish(float* __restrict__ job
   // ---- last block of this job ----
   const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
   double sum = 0.0;
-  if (c < GN_PARTIAL)
-    for (uint32_t t = slice; t < tiles; t += 4)
-      sum += (double)__uint_as_float(__hip_atomic_load((const unsigned*)job_partials + (size_t)t * GN_PARTIAL + c,
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  if (c < GN_PARTIAL) {
+    // tile t of slice s is t = s + 4 j; eight loads in flight per thread, summed in tile order
+    const unsigned* base = (const unsigned*)job_partials + c;
+    uint32_t t = slice;
+    for (; t + 28 < tiles; t += 32) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        v[k] = __uint_as_float(__hip_atomic_load(base + (size_t)(t + 4 * k) * GN_PARTIAL, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum += (double)v[k];
+    }
+    for (; t < tiles; t += 4)
+      sum += (double)__uint_as_float(
+          __hip_atomic_load(base + (size_t)t * GN_PARTIAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
   s_sums[slice][c] = sum;
   __syncthreads();
   if (threadIdx.x < 64) s_sums[0][c] = (s_sums[0][c] + s_sums[1][c]) + (s_sums[2][c] + s_sums[3][c]);

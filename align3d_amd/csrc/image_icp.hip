@@ -489,6 +489,9 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
   } while (0)
   const uint32_t g = b->group[level];
   switch (b->ppt[level] * 16 + g) {
+    case 16 * 16 + 2: A3D_LAUNCH(16, 2); break;
+    case 16 * 16 + 1: A3D_LAUNCH(16, 1); break;
+    case 32 * 16 + 2: A3D_LAUNCH(32, 2); break;
     case 8 * 16 + 4: A3D_LAUNCH(8, 4); break;
     case 8 * 16 + 2: A3D_LAUNCH(8, 2); break;
     case 8 * 16 + 1: A3D_LAUNCH(8, 1); break;
