@@ -410,7 +410,7 @@ struct a3d_multiscale_batch {
   std::vector<hipEvent_t> kev;  // per pixel-kernel launch: start/stop pairs, when profiling
   bool profile_kernels = false;
   bool raw_layout = true;
-  bool use_mfma = true;
+  bool use_mfma = false;  // VALU accumulation measured faster on MI355X so far (kernel variants)
   float last_total_ms = 0.f, last_kernel_ms = 0.f;
   uint64_t last_kernel_launches = 0;
 
@@ -547,7 +547,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   b->group.assign(n_levels, 1);
   b->h_descs.resize((size_t)n_levels * n_pairs);
   if (const char* env = getenv("A3D_ICP_LAYOUT")) b->raw_layout = strcmp(env, "packed") != 0;  // tuning knob
-  if (const char* env = getenv("A3D_ICP_ACCUM")) b->use_mfma = strcmp(env, "valu") != 0;        // tuning knob
+  if (const char* env = getenv("A3D_ICP_ACCUM")) b->use_mfma = strcmp(env, "mfma") == 0;        // tuning knob
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_states, n_pairs * sizeof(JobState)));
