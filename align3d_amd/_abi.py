@@ -155,6 +155,7 @@ SIGNATURES = {
     "a3d_pcl_icp_new": (_ST, [_P, C.POINTER(IcpParamsC), C.POINTER(PointCloudViewC), _PP]),
     "a3d_pcl_icp_align": (_ST, [_P, C.POINTER(PointCloudViewC), C.POINTER(PoseC)]),
     "a3d_pcl_icp_accumulate": (_ST, [_P, C.POINTER(PointCloudViewC), C.POINTER(PoseC), C.POINTER(GnStateC)]),
+    "a3d_pcl_icp_last_device_ms": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_pcl_icp_free": (_ST, [_P]),
     "a3d_bilateral_default_sigmas": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "a3d_bilateral_filter_u16": (

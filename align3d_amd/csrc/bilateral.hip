@@ -33,9 +33,12 @@ __global__ void __launch_bounds__(256)
     mi = min(mi, (uint32_t)__shfl_xor((int)mi, off, 64));
     ma = max(ma, (uint32_t)__shfl_xor((int)ma, off, 64));
   }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMin(&out_minmax[0], mi);
-    atomicMax(&out_minmax[1], ma);
+  __shared__ uint32_t s_mi[4], s_ma[4];
+  if ((threadIdx.x & 63) == 0) s_mi[threadIdx.x >> 6] = mi, s_ma[threadIdx.x >> 6] = ma;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one atomic pair per block: 64 blocks, not thousands of waves, meet on the two words
+    atomicMin(&out_minmax[0], min(min(s_mi[0], s_mi[1]), min(s_mi[2], s_mi[3])));
+    atomicMax(&out_minmax[1], max(max(s_ma[0], s_ma[1]), max(s_ma[2], s_ma[3])));
   }
 }
 
@@ -152,7 +155,7 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
                        hipMemcpyAsync(d_scal, h_scal, 12, hipMemcpyHostToDevice, s) != hipSuccess))
     fail("upload");
   if (st == A3D_OK) {
-    hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, s, d_img, n,
+    hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64)), dim3(256), 0, s, d_img, n,
                        d_scal);
     if (hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)

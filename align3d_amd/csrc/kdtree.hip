@@ -155,6 +155,8 @@ struct a3d_pcl_icp {
   float* d_partials = nullptr;
   unsigned* d_counter = nullptr;
   double* d_readback = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the iteration launches of the last align
+  float last_device_ms = 0.f;
 };
 
 extern "C" {
@@ -311,6 +313,11 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
   hipStream_t s = icp->ctx->stream;
   const uint32_t m = (uint32_t)source->len;
   // Icp::align starts from Transform::eye(): initial_transform is ignored (pcl_icp.rs:59)
+  if (!icp->ev0) {
+    hipEventCreate(&icp->ev0);
+    hipEventCreate(&icp->ev1);
+  }
+  if (st == A3D_OK) hipEventRecord(icp->ev0, s);
   if (st == A3D_OK) st = launch_job_init(s, icp->d_state, nullptr, 1);
   for (uint64_t it = 0; st == A3D_OK && it < icp->params.max_iterations; ++it) {
     SolveArgs sa{};
@@ -320,9 +327,11 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
     st = pcl_launch_pass(icp, d_pts, d_nrm, m, sa);
   }
   JobState h;
+  if (st == A3D_OK) hipEventRecord(icp->ev1, s);
   if (st == A3D_OK && hipMemcpyAsync(&h, icp->d_state, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess)
     st = A3D_HIP_ERROR;
   if (hipStreamSynchronize(s) != hipSuccess && st == A3D_OK) st = A3D_HIP_ERROR;
+  if (st == A3D_OK) hipEventElapsedTime(&icp->last_device_ms, icp->ev0, icp->ev1);
   hipFree(d_pts);
   hipFree(d_nrm);
   if (st == A3D_HIP_ERROR) set_error("a3d_pcl_icp_align: HIP failure: %s", hipGetErrorString(hipGetLastError()));
@@ -361,6 +370,14 @@ a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* 
   return A3D_OK;
 }
 
+// Instrumentation: device time of the iteration launches of the most recent a3d_pcl_icp_align
+// (source already uploaded), between hipEvents on the context stream.
+a3d_status a3d_pcl_icp_last_device_ms(a3d_pcl_icp* icp, float* out_ms) {
+  A3D_REQUIRE(icp && out_ms, A3D_INVALID_PARAMETER, "null argument");
+  *out_ms = icp->last_device_ms;
+  return A3D_OK;
+}
+
 a3d_status a3d_pcl_icp_free(a3d_pcl_icp* icp) {
   if (!icp) return A3D_OK;
   hipStreamSynchronize(icp->ctx->stream);
@@ -369,6 +386,8 @@ a3d_status a3d_pcl_icp_free(a3d_pcl_icp* icp) {
   hipFree(icp->d_partials);
   hipFree(icp->d_counter);
   hipFree(icp->d_readback);
+  if (icp->ev0) hipEventDestroy(icp->ev0);
+  if (icp->ev1) hipEventDestroy(icp->ev1);
   delete icp;
   return A3D_OK;
 }

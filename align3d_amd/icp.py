@@ -221,6 +221,11 @@ class Icp:
         _abi.check(self.ctx.lib.a3d_pcl_icp_align(self.handle, C.byref(v), C.byref(out)), "Icp::align")
         return Transform.from_c(out)
 
+    def last_device_ms(self):
+        ms = C.c_float()
+        _abi.check(self.ctx.lib.a3d_pcl_icp_last_device_ms(self.handle, C.byref(ms)))
+        return ms.value
+
     def accumulate(self, source, transform):
         v = source.view()
         t = transform.to_c()

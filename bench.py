@@ -77,6 +77,74 @@ def kdtree_bench(ctx, n=500_000, reps=20):
     }
 
 
+def pcl_icp_bench(ctx, n=500_000):
+    """configs[2]: Icp (kd-tree point-to-plane) on 500k target x 500k source points, IcpParams::default()."""
+    from align3d_amd import Icp, PointCloud, RangeImage
+
+    frames, poses = synth.frame_stream(7, 2, 880, 660)
+    cam = synth.camera(880, 660)
+    clouds = []
+    for d, rgb in frames:
+        ri = RangeImage.from_rgbd_image(cam, d, rgb, synth.DEPTH_SCALE).compute_normals(ctx)
+        pc = PointCloud.from_range_image(ri)
+        clouds.append(PointCloud(pc.points[:n], pc.normals[:n]))
+    tgt, src = clouds
+    t0 = time.time()
+    icp = Icp.new(ctx, IcpParams.default(), tgt)
+    build_s = time.time() - t0
+    icp.align(src)
+    times = []
+    for _ in range(3):
+        T = icp.align(src)
+        times.append(icp.last_device_ms())
+    ms = float(np.median(times))
+    iters = 15
+    alg = 252 * src.len() * iters  # SURVEY §8(d): 252 B per source point per iteration
+    gt = synth.relative_pose(poses[0], poses[1])
+    dm = np.linalg.inv(gt) @ T.matrix().astype(np.float64)
+    icp.free()
+    return {
+        "workload": f"Icp::align, {tgt.len()} target x {src.len()} source points, 15 iterations (configs[2])",
+        "device_ms_per_align": ms, "aligns_per_s": 1e3 / ms, "kdtree_host_build_s": build_s,
+        "error_vs_synthetic_gt": {"angle_rad": float(np.arccos(np.clip((np.trace(dm[:3, :3]) - 1) / 2, -1, 1))),
+                                  "translation_m": float(np.linalg.norm(dm[:3, 3]))},
+        "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+    }
+
+
+def frame_prep_bench(ctx, host_pyramid_level0, depth_u16):
+    """compute_normals (device-resident) and the bilateral filter (host in/out API, so the figure includes the
+    PCIe copies of the 0.6 MB image) on one 640x480 frame."""
+    import copy
+
+    ri = copy.copy(host_pyramid_level0)
+    ri._device = None
+    dev = ri.device(ctx)
+    for _ in range(3):
+        dev.compute_normals()
+    ctx.synchronize()
+    ctx.timer_start()
+    for _ in range(20):
+        dev.compute_normals()
+    n_ms = ctx.timer_stop() / 20  # includes the re-pack of the 32-byte target records after each call
+    dev.free()
+    f = BilateralFilter.default()
+    f.filter(ctx, depth_u16)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        f.filter(ctx, depth_u16)
+    b_ms = (time.perf_counter() - t0) / 5 * 1e3
+    n_px = depth_u16.size
+    cells = int(np.prod(f.last_grid_dims))
+    return {
+        "compute_normals_ms": n_ms,
+        "compute_normals_frac_of_8TBs": 25 * n_px / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bilateral_filter_ms_host_to_host": b_ms, "bilateral_grid_dims": list(f.last_grid_dims),
+        "bilateral_algorithmic_MB": (72 * n_px + 192 * cells) / 1e6,
+    }
+
+
 def cpu_baseline(host_pyramids, params, n_pairs, gpu_poses):
     """The CPU oracle ("port": a restatement, not the Rust reference) on the first n_pairs pairs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -227,6 +295,8 @@ def main():
                 ms1.align(sources[0])
             extra["single_pair_ms3x15_latency_ms"] = (time.perf_counter() - t1) / 5 * 1e3
             extra["kdtree"] = kdtree_bench(ctx)
+            extra["pcl_icp"] = pcl_icp_bench(ctx)
+            extra["frame_prep"] = frame_prep_bench(ctx, host_pyramids[0][0], synth.frame_stream(1000, 1, W, H)[0][0][0])
             # host -> HBM hand-over of one 3-level pyramid (what a caller with host buffers pays per new frame)
             import copy
 

@@ -235,6 +235,8 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
 /* One pass of the per-point body (pcl_icp.rs:68-92) from `pose`: test hook. */
 a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* source,
                                   const a3d_pose* pose, a3d_gn_state* out_state);
+/* Instrumentation: device time (ms) of the iteration launches of the most recent a3d_pcl_icp_align. */
+a3d_status a3d_pcl_icp_last_device_ms(a3d_pcl_icp* icp, float* out_ms);
 a3d_status a3d_pcl_icp_free(a3d_pcl_icp* icp);
 
 /* ---- BilateralFilter<u16> (src/bilateral/edge_aware_filter.rs:30-135, grid.rs:32-162) ----- */

@@ -72,3 +72,22 @@ def test_kdtree_nan_point_is_an_error(ctx):
     with pytest.raises(A3dError) as e:
         R3dTree.new(ctx, db)
     assert e.value.status == 5
+
+
+def test_kdtree_full_size_500k_bit_exact(ctx):
+    """BASELINE's kd-tree shape: 500 000 database x 500 000 queries, uniform [0,1)^3 (benches/bench_kdtree.rs)."""
+    n = 500_000
+    db = uniform01(10, 3 * n).reshape(n, 3)
+    q = uniform01(11, 3 * n).reshape(n, 3)
+    ref = O.KdTree(db)
+    tree = R3dTree.new(ctx, db)
+    assert tree.stats() == ref.stats() == (32768, 32767, 15)
+    ridx, rd = ref.nearest(q)
+    gidx, gd = tree.nearest(q)
+    assert np.array_equal(gidx, ridx) and np.array_equal(gd.view(np.uint32), rd.view(np.uint32))
+    # size-independent properties: every database point finds itself at distance 0 (distinct coordinates),
+    # and the search is a pure function of the query (idempotent on repeat)
+    sidx, sd = tree.nearest(db)
+    assert np.array_equal(sidx, np.arange(n, dtype=np.uint64)) and not sd.any()
+    g2, d2 = tree.nearest(q)
+    assert np.array_equal(g2, gidx) and np.array_equal(d2, gd)
