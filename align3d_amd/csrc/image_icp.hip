@@ -266,24 +266,31 @@ __global__ void __launch_bounds__(256)
     const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
     // transposed-read offsets of this lane: row 4m + (lane >> 4), feature lane & 15
     const int rd_row0 = lane >> 4, rd_chunk = (lane & 15) >> 2, rd_word = lane & 3;
+    auto load_source = [&](int k0, f32x4(&sv)[G], bool(&lv)[G]) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
+        const bool inb = (k0 < PPT) && (i < d.src_n);
+        const uint32_t ii = inb ? i : 0u;
+        if constexpr (RAW) {
+          sv[g].x = src_points[3 * ii], sv[g].y = src_points[3 * ii + 1], sv[g].z = src_points[3 * ii + 2];
+          sv[g].w = (float)src_int[ii];
+          lv[g] = inb && (src_mask[ii] != 0);
+        } else {
+          sv[g] = src[ii];
+          lv[g] = inb && (sv[g].w >= 0.0f);
+        }
+      }
+    };
+    f32x4 s_next[G];
+    bool live_next[G];
+    load_source(0, s_next, live_next);
 #pragma unroll 1
     for (int k0 = 0; k0 < PPT; k0 += G) {
       f32x4 s[G];
       bool live[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
-        const bool inb = i < d.src_n;
-        const uint32_t ii = inb ? i : 0u;
-        if constexpr (RAW) {
-          s[g].x = src_points[3 * ii], s[g].y = src_points[3 * ii + 1], s[g].z = src_points[3 * ii + 2];
-          s[g].w = (float)src_int[ii];
-          live[g] = inb && (src_mask[ii] != 0);
-        } else {
-          s[g] = src[ii];
-          live[g] = inb && (s[g].w >= 0.0f);
-        }
-      }
+      for (int g = 0; g < G; ++g) s[g] = s_next[g], live[g] = live_next[g];
       V3 p[G];
       float u[G], v[G];
       f32x4 tp[G], tn[G];
@@ -307,6 +314,7 @@ __global__ void __launch_bounds__(256)
           tn[g] = tgt[2 * tidx + 1];
         }
       }
+      if (PPT > G) load_source(k0 + G, s_next, live_next);
       float t00[G], t10[G], t01[G], t11[G];
       uint32_t ui[G], vi[G];
 #pragma unroll
