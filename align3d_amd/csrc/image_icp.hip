@@ -44,6 +44,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gptr_f4;
 typedef const float __attribute__((address_space(1)))* gptr_f;
 typedef const uint8_t __attribute__((address_space(1)))* gptr_u8;
+// One 12-byte Vector3<f32> as ONE global_load_dwordx3.  Three separate dword loads at a 12-byte lane
+// stride make the L1 look up every 64-byte line of the wave's 768-byte span three times; measured, that
+// tag traffic (5.3 line lookups per pixel) was what bounded the kernel, not HBM.
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef f32x3 __attribute__((aligned(4))) f32x3_u;
+typedef const f32x3_u __attribute__((address_space(1)))* gptr_f3;
+__device__ __forceinline__ f32x3 load3(gptr_f base, uint32_t idx) { return *(gptr_f3)(base + 3 * idx); }
 
 // IntensityMap::bilinear (src/intensity_map.rs:150-169) from four already-loaded texels.
 __device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v11, float uf, float vf) {
@@ -95,7 +102,8 @@ __global__ void __launch_bounds__(256)
         const bool inb = (k0 < PPT) && (i < d.src_n);
         const uint32_t ii = inb ? i : 0u;
         if constexpr (RAW) {
-          sv[g].x = src_points[3 * ii], sv[g].y = src_points[3 * ii + 1], sv[g].z = src_points[3 * ii + 2];
+          const f32x3 sp = load3(src_points, ii);
+          sv[g].x = sp.x, sv[g].y = sp.y, sv[g].z = sp.z;
           sv[g].w = (float)src_int[ii];
           lv[g] = inb && (src_mask[ii] != 0);  // mask != 0 (image_icp.rs:102)
         } else {
@@ -130,9 +138,10 @@ __global__ void __launch_bounds__(256)
         const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
         const uint32_t tidx = live[g] ? row * d.tw + col : 0u;
         if constexpr (RAW) {
-          tp[g].x = tgt_points[3 * tidx], tp[g].y = tgt_points[3 * tidx + 1], tp[g].z = tgt_points[3 * tidx + 2];
+          const f32x3 tpp = load3(tgt_points, tidx), tnn = load3(tgt_normals, tidx);
+          tp[g].x = tpp.x, tp[g].y = tpp.y, tp[g].z = tpp.z;
           tp[g].w = tgt_mask[tidx] == 1 ? 1.0f : 0.0f;
-          tn[g].x = tgt_normals[3 * tidx], tn[g].y = tgt_normals[3 * tidx + 1], tn[g].z = tgt_normals[3 * tidx + 2];
+          tn[g].x = tnn.x, tn[g].y = tnn.y, tn[g].z = tnn.z;
           tn[g].w = 0.0f;
         } else {
           tp[g] = tgt[2 * tidx];
@@ -273,7 +282,8 @@ __global__ void __launch_bounds__(256)
         const bool inb = (k0 < PPT) && (i < d.src_n);
         const uint32_t ii = inb ? i : 0u;
         if constexpr (RAW) {
-          sv[g].x = src_points[3 * ii], sv[g].y = src_points[3 * ii + 1], sv[g].z = src_points[3 * ii + 2];
+          const f32x3 sp = load3(src_points, ii);
+          sv[g].x = sp.x, sv[g].y = sp.y, sv[g].z = sp.z;
           sv[g].w = (float)src_int[ii];
           lv[g] = inb && (src_mask[ii] != 0);
         } else {
@@ -305,9 +315,10 @@ __global__ void __launch_bounds__(256)
         const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
         const uint32_t tidx = live[g] ? row * d.tw + col : 0u;
         if constexpr (RAW) {
-          tp[g].x = tgt_points[3 * tidx], tp[g].y = tgt_points[3 * tidx + 1], tp[g].z = tgt_points[3 * tidx + 2];
+          const f32x3 tpp = load3(tgt_points, tidx), tnn = load3(tgt_normals, tidx);
+          tp[g].x = tpp.x, tp[g].y = tpp.y, tp[g].z = tpp.z;
           tp[g].w = tgt_mask[tidx] == 1 ? 1.0f : 0.0f;
-          tn[g].x = tgt_normals[3 * tidx], tn[g].y = tgt_normals[3 * tidx + 1], tn[g].z = tgt_normals[3 * tidx + 2];
+          tn[g].x = tnn.x, tn[g].y = tnn.y, tn[g].z = tnn.z;
           tn[g].w = 0.0f;
         } else {
           tp[g] = tgt[2 * tidx];
