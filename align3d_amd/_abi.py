@@ -135,6 +135,7 @@ SIGNATURES = {
         _ST,
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(PoseC), _P],
     ),
+    "a3d_selftest_division": (_ST, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "a3d_multiscale_new": (_ST, [_P, C.POINTER(IcpParamsC), C.c_uint64, _PP, C.c_uint64, _PP]),
     "a3d_multiscale_align": (_ST, [_P, _PP, C.c_uint64, C.POINTER(PoseC)]),
     "a3d_multiscale_free": (_ST, [_P]),

@@ -61,8 +61,7 @@ struct a3d_context {
   int num_cus = 0;
 };
 
-// One RangeImage in HBM.  Raw arrays keep the reference layout; the packed arrays are what the ICP
-// kernel reads (DESIGN.md "Data layout in HBM").
+// One RangeImage in HBM, in the reference's own standard layout (DESIGN.md "Data layout in HBM").
 struct a3d_device_image {
   a3d_context* ctx = nullptr;
   uint32_t width = 0, height = 0;
@@ -72,14 +71,5 @@ struct a3d_device_image {
   float* normals = nullptr;              // [h][w][3] or null
   uint8_t* intensities = nullptr;        // [h*w] or null
   float* imap = nullptr;                 // [(h+2)][(w+2)] or null
-  float4* src_pack = nullptr;            // [h*w]   {x, y, z, intensity or -1 when mask == 0}
-  float4* tgt_pack = nullptr;            // [h*w][2] {x, y, z, mask == 1}, {nx, ny, nz, 0}
   bool has_normals = false, has_intensities = false, has_imap = false;
-  bool src_pack_valid = false, tgt_pack_valid = false;
 };
-
-namespace a3d {
-// Builds (or refreshes) the packed arrays an image needs to act as ICP source / target.
-a3d_status ensure_source_pack(a3d_device_image* im);
-a3d_status ensure_target_pack(a3d_device_image* im);
-}  // namespace a3d

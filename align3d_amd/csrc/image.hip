@@ -1,34 +1,9 @@
-// Range images resident in HBM: upload, the packed layouts the ICP kernel reads, and
-// RangeImage::compute_normals (src/range_image/structure.rs:184-262) as an LDS-tiled stencil.
+// Range images resident in HBM: upload and RangeImage::compute_normals (src/range_image/structure.rs:184-262) as an LDS-tiled stencil.
 #include "common.hpp"
 
 using namespace a3d;
 
 namespace {
-
-// ---- packing ----------------------------------------------------------------------------------
-// Source side of ImageIcp: one 16-byte record per pixel, read as a coalesced float4 stream.
-// w = intensity (exact in f32) when mask != 0 (src/icp/image_icp.rs:102), -1 otherwise.
-__global__ void pack_source_kernel(const float* __restrict__ points, const uint8_t* __restrict__ mask,
-                                   const uint8_t* __restrict__ intensities, float4* __restrict__ out,
-                                   uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float w = -1.0f;
-  if (mask[i] != 0) w = intensities ? (float)intensities[i] : 0.0f;
-  out[i] = make_float4(points[3 * i], points[3 * i + 1], points[3 * i + 2], w);
-}
-
-// Target side: one 32-byte record per pixel = point + validity (mask == 1, RangeImage::get_point,
-// structure.rs:176) and normal, so the projective gather touches one 32-byte sector.
-__global__ void pack_target_kernel(const float* __restrict__ points, const uint8_t* __restrict__ mask,
-                                   const float* __restrict__ normals, float4* __restrict__ out,
-                                   uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  out[2 * i] = make_float4(points[3 * i], points[3 * i + 1], points[3 * i + 2], mask[i] == 1 ? 1.0f : 0.0f);
-  out[2 * i + 1] = make_float4(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 0.0f);
-}
 
 // ---- compute_normals ----------------------------------------------------------------------------
 constexpr int TILE_W = 32, TILE_H = 8;  // 256 threads; LDS tile (TILE_W+2) x (TILE_H+2) with 1-px halo
@@ -40,11 +15,6 @@ __device__ __forceinline__ V3 masked_point(const float* __restrict__ points, con
   int idx = row * w + col;
   if (mask[idx] != 1) return {0.f, 0.f, 0.f};
   return {points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
-}
-
-__device__ __forceinline__ V3 pick_direction(V3 lo, V3 hi, V3 center, bool hi_minus_lo_is_result) {
-  (void)hi_minus_lo_is_result;
-  return hi - lo;
 }
 
 __global__ void __launch_bounds__(TILE_W* TILE_H)
@@ -116,39 +86,13 @@ a3d_status launch_compute_normals(a3d_context* ctx, const float* points, const u
 
 }  // namespace
 
-namespace a3d {
-
-a3d_status ensure_source_pack(a3d_device_image* im) {
-  if (im->src_pack_valid) return A3D_OK;
-  const uint32_t n = im->width * im->height;
-  if (!im->src_pack) A3D_HIP_TRY(hipMalloc((void**)&im->src_pack, (size_t)n * sizeof(float4)));
-  hipLaunchKernelGGL(pack_source_kernel, dim3((n + 255) / 256), dim3(256), 0, im->ctx->stream, im->points,
-                     im->mask, im->intensities, im->src_pack, n);
-  A3D_HIP_TRY(hipGetLastError());
-  im->src_pack_valid = true;
-  return A3D_OK;
-}
-
-a3d_status ensure_target_pack(a3d_device_image* im) {
-  if (im->tgt_pack_valid || !im->has_normals) return A3D_OK;
-  const uint32_t n = im->width * im->height;
-  if (!im->tgt_pack) A3D_HIP_TRY(hipMalloc((void**)&im->tgt_pack, (size_t)n * 2 * sizeof(float4)));
-  hipLaunchKernelGGL(pack_target_kernel, dim3((n + 255) / 256), dim3(256), 0, im->ctx->stream, im->points,
-                     im->mask, im->normals, im->tgt_pack, n);
-  A3D_HIP_TRY(hipGetLastError());
-  im->tgt_pack_valid = true;
-  return A3D_OK;
-}
-
-}  // namespace a3d
-
 extern "C" {
 
 a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* v, a3d_device_image** out) {
   A3D_REQUIRE(ctx && v && out, A3D_INVALID_PARAMETER, "null argument");
   A3D_REQUIRE(v->points && v->mask, A3D_INVALID_PARAMETER, "RangeImage needs points and mask");
-  A3D_REQUIRE(v->width > 0 && v->height > 0 && v->width * v->height < (1ull << 30), A3D_INVALID_PARAMETER,
-              "bad image size");
+  A3D_REQUIRE(v->width > 0 && v->height > 0 && v->width * v->height < (1ull << 28), A3D_INVALID_PARAMETER,
+              "bad image size (at most 2^28 pixels: the kernels address the arrays with 32-bit byte offsets)");
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   a3d_device_image* im = new a3d_device_image();
   im->ctx = ctx;
@@ -170,8 +114,6 @@ a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* 
     st = upload_array(ctx, v->intensity_map, (size_t)(im->width + 2) * (im->height + 2), &im->imap);
     im->has_imap = true;
   }
-  if (st == A3D_OK) st = ensure_source_pack(im);
-  if (st == A3D_OK) st = ensure_target_pack(im);
   if (st == A3D_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
     set_error("upload failed");
     st = A3D_HIP_ERROR;
@@ -192,8 +134,6 @@ a3d_status a3d_range_image_free(a3d_device_image* im) {
   hipFree(im->normals);
   hipFree(im->intensities);
   hipFree(im->imap);
-  hipFree(im->src_pack);
-  hipFree(im->tgt_pack);
   delete im;
   return A3D_OK;
 }
@@ -204,8 +144,7 @@ a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
   if (!im->normals) A3D_HIP_TRY(hipMalloc((void**)&im->normals, n * 3 * sizeof(float)));
   A3D_TRY(launch_compute_normals(im->ctx, im->points, im->mask, im->normals, im->width, im->height));
   im->has_normals = true;
-  im->tgt_pack_valid = false;
-  return ensure_target_pack(im);
+  return A3D_OK;
 }
 
 a3d_status a3d_range_image_download_normals(a3d_device_image* im, float* out) {

@@ -11,18 +11,16 @@ using namespace a3d;
 
 namespace {
 
-// What the per-pixel kernel needs to know about one (pair, level): resident arrays + intrinsics.
+// What the per-pixel kernel needs to know about one (pair, level): the resident arrays, in the
+// reference's own layout (14 B per source pixel, 25 B per target pixel, 4 B per map texel), + intrinsics.
 struct LevelDesc {
-  const float4* src;  // [src_n] {x, y, z, intensity | -1}
-  const float4* tgt;  // [th*tw][2] {x, y, z, valid}, {nx, ny, nz, 0}
-  const float* imap;  // [(th+2)][(tw+2)]
-  // the same data in the reference's own layout (RAW kernels): 14 B per source pixel, 25 B per target pixel
   const float* src_points;         // [src_n][3]
   const uint8_t* src_mask;         // [src_n]
   const uint8_t* src_intensities;  // [src_n]
   const float* tgt_points;         // [th*tw][3]
   const float* tgt_normals;        // [th*tw][3]
   const uint8_t* tgt_mask;         // [th*tw]
+  const float* imap;               // [(th+2)][(tw+2)]
   uint32_t src_n;
   uint32_t tw, th;
   float fx, fy, cx, cy;
@@ -38,19 +36,51 @@ struct Gates {
 // `u as usize` (Rust): NaN and negatives -> 0; the callers only see u < width.
 __device__ __forceinline__ uint32_t f32_as_usize(float x) { return x > 0.0f ? (uint32_t)x : 0u; }
 
-// Pointers read out of a descriptor are generic; the arrays live in global memory, and saying so
-// gives global_load instead of flat_load (one counter to wait on, free scheduling).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef const f32x4 __attribute__((address_space(1)))* gptr_f4;
-typedef const float __attribute__((address_space(1)))* gptr_f;
-typedef const uint8_t __attribute__((address_space(1)))* gptr_u8;
-// One 12-byte Vector3<f32> as ONE global_load_dwordx3.  Three separate dword loads at a 12-byte lane
-// stride make the L1 look up every 64-byte line of the wave's 768-byte span three times; measured, that
-// tag traffic (5.3 line lookups per pixel) was what bounded the kernel, not HBM.
+// ---- loads ------------------------------------------------------------------------------------------
+// Array bases come out of a descriptor (uniform, SGPRs); every access is base + 32-bit byte offset in
+// the global address space, which selects the `global_load … v_off, s[base]` form: no 64-bit address
+// arithmetic in the VALU.  (Images are limited to 2^28 pixels at upload, so offsets fit.)
+typedef const char __attribute__((address_space(1)))* gptr_c;
+template <typename T>
+__device__ __forceinline__ T ld(const void* base, uint32_t byte_off) {
+  return *(const T __attribute__((address_space(1)))*)((gptr_c)base + byte_off);
+}
+// One 12-byte Vector3<f32> is ONE global_load_dwordx3.  Three dword loads at a 12-byte lane stride make
+// the L1 look up every 64-byte line of the wave's 768-byte span three times (measured: 5.3 tag lookups
+// per pixel, which bounded the first versions of this kernel).
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef f32x3 __attribute__((aligned(4))) f32x3_u;
-typedef const f32x3_u __attribute__((address_space(1)))* gptr_f3;
-__device__ __forceinline__ f32x3 load3(gptr_f base, uint32_t idx) { return *(gptr_f3)(base + 3 * idx); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 __attribute__((aligned(4))) f32x2_u;
+__device__ __forceinline__ V3 ld_v3(const float* base, uint32_t idx) {
+  const f32x3 v = ld<f32x3_u>(base, idx * 12u);
+  return {v.x, v.y, v.z};
+}
+
+// ---- IEEE division with a shared reciprocal -------------------------------------------------------------
+// The reference divides six times per pixel, four times by z and twice by z*z.  a / z below is the
+// arithmetic of the compiler's own correctly rounded f32 division (reciprocal estimate, one Newton step,
+// quotient, two fma corrections) minus its range scaling, with the refined reciprocal computed once per
+// denominator.  It returns the correctly rounded quotient for operands in `div_fast_ok` range (checked on
+// 2e8 random pairs against IEEE division, and on the device by a3d_selftest_division); anything else takes
+// the plain `/`.
+struct DivBy {
+  float negz, y;
+};
+__device__ __forceinline__ DivBy div_prepare(float z) {
+  const float r = __builtin_amdgcn_rcpf(z);
+  const float e = __builtin_fmaf(-z, r, 1.0f);
+  return {-z, __builtin_fmaf(e, r, r)};
+}
+__device__ __forceinline__ float div_by(float a, const DivBy d) {
+  const float q = a * d.y;
+  const float r1 = __builtin_fmaf(d.negz, q, a);
+  const float q1 = __builtin_fmaf(r1, d.y, q);
+  const float r2 = __builtin_fmaf(d.negz, q1, a);
+  return __builtin_fmaf(r2, d.y, q1);
+}
+__device__ __forceinline__ bool div_den_ok(float z) { return fabsf(z) > 1e-9f && fabsf(z) < 1e9f; }
+__device__ __forceinline__ bool div_num_ok(float a) { return a == 0.0f || (fabsf(a) > 1e-20f && fabsf(a) < 1e9f); }
 
 // IntensityMap::bilinear (src/intensity_map.rs:150-169) from four already-loaded texels.
 __device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v11, float uf, float vf) {
@@ -58,19 +88,124 @@ __device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v
   float u1 = v01 * (1.0f - uf) + v11 * uf;
   return u0 * (1.0f - vf) + u1 * vf;
 }
-
-__device__ __forceinline__ float bilinear_at(gptr_f imap, uint32_t mw, float u, float v) {
-  uint32_t ui = f32_as_usize(u), vi = f32_as_usize(v);
-  gptr_f r0 = imap + (size_t)vi * mw + ui;
-  return bilerp(r0[0], r0[1], r0[mw], r0[mw + 1], u - (float)ui, v - (float)vi);
+__device__ __forceinline__ float bilinear_at(const float* imap, uint32_t mw, float u, float v) {
+  const uint32_t ui = f32_as_usize(u), vi = f32_as_usize(v);
+  const uint32_t o = (vi * mw + ui) * 4u;
+  const f32x2 a = ld<f32x2_u>(imap, o), b = ld<f32x2_u>(imap, o + mw * 4u);
+  return bilerp(a.x, a.y, b.x, b.y, u - (float)ui, v - (float)vi);
 }
 
-// The reference's pixel loop (image_icp.rs:101-139).  grid = (tiles, pairs); block = 256.  A thread
-// visits PPT source pixels, 256 apart (coalesced), G at a time: the G source records are loaded
-// together, then the G projective gathers of the target record, then the G intensity-map cells, so
-// that each dependent memory round trip is paid once per G pixels; only the accumulation is under
-// the per-pixel gates.
-template <int PPT, int G, bool RAW>
+// ---- the reference's pixel loop (image_icp.rs:101-139), in four stages -----------------------------------
+struct SrcPx {  // stage A: one source record
+  V3 sp;
+  float intensity;  // u8 as f32 (exact)
+  bool live;
+};
+__device__ __forceinline__ SrcPx stage_a(const LevelDesc& d, uint32_t i, bool in_range) {
+  const uint32_t ii = in_range ? i : 0u;
+  SrcPx s;
+  s.sp = ld_v3(d.src_points, ii);
+  s.intensity = (float)ld<uint8_t>(d.src_intensities, ii);
+  s.live = in_range && (ld<uint8_t>(d.src_mask, ii) != 0);  // mask != 0 (image_icp.rs:102)
+  return s;
+}
+
+struct ProjPx {  // stage B: transformed point, projection, the gathered target record
+  V3 p;
+  float u, v;
+  V3 tp, tn;
+  bool live;
+};
+__device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, const SrcPx& s, float twf, float thf) {
+  ProjPx o;
+  o.p = transform_vector(T, s.sp);
+  // CameraIntrinsics::project (src/camera.rs:64-70): x * fx / z + cx
+  const float z = o.p.z, au = o.p.x * d.fx, av = o.p.y * d.fy;
+  const DivBy dz = div_prepare(z);
+  float qu = div_by(au, dz), qv = div_by(av, dz);
+  if (!(div_den_ok(z) && div_num_ok(au) && div_num_ok(av))) qu = au / z, qv = av / z;  // rare: plain IEEE divide
+  o.u = qu + d.cx;
+  o.v = qv + d.cy;
+  // (u + 0.5) as i32 -> as usize -> get_point bounds test: in range iff -1 < x < dim (NaN casts to 0)
+  const float ur = o.u + 0.5f, vr = o.v + 0.5f;
+  o.live = s.live && !(ur <= -1.0f || ur >= twf || vr <= -1.0f || vr >= thf);
+  const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
+  const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
+  const uint32_t tidx = o.live ? row * d.tw + col : 0u;
+  o.tp = ld_v3(d.tgt_points, tidx);
+  o.tn = ld_v3(d.tgt_normals, tidx);
+  o.live = o.live && (ld<uint8_t>(d.tgt_mask, tidx) == 1);  // RangeImage::get_point: mask == 1 (structure.rs:176)
+  return o;
+}
+
+struct MapPx {  // stage C: gates passed, the intensity-map cell
+  float t00, t10, t01, t11;
+  uint32_t ui, vi;
+};
+__device__ __forceinline__ MapPx stage_c(const LevelDesc& d, const Gates& gt, ProjPx& px, uint32_t mw) {
+  const V3 diff = px.tp - px.p;
+  // angle_between_normals(&p, &n) >= max_normal_angle on the POINT p; NaN (|p.n| > 1) passes (image_icp.rs:118-123)
+  const float pn = dot(px.p, px.tn);
+  px.live = px.live && !(norm_squared(diff) > gt.max_distance_sqr)  // image_icp.rs:114
+            && !(pn >= -1.0f && pn <= gt.dot_reject_max);
+  MapPx m;
+  m.ui = px.live ? f32_as_usize(px.u) : 0u;
+  m.vi = px.live ? f32_as_usize(px.v) : 0u;
+  const uint32_t o = (m.vi * mw + m.ui) * 4u;
+  const f32x2 a = ld<f32x2_u>(d.imap, o), b = ld<f32x2_u>(d.imap, o + mw * 4u);
+  m.t00 = a.x, m.t10 = a.y, m.t01 = b.x, m.t11 = b.y;
+  return m;
+}
+
+struct Terms {  // stage D: the two residuals and Jacobians of a live pixel
+  float Jg[6], rg;
+  float Jc[6], rc;
+  bool color;
+};
+__device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, const ProjPx& px, const MapPx& m,
+                                         float intensity, uint32_t mw) {
+  Terms t;
+  const V3 P = px.p, n = px.tn;
+  {  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
+    t.rg = dot(px.tp - P, n);
+    const V3 tw = cross(P, n);
+    t.Jg[0] = n.x, t.Jg[1] = n.y, t.Jg[2] = n.z, t.Jg[3] = tw.x, t.Jg[4] = tw.y, t.Jg[5] = tw.z;
+  }
+  // IntensityMap::bilinear_grad (src/intensity_map.rs:184-210), H = 0.005
+  const float uf = px.u - (float)m.ui, vf = px.v - (float)m.vi;
+  const float value = bilerp(m.t00, m.t10, m.t01, m.t11, uf, vf);
+  const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
+  const float u2 = px.u + Hh, v2 = px.v + Hh;
+  // the shifted samples share the cell except within 0.005 of a texel boundary
+  const float uh = (f32_as_usize(u2) == m.ui) ? bilerp(m.t00, m.t10, m.t01, m.t11, u2 - (float)m.ui, vf)
+                                              : bilinear_at(d.imap, mw, u2, px.v);
+  const float vh = (f32_as_usize(v2) == m.vi) ? bilerp(m.t00, m.t10, m.t01, m.t11, uf, v2 - (float)m.vi)
+                                              : bilinear_at(d.imap, mw, px.u, v2);
+  const float du = (uh - value) * H_INV;
+  const float dv = (vh - value) * H_INV;
+  const float sc = intensity * 0.003921569f;  // image_icp.rs:131
+  // CameraIntrinsics::project_grad (src/camera.rs:82-89): fx / z, -x fx / zz, fy / z, -y fy / zz
+  const float z = P.z, zz = z * z;
+  const float nxf = -P.x * d.fx, nyf = -P.y * d.fy;
+  const DivBy dz = div_prepare(z), dzz = div_prepare(zz);
+  float dfx = div_by(d.fx, dz), dfy = div_by(d.fy, dz), dcx = div_by(nxf, dzz), dcy = div_by(nyf, dzz);
+  if (!(div_den_ok(z) && div_den_ok(zz) && div_num_ok(nxf) && div_num_ok(nyf) && div_num_ok(d.fx) &&
+        div_num_ok(d.fy)))
+    dfx = d.fx / z, dfy = d.fy / z, dcx = nxf / zz, dcy = nyf / zz;  // rare: plain IEEE divide
+  const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
+  t.rc = sc - value;
+  t.color = t.rc * t.rc <= gt.max_color_distance_sqr;  // image_icp.rs:136
+  const V3 twc = cross(P, gr);
+  t.Jc[0] = gr.x, t.Jc[1] = gr.y, t.Jc[2] = gr.z, t.Jc[3] = twc.x, t.Jc[4] = twc.y, t.Jc[5] = twc.z;
+  return t;
+}
+
+// grid = (tiles, pairs); block = 256.  A thread visits PPT source pixels, 256 apart (coalesced), G at a
+// time: the G target gathers are issued together, then the G map cells, so each dependent memory round
+// trip is paid once per G pixels; the source records run one batch ahead; only the accumulation sits
+// under the per-pixel gates.  ACCUM = 0: 58 per-thread f32 accumulators + wave reduce-scatter;
+// ACCUM = 1: X^T X on the matrix pipe (below).
+template <int PPT, int G>
 __global__ void __launch_bounds__(256)
     image_icp_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
                      float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve) {
@@ -83,125 +218,37 @@ __global__ void __launch_bounds__(256)
   if (st->status == A3D_OK) {
     const LevelDesc d = descs[pair];
     const Pose T = st->pose;
-    const gptr_f4 src = (gptr_f4)d.src;
-    const gptr_f4 tgt = (gptr_f4)d.tgt;
-    const gptr_f imap = (gptr_f)d.imap;
-    const gptr_f src_points = (gptr_f)d.src_points, tgt_points = (gptr_f)d.tgt_points,
-                 tgt_normals = (gptr_f)d.tgt_normals;
-    const gptr_u8 src_mask = (gptr_u8)d.src_mask, src_int = (gptr_u8)d.src_intensities,
-                  tgt_mask = (gptr_u8)d.tgt_mask;
     const uint32_t mw = d.tw + 2;
     const float twf = (float)d.tw, thf = (float)d.th;
     const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
-    // stage A (source records) runs one batch ahead: the loads of batch k+1 are issued right after the
-    // target gathers of batch k, so they fly under its gates, map fetches and accumulation
-    auto load_source = [&](int k0, f32x4(&sv)[G], bool(&lv)[G]) {
+    SrcPx s_next[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
-        const bool inb = (k0 < PPT) && (i < d.src_n);
-        const uint32_t ii = inb ? i : 0u;
-        if constexpr (RAW) {
-          const f32x3 sp = load3(src_points, ii);
-          sv[g].x = sp.x, sv[g].y = sp.y, sv[g].z = sp.z;
-          sv[g].w = (float)src_int[ii];
-          lv[g] = inb && (src_mask[ii] != 0);  // mask != 0 (image_icp.rs:102)
-        } else {
-          sv[g] = src[ii];
-          lv[g] = inb && (sv[g].w >= 0.0f);
-        }
-      }
-    };
-    f32x4 s_next[G];
-    bool live_next[G];
-    load_source(0, s_next, live_next);
+    for (int g = 0; g < G; ++g) s_next[g] = stage_a(d, base + g * 256u, base + g * 256u < d.src_n);
 #pragma unroll 1
     for (int k0 = 0; k0 < PPT; k0 += G) {
-      f32x4 s[G];
-      bool live[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) s[g] = s_next[g], live[g] = live_next[g];
-      // ---- stage B: transform, project, gather the target record -------------------------------
-      V3 p[G];
-      float u[G], v[G];
-      f32x4 tp[G], tn[G];
+      ProjPx px[G];
+      float intensity[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        p[g] = transform_vector(T, V3{s[g].x, s[g].y, s[g].z});
-        // CameraIntrinsics::project (src/camera.rs:64-70)
-        u[g] = p[g].x * d.fx / p[g].z + d.cx;
-        v[g] = p[g].y * d.fy / p[g].z + d.cy;
-        // (u + 0.5) as i32 -> as usize -> get_point bounds test: in range iff -1 < x < dim (NaN casts to 0)
-        const float ur = u[g] + 0.5f, vr = v[g] + 0.5f;
-        live[g] = live[g] && !(ur <= -1.0f || ur >= twf || vr <= -1.0f || vr >= thf);
-        const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
-        const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
-        const uint32_t tidx = live[g] ? row * d.tw + col : 0u;
-        if constexpr (RAW) {
-          const f32x3 tpp = load3(tgt_points, tidx), tnn = load3(tgt_normals, tidx);
-          tp[g].x = tpp.x, tp[g].y = tpp.y, tp[g].z = tpp.z;
-          tp[g].w = tgt_mask[tidx] == 1 ? 1.0f : 0.0f;
-          tn[g].x = tnn.x, tn[g].y = tnn.y, tn[g].z = tnn.z;
-          tn[g].w = 0.0f;
-        } else {
-          tp[g] = tgt[2 * tidx];
-          tn[g] = tgt[2 * tidx + 1];
+        px[g] = stage_b(d, T, s_next[g], twf, thf);
+        intensity[g] = s_next[g].intensity;
+      }
+      if (PPT > G) {  // source records of the next batch fly under this batch's gates, map fetches, accumulation
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const uint32_t i = base + (uint32_t)(k0 + G + g) * 256u;
+          s_next[g] = stage_a(d, i, (k0 + G < PPT) && (i < d.src_n));
         }
       }
-      if (PPT > G) load_source(k0 + G, s_next, live_next);
-      // ---- stage C: gates, intensity-map cell -----------------------------------------------------
-      float t00[G], t10[G], t01[G], t11[G];
-      uint32_t ui[G], vi[G];
+      MapPx mp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) mp[g] = stage_c(d, gt, px[g], mw);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const V3 diff = V3{tp[g].x, tp[g].y, tp[g].z} - p[g];
-        // angle_between_normals(&p, &n) >= max_normal_angle with NaN (|p.n| > 1) passing (image_icp.rs:118-123)
-        const float pn = dot(p[g], V3{tn[g].x, tn[g].y, tn[g].z});
-        live[g] = live[g] && (tp[g].w == 1.0f)                            // mask == 1 (structure.rs:176)
-                  && !(norm_squared(diff) > gt.max_distance_sqr)         // image_icp.rs:114
-                  && !(pn >= -1.0f && pn <= gt.dot_reject_max);
-        ui[g] = live[g] ? f32_as_usize(u[g]) : 0u;
-        vi[g] = live[g] ? f32_as_usize(v[g]) : 0u;
-        const gptr_f r0 = imap + (size_t)vi[g] * mw + ui[g];
-        t00[g] = r0[0], t10[g] = r0[1], t01[g] = r0[mw], t11[g] = r0[mw + 1];
-      }
-      // ---- stage D: residuals, Jacobians, accumulate -----------------------------------------------
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (!live[g]) continue;
-        const V3 P = p[g];
-        const V3 n{tn[g].x, tn[g].y, tn[g].z};
-        {  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
-          const V3 diff = V3{tp[g].x, tp[g].y, tp[g].z} - P;
-          const float r = dot(diff, n);
-          const V3 tw = cross(P, n);
-          const float J[6] = {n.x, n.y, n.z, tw.x, tw.y, tw.z};
-          gn_step(acc, r, J);
-        }
-        // IntensityMap::bilinear_grad (src/intensity_map.rs:184-210), H = 0.005
-        const float uf = u[g] - (float)ui[g], vf = v[g] - (float)vi[g];
-        const float value = bilerp(t00[g], t10[g], t01[g], t11[g], uf, vf);
-        const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
-        const float u2 = u[g] + Hh, v2 = v[g] + Hh;
-        // the shifted samples share the cell except within 0.005 of a texel boundary
-        const float uh = (f32_as_usize(u2) == ui[g]) ? bilerp(t00[g], t10[g], t01[g], t11[g], u2 - (float)ui[g], vf)
-                                                     : bilinear_at(imap, mw, u2, v[g]);
-        const float vh = (f32_as_usize(v2) == vi[g]) ? bilerp(t00[g], t10[g], t01[g], t11[g], uf, v2 - (float)vi[g])
-                                                     : bilinear_at(imap, mw, u[g], v2);
-        const float du = (uh - value) * H_INV;
-        const float dv = (vh - value) * H_INV;
-        const float sc = s[g].w * 0.003921569f;  // image_icp.rs:131
-        // CameraIntrinsics::project_grad (src/camera.rs:82-89)
-        const float z = P.z, zz = z * z;
-        const float dfx = d.fx / z, dcx = -P.x * d.fx / zz;
-        const float dfy = d.fy / z, dcy = -P.y * d.fy / zz;
-        const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
-        const float rc = sc - value;
-        if (rc * rc <= gt.max_color_distance_sqr) {  // image_icp.rs:136
-          const V3 tw = cross(P, gr);
-          const float J[6] = {gr.x, gr.y, gr.z, tw.x, tw.y, tw.z};
-          gn_step(acc + GN_ACC, rc, J);
-        }
+        if (!px[g].live) continue;
+        const Terms t = stage_d(d, gt, px[g], mp[g], intensity[g], mw);
+        gn_step(acc, t.rg, t.Jg);  // the geometric term is accumulated even when the colour term is rejected
+        if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
       }
     }
   }
@@ -212,7 +259,6 @@ __global__ void __launch_bounds__(256)
                            counters + pair, st, sa, pair);
 }
 
-
 // ---- MFMA accumulation -----------------------------------------------------------------------------
 // The per-pixel sums  H += J J^T, g += J r, ssq += r^2, count += 1  for the geometric and the colour
 // term are all entries of X^T X, where row p of X holds pixel p's 16 "features"
@@ -221,9 +267,9 @@ __global__ void __launch_bounds__(256)
 // A = X^T and B = X both operands are the SAME register: lane l supplies X[pixel l>>4][feature l&15]
 // (CDNA guide §3).  A wave's 64 pixels therefore take 16 MFMAs, fed by a transpose through a 4 KiB LDS
 // slab per wave: lane p writes its 16 features as one row, then reads X[4m + (l>>4)][l&15] for MFMA m.
-// What it buys: the 58 per-thread accumulators (58 VGPRs) become one 16x16 tile = 8 VGPRs (two
-// interleaved tiles), occupancy doubles, and the 54 accumulate FMAs per pixel leave the VALU for the
-// matrix pipe, which runs beside it.
+// What it buys: the 58 per-thread accumulators (58 VGPRs) become two 16x16 tiles = 8 VGPRs, and the 54
+// accumulate FMAs per pixel leave the VALU for the matrix pipe.  Measured on MI355X it does not beat the
+// VALU path yet, so it is opt-in (A3D_ICP_ACCUM=mfma).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // Row p of the slab is 16 floats; the four 16-byte chunks of a row are XOR-swizzled by (p >> 1) & 3 so
@@ -249,7 +295,7 @@ __device__ __forceinline__ int tile_index_of_partial(int k) {
   return row * 16 + col;
 }
 
-template <int PPT, int G, bool RAW>
+template <int PPT, int G>
 __global__ void __launch_bounds__(256)
     image_icp_mfma_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
                           float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve) {
@@ -263,118 +309,46 @@ __global__ void __launch_bounds__(256)
   if (st->status == A3D_OK) {
     const LevelDesc d = descs[pair];
     const Pose T = st->pose;
-    const gptr_f4 src = (gptr_f4)d.src;
-    const gptr_f4 tgt = (gptr_f4)d.tgt;
-    const gptr_f imap = (gptr_f)d.imap;
-    const gptr_f src_points = (gptr_f)d.src_points, tgt_points = (gptr_f)d.tgt_points,
-                 tgt_normals = (gptr_f)d.tgt_normals;
-    const gptr_u8 src_mask = (gptr_u8)d.src_mask, src_int = (gptr_u8)d.src_intensities,
-                  tgt_mask = (gptr_u8)d.tgt_mask;
     const uint32_t mw = d.tw + 2;
     const float twf = (float)d.tw, thf = (float)d.th;
     const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
     // transposed-read offsets of this lane: row 4m + (lane >> 4), feature lane & 15
     const int rd_row0 = lane >> 4, rd_chunk = (lane & 15) >> 2, rd_word = lane & 3;
-    auto load_source = [&](int k0, f32x4(&sv)[G], bool(&lv)[G]) {
+    SrcPx s_next[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
-        const bool inb = (k0 < PPT) && (i < d.src_n);
-        const uint32_t ii = inb ? i : 0u;
-        if constexpr (RAW) {
-          const f32x3 sp = load3(src_points, ii);
-          sv[g].x = sp.x, sv[g].y = sp.y, sv[g].z = sp.z;
-          sv[g].w = (float)src_int[ii];
-          lv[g] = inb && (src_mask[ii] != 0);
-        } else {
-          sv[g] = src[ii];
-          lv[g] = inb && (sv[g].w >= 0.0f);
-        }
-      }
-    };
-    f32x4 s_next[G];
-    bool live_next[G];
-    load_source(0, s_next, live_next);
+    for (int g = 0; g < G; ++g) s_next[g] = stage_a(d, base + g * 256u, base + g * 256u < d.src_n);
 #pragma unroll 1
     for (int k0 = 0; k0 < PPT; k0 += G) {
-      f32x4 s[G];
-      bool live[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) s[g] = s_next[g], live[g] = live_next[g];
-      V3 p[G];
-      float u[G], v[G];
-      f32x4 tp[G], tn[G];
+      ProjPx px[G];
+      float intensity[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        p[g] = transform_vector(T, V3{s[g].x, s[g].y, s[g].z});
-        u[g] = p[g].x * d.fx / p[g].z + d.cx;
-        v[g] = p[g].y * d.fy / p[g].z + d.cy;
-        const float ur = u[g] + 0.5f, vr = v[g] + 0.5f;
-        live[g] = live[g] && !(ur <= -1.0f || ur >= twf || vr <= -1.0f || vr >= thf);
-        const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
-        const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
-        const uint32_t tidx = live[g] ? row * d.tw + col : 0u;
-        if constexpr (RAW) {
-          const f32x3 tpp = load3(tgt_points, tidx), tnn = load3(tgt_normals, tidx);
-          tp[g].x = tpp.x, tp[g].y = tpp.y, tp[g].z = tpp.z;
-          tp[g].w = tgt_mask[tidx] == 1 ? 1.0f : 0.0f;
-          tn[g].x = tnn.x, tn[g].y = tnn.y, tn[g].z = tnn.z;
-          tn[g].w = 0.0f;
-        } else {
-          tp[g] = tgt[2 * tidx];
-          tn[g] = tgt[2 * tidx + 1];
+        px[g] = stage_b(d, T, s_next[g], twf, thf);
+        intensity[g] = s_next[g].intensity;
+      }
+      if (PPT > G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const uint32_t i = base + (uint32_t)(k0 + G + g) * 256u;
+          s_next[g] = stage_a(d, i, (k0 + G < PPT) && (i < d.src_n));
         }
       }
-      if (PPT > G) load_source(k0 + G, s_next, live_next);
-      float t00[G], t10[G], t01[G], t11[G];
-      uint32_t ui[G], vi[G];
+      MapPx mp[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const V3 diff = V3{tp[g].x, tp[g].y, tp[g].z} - p[g];
-        const float pn = dot(p[g], V3{tn[g].x, tn[g].y, tn[g].z});
-        live[g] = live[g] && (tp[g].w == 1.0f) && !(norm_squared(diff) > gt.max_distance_sqr) &&
-                  !(pn >= -1.0f && pn <= gt.dot_reject_max);
-        ui[g] = live[g] ? f32_as_usize(u[g]) : 0u;
-        vi[g] = live[g] ? f32_as_usize(v[g]) : 0u;
-        const gptr_f r0 = imap + (size_t)vi[g] * mw + ui[g];
-        t00[g] = r0[0], t10[g] = r0[1], t01[g] = r0[mw], t11[g] = r0[mw + 1];
-      }
+      for (int g = 0; g < G; ++g) mp[g] = stage_c(d, gt, px[g], mw);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         // ---- features of this lane's pixel (all zero when it is gated out) ----------------------
         f32x4_t f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0, f2 = f0, f3 = f0;
-        if (live[g]) {
-          const V3 P = p[g];
-          const V3 n{tn[g].x, tn[g].y, tn[g].z};
-          const V3 diff = V3{tp[g].x, tp[g].y, tp[g].z} - P;
-          const float r = dot(diff, n);
-          const V3 tw = cross(P, n);
-          f0 = f32x4_t{n.x, n.y, n.z, tw.x};
-          f1.x = tw.y, f1.y = tw.z, f1.z = r;
+        if (px[g].live) {
+          const Terms t = stage_d(d, gt, px[g], mp[g], intensity[g], mw);
+          f0 = f32x4_t{t.Jg[0], t.Jg[1], t.Jg[2], t.Jg[3]};
+          f1.x = t.Jg[4], f1.y = t.Jg[5], f1.z = t.rg;
           f3.z = 1.0f;
-          const float uf = u[g] - (float)ui[g], vf = v[g] - (float)vi[g];
-          const float value = bilerp(t00[g], t10[g], t01[g], t11[g], uf, vf);
-          const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
-          const float u2 = u[g] + Hh, v2 = v[g] + Hh;
-          const float uh = (f32_as_usize(u2) == ui[g])
-                               ? bilerp(t00[g], t10[g], t01[g], t11[g], u2 - (float)ui[g], vf)
-                               : bilinear_at(imap, mw, u2, v[g]);
-          const float vh = (f32_as_usize(v2) == vi[g])
-                               ? bilerp(t00[g], t10[g], t01[g], t11[g], uf, v2 - (float)vi[g])
-                               : bilinear_at(imap, mw, u[g], v2);
-          const float du = (uh - value) * H_INV;
-          const float dv = (vh - value) * H_INV;
-          const float sc = s[g].w * 0.003921569f;
-          const float z = P.z, zz = z * z;
-          const float dfx = d.fx / z, dcx = -P.x * d.fx / zz;
-          const float dfy = d.fy / z, dcy = -P.y * d.fy / zz;
-          const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
-          const float rc = sc - value;
-          if (rc * rc <= gt.max_color_distance_sqr) {
-            const V3 twc = cross(P, gr);
-            f1.w = gr.x;
-            f2 = f32x4_t{gr.y, gr.z, twc.x, twc.y};
-            f3.x = twc.z, f3.y = rc, f3.w = 1.0f;
+          if (t.color) {
+            f1.w = t.Jc[0];
+            f2 = f32x4_t{t.Jc[1], t.Jc[2], t.Jc[3], t.Jc[4]};
+            f3.x = t.Jc[5], f3.y = t.rc, f3.w = 1.0f;
           }
         }
         // ---- transpose through the wave's LDS slab, 16 MFMAs --------------------------------------
@@ -417,6 +391,17 @@ __global__ void __launch_bounds__(256)
   block_publish_and_finish(job_partials, gridDim.x, counters + pair, st, sa, pair);
 }
 
+// Device self-test of the shared-reciprocal division: counts pairs for which it differs from `/`.
+__global__ void division_selftest_kernel(const float* __restrict__ num, const float* __restrict__ den, uint32_t n,
+                                         unsigned* __restrict__ mismatches) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = num[i], z = den[i];
+  if (!(div_den_ok(z) && div_num_ok(a))) return;
+  const float q = div_by(a, div_prepare(z)), want = a / z;
+  if (__float_as_uint(q) != __float_as_uint(want)) atomicAdd(mismatches, 1u);
+}
+
 }  // namespace
 
 // P independent coarse-to-fine alignments.  Owns only small state; the images are borrowed.
@@ -437,7 +422,6 @@ struct a3d_multiscale_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;  // per pixel-kernel launch: start/stop pairs, when profiling
   bool profile_kernels = false;
-  bool raw_layout = true;
   bool use_mfma = false;  // VALU accumulation measured faster on MI355X so far (kernel variants)
   float last_total_ms = 0.f, last_kernel_ms = 0.f;
   uint64_t last_kernel_launches = 0;
@@ -465,9 +449,6 @@ a3d_status fill_desc(const a3d_device_image* target, const a3d_device_image* sou
   A3D_REQUIRE(target->has_normals, A3D_MISSING_FIELD, "Please, the target image should have normals.");
   A3D_REQUIRE(source->has_intensities, A3D_MISSING_FIELD,
               "Please, the source image should have intensity colors.");
-  A3D_REQUIRE(target->tgt_pack_valid && source->src_pack_valid, A3D_INVALID_PARAMETER, "image not packed");
-  d->src = source->src_pack;
-  d->tgt = target->tgt_pack;
   d->imap = target->imap;
   d->src_points = source->points, d->src_mask = source->mask, d->src_intensities = source->intensities;
   d->tgt_points = target->points, d->tgt_normals = target->normals, d->tgt_mask = target->mask;
@@ -502,18 +483,12 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
   hipStream_t s = b->ctx->stream;
 #define A3D_LAUNCH(PPT, G)                                                                               \
   do {                                                                                                      \
-    if (b->use_mfma && b->raw_layout)                                                                       \
-      hipLaunchKernelGGL((image_icp_mfma_kernel<PPT, G, true>), grid, block, 0, s, descs, b->d_states,      \
-                         b->gates[level], b->d_partials, b->d_counters, solve);                             \
-    else if (b->use_mfma)                                                                                   \
-      hipLaunchKernelGGL((image_icp_mfma_kernel<PPT, G, false>), grid, block, 0, s, descs, b->d_states,     \
-                         b->gates[level], b->d_partials, b->d_counters, solve);                             \
-    else if (b->raw_layout)                                                                                 \
-      hipLaunchKernelGGL((image_icp_kernel<PPT, G, true>), grid, block, 0, s, descs, b->d_states,           \
+    if (b->use_mfma)                                                                                        \
+      hipLaunchKernelGGL((image_icp_mfma_kernel<PPT, G>), grid, block, 0, s, descs, b->d_states,            \
                          b->gates[level], b->d_partials, b->d_counters, solve);                             \
     else                                                                                                    \
-      hipLaunchKernelGGL((image_icp_kernel<PPT, G, false>), grid, block, 0, s, descs, b->d_states,          \
-                         b->gates[level], b->d_partials, b->d_counters, solve);                             \
+      hipLaunchKernelGGL((image_icp_kernel<PPT, G>), grid, block, 0, s, descs, b->d_states, b->gates[level], \
+                         b->d_partials, b->d_counters, solve);                                              \
   } while (0)
   const uint32_t g = b->group[level];
   switch (b->ppt[level] * 16 + g) {
@@ -574,7 +549,6 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   b->ppt.assign(n_levels, 1);
   b->group.assign(n_levels, 1);
   b->h_descs.resize((size_t)n_levels * n_pairs);
-  if (const char* env = getenv("A3D_ICP_LAYOUT")) b->raw_layout = strcmp(env, "packed") != 0;  // tuning knob
   if (const char* env = getenv("A3D_ICP_ACCUM")) b->use_mfma = strcmp(env, "mfma") == 0;        // tuning knob
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
@@ -836,6 +810,38 @@ a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* b, float* o
   A3D_REQUIRE(b && out_kernel_ms, A3D_INVALID_PARAMETER, "null argument");
   A3D_TRY(batch_collect_timing(b));
   *out_kernel_ms = b->last_kernel_ms;
+  return A3D_OK;
+}
+
+// Instrumentation: runs the kernels' shared-reciprocal division on n (numerator, denominator) pairs
+// drawn by the caller and counts the results that differ from IEEE `/` (expected: 0).
+a3d_status a3d_selftest_division(a3d_context* ctx, const float* numerators, const float* denominators, uint64_t n,
+                                 uint64_t* out_mismatches) {
+  A3D_REQUIRE(ctx && numerators && denominators && out_mismatches && n > 0 && n < (1ull << 31), A3D_INVALID_PARAMETER,
+              "bad argument");
+  float *d_a = nullptr, *d_z = nullptr;
+  unsigned *d_m = nullptr, h_m = 0;
+  hipStream_t s = ctx->stream;
+  a3d_status st = A3D_OK;
+  if (hipMalloc((void**)&d_a, n * 4) != hipSuccess || hipMalloc((void**)&d_z, n * 4) != hipSuccess ||
+      hipMalloc((void**)&d_m, 4) != hipSuccess || hipMemsetAsync(d_m, 0, 4, s) != hipSuccess ||
+      hipMemcpyAsync(d_a, numerators, n * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_z, denominators, n * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+    st = A3D_HIP_ERROR;
+  if (st == A3D_OK) {
+    hipLaunchKernelGGL(division_selftest_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_a, d_z,
+                       (uint32_t)n, d_m);
+    if (hipMemcpyAsync(&h_m, d_m, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      st = A3D_HIP_ERROR;
+  }
+  hipFree(d_a);
+  hipFree(d_z);
+  hipFree(d_m);
+  if (st != A3D_OK) {
+    set_error("a3d_selftest_division: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+    return st;
+  }
+  *out_mismatches = h_m;
   return A3D_OK;
 }
 

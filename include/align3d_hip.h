@@ -170,6 +170,12 @@ a3d_status a3d_image_icp_align_trace(a3d_context* ctx, const a3d_icp_params* par
                                      const a3d_device_image* target, const a3d_device_image* source,
                                      const a3d_pose* init_pose, a3d_pose* out_pose, float* out_trace);
 
+/* Instrumentation: the ICP kernels divide with a reciprocal shared between the quotients of one pixel
+ * (same arithmetic as a correctly rounded f32 division); this runs that routine on n caller-drawn
+ * (numerator, denominator) pairs on the device and counts results that differ from IEEE `/`. */
+a3d_status a3d_selftest_division(a3d_context* ctx, const float* numerators, const float* denominators,
+                                 uint64_t n, uint64_t* out_mismatches);
+
 /* ---- MultiscaleAlign (src/icp/multiscale.rs:7-68) ---------------------------------------- */
 
 /* MultiscaleAlign::new(params, &target_pyramid): A3D_INVALID_PARAMETER unless

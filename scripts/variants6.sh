@@ -1,3 +1,3 @@
-for acc in valu mfma; do for lay in raw packed; do for v in 8,2 8,1; do
-  echo "accum $acc layout $lay variant $v: $(A3D_ICP_ACCUM=$acc A3D_ICP_LAYOUT=$lay A3D_ICP_VARIANT=$v timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-extras --cpu-pairs 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step %.3f pairs/s %.0f kernel_us %.1f frac %.3f'%(d['ms_per_step'], d['value'], d['roofline']['avg_launch_us'], d['roofline']['frac']))")"
-done; done; done
+for acc in valu mfma; do for v in 8,2 8,1 16,1 4,1; do
+  echo "accum $acc variant $v: $(A3D_ICP_ACCUM=$acc A3D_ICP_VARIANT=$v timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-extras --cpu-pairs 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms/step %.3f pairs/s %.0f kernel_us %.1f frac %.3f'%(d['ms_per_step'], d['value'], d['roofline']['avg_launch_us'], d['roofline']['frac']))")"
+done; done

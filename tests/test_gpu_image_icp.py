@@ -189,3 +189,21 @@ def test_batch_matches_single_pairs(ctx):
         ang, tr = transform_diff(poses[k], T_ref)
         assert ang <= ROT_TOL and tr <= TRANS_TOL
     ctx.free(d_mats)
+
+
+def test_shared_reciprocal_division_is_ieee_exact(ctx):
+    """The kernels' a / z (reciprocal shared between the quotients of a pixel) equals IEEE division bit for
+    bit over the operand ranges the path produces and well beyond (z and z^2 of 1 mm .. 1 km, numerators
+    1e-6 .. 1e8, both signs, zero numerators)."""
+    import ctypes as C
+    from align3d_amd import _abi
+
+    rng = np.random.default_rng(42)
+    n = 4_000_000
+    z = np.exp(rng.uniform(np.log(1e-3), np.log(1e6), n)).astype(np.float32)
+    a = (np.exp(rng.uniform(np.log(1e-6), np.log(1e8), n)) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    a[:1000] = 0.0
+    z[1000:2000] *= -1.0
+    bad = C.c_uint64(123)
+    _abi.check(ctx.lib.a3d_selftest_division(ctx.handle, _abi.ptr(a), _abi.ptr(z), n, C.byref(bad)))
+    assert bad.value == 0
