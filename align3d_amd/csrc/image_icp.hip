@@ -123,7 +123,10 @@ __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, con
   const float z = o.p.z, au = o.p.x * d.fx, av = o.p.y * d.fy;
   const DivBy dz = div_prepare(z);
   float qu = div_by(au, dz), qv = div_by(av, dz);
-  if (!(div_den_ok(z) && div_num_ok(au) && div_num_ok(av))) qu = au / z, qv = av / z;  // rare: plain IEEE divide
+  // rare: some lane is outside the fast range -> the whole wave takes the plain IEEE divide (same values
+  // where both apply); a wave-uniform branch, so the slow sequence is not speculated into the hot path
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(div_den_ok(z) && div_num_ok(au) && div_num_ok(av))) != 0ull, 0))
+    qu = au / z, qv = av / z;
   o.u = qu + d.cx;
   o.v = qv + d.cy;
   // (u + 0.5) as i32 -> as usize -> get_point bounds test: in range iff -1 < x < dim (NaN casts to 0)
@@ -189,9 +192,10 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
   const float nxf = -P.x * d.fx, nyf = -P.y * d.fy;
   const DivBy dz = div_prepare(z), dzz = div_prepare(zz);
   float dfx = div_by(d.fx, dz), dfy = div_by(d.fy, dz), dcx = div_by(nxf, dzz), dcy = div_by(nyf, dzz);
-  if (!(div_den_ok(z) && div_den_ok(zz) && div_num_ok(nxf) && div_num_ok(nyf) && div_num_ok(d.fx) &&
-        div_num_ok(d.fy)))
-    dfx = d.fx / z, dfy = d.fy / z, dcx = nxf / zz, dcy = nyf / zz;  // rare: plain IEEE divide
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(div_den_ok(z) && div_den_ok(zz) && div_num_ok(nxf) &&
+                                                     div_num_ok(nyf) && div_num_ok(d.fx) && div_num_ok(d.fy))) != 0ull,
+                       0))
+    dfx = d.fx / z, dfy = d.fy / z, dcx = nxf / zz, dcy = nyf / zz;  // rare: plain IEEE divide (wave-uniform)
   const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
   t.rc = sc - value;
   t.color = t.rc * t.rc <= gt.max_color_distance_sqr;  // image_icp.rs:136
