@@ -114,6 +114,7 @@ struct ProjPx {  // stage B: transformed point, projection, the gathered target 
   V3 p;
   float u, v;
   V3 tp, tn;
+  uint8_t tmask;  // consumed in stage C, so that stage B only ISSUES the gathers
   bool live;
 };
 __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, const SrcPx& s, float twf, float thf) {
@@ -137,7 +138,7 @@ __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, con
   const uint32_t tidx = o.live ? row * d.tw + col : 0u;
   o.tp = ld_v3(d.tgt_points, tidx);
   o.tn = ld_v3(d.tgt_normals, tidx);
-  o.live = o.live && (ld<uint8_t>(d.tgt_mask, tidx) == 1);  // RangeImage::get_point: mask == 1 (structure.rs:176)
+  o.tmask = ld<uint8_t>(d.tgt_mask, tidx);
   return o;
 }
 
@@ -149,7 +150,8 @@ __device__ __forceinline__ MapPx stage_c(const LevelDesc& d, const Gates& gt, Pr
   const V3 diff = px.tp - px.p;
   // angle_between_normals(&p, &n) >= max_normal_angle on the POINT p; NaN (|p.n| > 1) passes (image_icp.rs:118-123)
   const float pn = dot(px.p, px.tn);
-  px.live = px.live && !(norm_squared(diff) > gt.max_distance_sqr)  // image_icp.rs:114
+  px.live = px.live && (px.tmask == 1)                              // RangeImage::get_point: mask == 1 (structure.rs:176)
+            && !(norm_squared(diff) > gt.max_distance_sqr)       // image_icp.rs:114
             && !(pn >= -1.0f && pn <= gt.dot_reject_max);
   MapPx m;
   m.ui = px.live ? f32_as_usize(px.u) : 0u;
