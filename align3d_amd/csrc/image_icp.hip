@@ -594,7 +594,7 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
       }
       SolveArgs sa;
       sa.weight = prm.weight, sa.color_weight = prm.color_weight;
-      sa.mode = SOLVE_IMAGE_ICP;
+      sa.mode = getenv("A3D_ICP_NOSOLVE") ? SOLVE_NONE : SOLVE_IMAGE_ICP;  // diagnostics: time the body alone
       sa.first_in_level = it == 0, sa.last_in_level = it + 1 == prm.max_iterations;
       sa.trace = d_trace, sa.trace_stride = trace_stride, sa.trace_index = trace_index;
       A3D_TRY(launch_pixel_kernel(b, l, sa));
