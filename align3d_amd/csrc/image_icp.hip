@@ -227,35 +227,48 @@ __global__ void __launch_bounds__(256)
     const uint32_t mw = d.tw + 2;
     const float twf = (float)d.tw, thf = (float)d.th;
     const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
-    SrcPx s_next[G];
+    // Software pipeline, three batches deep: while batch k is being accumulated (stage D) the target
+    // gathers of batch k+1 and the source records of batch k+2 are in flight, so the L1 miss queue of the
+    // CU stays occupied during the arithmetic.
+    auto src_at = [&](int k0, int g) {
+      const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
+      return stage_a(d, i, (k0 < PPT) && (i < d.src_n));
+    };
+    SrcPx s1[G];
+    ProjPx cur[G];
+    float cur_int[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) s_next[g] = stage_a(d, base + g * 256u, base + g * 256u < d.src_n);
+    for (int g = 0; g < G; ++g) {
+      const SrcPx s0 = src_at(0, g);
+      s1[g] = src_at(G, g);
+      cur[g] = stage_b(d, T, s0, twf, thf);
+      cur_int[g] = s0.intensity;
+    }
 #pragma unroll 1
     for (int k0 = 0; k0 < PPT; k0 += G) {
-      ProjPx px[G];
-      float intensity[G];
+      SrcPx s2[G];
+      MapPx mp[G];
+      ProjPx nxt[G];
+      float nxt_int[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) s2[g] = src_at(k0 + 2 * G, g);  // issue source records of batch k+2
+#pragma unroll
+      for (int g = 0; g < G; ++g) mp[g] = stage_c(d, gt, cur[g], mw);  // gathers(k) land; issue map cells(k)
+#pragma unroll
+      for (int g = 0; g < G; ++g) {  // source(k+1) landed long ago; issue gathers(k+1)
+        nxt[g] = stage_b(d, T, s1[g], twf, thf);
+        nxt_int[g] = s1[g].intensity;
+      }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        px[g] = stage_b(d, T, s_next[g], twf, thf);
-        intensity[g] = s_next[g].intensity;
-      }
-      if (PPT > G) {  // source records of the next batch fly under this batch's gates, map fetches, accumulation
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const uint32_t i = base + (uint32_t)(k0 + G + g) * 256u;
-          s_next[g] = stage_a(d, i, (k0 + G < PPT) && (i < d.src_n));
+        if (cur[g].live) {
+          const Terms t = stage_d(d, gt, cur[g], mp[g], cur_int[g], mw);
+          gn_step(acc, t.rg, t.Jg);  // the geometric term is accumulated even when the colour term is rejected
+          if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
         }
       }
-      MapPx mp[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) mp[g] = stage_c(d, gt, px[g], mw);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (!px[g].live) continue;
-        const Terms t = stage_d(d, gt, px[g], mp[g], intensity[g], mw);
-        gn_step(acc, t.rg, t.Jg);  // the geometric term is accumulated even when the colour term is rejected
-        if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
-      }
+      for (int g = 0; g < G; ++g) cur[g] = nxt[g], cur_int[g] = nxt_int[g], s1[g] = s2[g];
     }
   }
   // a failed job stays frozen: its blocks contribute nothing and nobody runs its solve
