@@ -333,34 +333,42 @@ __global__ void __launch_bounds__(256)
     const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
     // transposed-read offsets of this lane: row 4m + (lane >> 4), feature lane & 15
     const int rd_row0 = lane >> 4, rd_chunk = (lane & 15) >> 2, rd_word = lane & 3;
-    SrcPx s_next[G];
+    // same three-deep software pipeline as the VALU kernel
+    auto src_at = [&](int k0, int g) {
+      const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
+      return stage_a(d, i, (k0 < PPT) && (i < d.src_n));
+    };
+    SrcPx s1[G];
+    ProjPx cur[G];
+    float cur_int[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) s_next[g] = stage_a(d, base + g * 256u, base + g * 256u < d.src_n);
+    for (int g = 0; g < G; ++g) {
+      const SrcPx s0 = src_at(0, g);
+      s1[g] = src_at(G, g);
+      cur[g] = stage_b(d, T, s0, twf, thf);
+      cur_int[g] = s0.intensity;
+    }
 #pragma unroll 1
     for (int k0 = 0; k0 < PPT; k0 += G) {
-      ProjPx px[G];
-      float intensity[G];
+      SrcPx s2[G];
+      MapPx mp[G];
+      ProjPx nxt[G];
+      float nxt_int[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) s2[g] = src_at(k0 + 2 * G, g);
+#pragma unroll
+      for (int g = 0; g < G; ++g) mp[g] = stage_c(d, gt, cur[g], mw);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        px[g] = stage_b(d, T, s_next[g], twf, thf);
-        intensity[g] = s_next[g].intensity;
+        nxt[g] = stage_b(d, T, s1[g], twf, thf);
+        nxt_int[g] = s1[g].intensity;
       }
-      if (PPT > G) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const uint32_t i = base + (uint32_t)(k0 + G + g) * 256u;
-          s_next[g] = stage_a(d, i, (k0 + G < PPT) && (i < d.src_n));
-        }
-      }
-      MapPx mp[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) mp[g] = stage_c(d, gt, px[g], mw);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         // ---- features of this lane's pixel (all zero when it is gated out) ----------------------
         f32x4_t f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0, f2 = f0, f3 = f0;
-        if (px[g].live) {
-          const Terms t = stage_d(d, gt, px[g], mp[g], intensity[g], mw);
+        if (cur[g].live) {
+          const Terms t = stage_d(d, gt, cur[g], mp[g], cur_int[g], mw);
           f0 = f32x4_t{t.Jg[0], t.Jg[1], t.Jg[2], t.Jg[3]};
           f1.x = t.Jg[4], f1.y = t.Jg[5], f1.z = t.rg;
           f3.z = 1.0f;
@@ -384,6 +392,8 @@ __global__ void __launch_bounds__(256)
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[m + 1], x[m + 1], acc1, 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int g = 0; g < G; ++g) cur[g] = nxt[g], cur_int[g] = nxt_int[g], s1[g] = s2[g];
     }
   }
   // ---- block partial: sum the four waves' tiles, pick the 58 entries, store write-through ----------
