@@ -497,9 +497,9 @@ Gates make_gates(const a3d_icp_params& p) {
   return g;
 }
 
-// Pixels per thread: as many as keep >= 1024 blocks in flight (4 per CU), at most 8.
+// Pixels per thread: as many as keep >= 1024 blocks in flight (4 per CU), at most 16.
 uint32_t choose_ppt(uint32_t n_pairs, uint32_t max_src_n) {
-  for (uint32_t ppt = 8; ppt > 1; ppt >>= 1) {
+  for (uint32_t ppt = 16; ppt > 1; ppt >>= 1) {
     uint64_t blocks = (uint64_t)n_pairs * ((max_src_n + 256 * ppt - 1) / (256 * ppt));
     if (blocks >= 1024) return ppt;
   }
@@ -523,14 +523,9 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
   switch (b->ppt[level] * 16 + g) {
     case 16 * 16 + 2: A3D_LAUNCH(16, 2); break;
     case 16 * 16 + 1: A3D_LAUNCH(16, 1); break;
-    case 32 * 16 + 2: A3D_LAUNCH(32, 2); break;
-    case 8 * 16 + 4: A3D_LAUNCH(8, 4); break;
     case 8 * 16 + 2: A3D_LAUNCH(8, 2); break;
     case 8 * 16 + 1: A3D_LAUNCH(8, 1); break;
-    case 4 * 16 + 4: A3D_LAUNCH(4, 4); break;
-    case 4 * 16 + 2: A3D_LAUNCH(4, 2); break;
     case 4 * 16 + 1: A3D_LAUNCH(4, 1); break;
-    case 2 * 16 + 2: A3D_LAUNCH(2, 2); break;
     case 2 * 16 + 1: A3D_LAUNCH(2, 1); break;
     case 1 * 16 + 1: A3D_LAUNCH(1, 1); break;
     default:
@@ -550,7 +545,7 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     uint32_t max_n = 0;
     for (uint32_t p = 0; p < P; ++p) max_n = std::max(max_n, b->h_descs[(size_t)l * P + p].src_n);
     b->ppt[l] = choose_ppt(P, max_n);
-    b->group[l] = std::min<uint32_t>(b->ppt[l], 2);  // measured best on MI355X (kernel variants)
+    b->group[l] = 1;  // pixels per pipeline stage; 1 measured best on MI355X (kernel variants)
     if (const char* env = getenv("A3D_ICP_VARIANT")) {  // tuning knob: "ppt,g"
       unsigned ep = 0, eg = 0;
       if (sscanf(env, "%u,%u", &ep, &eg) == 2 && ep && eg) b->ppt[l] = ep, b->group[l] = eg;
