@@ -1,0 +1,243 @@
+// align3d.hpp — C++17 host-side mirror of the reference's API for the ICP hot path, header-only,
+// over the C ABI of align3d_hip.h.  Names and argument meaning follow the Rust reference:
+//
+//   icp::IcpParams / MsIcpParams            src/icp/icp_params.rs:8-134
+//   icp::multiscale::MultiscaleAlign        src/icp/multiscale.rs:7-68
+//   icp::ImageIcp                           src/icp/image_icp.rs:19-165
+//   icp::Icp                                src/icp/pcl_icp.rs:15-108
+//   kdtree::R3dTree                         src/kdtree.rs:19-106
+//   range_image::RangeImage (borrowed view) src/range_image/structure.rs:20-36
+//   bilateral::BilateralFilter<u16>         src/bilateral/edge_aware_filter.rs:14-135
+//   transform::Transform                    src/transform.rs:18
+//
+// Error mapping: `Result::Err(A3dError::InvalidParameter)` -> align3d::InvalidParameter;
+// the reference's panics (`expect`, `unwrap`) -> align3d::Panic carrying the status and the library's text.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "align3d_hip.h"
+
+namespace align3d {
+
+struct Error : std::runtime_error {
+  a3d_status status;
+  Error(a3d_status s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+struct InvalidParameter : Error {  // A3dError::InvalidParameter (src/error.rs:3-9)
+  explicit InvalidParameter(const std::string& what) : Error(A3D_INVALID_PARAMETER, what) {}
+};
+struct Panic : Error {  // what the reference turns into a panic
+  using Error::Error;
+};
+
+inline void check(a3d_status s) {
+  if (s == A3D_OK) return;
+  std::string text = std::string(a3d_status_string(s)) + ": " + a3d_last_error();
+  if (s == A3D_INVALID_PARAMETER) throw InvalidParameter(text);
+  throw Panic(s, text);
+}
+
+/// One GPU + one HIP stream; every object below is created on a Context and must not outlive it.
+class Context {
+ public:
+  explicit Context(int device_index = 0) { check(a3d_context_create(device_index, &ctx_)); }
+  ~Context() { a3d_context_destroy(ctx_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  a3d_context* raw() const { return ctx_; }
+  void synchronize() const { check(a3d_context_synchronize(ctx_)); }
+
+ private:
+  a3d_context* ctx_ = nullptr;
+};
+
+/// Transform = Isometry3<f32>: translation + unit quaternion (i, j, k, w).
+struct Transform {
+  std::array<float, 3> translation{0.f, 0.f, 0.f};
+  std::array<float, 4> rotation_ijkw{0.f, 0.f, 0.f, 1.f};
+  static Transform eye() { return {}; }
+  a3d_pose to_c() const {
+    a3d_pose p;
+    for (int i = 0; i < 3; ++i) p.t[i] = translation[i];
+    for (int i = 0; i < 4; ++i) p.q[i] = rotation_ijkw[i];
+    return p;
+  }
+  static Transform from_c(const a3d_pose& p) {
+    Transform t;
+    for (int i = 0; i < 3; ++i) t.translation[i] = p.t[i];
+    for (int i = 0; i < 4; ++i) t.rotation_ijkw[i] = p.q[i];
+    return t;
+  }
+};
+
+/// IcpParams: the C struct is the field-for-field mirror; default() is IcpParams::default().
+struct IcpParams : a3d_icp_params {
+  IcpParams() { a3d_icp_params_default(this); }
+  static IcpParams default_() { return IcpParams(); }
+  IcpParams& with_max_iterations(uint64_t v) {
+    max_iterations = v;
+    return *this;
+  }
+  IcpParams& with_weight(float v) {
+    weight = v;
+    return *this;
+  }
+};
+
+/// MsIcpParams: per-level parameters, index 0 = finest level = last to run.
+class MsIcpParams {
+ public:
+  explicit MsIcpParams(std::vector<IcpParams> pyramid) : pyramid_(std::move(pyramid)) {}
+  static MsIcpParams repeat(size_t levels, const IcpParams& p) { return MsIcpParams(std::vector<IcpParams>(levels, p)); }
+  static MsIcpParams default_() {  // MsIcpParams::default(): 3 levels, 20/20/30 iterations
+    a3d_icp_params raw[3];
+    a3d_ms_icp_params_default(raw);
+    std::vector<IcpParams> v(3);
+    for (int i = 0; i < 3; ++i) static_cast<a3d_icp_params&>(v[i]) = raw[i];
+    return MsIcpParams(std::move(v));
+  }
+  MsIcpParams customize(const std::function<void(size_t, IcpParams&)>& f) && {
+    for (size_t i = 0; i < pyramid_.size(); ++i) f(i, pyramid_[i]);
+    return std::move(*this);
+  }
+  size_t len() const { return pyramid_.size(); }
+  bool is_empty() const { return pyramid_.empty(); }
+  IcpParams& operator[](size_t i) { return pyramid_[i]; }
+  const IcpParams& operator[](size_t i) const { return pyramid_[i]; }
+  auto begin() const { return pyramid_.begin(); }
+  auto end() const { return pyramid_.end(); }
+  std::vector<a3d_icp_params> to_c() const { return std::vector<a3d_icp_params>(pyramid_.begin(), pyramid_.end()); }
+
+ private:
+  std::vector<IcpParams> pyramid_;
+};
+
+/// A RangeImage resident in HBM (uploaded from a borrowed host view in the reference's standard layout).
+class RangeImage {
+ public:
+  RangeImage(const Context& ctx, const a3d_range_image_view& host_view) {
+    check(a3d_range_image_upload(ctx.raw(), &host_view, &img_));
+  }
+  ~RangeImage() { a3d_range_image_free(img_); }
+  RangeImage(RangeImage&& o) noexcept : img_(o.img_) { o.img_ = nullptr; }
+  RangeImage(const RangeImage&) = delete;
+  RangeImage& operator=(const RangeImage&) = delete;
+  /// RangeImage::compute_normals
+  RangeImage& compute_normals() {
+    check(a3d_range_image_compute_normals(img_));
+    return *this;
+  }
+  void download_normals(float* out_hw3) { check(a3d_range_image_download_normals(img_, out_hw3)); }
+  const a3d_device_image* raw() const { return img_; }
+
+ private:
+  a3d_device_image* img_ = nullptr;
+};
+
+inline std::vector<const a3d_device_image*> raw_pointers(const std::vector<RangeImage>& v) {
+  std::vector<const a3d_device_image*> out;
+  for (const auto& r : v) out.push_back(r.raw());
+  return out;
+}
+
+/// ImageIcp::new(params, &target); initial_transform; align(&source)
+class ImageIcp {
+ public:
+  ImageIcp(const Context& ctx, const IcpParams& params, const RangeImage& target)
+      : params(params), ctx_(ctx), target_(target) {}
+  IcpParams params;
+  Transform initial_transform = Transform::eye();
+  Transform align(const RangeImage& source) const {
+    a3d_pose init = initial_transform.to_c(), out;
+    check(a3d_image_icp_align(ctx_.raw(), &params, target_.raw(), source.raw(), &init, &out));
+    return Transform::from_c(out);
+  }
+
+ private:
+  const Context& ctx_;
+  const RangeImage& target_;
+};
+
+/// MultiscaleAlign::new(params, &target_pyramid) -> Result ; align(&source_pyramid) -> Transform
+class MultiscaleAlign {
+ public:
+  MultiscaleAlign(const Context& ctx, const MsIcpParams& params, const std::vector<RangeImage>& target_pyramid) {
+    auto p = params.to_c();
+    auto t = raw_pointers(target_pyramid);
+    check(a3d_multiscale_new(ctx.raw(), p.data(), p.size(), t.data(), t.size(), &ms_));  // throws InvalidParameter
+  }
+  ~MultiscaleAlign() { a3d_multiscale_free(ms_); }
+  MultiscaleAlign(const MultiscaleAlign&) = delete;
+  MultiscaleAlign& operator=(const MultiscaleAlign&) = delete;
+  Transform align(const std::vector<RangeImage>& source_pyramid) const {
+    auto s = raw_pointers(source_pyramid);
+    a3d_pose out;
+    check(a3d_multiscale_align(ms_, s.data(), s.size(), &out));
+    return Transform::from_c(out);
+  }
+
+ private:
+  a3d_multiscale* ms_ = nullptr;
+};
+
+/// R3dTree::new(&points) ; nearest(&query) -> (index, squared distance)
+class R3dTree {
+ public:
+  R3dTree(const Context& ctx, const float* points_n3, uint64_t n) { check(a3d_kdtree_new(ctx.raw(), points_n3, n, &t_)); }
+  ~R3dTree() { a3d_kdtree_free(t_); }
+  R3dTree(const R3dTree&) = delete;
+  R3dTree& operator=(const R3dTree&) = delete;
+  std::pair<uint64_t, float> nearest(const std::array<float, 3>& q) const {
+    uint64_t idx;
+    float d;
+    check(a3d_kdtree_nearest(t_, q.data(), 1, &idx, &d));
+    return {idx, d};
+  }
+  void nearest(const float* queries_m3, uint64_t m, uint64_t* out_idx, float* out_sqr) const {
+    check(a3d_kdtree_nearest(t_, queries_m3, m, out_idx, out_sqr));
+  }
+
+ private:
+  a3d_kdtree* t_ = nullptr;
+};
+
+/// Icp::new(params, &target_cloud) ; align(&source_cloud)
+class Icp {
+ public:
+  Icp(const Context& ctx, const IcpParams& params, const a3d_point_cloud_view& target) {
+    check(a3d_pcl_icp_new(ctx.raw(), &params, &target, &icp_));
+  }
+  ~Icp() { a3d_pcl_icp_free(icp_); }
+  Icp(const Icp&) = delete;
+  Icp& operator=(const Icp&) = delete;
+  Transform align(const a3d_point_cloud_view& source) const {
+    a3d_pose out;
+    check(a3d_pcl_icp_align(icp_, &source, &out));
+    return Transform::from_c(out);
+  }
+
+ private:
+  a3d_pcl_icp* icp_ = nullptr;
+};
+
+/// BilateralFilter::<u16>::{default, new}(sigma_space, sigma_color).filter(&image)
+class BilateralFilter {
+ public:
+  double sigma_space, sigma_color;
+  BilateralFilter() { a3d_bilateral_default_sigmas(&sigma_space, &sigma_color); }
+  BilateralFilter(double ss, double sc) : sigma_space(ss), sigma_color(sc) {}
+  std::vector<uint16_t> filter(const Context& ctx, const uint16_t* image, uint64_t width, uint64_t height) const {
+    std::vector<uint16_t> out(width * height);
+    check(a3d_bilateral_filter_u16(ctx.raw(), image, width, height, sigma_space, sigma_color, out.data(), nullptr));
+    return out;
+  }
+};
+
+}  // namespace align3d

@@ -1,0 +1,79 @@
+// Exercises include/align3d.hpp (the C++ host-side mirror of the reference API) against libalign3d_hip.so.
+//   ./host_mirror_test        CPU-only checks (parameters, error mapping without a GPU)
+//   ./host_mirror_test gpu    + the kd-tree KAT of src/kdtree.rs:121-139, MultiscaleAlign::new's length check
+//                             (src/icp/multiscale.rs:30-34) and one tiny ImageIcp on the device
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/align3d.hpp"
+
+#define EXPECT(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+using namespace align3d;
+
+int main(int argc, char** argv) {
+  // IcpParams::default() / MsIcpParams::default() (src/icp/icp_params.rs:33-43, :112-133)
+  IcpParams p;
+  EXPECT(p.max_iterations == 15 && p.weight == 1.0f && p.color_weight == 0.1f && p.max_distance == 0.5f);
+  EXPECT(std::fabs(p.max_normal_angle - 18.0f * 3.14159265f / 180.0f) < 1e-7f && p.max_color_distance == 0.25f);
+  MsIcpParams ms = MsIcpParams::default_();
+  EXPECT(ms.len() == 3 && ms[0].max_iterations == 20 && ms[1].max_iterations == 20 && ms[2].max_iterations == 30);
+  EXPECT(ms[0].color_weight == 1.0f && ms[2].max_color_distance == 2.75f);
+  MsIcpParams rep = MsIcpParams::repeat(3, IcpParams()).customize([](size_t i, IcpParams& q) { q.max_iterations = 5 + i; });
+  EXPECT(rep[0].max_iterations == 5 && rep[2].max_iterations == 7 && !rep.is_empty());
+  BilateralFilter bf;
+  EXPECT(bf.sigma_space == 4.50000000225 && bf.sigma_color == 29.9999880000072);
+  const bool want_gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
+  if (!want_gpu) {
+    try {
+      Context ctx(0);
+      std::printf("a GPU is present; run with `gpu` for the device checks\n");
+    } catch (const Panic& e) {
+      EXPECT(e.status == A3D_HIP_ERROR);  // no device: a loud error, never a CPU fallback
+    }
+    std::printf("host mirror CPU checks OK\n");
+    return 0;
+  }
+  Context ctx(0);
+  {  // src/kdtree.rs:121-139
+    const float pts[] = {1, 2, 3, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+    R3dTree tree(ctx, pts, 4);
+    EXPECT(tree.nearest({8.f, 9.1f, 1.3f}).first == 3 && tree.nearest({5.1f, 6.4f, 7.f}).first == 2);
+    EXPECT(tree.nearest({1.5f, 2.1f, 3.3f}).first == 0 && tree.nearest({2.2f, 3.1f, 4.2f}).first == 1);
+  }
+  // a 32x24 fronto-parallel plane at z = 2 with a gradient texture, seen twice
+  const int W = 32, H = 24;
+  std::vector<float> pts(W * H * 3), nrm(W * H * 3), imap((W + 2) * (H + 2), 0.f);
+  std::vector<uint8_t> mask(W * H, 1), inten(W * H);
+  for (int r = 0; r < H; ++r)
+    for (int c = 0; c < W; ++c) {
+      int i = r * W + c;
+      pts[3 * i] = (c - 16.f) * 2.f / 40.f, pts[3 * i + 1] = (r - 12.f) * 2.f / 40.f, pts[3 * i + 2] = 2.f;
+      nrm[3 * i] = 0, nrm[3 * i + 1] = 0, nrm[3 * i + 2] = -1;
+      inten[i] = (uint8_t)(4 * c + 3 * r);
+      imap[r * (W + 2) + c] = inten[i] / 255.0f;
+    }
+  a3d_range_image_view v{pts.data(), mask.data(), nrm.data(), inten.data(), imap.data(), 40, 40, 16, 12, (uint64_t)W, (uint64_t)H};
+  std::vector<RangeImage> target, source;
+  target.emplace_back(ctx, v);
+  source.emplace_back(ctx, v);
+  try {  // MultiscaleAlign::new: Err(InvalidParameter) on a length mismatch
+    MultiscaleAlign bad(ctx, MsIcpParams::repeat(2, IcpParams()), target);
+    EXPECT(false);
+  } catch (const InvalidParameter& e) {
+    EXPECT(std::strstr(e.what(), "must be equal") != nullptr);
+  }
+  IcpParams one = IcpParams().with_max_iterations(2);
+  one.color_weight = 1.0f;
+  Transform T = MultiscaleAlign(ctx, MsIcpParams::repeat(1, one), target).align(source);
+  // identical frames: the estimate stays at the identity to rounding
+  for (int i = 0; i < 3; ++i) EXPECT(std::fabs(T.translation[i]) < 1e-4f && std::fabs(T.rotation_ijkw[i]) < 1e-4f);
+  EXPECT(std::fabs(T.rotation_ijkw[3] - 1.0f) < 1e-6f);
+  ImageIcp icp(ctx, one, target[0]);
+  Transform T2 = icp.align(source[0]);
+  EXPECT(std::fabs(T2.translation[0] - T.translation[0]) < 1e-6f);
+  std::printf("host mirror GPU checks OK\n");
+  return 0;
+}

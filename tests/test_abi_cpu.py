@@ -95,3 +95,13 @@ def test_host_frame_preparation_matches_oracle():
     small = blur_rgb_and_halve(rgb, 1.0)
     assert small.shape == (240, 320, 3)
     assert np.max(np.abs(small.astype(int) - down.colors.astype(int))) <= 1
+
+
+def test_cpp_host_mirror_cpu_checks():
+    """include/align3d.hpp (C++ mirror of the reference API) compiles with g++ and its host logic holds."""
+    import subprocess
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "host_mirror_test")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout or "GPU is present" in out.stdout

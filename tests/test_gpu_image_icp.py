@@ -207,3 +207,16 @@ def test_shared_reciprocal_division_is_ieee_exact(ctx):
     bad = C.c_uint64(123)
     _abi.check(ctx.lib.a3d_selftest_division(ctx.handle, _abi.ptr(a), _abi.ptr(z), n, C.byref(bad)))
     assert bad.value == 0
+
+
+def test_cpp_host_mirror_on_gpu():
+    """The C++ mirror (include/align3d.hpp) drives the same library: kd-tree KAT, InvalidParameter, ImageIcp."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "host_mirror_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "GPU checks OK" in out.stdout, out.stdout + out.stderr
