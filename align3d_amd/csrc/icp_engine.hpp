@@ -251,43 +251,64 @@ __device__ __forceinline__ void block_publish_and_finish(float* __restrict__ job
                                                          const SolveArgs& args, int job) {
   if (args.mode == SOLVE_NONE) return;
   __shared__ unsigned s_is_last;
-  __shared__ double s_sums[4][64];
+  __shared__ double s_sums[8][64];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned last = ticket == tiles - 1 ? 1u : 0u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    s_is_last = last;
+    s_is_last = ticket == tiles - 1 ? 1u : 0u;
   }
   __syncthreads();
   if (!s_is_last) return;
   // ---- last block of this job ----
-  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  double sum = 0.0;
-  if (c < GN_PARTIAL) {
-    // tile t of slice s is t = s + 4 j; eight loads in flight per thread, summed in tile order
-    const unsigned* base = (const unsigned*)job_partials + c;
-    uint32_t t = slice;
-    for (; t + 28 < tiles; t += 32) {
-      float v[8];
+  // Every load of the handed-off partials below is an sc1 (agent-scope) load that bypasses this CU's L1,
+  // so no acquire fence (an L1 invalidate) is needed.  Thread (pair of components cg, slice s) sums tiles
+  // s, s + 8, ... in tile order with 8-byte loads, up to eight in flight; then the 8 slices are added in a
+  // fixed order: the totals do not depend on which block came last.
+  {
+    const int cg = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double sum0 = 0.0, sum1 = 0.0;
+    if (cg < GN_PARTIAL / 2) {
+      const unsigned long long* base = (const unsigned long long*)job_partials + cg;
+      uint32_t t = slice;
+      for (; t + 56 < tiles; t += 64) {
+        unsigned long long v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        v[k] = __uint_as_float(__hip_atomic_load(base + (size_t)(t + 4 * k) * GN_PARTIAL, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT));
+        for (int k = 0; k < 8; ++k)
+          v[k] = __hip_atomic_load(base + (size_t)(t + 8 * k) * (GN_PARTIAL / 2), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sum += (double)v[k];
+        for (int k = 0; k < 8; ++k) {
+          sum0 += (double)__uint_as_float((unsigned)v[k]);
+          sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
+        }
+      }
+      unsigned long long v[8];
+      int n = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t tt = t + 8 * k;
+        v[k] = tt < tiles ? __hip_atomic_load(base + (size_t)tt * (GN_PARTIAL / 2), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT)
+                          : 0ull;  // +0.0f, +0.0f: adds nothing
+        n += tt < tiles;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        sum0 += (double)__uint_as_float((unsigned)v[k]);
+        sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
+      }
+      (void)n;
+      s_sums[slice][2 * cg] = sum0;
+      s_sums[slice][2 * cg + 1] = sum1;
     }
-    for (; t < tiles; t += 4)
-      sum += (double)__uint_as_float(
-          __hip_atomic_load(base + (size_t)t * GN_PARTIAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   }
-  s_sums[slice][c] = sum;
   __syncthreads();
-  if (threadIdx.x < 64) s_sums[0][c] = (s_sums[0][c] + s_sums[1][c]) + (s_sums[2][c] + s_sums[3][c]);
+  if (threadIdx.x < GN_PARTIAL) {
+    const int c = threadIdx.x;
+    s_sums[0][c] = ((s_sums[0][c] + s_sums[1][c]) + (s_sums[2][c] + s_sums[3][c])) +
+                   ((s_sums[4][c] + s_sums[5][c]) + (s_sums[6][c] + s_sums[7][c]));
+  }
   __syncthreads();
   if (threadIdx.x == 0)  // ready for the next launch (ordered by the kernel boundary)
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
