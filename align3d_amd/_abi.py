@@ -75,6 +75,20 @@ class PointCloudViewC(C.Structure):
     _fields_ = [("points", C.c_void_p), ("normals", C.c_void_p), ("len", C.c_uint64)]
 
 
+class BuilderParamsC(C.Structure):
+    _fields_ = [
+        ("with_normals", C.c_uint32),
+        ("with_intensity", C.c_uint32),
+        ("use_bilateral", C.c_uint32),
+        ("pad", C.c_uint32),
+        ("sigma_space", C.c_double),
+        ("sigma_color", C.c_double),
+        ("pyramid_levels", C.c_uint64),
+        ("blur_sigma", C.c_float),
+        ("pad2", C.c_uint32),
+    ]
+
+
 class GnStateC(C.Structure):
     _fields_ = [
         ("hessian", C.c_float * 36),
@@ -125,6 +139,14 @@ SIGNATURES = {
     "a3d_range_image_free": (_ST, [_P]),
     "a3d_range_image_compute_normals": (_ST, [_P]),
     "a3d_range_image_download_normals": (_ST, [_P, _P]),
+    "a3d_builder_params_default": (None, [C.POINTER(BuilderParamsC)]),
+    "a3d_range_image_build_pyramid": (
+        _ST,
+        [_P, C.POINTER(BuilderParamsC), _P, _P, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double,
+         C.c_double, C.c_double, _PP],
+    ),
+    "a3d_range_image_size": (_ST, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "a3d_range_image_download": (_ST, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double)]),
     "a3d_compute_normals": (_ST, [_P, _P, _P, C.c_uint64, C.c_uint64, _P]),
     "a3d_image_icp_align": (_ST, [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(PoseC)]),
     "a3d_image_icp_accumulate": (

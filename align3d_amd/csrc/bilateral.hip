@@ -130,30 +130,23 @@ __global__ void __launch_bounds__(256)
 
 }  // namespace
 
-extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t* image, uint64_t width,
-                                               uint64_t height, double sigma_space, double sigma_color,
-                                               uint16_t* out_image, uint64_t out_grid_dims[3]) {
-  A3D_REQUIRE(ctx && image && out_image, A3D_INVALID_PARAMETER, "null argument");
-  A3D_REQUIRE(width > 0 && height > 0 && width * height < (1ull << 30), A3D_INVALID_PARAMETER, "bad image size");
-  A3D_REQUIRE(sigma_space > 0.0 && sigma_color > 0.0, A3D_INVALID_PARAMETER, "sigmas must be positive");
-  A3D_HIP_TRY(hipSetDevice(ctx->device));
+namespace a3d {
+
+// The whole filter on device-resident images.  One small host round trip (min / max) sizes the grid.
+a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w, uint32_t h,
+                                   double sigma_space, double sigma_color, uint64_t out_grid_dims[3]) {
   hipStream_t s = ctx->stream;
-  const uint32_t w = (uint32_t)width, h = (uint32_t)height, n = w * h;
-  uint16_t *d_img = nullptr, *d_out = nullptr;
+  const uint32_t n = w * h;
   uint32_t* d_scal = nullptr;  // [0] min, [1] max, [2] overflow flag
   double2 *d_a = nullptr, *d_b = nullptr;
   a3d_status st = A3D_OK;
   auto fail = [&](const char* what) {
-    set_error("a3d_bilateral_filter_u16: %s: %s", what, hipGetErrorString(hipGetLastError()));
+    set_error("bilateral filter: %s: %s", what, hipGetErrorString(hipGetLastError()));
     st = A3D_HIP_ERROR;
   };
   uint32_t h_scal[3] = {0xFFFFu, 0u, 0u};
-  if (hipMalloc((void**)&d_img, n * 2) != hipSuccess || hipMalloc((void**)&d_out, n * 2) != hipSuccess ||
-      hipMalloc((void**)&d_scal, 12) != hipSuccess)
-    fail("hipMalloc");
-  if (st == A3D_OK && (hipMemcpyAsync(d_img, image, n * 2, hipMemcpyHostToDevice, s) != hipSuccess ||
-                       hipMemcpyAsync(d_scal, h_scal, 12, hipMemcpyHostToDevice, s) != hipSuccess))
-    fail("upload");
+  if (hipMalloc((void**)&d_scal, 12) != hipSuccess) fail("hipMalloc");
+  if (st == A3D_OK && hipMemcpyAsync(d_scal, h_scal, 12, hipMemcpyHostToDevice, s) != hipSuccess) fail("upload");
   if (st == A3D_OK) {
     hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64)), dim3(256), 0, s, d_img, n,
                        d_scal);
@@ -192,13 +185,10 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
                          src, d_out, d_scal + 2);
       if (hipGetLastError() != hipSuccess) fail("kernel launch");
     }
-    if (st == A3D_OK && (hipMemcpyAsync(out_image, d_out, n * 2, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                         hipMemcpyAsync(h_scal + 2, d_scal + 2, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+    if (st == A3D_OK && (hipMemcpyAsync(h_scal + 2, d_scal + 2, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
                          hipStreamSynchronize(s) != hipSuccess))
-      fail("download");
+      fail("flag download");
   }
-  hipFree(d_img);
-  hipFree(d_out);
   hipFree(d_scal);
   hipFree(d_a);
   hipFree(d_b);
@@ -208,4 +198,33 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
     return A3D_CAST_OVERFLOW;
   }
   return A3D_OK;
+}
+
+}  // namespace a3d
+
+extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t* image, uint64_t width,
+                                               uint64_t height, double sigma_space, double sigma_color,
+                                               uint16_t* out_image, uint64_t out_grid_dims[3]) {
+  A3D_REQUIRE(ctx && image && out_image, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(width > 0 && height > 0 && width * height < (1ull << 28), A3D_INVALID_PARAMETER, "bad image size");
+  A3D_REQUIRE(sigma_space > 0.0 && sigma_color > 0.0, A3D_INVALID_PARAMETER, "sigmas must be positive");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint32_t w = (uint32_t)width, h = (uint32_t)height, n = w * h;
+  uint16_t *d_img = nullptr, *d_out = nullptr;
+  a3d_status st = A3D_OK;
+  if (hipMalloc((void**)&d_img, n * 2) != hipSuccess || hipMalloc((void**)&d_out, n * 2) != hipSuccess ||
+      hipMemcpyAsync(d_img, image, n * 2, hipMemcpyHostToDevice, s) != hipSuccess) {
+    set_error("a3d_bilateral_filter_u16: upload: %s", hipGetErrorString(hipGetLastError()));
+    st = A3D_HIP_ERROR;
+  }
+  if (st == A3D_OK) st = bilateral_filter_device(ctx, d_img, d_out, w, h, sigma_space, sigma_color, out_grid_dims);
+  if (st == A3D_OK && (hipMemcpyAsync(out_image, d_out, n * 2, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                       hipStreamSynchronize(s) != hipSuccess)) {
+    set_error("a3d_bilateral_filter_u16: download: %s", hipGetErrorString(hipGetLastError()));
+    st = A3D_HIP_ERROR;
+  }
+  hipFree(d_img);
+  hipFree(d_out);
+  return st;
 }

@@ -11,6 +11,8 @@
 #include "../../include/align3d_hip.h"
 #include "devmath.hpp"
 
+struct a3d_context;
+
 namespace a3d {
 
 void set_error(const char* fmt, ...);
@@ -54,6 +56,15 @@ float acos_gate_threshold(float thr, bool strict);
 
 }  // namespace a3d
 
+namespace a3d {
+// BilateralFilter::filter on device-resident u16 images (bilateral.hip).
+a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w, uint32_t h,
+                                   double sigma_space, double sigma_color, uint64_t out_grid_dims[3]);
+// RangeImage::compute_normals on device-resident arrays (image.hip).
+a3d_status compute_normals_device(a3d_context* ctx, const float* d_points, const uint8_t* d_mask, float* d_normals,
+                                  uint32_t w, uint32_t h);
+}  // namespace a3d
+
 struct a3d_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -65,11 +76,13 @@ struct a3d_context {
 struct a3d_device_image {
   a3d_context* ctx = nullptr;
   uint32_t width = 0, height = 0;
+  double fx64 = 0, fy64 = 0, cx64 = 0, cy64 = 0;  // CameraIntrinsics as given (pyramid levels scale these)
   float fx = 0, fy = 0, cx = 0, cy = 0;  // cast f64 -> f32 once, as the reference does at each use
   float* points = nullptr;               // [h][w][3]
   uint8_t* mask = nullptr;               // [h][w]
   float* normals = nullptr;              // [h][w][3] or null
   uint8_t* intensities = nullptr;        // [h*w] or null
   float* imap = nullptr;                 // [(h+2)][(w+2)] or null
+  uint8_t* colors = nullptr;             // [h][w][3] or null (kept by the device-side builder for the pyramid)
   bool has_normals = false, has_intensities = false, has_imap = false;
 };

@@ -1,0 +1,336 @@
+// RangeImageBuilder::build (src/range_image/builder.rs:74-91) entirely on the device: a frame enters
+// HBM as u16 depth + u8 RGB (1.5 MB for 640x480 instead of ~12 MB of f32 pyramid levels) and leaves as a
+// resident pyramid:
+//   bilateral filter                 src/bilateral/edge_aware_filter.rs:126-135   (bilateral.hip)
+//   RangeImage::from_rgbd_image      src/range_image/structure.rs:56-95
+//   RangeImage::compute_normals      src/range_image/structure.rs:184-262        (image.hip)
+//   RangeImage::pyr_scale_down       src/range_image/structure.rs:309-340, src/range_image/resize.rs:4-104
+//   compute_intensity / _map         src/range_image/structure.rs:266-297, src/image/luma.rs:81-83,
+//                                    src/intensity_map.rs:37-92
+// The RGB blur of the pyramid (image 0.24.7 imageops::blur) is restated from its published algorithm
+// like the oracle's: PARITY UNPINNED (no reference test pins its values).
+#include <cmath>
+#include <memory>
+
+#include "common.hpp"
+
+using namespace a3d;
+
+namespace {
+
+// CameraIntrinsics::backproject (src/camera.rs:101-107) over a depth image; mask = depth > 0.
+__global__ void backproject_kernel(const uint16_t* __restrict__ depth, uint32_t w, uint32_t h, float fx, float fy,
+                                   float cx, float cy, float scale, float* __restrict__ points,
+                                   uint8_t* __restrict__ mask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const uint32_t y = i / w, x = i % w;
+  const uint16_t d = depth[i];
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (d > 0) {
+    pz = (float)d * scale;
+    px = ((float)x - cx) * pz / fx;
+    py = ((float)y - cy) * pz / fy;
+  }
+  points[3 * i] = px, points[3 * i + 1] = py, points[3 * i + 2] = pz;
+  mask[i] = d > 0 ? 1 : 0;
+}
+
+// rgb_to_luma_u8 (src/image/luma.rs:81-83): (r*0.3 + g*0.59 + b*0.11) as u8 (saturating truncation)
+__global__ void luma_kernel(const uint8_t* __restrict__ rgb, uint32_t n, uint8_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float l = (float)rgb[3 * i] * 0.3f + (float)rgb[3 * i + 1] * 0.59f + (float)rgb[3 * i + 2] * 0.11f;
+  out[i] = l >= 255.0f ? 255 : (l <= 0.0f ? 0 : (uint8_t)l);
+}
+
+// IntensityMap::from_luma_image (src/intensity_map.rs:37-92), one thread per cell of the (h+2) x (w+2) map,
+// including the incomplete border: rows h, h+1 copy row h-1 for cols < w-1; cols w, w+1 copy col w-1 for
+// rows < h-1; (h, w) and (h+1, w+1) take the last pixel; the other border cells stay 0.
+__global__ void intensity_map_kernel(const uint8_t* __restrict__ luma, uint32_t w, uint32_t h, float* __restrict__ map) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t mw = w + 2, mh = h + 2;
+  if (i >= mw * mh) return;
+  const uint32_t r = i / mw, c = i % mw;
+  float v = 0.0f;
+  if (r < h && c < w)
+    v = (float)luma[r * w + c] / 255.0f;
+  else if (r >= h && c + 1 < w)
+    v = (float)luma[(h - 1) * w + c] / 255.0f;
+  else if (c >= w && r + 1 < h)
+    v = (float)luma[r * w + (w - 1)] / 255.0f;
+  else if ((r == h && c == w) || (r == h + 1 && c == w + 1))
+    v = (float)luma[(h - 1) * w + (w - 1)] / 255.0f;
+  map[i] = v;
+}
+
+// get_neighborhood_mean_point over every 2x2 block (src/range_image/resize.rs:4-40): among the entries
+// whose SOURCE mask is 1, the one nearest to their mean (strict <, first wins).  Used for points
+// (writes the destination mask) and for normals (mask output null).
+__global__ void resize_pick_kernel(const float* __restrict__ src, const uint8_t* __restrict__ src_mask, uint32_t sw,
+                                   uint32_t sh, uint32_t dw, uint32_t dh, float* __restrict__ dst,
+                                   uint8_t* __restrict__ dst_mask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dw * dh) return;
+  const uint32_t dv = i / dw, du = i % dw;
+  const float hr = (float)sh / (float)dh, wr = (float)sw / (float)dw;
+  const uint32_t sv = (uint32_t)((float)dv * hr), su = (uint32_t)((float)du * wr);
+  V3 local[4];
+  int n = 0;
+#pragma unroll
+  for (uint32_t a = 0; a < 2; ++a)
+#pragma unroll
+    for (uint32_t b = 0; b < 2; ++b) {
+      const uint32_t r = sv + a, c = su + b;
+      if (r < sh && c < sw && src_mask[r * sw + c] == 1) {
+        const uint32_t k = r * sw + c;
+        local[n++] = V3{src[3 * k], src[3 * k + 1], src[3 * k + 2]};
+      }
+    }
+  V3 nearest{0.f, 0.f, 0.f};
+  if (n > 0) {
+    V3 sum{0.f, 0.f, 0.f};
+    for (int k = 0; k < n; ++k) sum = sum + local[k];
+    const V3 mean = sum / (float)n;
+    float min_dist = 3.402823466e+38f;
+    for (int k = 0; k < n; ++k) {
+      const float d = norm_squared(local[k] - mean);
+      if (d < min_dist) {
+        min_dist = d;
+        nearest = local[k];
+      }
+    }
+  }
+  dst[3 * i] = nearest.x, dst[3 * i + 1] = nearest.y, dst[3 * i + 2] = nearest.z;
+  if (dst_mask) dst_mask[i] = n > 0 ? 1 : 0;
+}
+
+// One tap table entry per output row / column: first tap, tap count, normalised weights.
+struct TapRow {
+  int32_t left, count;
+  float w[6];
+};
+
+// vertical pass of the blur: u8 rgb -> f32, every row
+__global__ void blur_vertical_kernel(const uint8_t* __restrict__ rgb, uint32_t w, uint32_t h,
+                                     const TapRow* __restrict__ taps, float* __restrict__ tmp) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // over h * w * 3
+  if (i >= w * h * 3) return;
+  const uint32_t oy = i / (w * 3), rem = i % (w * 3);
+  const TapRow t = taps[oy];
+  float acc = 0.0f;
+  for (int k = 0; k < t.count; ++k) acc += (float)rgb[(size_t)(t.left + k) * w * 3 + rem] * t.w[k];
+  tmp[i] = acc;
+}
+
+// horizontal pass at even rows / columns only, clamp, round to nearest (half away from zero), u8
+__global__ void blur_horizontal_halve_kernel(const float* __restrict__ tmp, uint32_t w, uint32_t dw, uint32_t dh,
+                                             const TapRow* __restrict__ taps, uint8_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // over dh * dw * 3
+  if (i >= dw * dh * 3) return;
+  const uint32_t ch = i % 3, dx = (i / 3) % dw, dy = i / (3 * dw);
+  const TapRow t = taps[dx];
+  float acc = 0.0f;
+  for (int k = 0; k < t.count; ++k) acc += tmp[((size_t)(2 * dy) * w + (uint32_t)(t.left + k)) * 3 + ch] * t.w[k];
+  acc = fminf(fmaxf(acc, 0.0f), 255.0f);
+  out[i] = (uint8_t)roundf(acc);
+}
+
+// Tap tables of image::imageops::blur's sampling filter (support 2 sigma, weights renormalised over the
+// clamped range), computed on the host in f32 exactly as the oracle computes them.
+std::vector<TapRow> make_taps(uint32_t size, float sigma, uint32_t stride, uint32_t count) {
+  const float support = 2.0f * sigma;
+  std::vector<TapRow> rows(count);
+  for (uint32_t k = 0; k < count; ++k) {
+    const uint32_t o = k * stride;
+    const float in = (float)o + 0.5f;
+    int64_t left = (int64_t)std::floor(in - support);
+    left = std::min<int64_t>(std::max<int64_t>(left, 0), (int64_t)size - 1);
+    int64_t right = (int64_t)std::ceil(in + support);
+    right = std::min<int64_t>(std::max<int64_t>(right, left + 1), (int64_t)size);
+    const float c = in - 0.5f;
+    TapRow r{};
+    r.left = (int32_t)left;
+    r.count = (int32_t)std::min<int64_t>(right - left, 6);
+    float sum = 0.0f, wv[6];
+    for (int i = 0; i < r.count; ++i) {
+      const float x = (float)(left + i) - c;
+      wv[i] = 1.0f / (std::sqrt(2.0f * 3.14159265358979323846f) * sigma) * std::exp(-(x * x) / (2.0f * sigma * sigma));
+      sum += wv[i];
+    }
+    for (int i = 0; i < r.count; ++i) r.w[i] = wv[i] / sum;
+    rows[k] = r;
+  }
+  return rows;
+}
+
+template <typename T>
+a3d_status dev_alloc(T** p, size_t count) {
+  A3D_HIP_TRY(hipMalloc((void**)p, std::max<size_t>(1, count) * sizeof(T)));
+  return A3D_OK;
+}
+
+inline dim3 grid_for(size_t n) { return dim3((uint32_t)((n + 255) / 256)); }
+
+// compute_intensity + compute_intensity_map on a resident level that has colours
+a3d_status add_intensity(a3d_device_image* im) {
+  const uint32_t w = im->width, h = im->height, n = w * h;
+  hipStream_t s = im->ctx->stream;
+  A3D_TRY(dev_alloc(&im->intensities, n));
+  A3D_TRY(dev_alloc(&im->imap, (size_t)(w + 2) * (h + 2)));
+  hipLaunchKernelGGL(luma_kernel, grid_for(n), dim3(256), 0, s, im->colors, n, im->intensities);
+  hipLaunchKernelGGL(intensity_map_kernel, grid_for((size_t)(w + 2) * (h + 2)), dim3(256), 0, s, im->intensities, w, h,
+                     im->imap);
+  A3D_HIP_TRY(hipGetLastError());
+  im->has_intensities = im->has_imap = true;
+  return A3D_OK;
+}
+
+// RangeImage::pyr_scale_down(sigma) (structure.rs:309-340)
+a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_image* dst) {
+  a3d_context* ctx = src->ctx;
+  hipStream_t s = ctx->stream;
+  const uint32_t sw = src->width, sh = src->height, dw = sw / 2, dh = sh / 2, dn = dw * dh;
+  dst->ctx = ctx;
+  dst->width = dw, dst->height = dh;
+  dst->fx64 = src->fx64 * 0.5, dst->fy64 = src->fy64 * 0.5, dst->cx64 = src->cx64 * 0.5, dst->cy64 = src->cy64 * 0.5;
+  dst->fx = (float)dst->fx64, dst->fy = (float)dst->fy64, dst->cx = (float)dst->cx64, dst->cy = (float)dst->cy64;
+  A3D_TRY(dev_alloc(&dst->points, (size_t)dn * 3));
+  A3D_TRY(dev_alloc(&dst->mask, dn));
+  hipLaunchKernelGGL(resize_pick_kernel, grid_for(dn), dim3(256), 0, s, src->points, src->mask, sw, sh, dw, dh,
+                     dst->points, dst->mask);
+  if (src->has_normals) {
+    A3D_TRY(dev_alloc(&dst->normals, (size_t)dn * 3));
+    hipLaunchKernelGGL(resize_pick_kernel, grid_for(dn), dim3(256), 0, s, src->normals, src->mask, sw, sh, dw, dh,
+                       dst->normals, (uint8_t*)nullptr);
+    dst->has_normals = true;
+  }
+  if (src->colors) {
+    if (sigma <= 0.0f) sigma = 1.0f;
+    const std::vector<TapRow> tv = make_taps(sh, sigma, 1, sh), th = make_taps(sw, sigma, 2, dw);
+    TapRow *d_tv = nullptr, *d_th = nullptr;
+    float* d_tmp = nullptr;
+    A3D_TRY(dev_alloc(&d_tv, tv.size()));
+    A3D_TRY(dev_alloc(&d_th, th.size()));
+    A3D_TRY(dev_alloc(&d_tmp, (size_t)sw * sh * 3));
+    A3D_TRY(dev_alloc(&dst->colors, (size_t)dn * 3));
+    A3D_HIP_TRY(hipMemcpyAsync(d_tv, tv.data(), tv.size() * sizeof(TapRow), hipMemcpyHostToDevice, s));
+    A3D_HIP_TRY(hipMemcpyAsync(d_th, th.data(), th.size() * sizeof(TapRow), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(blur_vertical_kernel, grid_for((size_t)sw * sh * 3), dim3(256), 0, s, src->colors, sw, sh, d_tv,
+                       d_tmp);
+    hipLaunchKernelGGL(blur_horizontal_halve_kernel, grid_for((size_t)dn * 3), dim3(256), 0, s, d_tmp, sw, dw, dh, d_th,
+                       dst->colors);
+    A3D_HIP_TRY(hipStreamSynchronize(s));  // the tap tables above are host vectors
+    hipFree(d_tv);
+    hipFree(d_th);
+    hipFree(d_tmp);
+  }
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// RangeImageBuilder::default() (builder.rs:16-26)
+void a3d_builder_params_default(a3d_builder_params* out) {
+  out->with_normals = 1;
+  out->with_intensity = 1;
+  out->use_bilateral = 0;
+  a3d_bilateral_default_sigmas(&out->sigma_space, &out->sigma_color);
+  out->pyramid_levels = 3;
+  out->blur_sigma = 1.0f;
+}
+
+a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_params* prm, const uint16_t* depth,
+                                         const uint8_t* rgb, uint64_t width, uint64_t height, double fx, double fy,
+                                         double cx, double cy, double depth_scale, a3d_device_image** out_levels) {
+  A3D_REQUIRE(ctx && prm && depth && rgb && out_levels, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(width > 0 && height > 0 && width * height < (1ull << 28), A3D_INVALID_PARAMETER, "bad image size");
+  A3D_REQUIRE(prm->pyramid_levels >= 1 && prm->pyramid_levels <= 16, A3D_INVALID_PARAMETER, "bad pyramid_levels");
+  A3D_REQUIRE((width >> (prm->pyramid_levels - 1)) >= 2 && (height >> (prm->pyramid_levels - 1)) >= 2,
+              A3D_INVALID_PARAMETER, "image too small for this many pyramid levels");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint32_t w = (uint32_t)width, h = (uint32_t)height, n = w * h;
+  std::vector<std::unique_ptr<a3d_device_image, a3d_status (*)(a3d_device_image*)>> levels;
+  auto new_level = [&]() {
+    levels.emplace_back(new a3d_device_image(), a3d_range_image_free);
+    levels.back()->ctx = ctx;
+    return levels.back().get();
+  };
+  uint16_t *d_depth = nullptr, *d_filtered = nullptr;
+  struct Scratch {
+    uint16_t **a, **b;
+    ~Scratch() {
+      hipFree(*a);
+      hipFree(*b);
+    }
+  } scratch{&d_depth, &d_filtered};
+  a3d_device_image* l0 = new_level();
+  l0->width = w, l0->height = h;
+  l0->fx64 = fx, l0->fy64 = fy, l0->cx64 = cx, l0->cy64 = cy;
+  l0->fx = (float)fx, l0->fy = (float)fy, l0->cx = (float)cx, l0->cy = (float)cy;
+  A3D_TRY(dev_alloc(&d_depth, n));
+  A3D_TRY(dev_alloc(&l0->colors, (size_t)n * 3));
+  A3D_TRY(dev_alloc(&l0->points, (size_t)n * 3));
+  A3D_TRY(dev_alloc(&l0->mask, n));
+  A3D_HIP_TRY(hipMemcpyAsync(d_depth, depth, (size_t)n * 2, hipMemcpyHostToDevice, s));
+  A3D_HIP_TRY(hipMemcpyAsync(l0->colors, rgb, (size_t)n * 3, hipMemcpyHostToDevice, s));
+  const uint16_t* d_use = d_depth;
+  if (prm->use_bilateral) {  // builder.rs:75-77
+    A3D_TRY(dev_alloc(&d_filtered, n));
+    A3D_TRY(bilateral_filter_device(ctx, d_depth, d_filtered, w, h, prm->sigma_space, prm->sigma_color, nullptr));
+    d_use = d_filtered;
+  }
+  hipLaunchKernelGGL(backproject_kernel, grid_for(n), dim3(256), 0, s, d_use, w, h, l0->fx, l0->fy, l0->cx, l0->cy,
+                     (float)depth_scale, l0->points, l0->mask);
+  if (prm->with_normals) {  // level 0 only (builder.rs:79-82); coarser levels inherit picked normals
+    A3D_TRY(dev_alloc(&l0->normals, (size_t)n * 3));
+    A3D_TRY(compute_normals_device(ctx, l0->points, l0->mask, l0->normals, w, h));
+    l0->has_normals = true;
+  }
+  for (uint64_t l = 1; l < prm->pyramid_levels; ++l) {  // RangeImage::pyramid (structure.rs:342-351)
+    a3d_device_image* prev = levels.back().get();
+    a3d_device_image* next = new_level();
+    A3D_TRY(pyr_scale_down(prev, prm->blur_sigma, next));
+  }
+  if (prm->with_intensity)
+    for (auto& lv : levels) A3D_TRY(add_intensity(lv.get()));
+  A3D_HIP_TRY(hipGetLastError());
+  A3D_HIP_TRY(hipStreamSynchronize(s));
+  for (size_t l = 0; l < levels.size(); ++l) out_levels[l] = levels[l].release();
+  return A3D_OK;
+}
+
+a3d_status a3d_range_image_size(const a3d_device_image* im, uint64_t* out_width, uint64_t* out_height) {
+  A3D_REQUIRE(im && out_width && out_height, A3D_INVALID_PARAMETER, "null argument");
+  *out_width = im->width, *out_height = im->height;
+  return A3D_OK;
+}
+
+a3d_status a3d_range_image_download(a3d_device_image* im, float* points, uint8_t* mask, float* normals,
+                                    uint8_t* intensities, float* intensity_map, uint8_t* colors, double out_intrinsics[4]) {
+  A3D_REQUIRE(im, A3D_INVALID_PARAMETER, "image is null");
+  hipStream_t s = im->ctx->stream;
+  const size_t n = (size_t)im->width * im->height;
+  auto get = [&](void* dst, const void* src, size_t bytes, const char* what) -> a3d_status {
+    if (!dst) return A3D_OK;
+    A3D_REQUIRE(src, A3D_MISSING_FIELD, what);
+    A3D_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    return A3D_OK;
+  };
+  A3D_TRY(get(points, im->points, n * 12, "image has no points"));
+  A3D_TRY(get(mask, im->mask, n, "image has no mask"));
+  A3D_TRY(get(normals, im->has_normals ? im->normals : nullptr, n * 12, "image has no normals"));
+  A3D_TRY(get(intensities, im->has_intensities ? im->intensities : nullptr, n, "image has no intensities"));
+  A3D_TRY(get(intensity_map, im->has_imap ? im->imap : nullptr, (size_t)(im->width + 2) * (im->height + 2) * 4,
+              "image has no intensity map"));
+  A3D_TRY(get(colors, im->colors, n * 3, "image has no colors"));
+  if (out_intrinsics) out_intrinsics[0] = im->fx64, out_intrinsics[1] = im->fy64, out_intrinsics[2] = im->cx64, out_intrinsics[3] = im->cy64;
+  A3D_HIP_TRY(hipStreamSynchronize(s));
+  return A3D_OK;
+}
+
+}  // extern "C"

@@ -86,6 +86,13 @@ a3d_status launch_compute_normals(a3d_context* ctx, const float* points, const u
 
 }  // namespace
 
+namespace a3d {
+a3d_status compute_normals_device(a3d_context* ctx, const float* d_points, const uint8_t* d_mask, float* d_normals,
+                                  uint32_t w, uint32_t h) {
+  return launch_compute_normals(ctx, d_points, d_mask, d_normals, w, h);
+}
+}  // namespace a3d
+
 extern "C" {
 
 a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* v, a3d_device_image** out) {
@@ -98,6 +105,7 @@ a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* 
   im->ctx = ctx;
   im->width = (uint32_t)v->width;
   im->height = (uint32_t)v->height;
+  im->fx64 = v->fx, im->fy64 = v->fy, im->cx64 = v->cx, im->cy64 = v->cy;
   im->fx = (float)v->fx, im->fy = (float)v->fy, im->cx = (float)v->cx, im->cy = (float)v->cy;
   const size_t n = (size_t)im->width * im->height;
   a3d_status st = upload_array(ctx, v->points, n * 3, &im->points);
@@ -134,6 +142,7 @@ a3d_status a3d_range_image_free(a3d_device_image* im) {
   hipFree(im->normals);
   hipFree(im->intensities);
   hipFree(im->imap);
+  hipFree(im->colors);
   delete im;
   return A3D_OK;
 }

@@ -233,12 +233,19 @@ class RangeImage:
 class DeviceRangeImage:
     """a3d_device_image: one RangeImage resident in HBM."""
 
-    def __init__(self, ctx, host):
+    def __init__(self, ctx, host=None, handle=None):
         self.ctx = ctx
-        self.handle = C.c_void_p()
-        v = host.view()
-        _abi.check(ctx.lib.a3d_range_image_upload(ctx.handle, C.byref(v), C.byref(self.handle)), "a3d_range_image_upload")
-        self.shape = host.mask.shape
+        if handle is not None:
+            self.handle = handle
+            w, h = C.c_uint64(), C.c_uint64()
+            _abi.check(ctx.lib.a3d_range_image_size(self.handle, C.byref(w), C.byref(h)))
+            self.shape = (int(h.value), int(w.value))
+        else:
+            self.handle = C.c_void_p()
+            v = host.view()
+            _abi.check(ctx.lib.a3d_range_image_upload(ctx.handle, C.byref(v), C.byref(self.handle)),
+                       "a3d_range_image_upload")
+            self.shape = host.mask.shape
 
     def compute_normals(self):
         _abi.check(self.ctx.lib.a3d_range_image_compute_normals(self.handle))
@@ -248,6 +255,24 @@ class DeviceRangeImage:
         out = np.empty(self.shape + (3,), np.float32)
         _abi.check(self.ctx.lib.a3d_range_image_download_normals(self.handle, _abi.ptr(out)))
         return out
+
+    def download(self, normals=True, intensity=True, colors=True):
+        """Reads the resident arrays back into a host RangeImage (whose device copy is this image)."""
+        h, w = self.shape
+        pts = np.empty((h, w, 3), np.float32)
+        mask = np.empty((h, w), np.uint8)
+        nrm = np.empty((h, w, 3), np.float32) if normals else None
+        inten = np.empty(h * w, np.uint8) if intensity else None
+        imap = np.empty((h + 2, w + 2), np.float32) if intensity else None
+        col = np.empty((h, w, 3), np.uint8) if colors else None
+        k = (C.c_double * 4)()
+        _abi.check(self.ctx.lib.a3d_range_image_download(self.handle, _abi.ptr(pts), _abi.ptr(mask), _abi.ptr(nrm),
+                                                         _abi.ptr(inten), _abi.ptr(imap), _abi.ptr(col), k),
+                   "a3d_range_image_download")
+        ri = RangeImage(pts, mask, CameraIntrinsics(k[0], k[1], k[2], k[3], w, h), normals=nrm, colors=col,
+                        intensities=inten, intensity_map=imap)
+        ri._device = self
+        return ri
 
     def free(self):
         if self.handle and self.ctx.handle:
@@ -293,8 +318,33 @@ class RangeImageBuilder:
         self._blur_sigma = s
         return self
 
+    def build_device(self, camera, depth_u16, rgb, depth_scale):
+        """builder.rs:74-91 entirely on the GPU (a3d_range_image_build_pyramid): the frame crosses PCIe as
+        u16 depth + u8 RGB and the pyramid levels stay resident.  Returns a list of DeviceRangeImage."""
+        depth_u16 = np.ascontiguousarray(depth_u16, np.uint16)
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        h, w = depth_u16.shape
+        p = _abi.BuilderParamsC()
+        self.ctx.lib.a3d_builder_params_default(C.byref(p))
+        p.with_normals = 1 if self._with_normals else 0
+        p.with_intensity = 1 if self._with_intensity else 0
+        p.pyramid_levels = self._pyramid_levels
+        p.blur_sigma = self._blur_sigma
+        if self._bilateral_filter is not None:
+            p.use_bilateral = 1
+            p.sigma_space = self._bilateral_filter.sigma_space
+            p.sigma_color = self._bilateral_filter.sigma_color
+        out = (C.c_void_p * self._pyramid_levels)()
+        _abi.check(
+            self.ctx.lib.a3d_range_image_build_pyramid(self.ctx.handle, C.byref(p), _abi.ptr(depth_u16), _abi.ptr(rgb), w, h,
+                                                       camera.fx, camera.fy, camera.cx, camera.cy, float(depth_scale), out),
+            "a3d_range_image_build_pyramid",
+        )
+        return [DeviceRangeImage(self.ctx, handle=C.c_void_p(out[i])) for i in range(self._pyramid_levels)]
+
     def build(self, camera, depth_u16, rgb, depth_scale):
-        """builder.rs:74-91: bilateral -> back-project -> normals (level 0 only) -> pyramid -> intensity."""
+        """builder.rs:74-91 with the host (numpy) restatements of the per-level steps; bilateral filter and
+        normals still run on the GPU.  Kept as the cross-check of build_device."""
         if self._bilateral_filter is not None:
             depth_u16 = self._bilateral_filter.filter(self.ctx, depth_u16)
         first = RangeImage.from_rgbd_image(camera, depth_u16, rgb, depth_scale)

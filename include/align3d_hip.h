@@ -91,6 +91,18 @@ typedef struct a3d_gn_state {
   uint64_t count;
 } a3d_gn_state;
 
+/* RangeImageBuilder (src/range_image/builder.rs:7-14). */
+typedef struct a3d_builder_params {
+  uint32_t with_normals;     /* RangeImage::compute_normals on level 0 */
+  uint32_t with_intensity;   /* compute_intensity + compute_intensity_map on every level */
+  uint32_t use_bilateral;    /* with_bilateral_filter(Some(BilateralFilter::new(sigma_space, sigma_color))) */
+  uint32_t pad;
+  double sigma_space, sigma_color;
+  uint64_t pyramid_levels;
+  float blur_sigma;
+  uint32_t pad2;
+} a3d_builder_params;
+
 typedef struct a3d_context a3d_context;
 typedef struct a3d_device_image a3d_device_image;       /* one RangeImage resident in HBM */
 typedef struct a3d_multiscale a3d_multiscale;           /* MultiscaleAlign */
@@ -143,6 +155,24 @@ a3d_status a3d_range_image_free(a3d_device_image* image);
 a3d_status a3d_range_image_compute_normals(a3d_device_image* image);
 /* Reads the resident normals back: [height][width][3] f32. */
 a3d_status a3d_range_image_download_normals(a3d_device_image* image, float* out_normals);
+
+/* RangeImageBuilder::default() (src/range_image/builder.rs:16-26): normals, intensity, no bilateral
+ * filter, 3 levels, blur sigma 1; the sigmas are BilateralFilter::default()'s. */
+void a3d_builder_params_default(a3d_builder_params* out);
+/* RangeImageBuilder::build(frame) (src/range_image/builder.rs:74-91) on the device: depth u16 [h][w] and
+ * rgb u8 [h][w][3] come from host memory, every level of the pyramid stays resident.  out_levels receives
+ * params->pyramid_levels handles (index 0 = full resolution); free each with a3d_range_image_free.
+ * The pyramid's RGB blur restates image-0.24.7's imageops::blur (parity unpinned). */
+a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_params* params,
+                                         const uint16_t* depth, const uint8_t* rgb, uint64_t width,
+                                         uint64_t height, double fx, double fy, double cx, double cy,
+                                         double depth_scale, a3d_device_image** out_levels);
+a3d_status a3d_range_image_size(const a3d_device_image* image, uint64_t* out_width, uint64_t* out_height);
+/* Reads resident arrays back (each pointer nullable): points [h][w][3], mask [h][w], normals [h][w][3],
+ * intensities [h*w], intensity_map [(h+2)][(w+2)], colors [h][w][3] u8, intrinsics fx fy cx cy. */
+a3d_status a3d_range_image_download(a3d_device_image* image, float* points, uint8_t* mask, float* normals,
+                                    uint8_t* intensities, float* intensity_map, uint8_t* colors,
+                                    double out_intrinsics[4]);
 
 /* RangeImage::compute_normals, host in / host out convenience form. */
 a3d_status a3d_compute_normals(a3d_context* ctx, const float* points, const uint8_t* mask,

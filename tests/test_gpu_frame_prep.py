@@ -75,3 +75,55 @@ def test_bilateral_bit_exact_synthetic_and_edges(ctx):
         out = f.filter(ctx, img)
         assert st == 0 and f.last_grid_dims == dims
         assert np.array_equal(out, ref)
+
+
+def _assert_same_level(dev_level, ref):
+    got = dev_level.download()
+    assert got.mask.shape == ref.mask.shape
+    assert np.array_equal(got.mask, ref.mask)
+    assert np.array_equal(_bits(got.points), _bits(ref.points))
+    assert np.array_equal(_bits(got.normals), _bits(ref.normals))
+    assert np.array_equal(got.colors, ref.colors)
+    assert np.array_equal(got.intensities, ref.intensities)
+    assert np.array_equal(_bits(got.intensity_map), _bits(ref.intensity_map))
+    k = got.intrinsics
+    assert (k.fx, k.fy, k.cx, k.cy) == (ref.fx, ref.fy, ref.cx, ref.cy)
+
+
+@pytest.mark.parametrize("sample,frame,bilateral", [("sample1", 0, True), ("sample1", 5, False), ("sample2", 1, True)])
+def test_device_pyramid_builder_bit_exact(ctx, sample, frame, bilateral):
+    """RangeImageBuilder::build on the device (bilateral, back-projection, normals, 2x2 nearest-to-mean
+    resize of points and normals, RGB blur + halve, luma, intensity map with its border quirks) equals the
+    oracle's pyramid bit for bit on every level."""
+    from align3d_amd import CameraIntrinsics, RangeImageBuilder
+    from gpu_util import oracle_pyramid
+
+    s = SlamTbSample(sample)
+    depth, rgb = s.load(frame)
+    fx, fy, cx, cy = s.intrinsics(frame)
+    ref = oracle_pyramid(sample, frame, levels=3, use_bilateral=bilateral)
+    b = RangeImageBuilder(ctx)
+    if bilateral:
+        b = b.with_bilateral_filter(BilateralFilter.default())
+    levels = b.build_device(CameraIntrinsics(fx, fy, cx, cy, 640, 480), depth, rgb, s.depth_scale(frame))
+    assert [lv.shape for lv in levels] == [(480, 640), (240, 320), (120, 160)]
+    for lv, r in zip(levels, ref):
+        _assert_same_level(lv, r)
+
+
+def test_device_pyramid_builder_options_and_errors(ctx):
+    from align3d_amd import A3dError, CameraIntrinsics, RangeImageBuilder
+
+    s = SlamTbSample("sample1")
+    depth, rgb = s.load(1)
+    cam = CameraIntrinsics(*s.intrinsics(1), 640, 480)
+    one = RangeImageBuilder(ctx).pyramid_levels(1).with_normals(False).with_intensity(False).build_device(
+        cam, depth, rgb, s.depth_scale(1))
+    assert len(one) == 1
+    with pytest.raises(A3dError) as e:
+        one[0].download(normals=True, intensity=False)
+    assert e.value.status == 2  # no normals were requested
+    ri = one[0].download(normals=False, intensity=False)
+    assert int(ri.mask.sum()) == int((depth > 0).sum())
+    with pytest.raises(A3dError):
+        RangeImageBuilder(ctx).pyramid_levels(12).build_device(cam, depth, rgb, 0.001)  # too many levels for 640x480
