@@ -24,6 +24,60 @@ class Transform:
         p.q[:] = [float(x) for x in self.q]
         return p
 
+    # -- Isometry3 algebra in f32, nalgebra's formulas (src/transform.rs:138-153, :191, :205-220) -------------
+    @staticmethod
+    def _rotate(q, v):
+        """UnitQuaternion * Vector3: t = 2 (q_v x v); v' = (t w + q_v x t) + v"""
+        q = np.asarray(q, np.float32)
+        v = np.asarray(v, np.float32)
+        qv = q[:3]
+        t = np.cross(qv, v).astype(np.float32) * np.float32(2)
+        c = np.cross(qv, t).astype(np.float32)
+        return ((t * q[3] + c) + v).astype(np.float32)
+
+    def transform_vector(self, v):
+        return (self._rotate(self.q, v) + self.t).astype(np.float32)
+
+    def __mul__(self, rhs):
+        """self * rhs (rhs applied first): t = t1 + R1 t2, q = q1 q2 (Hamilton product, not renormalised)."""
+        a, b = self.q, rhs.q
+        q = np.array(
+            [
+                a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1],
+                a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0],
+                a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3],
+                a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2],
+            ],
+            np.float32,
+        )
+        return Transform(self.t + self._rotate(self.q, rhs.t), q)
+
+    def inverse(self):
+        qi = np.array([-self.q[0], -self.q[1], -self.q[2], self.q[3]], np.float32)
+        return Transform(-self._rotate(qi, self.t), qi)
+
+    @staticmethod
+    def from_matrix4(m):
+        """Transform::from_matrix4 (src/transform.rs:112-118) for a rigid 4x4 (trace-based extraction)."""
+        m = np.asarray(m, np.float64)
+        r = m[:3, :3]
+        tr = np.trace(r)
+        if tr > 0:
+            s = np.sqrt(tr + 1.0) * 2
+            w, i, j, k = 0.25 * s, (r[2, 1] - r[1, 2]) / s, (r[0, 2] - r[2, 0]) / s, (r[1, 0] - r[0, 1]) / s
+        elif r[0, 0] > r[1, 1] and r[0, 0] > r[2, 2]:
+            s = np.sqrt(1.0 + r[0, 0] - r[1, 1] - r[2, 2]) * 2
+            w, i, j, k = (r[2, 1] - r[1, 2]) / s, 0.25 * s, (r[0, 1] + r[1, 0]) / s, (r[0, 2] + r[2, 0]) / s
+        elif r[1, 1] > r[2, 2]:
+            s = np.sqrt(1.0 + r[1, 1] - r[0, 0] - r[2, 2]) * 2
+            w, i, j, k = (r[0, 2] - r[2, 0]) / s, (r[0, 1] + r[1, 0]) / s, 0.25 * s, (r[1, 2] + r[2, 1]) / s
+        else:
+            s = np.sqrt(1.0 + r[2, 2] - r[0, 0] - r[1, 1]) * 2
+            w, i, j, k = (r[1, 0] - r[0, 1]) / s, (r[0, 2] + r[2, 0]) / s, (r[1, 2] + r[2, 1]) / s, 0.25 * s
+        q = np.array([i, j, k, w], np.float64)
+        q /= np.linalg.norm(q)
+        return Transform(m[:3, 3], q)
+
     def matrix(self):
         """4x4 homogeneous matrix (From<&Transform> for Matrix4, src/transform.rs:229-234)."""
         i, j, k, w = [np.float32(x) for x in self.q]

@@ -1,0 +1,86 @@
+"""Host-side logic around the hot path (no GPU): Transform algebra, Trajectory, TransformMetrics,
+dataset readers — checked against the oracle and the reference's KATs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from align3d_amd import InvalidParameter, SlamTbDataset, SyntheticDataset, Trajectory, TrajectoryBuilder, Transform, TransformMetrics
+from align3d_amd._abi import PoseC
+from data_util import GOLDEN
+
+
+def _rand_transform(rng):
+    u = np.concatenate([rng.normal(size=3) * 0.5, rng.normal(size=3) * 0.7]).astype(np.float32)
+    return Transform.from_c(O.exp_se3(u))
+
+
+def test_transform_algebra_matches_oracle():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        a, b = _rand_transform(rng), _rand_transform(rng)
+        ab = a * b
+        ref = O.compose(a.to_c(), b.to_c())
+        assert np.array_equal(ab.t, np.array(ref.t[:], np.float32)) and np.array_equal(ab.q, np.array(ref.q[:], np.float32))
+        inv = PoseC()
+        O.load().orc_inverse(C.byref(a.to_c()), C.byref(inv))
+        ai = a.inverse()
+        assert np.allclose(ai.t, inv.t[:], atol=1e-7) and np.array_equal(ai.q, np.array(inv.q[:], np.float32))
+        v = rng.normal(size=3).astype(np.float32)
+        assert np.array_equal(a.transform_vector(v), O.transform_points(a.to_c(), v[None])[0])
+        ang, tr = O.transform_metrics(a.to_c(), b.to_c())
+        m = TransformMetrics.new(a, b)
+        assert abs(m.angle - ang) < 1e-6 and abs(m.translation - tr) < 1e-6
+        assert np.allclose(a.matrix(), O.pose_to_matrix(a.to_c()), atol=1e-7)
+
+
+# src/metrics.rs:78-93
+def test_transform_metrics_kat():
+    s = Transform((0.00022050377, 7.3633055e-5, -1.51071e-5), (0.00888227, 0.0008264509, 0.99996024, 2.059626e-5))
+    s.q = (s.q / np.linalg.norm(s.q)).astype(np.float32)  # Transform::new normalises
+    m = TransformMetrics.new(s, s)
+    assert m.translation == 0.0 and abs(m.angle) < 1e-3 and abs(m.total()) < 1e-3
+
+
+def test_trajectory_builder_semantics():
+    rng = np.random.default_rng(1)
+    steps = [_rand_transform(rng) for _ in range(4)]
+    tb = TrajectoryBuilder.with_start(Transform.eye(), 0.0)
+    last = Transform.eye()
+    for i, s in enumerate(steps):
+        tb.accumulate(s, float(i + 1))
+        last = s * last  # trajectory.rs:164-168: left multiplication
+        cur = tb.current_camera_to_world()
+        assert np.array_equal(cur.t, last.t) and np.array_equal(cur.q, last.q)
+    traj = tb.build()
+    assert traj.len() == 5 and traj.times == [0.0, 1.0, 2.0, 3.0, 4.0]
+    rel = traj.get_relative_transform(3, 1)
+    want = traj[1].inverse() * traj[3]
+    assert np.array_equal(rel.t, want.t)
+    origin = traj.slice(1, 5).first_frame_at_origin()
+    assert np.allclose(origin[0].t, 0, atol=1e-6) and abs(origin[0].q[3]) > 0.999999
+    assert str(TransformMetrics.mean_trajectory_error(traj, traj)).startswith("angle: 0.0")
+    with pytest.raises(InvalidParameter):
+        TransformMetrics.mean_trajectory_error(traj, traj.slice(0, 2))
+
+
+# src/io/dataset/slamtb.rs:161-173
+def test_slamtb_reader():
+    ds = SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1"))
+    assert ds.len() == 4
+    cam, depth, rgb, scale = ds.get(0)
+    assert (cam.fx, cam.fy, cam.cx, cam.cy) == (544.4732666015625, 544.4732666015625, 320.0, 240.0)
+    assert depth.shape == (480, 640) and depth.dtype == np.uint16 and rgb.shape == (480, 640, 3) and scale == 0.001
+    assert int((depth > 0).sum()) == 270213
+    t = ds.trajectory()
+    ref = O.pose_from_matrix(np.array(ds.frames[1]["info"]["rt_cam"]["matrix"], np.float32))
+    assert np.allclose(t[1].t, ref.t[:], atol=1e-7) and np.allclose(t[1].q, ref.q[:], atol=1e-6)
+
+
+def test_synthetic_dataset_is_seeded():
+    a, b = SyntheticDataset(3, 2, 160, 120), SyntheticDataset(3, 2, 160, 120)
+    assert np.array_equal(a.get(1)[1], b.get(1)[1]) and np.array_equal(a.get(1)[2], b.get(1)[2])
+    rel = a.trajectory().get_relative_transform(1, 0)
+    assert 0.0005 < TransformMetrics.new(Transform.eye(), rel).angle < 0.02
