@@ -151,6 +151,21 @@ def frame_prep_bench(ctx, host_pyramid_level0, depth_u16):
     }
 
 
+def odometry_bench(ctx, n_frames=20):
+    """configs[3] shape: a 20-frame odometry stream (synthetic: no TUM / IL-RGBD data exists on the box), frames
+    enter as u16 depth + u8 RGB, persistent device pyramids, MsIcpParams::default() (README usage)."""
+    from align3d_amd import SyntheticDataset, run_odometry
+
+    ds = SyntheticDataset(7, n_frames)
+    run_odometry(ctx, ds, max_frames=3)
+    t0 = time.perf_counter()
+    pred, metrics = run_odometry(ctx, ds)
+    dt = time.perf_counter() - t0
+    return {"workload": f"{n_frames}-frame synthetic stream, device RangeImageBuilder + MsIcpParams::default()",
+            "frames_per_s": (n_frames - 1) / dt, "ms_per_frame": dt / (n_frames - 1) * 1e3,
+            "mean_trajectory_error": {"angle_deg": float(np.degrees(metrics.angle)), "translation_m": metrics.translation}}
+
+
 def cpu_baseline(host_pyramids, params, n_pairs, gpu_poses):
     """The CPU oracle ("port": a restatement, not the Rust reference) on the first n_pairs pairs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -304,6 +319,7 @@ def main():
             extra["single_pair_ms3x15_latency_ms"] = (time.perf_counter() - t1) / 5 * 1e3
             extra["kdtree"] = kdtree_bench(ctx)
             extra["pcl_icp"] = pcl_icp_bench(ctx)
+            extra["odometry"] = odometry_bench(ctx)
             extra["frame_prep"] = frame_prep_bench(ctx, host_pyramids[0][0].download(), synth.frame_stream(1000, 1, W, H)[0][0][0])
             # what a caller with host buffers pays per new frame: u16 depth + u8 RGB over PCIe, then bilateral,
             # back-projection, normals, pyramid, luma and intensity maps on the device
