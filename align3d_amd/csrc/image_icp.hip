@@ -211,11 +211,10 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
 // trip is paid once per G pixels; the source records run one batch ahead; only the accumulation sits
 // under the per-pixel gates.  ACCUM = 0: 58 per-thread f32 accumulators + wave reduce-scatter;
 // ACCUM = 1: X^T X on the matrix pipe (below).
-template <int PPT, int G>
+template <int G>
 __global__ void __launch_bounds__(256)
     image_icp_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
-                     float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve) {
-  static_assert(PPT % G == 0, "PPT must be a multiple of G");
+                     float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve, int PPT) {
   const int pair = blockIdx.y;
   float acc[GN_PARTIAL];
 #pragma unroll
@@ -226,7 +225,7 @@ __global__ void __launch_bounds__(256)
     const Pose T = st->pose;
     const uint32_t mw = d.tw + 2;
     const float twf = (float)d.tw, thf = (float)d.th;
-    const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
+    const uint32_t base = blockIdx.x * (256u * (uint32_t)PPT) + threadIdx.x;
     // Software pipeline, three batches deep: while batch k is being accumulated (stage D) the target
     // gathers of batch k+1 and the source records of batch k+2 are in flight, so the L1 miss queue of the
     // CU stays occupied during the arithmetic.
@@ -314,11 +313,10 @@ __device__ __forceinline__ int tile_index_of_partial(int k) {
   return row * 16 + col;
 }
 
-template <int PPT, int G>
+template <int G>
 __global__ void __launch_bounds__(256)
     image_icp_mfma_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
-                          float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve) {
-  static_assert(PPT % G == 0, "PPT must be a multiple of G");
+                          float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve, int PPT) {
   __shared__ __attribute__((aligned(16))) float slab[4][64 * 16];  // per wave: 64 pixels x 16 features
   const int pair = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -330,7 +328,7 @@ __global__ void __launch_bounds__(256)
     const Pose T = st->pose;
     const uint32_t mw = d.tw + 2;
     const float twf = (float)d.tw, thf = (float)d.th;
-    const uint32_t base = blockIdx.x * (256u * PPT) + threadIdx.x;
+    const uint32_t base = blockIdx.x * (256u * (uint32_t)PPT) + threadIdx.x;
     // transposed-read offsets of this lane: row 4m + (lane >> 4), feature lane & 15
     const int rd_row0 = lane >> 4, rd_chunk = (lane & 15) >> 2, rd_word = lane & 3;
     // same three-deep software pipeline as the VALU kernel
@@ -451,6 +449,7 @@ struct a3d_multiscale_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;  // per pixel-kernel launch: start/stop pairs, when profiling
   bool profile_kernels = false;
+  uint32_t resident_blocks = 1024;  // blocks of the per-pixel kernel the chip holds at once
   bool use_mfma = false;  // VALU accumulation measured faster on MI355X so far (kernel variants)
   float last_total_ms = 0.f, last_kernel_ms = 0.f;
   uint64_t last_kernel_launches = 0;
@@ -497,42 +496,40 @@ Gates make_gates(const a3d_icp_params& p) {
   return g;
 }
 
-// Pixels per thread: as many as keep >= 1024 blocks in flight (4 per CU), at most 16.
-uint32_t choose_ppt(uint32_t n_pairs, uint32_t max_src_n) {
-  for (uint32_t ppt = 16; ppt > 1; ppt >>= 1) {
-    uint64_t blocks = (uint64_t)n_pairs * ((max_src_n + 256 * ppt - 1) / (256 * ppt));
-    if (blocks >= 1024) return ppt;
-  }
-  return 1;
+// Tiling of one level: `tiles` blocks per pair, each thread visiting `ppt` pixels.  The grid is sized to
+// `waves` full rounds of the blocks the chip holds at once (CUs x blocks per CU), so that every block gets
+// the same amount of work and the launch does not end on a partly filled round.
+void choose_tiling(uint32_t n_pairs, uint32_t max_src_n, uint32_t resident_blocks, float waves, uint32_t group,
+                   uint32_t* tiles, uint32_t* ppt) {
+  const uint32_t max_tiles = (max_src_n + 256 * group - 1) / (256 * group);  // at least `group` pixels per thread
+  uint32_t t = (uint32_t)((float)resident_blocks * waves / (float)n_pairs + 0.5f);
+  t = std::max(1u, std::min(t, std::max(1u, max_tiles)));
+  uint32_t p = (max_src_n + 256 * t - 1) / (256 * t);
+  p = ((p + group - 1) / group) * group;
+  *ppt = std::max(p, group);
+  *tiles = (max_src_n + 256 * *ppt - 1) / (256 * *ppt);
 }
 
 a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const SolveArgs& solve) {
   dim3 grid(b->tiles[level], b->n_pairs), block(256);
   const LevelDesc* descs = b->d_descs + (size_t)level * b->n_pairs;
   hipStream_t s = b->ctx->stream;
-#define A3D_LAUNCH(PPT, G)                                                                               \
-  do {                                                                                                      \
-    if (b->use_mfma)                                                                                        \
-      hipLaunchKernelGGL((image_icp_mfma_kernel<PPT, G>), grid, block, 0, s, descs, b->d_states,            \
-                         b->gates[level], b->d_partials, b->d_counters, solve);                             \
-    else                                                                                                    \
-      hipLaunchKernelGGL((image_icp_kernel<PPT, G>), grid, block, 0, s, descs, b->d_states, b->gates[level], \
-                         b->d_partials, b->d_counters, solve);                                              \
-  } while (0)
-  const uint32_t g = b->group[level];
-  switch (b->ppt[level] * 16 + g) {
-    case 16 * 16 + 2: A3D_LAUNCH(16, 2); break;
-    case 16 * 16 + 1: A3D_LAUNCH(16, 1); break;
-    case 8 * 16 + 2: A3D_LAUNCH(8, 2); break;
-    case 8 * 16 + 1: A3D_LAUNCH(8, 1); break;
-    case 4 * 16 + 1: A3D_LAUNCH(4, 1); break;
-    case 2 * 16 + 1: A3D_LAUNCH(2, 1); break;
-    case 1 * 16 + 1: A3D_LAUNCH(1, 1); break;
-    default:
-      set_error("unsupported kernel variant ppt=%u g=%u", b->ppt[level], g);
-      return A3D_INVALID_PARAMETER;
+  const int ppt = (int)b->ppt[level];
+  if (b->use_mfma) {
+    if (b->group[level] == 2)
+      hipLaunchKernelGGL((image_icp_mfma_kernel<2>), grid, block, 0, s, descs, b->d_states, b->gates[level],
+                         b->d_partials, b->d_counters, solve, ppt);
+    else
+      hipLaunchKernelGGL((image_icp_mfma_kernel<1>), grid, block, 0, s, descs, b->d_states, b->gates[level],
+                         b->d_partials, b->d_counters, solve, ppt);
+  } else {
+    if (b->group[level] == 2)
+      hipLaunchKernelGGL((image_icp_kernel<2>), grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials,
+                         b->d_counters, solve, ppt);
+    else
+      hipLaunchKernelGGL((image_icp_kernel<1>), grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials,
+                         b->d_counters, solve, ppt);
   }
-#undef A3D_LAUNCH
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }
@@ -544,13 +541,19 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
   for (uint32_t l = 0; l < L; ++l) {
     uint32_t max_n = 0;
     for (uint32_t p = 0; p < P; ++p) max_n = std::max(max_n, b->h_descs[(size_t)l * P + p].src_n);
-    b->ppt[l] = choose_ppt(P, max_n);
     b->group[l] = 1;  // pixels per pipeline stage; 1 measured best on MI355X (kernel variants)
+    float waves = 1.0f;
+    if (const char* env = getenv("A3D_ICP_WAVES")) waves = (float)atof(env);  // tuning knob
+    if (const char* env = getenv("A3D_ICP_GROUP")) b->group[l] = atoi(env) == 2 ? 2 : 1;
+    choose_tiling(P, max_n, b->resident_blocks, waves, b->group[l], &b->tiles[l], &b->ppt[l]);
     if (const char* env = getenv("A3D_ICP_VARIANT")) {  // tuning knob: "ppt,g"
       unsigned ep = 0, eg = 0;
-      if (sscanf(env, "%u,%u", &ep, &eg) == 2 && ep && eg) b->ppt[l] = ep, b->group[l] = eg;
+      if (sscanf(env, "%u,%u", &ep, &eg) == 2 && ep && (eg == 1 || eg == 2)) {
+        b->group[l] = eg;
+        b->ppt[l] = ((ep + eg - 1) / eg) * eg;
+        b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
+      }
     }
-    b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
     max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
   }
   if (b->d_partials) A3D_HIP_TRY(hipFree(b->d_partials));
@@ -573,6 +576,12 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   b->ppt.assign(n_levels, 1);
   b->group.assign(n_levels, 1);
   b->h_descs.resize((size_t)n_levels * n_pairs);
+  {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_kernel<1>, 256, 0) != hipSuccess || per_cu < 1)
+      per_cu = 4;
+    b->resident_blocks = (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)per_cu;
+  }
   if (const char* env = getenv("A3D_ICP_ACCUM")) b->use_mfma = strcmp(env, "mfma") == 0;        // tuning knob
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
