@@ -119,6 +119,34 @@ __device__ __forceinline__ void block_reduce_store(const float (&acc)[N], float*
   }
 }
 
+// ---- job state accessors ---------------------------------------------------------------------------
+// Inside the persistent level kernel the state is handed from block to block within one launch, so it is
+// always read and written with agent-scope (sc1) accesses that bypass the CU's L1.
+__device__ __forceinline__ float ld_coherent(const float* p) {
+  return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_coherent(float* p, float v) {
+  __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ Pose load_pose(const Pose* p) {
+  const float* f = (const float*)p;
+  Pose r;
+  r.t = {ld_coherent(f), ld_coherent(f + 1), ld_coherent(f + 2)};
+  r.q = {ld_coherent(f + 3), ld_coherent(f + 4), ld_coherent(f + 5), ld_coherent(f + 6)};
+  return r;
+}
+__device__ __forceinline__ void store_pose(Pose* p, const Pose& v) {
+  float* f = (float*)p;
+  st_coherent(f, v.t.x), st_coherent(f + 1, v.t.y), st_coherent(f + 2, v.t.z);
+  st_coherent(f + 3, v.q.i), st_coherent(f + 4, v.q.j), st_coherent(f + 5, v.q.k), st_coherent(f + 6, v.q.w);
+}
+__device__ __forceinline__ int load_status(const JobState* st) {
+  return __hip_atomic_load(&st->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_status(JobState* st, int v) {
+  __hip_atomic_store(&st->status, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- finishing an iteration on the device ---------------------------------------------------------
 // Called by every thread of the job's last block.  sums = GN_PARTIAL f64 totals in LDS.
 //   GaussNewton::add_weighted / weight / mean_squared_residual   src/optim/gaussnewton.rs:115-133
@@ -175,8 +203,8 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
   if (tid != 0) return;
   const float residual = s_residual;
   if (!s_ok) {  // the reference's unwrap() panics here
-    st->status = A3D_SOLVE_FAILED;
-    st->last_residual = residual;
+    st_coherent(&st->last_residual, residual);
+    store_status(st, A3D_SOLVE_FAILED);
     return;
   }
   // The substitutions work in place on the LDS vector, loops kept rolled: this single-lane code must
@@ -198,9 +226,9 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
   float update[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) update[i] = (float)bvec[i];
-  Pose pose = st->pose;
-  float best_residual = st->best_residual;
-  Pose best = st->best;
+  Pose pose = load_pose(&st->pose);
+  float best_residual = ld_coherent(&st->best_residual);
+  Pose best = load_pose(&st->best);
   if (a.first_in_level) {  // ImageIcp::align starts every level with best = initial, +inf
     best_residual = __builtin_inff();
     best = pose;
@@ -217,10 +245,10 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
     tr[4] = pose.q.i, tr[5] = pose.q.j, tr[6] = pose.q.k, tr[7] = pose.q.w;
   }
   if (a.last_in_level) pose = best;  // align() returns best_transform; the next level starts from it
-  st->pose = pose;
-  st->best = best;
-  st->best_residual = best_residual;
-  st->last_residual = residual;
+  store_pose(&st->pose, pose);
+  store_pose(&st->best, best);
+  st_coherent(&st->best_residual, best_residual);
+  st_coherent(&st->last_residual, residual);
 }
 
 // Tail of an accumulate kernel (all 256 threads call it): reduce the block's accumulators to one
@@ -231,7 +259,7 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
 // release fence, which would write back the whole L2 once per block.  The last block does one agent
 // acquire, a barrier, and reads the partials with sc1 loads.  `job_partials` = [tiles][GN_PARTIAL].
 // Second half of the tail: the block's partial has been stored write-through by its wave 0.
-__device__ __forceinline__ void block_publish_and_finish(float* __restrict__ job_partials, uint32_t tiles,
+__device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job_partials, uint32_t tiles,
                                                          unsigned* __restrict__ counter, JobState* st,
                                                          const SolveArgs& args, int job);
 
@@ -246,10 +274,11 @@ __device__ __forceinline__ void block_finish(const float (&acc)[N], float* __res
   block_publish_and_finish(job_partials, tiles, counter, st, args, job);
 }
 
-__device__ __forceinline__ void block_publish_and_finish(float* __restrict__ job_partials, uint32_t tiles,
+// Returns true in the block that came last and ran the solve.
+__device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job_partials, uint32_t tiles,
                                                          unsigned* __restrict__ counter, JobState* st,
                                                          const SolveArgs& args, int job) {
-  if (args.mode == SOLVE_NONE) return;
+  if (args.mode == SOLVE_NONE) return false;
   __shared__ unsigned s_is_last;
   __shared__ double s_sums[8][64];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
@@ -259,7 +288,7 @@ __device__ __forceinline__ void block_publish_and_finish(float* __restrict__ job
     s_is_last = ticket == tiles - 1 ? 1u : 0u;
   }
   __syncthreads();
-  if (!s_is_last) return;
+  if (!s_is_last) return false;
   // ---- last block of this job ----
   // Every load of the handed-off partials below is an sc1 (agent-scope) load that bypasses this CU's L1,
   // so no acquire fence (an L1 invalidate) is needed.  Thread (pair of components cg, slice s) sums tiles
@@ -313,6 +342,7 @@ __device__ __forceinline__ void block_publish_and_finish(float* __restrict__ job
   if (threadIdx.x == 0)  // ready for the next launch (ordered by the kernel boundary)
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   gn_finish_block(st, s_sums[0], args, job);
+  return true;
 }
 
 // acc[0..21) += J J^T (upper triangle), acc[21..27) += J r, acc[27] += r^2, acc[28] += 1

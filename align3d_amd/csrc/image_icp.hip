@@ -277,6 +277,124 @@ __global__ void __launch_bounds__(256)
                            counters + pair, st, sa, pair);
 }
 
+// ---- one launch per pyramid level ------------------------------------------------------------------
+// When the grid of a level is exactly the set of blocks the chip holds at once (choose_tiling, waves = 1),
+// every block of every pair is resident for the whole launch, so the iterations of the level can run inside
+// ONE launch: after publishing its partial a block waits for its pair's next pose instead of exiting.
+//   * the pair's last block runs the solve and then publishes `epoch = epoch_base + it + 1` (state stored
+//     with sc1 stores, drained, then the epoch word: CDNA guide Guideline 16, form R1);
+//   * the pair's other blocks poll that word (one lane, relaxed agent-scope load, s_sleep), bounded, then read
+//     the pose with sc1 loads; nothing handed off is ever read through the L1;
+//   * pairs never wait for each other: there is no grid-wide barrier.
+// No block can wait for one that is not resident because the host only uses this kernel when
+// pairs x tiles <= resident blocks (occupancy query of THIS kernel); a spin that still exceeds its bound
+// marks the job A3D_HIP_ERROR and leaves.
+struct LevelPlan {
+  uint32_t iterations;
+  uint32_t epoch_base;  // iterations completed by the levels run before this one
+  int trace_base;
+};
+
+template <int G>
+__global__ void __launch_bounds__(256)
+    image_icp_level_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
+                           float* __restrict__ partials, unsigned* __restrict__ counters,
+                           unsigned* __restrict__ epochs, SolveArgs solve, LevelPlan plan, int PPT) {
+  __shared__ float s_pose[8];
+  __shared__ int s_go;
+  const int pair = blockIdx.y;
+  JobState* st = &states[pair];
+  const LevelDesc d = descs[pair];
+  const uint32_t mw = d.tw + 2;
+  const float twf = (float)d.tw, thf = (float)d.th;
+  const uint32_t base = blockIdx.x * (256u * (uint32_t)PPT) + threadIdx.x;
+  float* job_partials = partials + (size_t)pair * gridDim.x * GN_PARTIAL;
+#pragma unroll 1
+  for (uint32_t it = 0; it < plan.iterations; ++it) {
+    // ---- this iteration's pose: wait until the pair has completed `epoch_base + it` iterations ----------
+    if (threadIdx.x == 0) {
+      const unsigned want = plan.epoch_base + it;
+      int go = 1;
+      unsigned spins = 0;
+      while (__hip_atomic_load(&epochs[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 22)) {  // ~1 s: a resident partner can not be this late
+          store_status(st, A3D_HIP_ERROR);
+          go = 0;
+          break;
+        }
+      }
+      if (go && load_status(st) != A3D_OK) go = 0;  // a failed job stays frozen
+      const Pose T0 = load_pose(&st->pose);
+      s_pose[0] = T0.t.x, s_pose[1] = T0.t.y, s_pose[2] = T0.t.z;
+      s_pose[3] = T0.q.i, s_pose[4] = T0.q.j, s_pose[5] = T0.q.k, s_pose[6] = T0.q.w;
+      s_go = go;
+    }
+    __syncthreads();
+    if (!s_go) return;  // uniform over the block, and every block of the pair sees the same status
+    const Pose T{{s_pose[0], s_pose[1], s_pose[2]}, {s_pose[3], s_pose[4], s_pose[5], s_pose[6]}};
+    float acc[GN_PARTIAL];
+#pragma unroll
+    for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
+    {
+      auto src_at = [&](int k0, int g) {
+        const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
+        return stage_a(d, i, (k0 < PPT) && (i < d.src_n));
+      };
+      SrcPx s1[G];
+      ProjPx cur[G];
+      float cur_int[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const SrcPx s0 = src_at(0, g);
+        s1[g] = src_at(G, g);
+        cur[g] = stage_b(d, T, s0, twf, thf);
+        cur_int[g] = s0.intensity;
+      }
+#pragma unroll 1
+      for (int k0 = 0; k0 < PPT; k0 += G) {
+        SrcPx s2[G];
+        MapPx mp[G];
+        ProjPx nxt[G];
+        float nxt_int[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) s2[g] = src_at(k0 + 2 * G, g);
+#pragma unroll
+        for (int g = 0; g < G; ++g) mp[g] = stage_c(d, gt, cur[g], mw);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          nxt[g] = stage_b(d, T, s1[g], twf, thf);
+          nxt_int[g] = s1[g].intensity;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (cur[g].live) {
+            const Terms t = stage_d(d, gt, cur[g], mp[g], cur_int[g], mw);
+            gn_step(acc, t.rg, t.Jg);
+            if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) cur[g] = nxt[g], cur_int[g] = nxt_int[g], s1[g] = s2[g];
+      }
+    }
+    __syncthreads();  // s_pose is rewritten next iteration; the reduction below also reuses LDS
+    SolveArgs sa = solve;
+    sa.first_in_level = it == 0;
+    sa.last_in_level = it + 1 == plan.iterations;
+    sa.trace_index = plan.trace_base + (int)it;
+    float* out = job_partials + (size_t)blockIdx.x * GN_PARTIAL;
+    block_reduce_store<GN_PARTIAL, true>(acc, out);
+    const bool was_last = block_publish_and_finish(job_partials, gridDim.x, counters + pair, st, sa, pair);
+    if (was_last && threadIdx.x == 0) {
+      // the state stores above were sc1; drain them, then let the pair's other blocks go on
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&epochs[pair], plan.epoch_base + it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+}
+
 // ---- MFMA accumulation -----------------------------------------------------------------------------
 // The per-pixel sums  H += J J^T, g += J r, ssq += r^2, count += 1  for the geometric and the colour
 // term are all entries of X^T X, where row p of X holds pixel p's 16 "features"
@@ -443,6 +561,9 @@ struct a3d_multiscale_batch {
   JobState* d_states = nullptr;
   float* d_partials = nullptr;
   unsigned* d_counters = nullptr;  // per pair: blocks that have published their partial in this launch
+  unsigned* d_epochs = nullptr;    // per pair: iterations completed (level kernel hand-off word)
+  bool use_level_kernel = false;   // one launch per level when the whole grid is resident (A3D_ICP_PERSISTENT)
+  uint32_t level_resident_blocks = 0;  // blocks of image_icp_level_kernel the chip holds at once
   Pose* d_poses = nullptr;
   int32_t* d_status = nullptr;
   double* d_readback = nullptr;
@@ -459,6 +580,7 @@ struct a3d_multiscale_batch {
     hipFree(d_states);
     hipFree(d_partials);
     hipFree(d_counters);
+    hipFree(d_epochs);
     hipFree(d_poses);
     hipFree(d_status);
     hipFree(d_readback);
@@ -588,7 +710,16 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   A3D_HIP_TRY(hipMalloc((void**)&b->d_states, n_pairs * sizeof(JobState)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_counters, n_pairs * sizeof(unsigned)));
   A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_epochs, n_pairs * sizeof(unsigned)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_poses, n_pairs * sizeof(Pose)));
+  if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
+  {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_level_kernel<1>, 256, 0) != hipSuccess)
+      per_cu = 0;
+    b->level_resident_blocks = (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)std::max(0, per_cu);
+    if (b->use_level_kernel && b->level_resident_blocks) b->resident_blocks = b->level_resident_blocks;
+  }
   A3D_HIP_TRY(hipMalloc((void**)&b->d_status, n_pairs * sizeof(int32_t)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_readback, GN_PARTIAL * sizeof(double)));
   A3D_HIP_TRY(hipEventCreate(&b->ev0));
@@ -606,27 +737,59 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   A3D_TRY(launch_job_init(s, b->d_states, d_init, (int)P));
   size_t kidx = 0;
   int trace_index = 0;
+  auto profile_begin = [&]() -> a3d_status {
+    if (!b->profile_kernels) return A3D_OK;
+    if (b->kev.size() < 2 * (kidx + 1)) {
+      hipEvent_t e0, e1;
+      A3D_HIP_TRY(hipEventCreate(&e0));
+      A3D_HIP_TRY(hipEventCreate(&e1));
+      b->kev.push_back(e0);
+      b->kev.push_back(e1);
+    }
+    A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx], s));
+    return A3D_OK;
+  };
+  auto profile_end = [&]() -> a3d_status {
+    if (b->profile_kernels) A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx + 1], s));
+    ++kidx;
+    return A3D_OK;
+  };
+  // one launch per level is only legal when every block of the level is resident at once
+  bool level_kernel = b->use_level_kernel && !b->use_mfma && b->level_resident_blocks > 0;
+  for (uint32_t l = 0; l < levels_to_run; ++l)
+    level_kernel = level_kernel && (uint64_t)b->tiles[l] * P <= b->level_resident_blocks && b->group[l] == 1;
+  if (level_kernel) A3D_HIP_TRY(hipMemsetAsync(b->d_epochs, 0, P * sizeof(unsigned), s));
+  uint32_t epoch_base = 0;
   for (uint32_t l = levels_to_run; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
     const a3d_icp_params& prm = b->params[l];
+    SolveArgs sa;
+    sa.weight = prm.weight, sa.color_weight = prm.color_weight;
+    sa.mode = getenv("A3D_ICP_NOSOLVE") ? SOLVE_NONE : SOLVE_IMAGE_ICP;  // diagnostics: time the body alone
+    sa.trace = d_trace, sa.trace_stride = trace_stride;
+    if (level_kernel) {
+      if (prm.max_iterations == 0) continue;
+      A3D_TRY(profile_begin());
+      LevelPlan plan;
+      plan.iterations = (uint32_t)prm.max_iterations;
+      plan.epoch_base = epoch_base;
+      plan.trace_base = trace_index;
+      sa.first_in_level = sa.last_in_level = 0;
+      sa.trace_index = 0;
+      hipLaunchKernelGGL((image_icp_level_kernel<1>), dim3(b->tiles[l], P), dim3(256), 0, s,
+                         b->d_descs + (size_t)l * P, b->d_states, b->gates[l], b->d_partials, b->d_counters, b->d_epochs,
+                         sa, plan, (int)b->ppt[l]);
+      A3D_HIP_TRY(hipGetLastError());
+      A3D_TRY(profile_end());
+      epoch_base += plan.iterations;
+      trace_index += (int)plan.iterations;
+      continue;
+    }
     for (uint64_t it = 0; it < prm.max_iterations; ++it) {
-      if (b->profile_kernels) {
-        if (b->kev.size() < 2 * (kidx + 1)) {
-          hipEvent_t e0, e1;
-          A3D_HIP_TRY(hipEventCreate(&e0));
-          A3D_HIP_TRY(hipEventCreate(&e1));
-          b->kev.push_back(e0);
-          b->kev.push_back(e1);
-        }
-        A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx], s));
-      }
-      SolveArgs sa;
-      sa.weight = prm.weight, sa.color_weight = prm.color_weight;
-      sa.mode = getenv("A3D_ICP_NOSOLVE") ? SOLVE_NONE : SOLVE_IMAGE_ICP;  // diagnostics: time the body alone
+      A3D_TRY(profile_begin());
       sa.first_in_level = it == 0, sa.last_in_level = it + 1 == prm.max_iterations;
-      sa.trace = d_trace, sa.trace_stride = trace_stride, sa.trace_index = trace_index;
+      sa.trace_index = trace_index;
       A3D_TRY(launch_pixel_kernel(b, l, sa));
-      if (b->profile_kernels) A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx + 1], s));
-      ++kidx;
+      A3D_TRY(profile_end());
       ++trace_index;
     }
   }
