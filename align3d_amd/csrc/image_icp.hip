@@ -296,7 +296,7 @@ struct LevelPlan {
 };
 
 template <int G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)  // at most 168 VGPRs: three blocks per CU
     image_icp_level_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
                            float* __restrict__ partials, unsigned* __restrict__ counters,
                            unsigned* __restrict__ epochs, SolveArgs solve, LevelPlan plan, int PPT) {
@@ -332,7 +332,10 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
     if (!s_go) return;  // uniform over the block, and every block of the pair sees the same status
-    const Pose T{{s_pose[0], s_pose[1], s_pose[2]}, {s_pose[3], s_pose[4], s_pose[5], s_pose[6]}};
+    // the pose is wave-uniform: keep it in scalar registers like a kernel argument
+    auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+    const Pose T{{uni(s_pose[0]), uni(s_pose[1]), uni(s_pose[2])},
+                 {uni(s_pose[3]), uni(s_pose[4]), uni(s_pose[5]), uni(s_pose[6])}};
     float acc[GN_PARTIAL];
 #pragma unroll
     for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
