@@ -84,18 +84,35 @@ a3d_status kdtree_build_host(const float* points, uint32_t n, std::vector<float>
 
 namespace {
 
+constexpr uint32_t KD_TOP = 4095;  // heap entries of the split table kept in LDS (levels 0..11, 16 KiB)
+
 __global__ void __launch_bounds__(256)
     kdtree_nearest_kernel(const float* __restrict__ split, const float4* __restrict__ leaves, uint32_t n,
-                          uint32_t max_depth, const float* __restrict__ queries, uint32_t m,
+                          uint32_t n_split, uint32_t max_depth, const float* __restrict__ queries, uint32_t m,
                           uint32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const V3 q{queries[3 * i], queries[3 * i + 1], queries[3 * i + 2]};
-  float dist;
-  float4 win;
-  kdtree_nearest_slot(split, leaves, n, max_depth, q, &dist, &win);
-  out_idx[i] = __float_as_uint(win.w);
-  out_dist[i] = dist;
+  __shared__ float split_top[KD_TOP];
+  const uint32_t top = n_split < KD_TOP ? n_split : KD_TOP;
+  for (uint32_t k = threadIdx.x; k < top; k += blockDim.x) split_top[k] = split[k];
+  __syncthreads();
+  // grid-stride over queries; every lane stays in the loop (the cooperative scan needs the whole wave)
+  const uint32_t rounds = (m + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint32_t ii = i < m ? i : m - 1;
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    typedef f32x3 __attribute__((aligned(4))) f32x3_u;
+    const f32x3 qv = *(const f32x3_u*)(queries + 3 * (size_t)ii);  // one dwordx3
+    const V3 q{qv.x, qv.y, qv.z};
+    const uint32_t base = kdtree_descend(split, split_top, top, n, max_depth, q);
+    uint32_t slot;
+    float dist;
+    float4 win;
+    kdtree_scan_leaves_coop(leaves, base, q, &slot, &dist, &win);
+    if (i < m) {
+      out_idx[i] = __float_as_uint(win.w);
+      out_dist[i] = dist;
+    }
+  }
 }
 
 struct PclGates {
@@ -191,9 +208,11 @@ a3d_status a3d_kdtree_nearest_device(a3d_kdtree* t, const void* d_queries, uint6
   A3D_REQUIRE(t && (m == 0 || (d_queries && d_indices && d_sqr)), A3D_INVALID_PARAMETER, "null argument");
   A3D_TRY(check_finite_query_count(m));
   if (m == 0) return A3D_OK;
-  hipLaunchKernelGGL(kdtree_nearest_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, t->ctx->stream,
-                     t->d_split, t->d_leaves, t->n, t->max_depth, (const float*)d_queries, (uint32_t)m,
-                     (uint32_t*)d_indices, (float*)d_sqr);
+  // enough blocks to fill the chip, few enough that the 16 KiB LDS copy of the split table's top is amortised
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((m + 255) / 256, (uint64_t)std::max(1, t->ctx->num_cus) * 8);
+  hipLaunchKernelGGL(kdtree_nearest_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, t->d_split, t->d_leaves, t->n,
+                     t->n_split, t->max_depth, (const float*)d_queries, (uint32_t)m, (uint32_t*)d_indices,
+                     (float*)d_sqr);
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }
