@@ -127,27 +127,42 @@ __global__ void __launch_bounds__(256)
                    const float* __restrict__ src_points, const float* __restrict__ src_normals, uint32_t m,
                    JobState* __restrict__ states, PclGates gates, float* __restrict__ partials,
                    unsigned* __restrict__ counter, SolveArgs solve) {
+  __shared__ float split_top[KD_TOP];
+  const uint32_t n_split = (1u << max_depth) - 1u;
+  const uint32_t top = n_split < KD_TOP ? n_split : KD_TOP;
+  for (uint32_t k = threadIdx.x; k < top; k += blockDim.x) split_top[k] = split[k];
+  __syncthreads();
   float acc[GN_ACC];
 #pragma unroll
   for (int k = 0; k < GN_ACC; ++k) acc[k] = 0.0f;
   if (states->status == A3D_OK) {
     const Pose T = states->pose;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-      const V3 sp = transform_vector(T, V3{src_points[3 * i], src_points[3 * i + 1], src_points[3 * i + 2]});
-      const V3 sn = transform_normal(T, V3{src_normals[3 * i], src_normals[3 * i + 1], src_normals[3 * i + 2]});
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    typedef f32x3 __attribute__((aligned(4))) f32x3_u;
+    // every lane stays in the loop: the cooperative leaf scan needs the whole wave
+    const uint32_t rounds = (m + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (uint32_t r = 0; r < rounds; ++r) {
+      const uint32_t i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+      const uint32_t ii = i < m ? i : m - 1;
+      const f32x3 pv = *(const f32x3_u*)(src_points + 3 * (size_t)ii), nv = *(const f32x3_u*)(src_normals + 3 * (size_t)ii);
+      const V3 sp = transform_vector(T, V3{pv.x, pv.y, pv.z});
+      const V3 sn = transform_normal(T, V3{nv.x, nv.y, nv.z});
+      const uint32_t base = kdtree_descend(split, split_top, top, n, max_depth, sp);
+      uint32_t slot;
       float d2;
       float4 win;
-      const uint32_t slot = kdtree_nearest_slot(split, leaves, n, max_depth, sp, &d2, &win);
+      kdtree_scan_leaves_coop(leaves, base, sp, &slot, &d2, &win);
+      if (i >= m) continue;
       if (d2 > gates.max_distance_sqr) continue;
       const float4 tn4 = leaf_normals[slot];
       const V3 tn{tn4.x, tn4.y, tn4.z};
       const float c = dot(sn, tn);
       if (c >= -1.0f && c <= gates.dot_reject_max) continue;
       const V3 tp{win.x, win.y, win.z};
-      const float r = dot(tp - sp, tn);
+      const float rr = dot(tp - sp, tn);
       const V3 tw = cross(sp, tn);
       const float J[6] = {tn.x, tn.y, tn.z, tw.x, tw.y, tw.z};
-      gn_step(acc, r, J);
+      gn_step(acc, rr, J);
     }
   }
   SolveArgs sa = solve;
