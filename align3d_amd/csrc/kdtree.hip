@@ -1,6 +1,7 @@
 // R3dTree::new / nearest (src/kdtree.rs:28-105) and Icp (src/icp/pcl_icp.rs:15-108).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <memory>
 
@@ -295,7 +296,8 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
       st = A3D_HIP_ERROR;
     icp->target_has_normals = true;
   }
-  icp->blocks = (uint32_t)std::max(1, ctx->num_cus * 8);
+  // few, fat blocks: the last block sums one partial per block, so the tail grows with the block count
+  icp->blocks = (uint32_t)std::max(1, ctx->num_cus * (getenv("A3D_PCL_BLOCKS_PER_CU") ? atoi(getenv("A3D_PCL_BLOCKS_PER_CU")) : 2));
   if (st == A3D_OK &&
       (hipMalloc((void**)&icp->d_state, sizeof(JobState)) != hipSuccess ||
        hipMalloc((void**)&icp->d_partials, (size_t)icp->blocks * GN_PARTIAL * sizeof(float)) != hipSuccess ||
