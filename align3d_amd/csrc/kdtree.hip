@@ -297,7 +297,7 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
     icp->target_has_normals = true;
   }
   // few, fat blocks: the last block sums one partial per block, so the tail grows with the block count
-  icp->blocks = (uint32_t)std::max(1, ctx->num_cus * (getenv("A3D_PCL_BLOCKS_PER_CU") ? atoi(getenv("A3D_PCL_BLOCKS_PER_CU")) : 2));
+  icp->blocks = (uint32_t)std::max(1, ctx->num_cus * (getenv("A3D_PCL_BLOCKS_PER_CU") ? atoi(getenv("A3D_PCL_BLOCKS_PER_CU")) : 4));
   if (st == A3D_OK &&
       (hipMalloc((void**)&icp->d_state, sizeof(JobState)) != hipSuccess ||
        hipMalloc((void**)&icp->d_partials, (size_t)icp->blocks * GN_PARTIAL * sizeof(float)) != hipSuccess ||

@@ -220,3 +220,32 @@ def test_cpp_host_mirror_on_gpu():
         subprocess.check_call(["make", "-C", os.path.join(root, "tests", "cpp")], stdout=subprocess.DEVNULL)
     out = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "GPU checks OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_level_kernel_matches_per_iteration_launches(ctx, monkeypatch):
+    """The opt-in persistent form (one launch per pyramid level, blocks wait on a per-pair epoch word instead of
+    exiting: A3D_ICP_PERSISTENT=1) computes the same alignment as the default one-launch-per-iteration form."""
+    prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 6))
+    pairs = [("sample1", 0, 5), ("sample2", 0, 4), ("sample1", 1, 4)]
+    tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs]
+    sps = [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in pairs]
+    ref_poses, ref_status = MultiscaleAlignBatch(ctx, prm, tps, sps).align()
+    monkeypatch.setenv("A3D_ICP_PERSISTENT", "1")
+    batch = MultiscaleAlignBatch(ctx, prm, tps, sps)
+    monkeypatch.delenv("A3D_ICP_PERSISTENT")
+    poses, status = batch.align()
+    poses2, _ = batch.align()  # epochs and counters are reset per call
+    assert not status.any() and not ref_status.any()
+    for a, b, c in zip(poses, ref_poses, poses2):
+        assert np.allclose(a.t, b.t, atol=2e-6) and np.allclose(a.q, b.q, atol=2e-6)
+        assert np.array_equal(a.t, c.t) and np.array_equal(a.q, c.q)
+    # a pair that fails (empty source) freezes without stalling the others
+    empty = [to_range_image(f) for f in oracle_pyramid("sample1", 5)]
+    for lv in empty:
+        lv.mask = np.zeros_like(lv.mask)
+    monkeypatch.setenv("A3D_ICP_PERSISTENT", "1")
+    mixed = MultiscaleAlignBatch(ctx, prm, [tps[0], tps[1]], [empty, sps[1]])
+    monkeypatch.delenv("A3D_ICP_PERSISTENT")
+    p2, st2 = mixed.align()
+    assert st2[0] == 3 and st2[1] == 0
+    assert np.allclose(p2[1].t, ref_poses[1].t, atol=2e-6)
