@@ -314,17 +314,19 @@ __global__ void __launch_bounds__(256, 3)  // at most 168 VGPRs: three blocks pe
     // ---- this iteration's pose: wait until the pair has completed `epoch_base + it` iterations ----------
     if (threadIdx.x == 0) {
       const unsigned want = plan.epoch_base + it;
-      int go = 1;
+      // a failed job stays frozen: its epoch stops advancing, so look at the status before (and while) waiting
+      int go = load_status(st) == A3D_OK;
       unsigned spins = 0;
-      while (__hip_atomic_load(&epochs[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+      while (go && __hip_atomic_load(&epochs[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 22)) {  // ~1 s: a resident partner can not be this late
+        ++spins;
+        if ((spins & 63u) == 0 && load_status(st) != A3D_OK) go = 0;
+        if (spins > (1u << 22)) {  // ~1 s: a resident partner can not be this late
           store_status(st, A3D_HIP_ERROR);
           go = 0;
-          break;
         }
       }
-      if (go && load_status(st) != A3D_OK) go = 0;  // a failed job stays frozen
+      if (go && load_status(st) != A3D_OK) go = 0;
       const Pose T0 = load_pose(&st->pose);
       s_pose[0] = T0.t.x, s_pose[1] = T0.t.y, s_pose[2] = T0.t.z;
       s_pose[3] = T0.q.i, s_pose[4] = T0.q.j, s_pose[5] = T0.q.k, s_pose[6] = T0.q.w;
