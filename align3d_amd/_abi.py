@@ -187,7 +187,9 @@ SIGNATURES = {
     ),
 }
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libalign3d_hip.so")
+# A3D_LIBRARY selects another build of the same library (diagnostic builds); never a different implementation.
+LIB_PATH = os.environ.get("A3D_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                         "libalign3d_hip.so")
 _lib = None
 
 

@@ -119,6 +119,18 @@ __device__ __forceinline__ void block_reduce_store(const float (&acc)[N], float*
   }
 }
 
+#ifdef A3D_TAIL_STAMPS
+__device__ unsigned long long g_tail_stamps[16];
+#define A3D_STAMP(k)                                                                       \
+  do {                                                                                     \
+    if (threadIdx.x == 0 && job == 0) g_tail_stamps[k] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define A3D_STAMP(k) \
+  do {               \
+  } while (0)
+#endif
+
 // ---- job state accessors ---------------------------------------------------------------------------
 // Inside the persistent level kernel the state is handed from block to block within one launch, so it is
 // always read and written with agent-scope (sc1) accesses that bypass the CU's L1.
@@ -186,6 +198,7 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
     s_ok = count != 0.0;  // solve(): None if count == 0
   }
   __syncthreads();
+  A3D_STAMP(3);
   for (int k = 0; k < 6; ++k) {
     if (tid == 0 && s_ok) {
       const double diag = L[k * 6 + k];
@@ -200,6 +213,7 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
     if (tid < 36 && s_ok && c > k && r >= c) L[tid] = (-L[c * 6 + k]) * L[r * 6 + k] + L[tid];
     __syncthreads();
   }
+  A3D_STAMP(4);
   if (tid != 0) return;
   const float residual = s_residual;
   if (!s_ok) {  // the reference's unwrap() panics here
@@ -226,6 +240,7 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
   float update[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) update[i] = (float)bvec[i];
+  A3D_STAMP(5);
   Pose pose = load_pose(&st->pose);
   float best_residual = ld_coherent(&st->best_residual);
   Pose best = load_pose(&st->best);
@@ -249,6 +264,7 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
   store_pose(&st->best, best);
   st_coherent(&st->best_residual, best_residual);
   st_coherent(&st->last_residual, residual);
+  A3D_STAMP(6);
 }
 
 // Tail of an accumulate kernel (all 256 threads call it): reduce the block's accumulators to one
@@ -281,6 +297,7 @@ __device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job
   if (args.mode == SOLVE_NONE) return false;
   __shared__ unsigned s_is_last;
   __shared__ double s_sums[8][64];
+  A3D_STAMP(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -289,6 +306,7 @@ __device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job
   }
   __syncthreads();
   if (!s_is_last) return false;
+  A3D_STAMP(1);
   // ---- last block of this job ----
   // Every load of the handed-off partials below is an sc1 (agent-scope) load that bypasses this CU's L1,
   // so no acquire fence (an L1 invalidate) is needed.  Thread (pair of components cg, slice s) sums tiles
@@ -339,6 +357,7 @@ __device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job
                    ((s_sums[4][c] + s_sums[5][c]) + (s_sums[6][c] + s_sums[7][c]));
   }
   __syncthreads();
+  A3D_STAMP(2);
   if (threadIdx.x == 0)  // ready for the next launch (ordered by the kernel boundary)
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   gn_finish_block(st, s_sums[0], args, job);

@@ -1046,6 +1046,12 @@ a3d_status a3d_selftest_division(a3d_context* ctx, const float* numerators, cons
   return A3D_OK;
 }
 
+#ifdef A3D_TAIL_STAMPS
+extern "C" int a3d_debug_tail_stamps(unsigned long long out[16]) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* b) {
   if (!b) return A3D_OK;
   hipStreamSynchronize(b->ctx->stream);
