@@ -145,8 +145,11 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
     st = A3D_HIP_ERROR;
   };
   uint32_t h_scal[3] = {0xFFFFu, 0u, 0u};
-  if (hipMalloc((void**)&d_scal, 12) != hipSuccess) fail("hipMalloc");
-  if (st == A3D_OK && hipMemcpyAsync(d_scal, h_scal, 12, hipMemcpyHostToDevice, s) != hipSuccess) fail("upload");
+  void* scratch = nullptr;
+  // the three scalar words sit at the start of the grid scratch region; the grids follow once their size is known
+  if (ctx_scratch(ctx, 1, 256, &scratch) != A3D_OK) return A3D_HIP_ERROR;
+  d_scal = (uint32_t*)scratch;
+  if (hipMemcpyAsync(d_scal, h_scal, 12, hipMemcpyHostToDevice, s) != hipSuccess) fail("upload");
   if (st == A3D_OK) {
     hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64)), dim3(256), 0, s, d_img, n,
                        d_scal);
@@ -163,11 +166,19 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
     g.gd = (uint32_t)((double)(cmax - cmin) / sigma_color) + 1 + 4;
     if (out_grid_dims) out_grid_dims[0] = g.gh, out_grid_dims[1] = g.gw, out_grid_dims[2] = g.gd;
     const size_t cells = (size_t)g.gh * g.gw * g.gd;
-    if (hipMalloc((void**)&d_a, cells * sizeof(double2)) != hipSuccess ||
-        hipMalloc((void**)&d_b, cells * sizeof(double2)) != hipSuccess ||
-        hipMemsetAsync(d_a, 0, cells * sizeof(double2), s) != hipSuccess ||
-        hipMemsetAsync(d_b, 0, cells * sizeof(double2), s) != hipSuccess)
-      fail("grid allocation");
+    const size_t grid_bytes = ((cells * sizeof(double2) + 255) / 256) * 256;
+    // (growing the region synchronises; the stream is idle here anyway after the min/max read-back)
+    if (ctx_scratch(ctx, 1, 256 + 2 * grid_bytes, &scratch) != A3D_OK) {
+      st = A3D_HIP_ERROR;
+    } else {
+      if ((uint32_t*)scratch != d_scal) {  // the region moved: restore the flag word
+        d_scal = (uint32_t*)scratch;
+        if (hipMemsetAsync(d_scal, 0, 12, s) != hipSuccess) fail("flag reset");
+      }
+      d_a = (double2*)((char*)scratch + 256);
+      d_b = (double2*)((char*)scratch + 256 + grid_bytes);
+      if (hipMemsetAsync(d_a, 0, 2 * grid_bytes, s) != hipSuccess) fail("grid clear");
+    }
     if (st == A3D_OK) {
       const double inv_ss = 1.0 / sigma_space, inv_sc = 1.0 / sigma_color;
       hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
@@ -189,9 +200,6 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
                          hipStreamSynchronize(s) != hipSuccess))
       fail("flag download");
   }
-  hipFree(d_scal);
-  hipFree(d_a);
-  hipFree(d_b);
   if (st != A3D_OK) return st;
   if (h_scal[2]) {
     set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");

@@ -70,7 +70,22 @@ struct a3d_context {
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int num_cus = 0;
+  // Grow-only scratch regions for per-call temporaries (all work on a context is ordered on its one stream,
+  // so successive calls may reuse them): [0] frame builder temporaries, [1] bilateral grids.
+  void* scratch[2] = {nullptr, nullptr};
+  size_t scratch_size[2] = {0, 0};
 };
+
+namespace a3d {
+// Returns a scratch region of at least `bytes` (256-byte aligned); growing one synchronises the stream first.
+a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out);
+
+// One hipMalloc shared by the arrays of several device images (a pyramid); freed with its last user.
+struct DeviceArena {
+  void* base = nullptr;
+  int refs = 0;
+};
+}  // namespace a3d
 
 // One RangeImage in HBM, in the reference's own standard layout (DESIGN.md "Data layout in HBM").
 struct a3d_device_image {
@@ -85,4 +100,5 @@ struct a3d_device_image {
   float* imap = nullptr;                 // [(h+2)][(w+2)] or null
   uint8_t* colors = nullptr;             // [h][w][3] or null (kept by the device-side builder for the pyramid)
   bool has_normals = false, has_intensities = false, has_imap = false;
+  a3d::DeviceArena* arena = nullptr;     // when set, the arrays above are carved out of it and not freed one by one
 };

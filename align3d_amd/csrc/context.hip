@@ -53,6 +53,20 @@ float acos_gate_threshold(float thr, bool strict) {
   return unordered(lo);
 }
 
+a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out) {
+  if (ctx->scratch_size[which] < bytes) {
+    A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));  // nothing enqueued may still use the old region
+    if (ctx->scratch[which]) A3D_HIP_TRY(hipFree(ctx->scratch[which]));
+    ctx->scratch[which] = nullptr;
+    ctx->scratch_size[which] = 0;
+    const size_t grown = bytes + bytes / 4;
+    A3D_HIP_TRY(hipMalloc(&ctx->scratch[which], grown));
+    ctx->scratch_size[which] = grown;
+  }
+  *out = ctx->scratch[which];
+  return A3D_OK;
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -100,6 +114,8 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   if (!ctx) return A3D_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  hipFree(ctx->scratch[0]);
+  hipFree(ctx->scratch[1]);
   hipEventDestroy(ctx->ev_start);
   hipEventDestroy(ctx->ev_stop);
   hipStreamDestroy(ctx->stream);

@@ -164,20 +164,30 @@ std::vector<TapRow> make_taps(uint32_t size, float sigma, uint32_t stride, uint3
   return rows;
 }
 
-template <typename T>
-a3d_status dev_alloc(T** p, size_t count) {
-  A3D_HIP_TRY(hipMalloc((void**)p, std::max<size_t>(1, count) * sizeof(T)));
-  return A3D_OK;
-}
+// Bump allocator over one region (256-byte aligned pieces): the pyramid's arrays share one arena, the
+// temporaries share the context's scratch region, so a frame costs one hipMalloc instead of ~40.
+struct Carver {
+  char* base = nullptr;
+  size_t used = 0, capacity = 0;
+  template <typename T>
+  a3d_status take(T** p, size_t count) {
+    const size_t bytes = ((std::max<size_t>(1, count) * sizeof(T) + 255) / 256) * 256;
+    A3D_REQUIRE(used + bytes <= capacity, A3D_INVALID_PARAMETER, "internal: arena too small");
+    *p = (T*)(base + used);
+    used += bytes;
+    return A3D_OK;
+  }
+};
+inline size_t padded(size_t bytes) { return ((std::max<size_t>(1, bytes) + 255) / 256) * 256; }
 
 inline dim3 grid_for(size_t n) { return dim3((uint32_t)((n + 255) / 256)); }
 
 // compute_intensity + compute_intensity_map on a resident level that has colours
-a3d_status add_intensity(a3d_device_image* im) {
+a3d_status add_intensity(a3d_device_image* im, Carver& arena) {
   const uint32_t w = im->width, h = im->height, n = w * h;
   hipStream_t s = im->ctx->stream;
-  A3D_TRY(dev_alloc(&im->intensities, n));
-  A3D_TRY(dev_alloc(&im->imap, (size_t)(w + 2) * (h + 2)));
+  A3D_TRY(arena.take(&im->intensities, n));
+  A3D_TRY(arena.take(&im->imap, (size_t)(w + 2) * (h + 2)));
   hipLaunchKernelGGL(luma_kernel, grid_for(n), dim3(256), 0, s, im->colors, n, im->intensities);
   hipLaunchKernelGGL(intensity_map_kernel, grid_for((size_t)(w + 2) * (h + 2)), dim3(256), 0, s, im->intensities, w, h,
                      im->imap);
@@ -187,7 +197,8 @@ a3d_status add_intensity(a3d_device_image* im) {
 }
 
 // RangeImage::pyr_scale_down(sigma) (structure.rs:309-340)
-a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_image* dst) {
+a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_image* dst, Carver& arena,
+                          Carver& scratch) {
   a3d_context* ctx = src->ctx;
   hipStream_t s = ctx->stream;
   const uint32_t sw = src->width, sh = src->height, dw = sw / 2, dh = sh / 2, dn = dw * dh;
@@ -195,12 +206,12 @@ a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_i
   dst->width = dw, dst->height = dh;
   dst->fx64 = src->fx64 * 0.5, dst->fy64 = src->fy64 * 0.5, dst->cx64 = src->cx64 * 0.5, dst->cy64 = src->cy64 * 0.5;
   dst->fx = (float)dst->fx64, dst->fy = (float)dst->fy64, dst->cx = (float)dst->cx64, dst->cy = (float)dst->cy64;
-  A3D_TRY(dev_alloc(&dst->points, (size_t)dn * 3));
-  A3D_TRY(dev_alloc(&dst->mask, dn));
+  A3D_TRY(arena.take(&dst->points, (size_t)dn * 3));
+  A3D_TRY(arena.take(&dst->mask, dn));
   hipLaunchKernelGGL(resize_pick_kernel, grid_for(dn), dim3(256), 0, s, src->points, src->mask, sw, sh, dw, dh,
                      dst->points, dst->mask);
   if (src->has_normals) {
-    A3D_TRY(dev_alloc(&dst->normals, (size_t)dn * 3));
+    A3D_TRY(arena.take(&dst->normals, (size_t)dn * 3));
     hipLaunchKernelGGL(resize_pick_kernel, grid_for(dn), dim3(256), 0, s, src->normals, src->mask, sw, sh, dw, dh,
                        dst->normals, (uint8_t*)nullptr);
     dst->has_normals = true;
@@ -210,20 +221,17 @@ a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_i
     const std::vector<TapRow> tv = make_taps(sh, sigma, 1, sh), th = make_taps(sw, sigma, 2, dw);
     TapRow *d_tv = nullptr, *d_th = nullptr;
     float* d_tmp = nullptr;
-    A3D_TRY(dev_alloc(&d_tv, tv.size()));
-    A3D_TRY(dev_alloc(&d_th, th.size()));
-    A3D_TRY(dev_alloc(&d_tmp, (size_t)sw * sh * 3));
-    A3D_TRY(dev_alloc(&dst->colors, (size_t)dn * 3));
+    A3D_TRY(scratch.take(&d_tv, tv.size()));
+    A3D_TRY(scratch.take(&d_th, th.size()));
+    A3D_TRY(scratch.take(&d_tmp, (size_t)sw * sh * 3));
+    A3D_TRY(arena.take(&dst->colors, (size_t)dn * 3));
+    // pageable -> device async copies return once the host buffer has been staged, so the vectors may die
     A3D_HIP_TRY(hipMemcpyAsync(d_tv, tv.data(), tv.size() * sizeof(TapRow), hipMemcpyHostToDevice, s));
     A3D_HIP_TRY(hipMemcpyAsync(d_th, th.data(), th.size() * sizeof(TapRow), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(blur_vertical_kernel, grid_for((size_t)sw * sh * 3), dim3(256), 0, s, src->colors, sw, sh, d_tv,
                        d_tmp);
     hipLaunchKernelGGL(blur_horizontal_halve_kernel, grid_for((size_t)dn * 3), dim3(256), 0, s, d_tmp, sw, dw, dh, d_th,
                        dst->colors);
-    A3D_HIP_TRY(hipStreamSynchronize(s));  // the tap tables above are host vectors
-    hipFree(d_tv);
-    hipFree(d_th);
-    hipFree(d_tmp);
   }
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
@@ -254,53 +262,82 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const uint32_t w = (uint32_t)width, h = (uint32_t)height, n = w * h;
-  std::vector<std::unique_ptr<a3d_device_image, a3d_status (*)(a3d_device_image*)>> levels;
+  // ---- sizes: one arena for everything that stays resident, the context's scratch for the temporaries ----
+  const uint64_t L = prm->pyramid_levels;
+  size_t arena_bytes = 0, scratch_bytes = 2 * padded((size_t)n * 2);
+  for (uint64_t l = 0; l < L; ++l) {
+    const size_t wl = w >> l, hl = h >> l, nl = wl * hl;
+    arena_bytes += padded(nl * 12) + padded(nl) + padded(nl * 3);                 // points, mask, colors
+    if (prm->with_normals) arena_bytes += padded(nl * 12);
+    if (prm->with_intensity) arena_bytes += padded(nl) + padded((wl + 2) * (hl + 2) * 4);
+    if (l + 1 < L) scratch_bytes += padded(nl * 12) + padded(hl * sizeof(TapRow)) + padded((wl / 2) * sizeof(TapRow));
+  }
+  DeviceArena* shared = new DeviceArena();
+  if (hipMalloc(&shared->base, arena_bytes) != hipSuccess) {
+    delete shared;
+    set_error("a3d_range_image_build_pyramid: hipMalloc(%zu) failed", arena_bytes);
+    return A3D_HIP_ERROR;
+  }
+  Carver arena{(char*)shared->base, 0, arena_bytes};
+  std::vector<a3d_device_image*> levels;
   auto new_level = [&]() {
-    levels.emplace_back(new a3d_device_image(), a3d_range_image_free);
-    levels.back()->ctx = ctx;
-    return levels.back().get();
+    a3d_device_image* im = new a3d_device_image();
+    im->ctx = ctx;
+    im->arena = shared;
+    ++shared->refs;
+    levels.push_back(im);
+    return im;
   };
-  uint16_t *d_depth = nullptr, *d_filtered = nullptr;
-  struct Scratch {
-    uint16_t **a, **b;
-    ~Scratch() {
-      hipFree(*a);
-      hipFree(*b);
+  auto build = [&]() -> a3d_status {
+    void* scratch_base = nullptr;
+    A3D_TRY(ctx_scratch(ctx, 0, scratch_bytes, &scratch_base));
+    Carver scratch{(char*)scratch_base, 0, scratch_bytes};
+    uint16_t *d_depth = nullptr, *d_filtered = nullptr;
+    a3d_device_image* l0 = new_level();
+    l0->width = w, l0->height = h;
+    l0->fx64 = fx, l0->fy64 = fy, l0->cx64 = cx, l0->cy64 = cy;
+    l0->fx = (float)fx, l0->fy = (float)fy, l0->cx = (float)cx, l0->cy = (float)cy;
+    A3D_TRY(scratch.take(&d_depth, n));
+    A3D_TRY(scratch.take(&d_filtered, n));
+    A3D_TRY(arena.take(&l0->colors, (size_t)n * 3));
+    A3D_TRY(arena.take(&l0->points, (size_t)n * 3));
+    A3D_TRY(arena.take(&l0->mask, n));
+    A3D_HIP_TRY(hipMemcpyAsync(d_depth, depth, (size_t)n * 2, hipMemcpyHostToDevice, s));
+    A3D_HIP_TRY(hipMemcpyAsync(l0->colors, rgb, (size_t)n * 3, hipMemcpyHostToDevice, s));
+    const uint16_t* d_use = d_depth;
+    if (prm->use_bilateral) {  // builder.rs:75-77
+      A3D_TRY(bilateral_filter_device(ctx, d_depth, d_filtered, w, h, prm->sigma_space, prm->sigma_color, nullptr));
+      d_use = d_filtered;
     }
-  } scratch{&d_depth, &d_filtered};
-  a3d_device_image* l0 = new_level();
-  l0->width = w, l0->height = h;
-  l0->fx64 = fx, l0->fy64 = fy, l0->cx64 = cx, l0->cy64 = cy;
-  l0->fx = (float)fx, l0->fy = (float)fy, l0->cx = (float)cx, l0->cy = (float)cy;
-  A3D_TRY(dev_alloc(&d_depth, n));
-  A3D_TRY(dev_alloc(&l0->colors, (size_t)n * 3));
-  A3D_TRY(dev_alloc(&l0->points, (size_t)n * 3));
-  A3D_TRY(dev_alloc(&l0->mask, n));
-  A3D_HIP_TRY(hipMemcpyAsync(d_depth, depth, (size_t)n * 2, hipMemcpyHostToDevice, s));
-  A3D_HIP_TRY(hipMemcpyAsync(l0->colors, rgb, (size_t)n * 3, hipMemcpyHostToDevice, s));
-  const uint16_t* d_use = d_depth;
-  if (prm->use_bilateral) {  // builder.rs:75-77
-    A3D_TRY(dev_alloc(&d_filtered, n));
-    A3D_TRY(bilateral_filter_device(ctx, d_depth, d_filtered, w, h, prm->sigma_space, prm->sigma_color, nullptr));
-    d_use = d_filtered;
+    hipLaunchKernelGGL(backproject_kernel, grid_for(n), dim3(256), 0, s, d_use, w, h, l0->fx, l0->fy, l0->cx, l0->cy,
+                       (float)depth_scale, l0->points, l0->mask);
+    if (prm->with_normals) {  // level 0 only (builder.rs:79-82); coarser levels inherit picked normals
+      A3D_TRY(arena.take(&l0->normals, (size_t)n * 3));
+      A3D_TRY(compute_normals_device(ctx, l0->points, l0->mask, l0->normals, w, h));
+      l0->has_normals = true;
+    }
+    for (uint64_t l = 1; l < L; ++l) {  // RangeImage::pyramid (structure.rs:342-351)
+      a3d_device_image* prev = levels.back();
+      a3d_device_image* next = new_level();
+      A3D_TRY(pyr_scale_down(prev, prm->blur_sigma, next, arena, scratch));
+    }
+    if (prm->with_intensity)
+      for (a3d_device_image* lv : levels) A3D_TRY(add_intensity(lv, arena));
+    A3D_HIP_TRY(hipGetLastError());
+    A3D_HIP_TRY(hipStreamSynchronize(s));
+    return A3D_OK;
+  };
+  const a3d_status st = build();
+  if (st != A3D_OK) {
+    hipStreamSynchronize(s);
+    for (a3d_device_image* lv : levels) a3d_range_image_free(lv);  // the last one releases the arena
+    if (levels.empty()) {
+      hipFree(shared->base);
+      delete shared;
+    }
+    return st;
   }
-  hipLaunchKernelGGL(backproject_kernel, grid_for(n), dim3(256), 0, s, d_use, w, h, l0->fx, l0->fy, l0->cx, l0->cy,
-                     (float)depth_scale, l0->points, l0->mask);
-  if (prm->with_normals) {  // level 0 only (builder.rs:79-82); coarser levels inherit picked normals
-    A3D_TRY(dev_alloc(&l0->normals, (size_t)n * 3));
-    A3D_TRY(compute_normals_device(ctx, l0->points, l0->mask, l0->normals, w, h));
-    l0->has_normals = true;
-  }
-  for (uint64_t l = 1; l < prm->pyramid_levels; ++l) {  // RangeImage::pyramid (structure.rs:342-351)
-    a3d_device_image* prev = levels.back().get();
-    a3d_device_image* next = new_level();
-    A3D_TRY(pyr_scale_down(prev, prm->blur_sigma, next));
-  }
-  if (prm->with_intensity)
-    for (auto& lv : levels) A3D_TRY(add_intensity(lv.get()));
-  A3D_HIP_TRY(hipGetLastError());
-  A3D_HIP_TRY(hipStreamSynchronize(s));
-  for (size_t l = 0; l < levels.size(); ++l) out_levels[l] = levels[l].release();
+  for (size_t l = 0; l < levels.size(); ++l) out_levels[l] = levels[l];
   return A3D_OK;
 }
 

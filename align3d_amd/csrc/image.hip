@@ -137,12 +137,19 @@ a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* 
 a3d_status a3d_range_image_free(a3d_device_image* im) {
   if (!im) return A3D_OK;
   hipStreamSynchronize(im->ctx->stream);
-  hipFree(im->points);
-  hipFree(im->mask);
-  hipFree(im->normals);
-  hipFree(im->intensities);
-  hipFree(im->imap);
-  hipFree(im->colors);
+  if (im->arena) {  // arrays live in a shared arena: release it with its last user
+    if (--im->arena->refs == 0) {
+      hipFree(im->arena->base);
+      delete im->arena;
+    }
+  } else {
+    hipFree(im->points);
+    hipFree(im->mask);
+    hipFree(im->normals);
+    hipFree(im->intensities);
+    hipFree(im->imap);
+    hipFree(im->colors);
+  }
   delete im;
   return A3D_OK;
 }
@@ -150,6 +157,8 @@ a3d_status a3d_range_image_free(a3d_device_image* im) {
 a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
   A3D_REQUIRE(im, A3D_INVALID_PARAMETER, "image is null");
   const size_t n = (size_t)im->width * im->height;
+  A3D_REQUIRE(im->normals || !im->arena, A3D_INVALID_PARAMETER,
+              "this image was built without normals (a3d_builder_params.with_normals = 0)");
   if (!im->normals) A3D_HIP_TRY(hipMalloc((void**)&im->normals, n * 3 * sizeof(float)));
   A3D_TRY(launch_compute_normals(im->ctx, im->points, im->mask, im->normals, im->width, im->height));
   im->has_normals = true;
