@@ -216,20 +216,28 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-extras", action="store_true", help="skip the kd-tree / single-pair secondary numbers")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (gloo + --device 0 rehearses the multi-rank path on one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device for this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = torch = None
+    device = local_rank if args.device is None else args.device
+    use_nccl = args.backend == "nccl"
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        if use_nccl:
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
-    ctx = Context(local_rank)
+    ctx = Context(device)
     P, W, H = args.pairs_per_gpu, args.width, args.height
     params = MsIcpParams.repeat(3, IcpParams.default())  # ms3x15
     t0 = time.time()
@@ -242,23 +250,31 @@ def main():
     sources = [host_pyramids[p + 1] for p in range(P)]
     batch = MultiscaleAlignBatch(ctx, params, targets, sources)
 
-    d_mats = gathered = ext_stream = None
-    if world > 1:
+    d_mats = gathered = ext_stream = host_mats = None
+    if world > 1 and use_nccl:
         mats = torch.zeros((P, 16), dtype=torch.float32, device="cuda")
         gathered = torch.zeros((world * P, 16), dtype=torch.float32, device="cuda")
         d_mats = C.c_void_p(mats.data_ptr())
         ext_stream = torch.cuda.ExternalStream(ctx.lib.a3d_context_stream(ctx.handle))
+    elif world > 1:  # gloo rehearsal: the poses go through host memory
+        d_mats = ctx.malloc(P * 64)
+        host_mats = np.zeros((P, 16), np.float32)
+        gathered = torch.zeros((world * P, 16), dtype=torch.float32)
 
     def step():
         batch.enqueue(matrices_device=d_mats)
-        if world > 1:
+        if world > 1 and use_nccl:
             with torch.cuda.stream(ext_stream):  # ordered after the kernels on the context stream
                 dist.all_gather_into_tensor(gathered, mats)
+        elif world > 1:
+            ctx.to_host(d_mats, host_mats)
+            dist.all_gather_into_tensor(gathered, torch.from_numpy(host_mats))
 
     def sync_all():
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if use_nccl:
+                torch.cuda.synchronize()
         ctx.synchronize()
 
     for _ in range(args.warmup):
@@ -270,7 +286,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_nccl else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -300,6 +316,10 @@ def main():
         }
         poses, status = batch.align()
         extra = {"failed_pairs": int(np.count_nonzero(status))}
+        if world > 1:  # the gathered buffer starts with this rank's own 4x4 poses
+            own = gathered[:P].cpu().numpy().reshape(P, 4, 4)
+            extra["gather_matches_local_poses"] = bool(
+                all(np.allclose(own[p], poses[p].matrix(), atol=1e-6) for p in range(P)))
         # accuracy against the synthetic ground truth (reported, not a parity claim)
         errs = []
         for p in range(P):
@@ -337,7 +357,8 @@ def main():
                                    "MsIcpParams::repeat(3, IcpParams::default()) = 3 levels x 15 iterations "
                                    "(configs[1] pair shape, batched as the per-GPU shard of configs[4])",
                        "pairs_per_gpu": P, "levels": 3, "iterations_per_level": iters,
-                       "collective": "one RCCL all-gather of 16 f32 per pair per step" if world > 1 else "none"},
+                       "collective": (f"one all-gather of 16 f32 per pair per step ({'RCCL' if use_nccl else 'gloo rehearsal'})"
+                                      if world > 1 else "none")},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
     sync_all()
