@@ -171,6 +171,7 @@ SIGNATURES = {
     "a3d_multiscale_batch_set_profiling": (_ST, [_P, C.c_int32]),
     "a3d_multiscale_batch_last_kernel_ms": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_kdtree_stats": (_ST, [_P, C.POINTER(C.c_uint64)]),
+    "a3d_kdtree_download": (_ST, [_P, _P, _P, C.POINTER(C.c_uint64)]),
     "a3d_kdtree_new": (_ST, [_P, _P, C.c_uint64, _PP]),
     "a3d_kdtree_nearest": (_ST, [_P, _P, C.c_uint64, _P, _P]),
     "a3d_kdtree_nearest_device": (_ST, [_P, _P, C.c_uint64, _P, _P]),

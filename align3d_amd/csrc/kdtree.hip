@@ -12,26 +12,36 @@ using namespace a3d;
 
 namespace a3d {
 
+// Shape pass: the (start, len) recursion is data independent, so the depth of the deepest leaf is known
+// before any sorting.
+void kdtree_shape(uint32_t n, uint32_t* max_depth_out, uint64_t* n_leaves_out, uint64_t* n_internal_out) {
+  uint32_t max_depth = 0;
+  uint64_t n_leaves = 0, n_internal = 0;
+  struct Item { uint32_t len, depth; };
+  std::vector<Item> stack{{n, 0}};
+  while (!stack.empty()) {
+    Item it = stack.back();
+    stack.pop_back();
+    if (it.len <= 16) {
+      max_depth = std::max(max_depth, it.depth);
+      ++n_leaves;
+      continue;
+    }
+    ++n_internal;
+    uint32_t mid = it.len / 2;
+    stack.push_back({mid, it.depth + 1});
+    stack.push_back({it.len - mid, it.depth + 1});
+  }
+  *max_depth_out = max_depth, *n_leaves_out = n_leaves, *n_internal_out = n_internal;
+}
+
 a3d_status kdtree_build_host(const float* points, uint32_t n, std::vector<float>* split,
                              std::vector<float4>* leaves, std::vector<uint32_t>* slot_of_point,
                              uint32_t* max_depth_out, uint64_t* n_leaves_out, uint64_t* n_internal_out) {
-  // Shape pass: the (start, len) recursion is data independent, so the depth of the deepest leaf is known
-  // before any sorting.
   uint32_t max_depth = 0;
   {
-    struct Item { uint32_t len, depth; };
-    std::vector<Item> stack{{n, 0}};
-    while (!stack.empty()) {
-      Item it = stack.back();
-      stack.pop_back();
-      if (it.len <= 16) {
-        max_depth = std::max(max_depth, it.depth);
-        continue;
-      }
-      uint32_t mid = it.len / 2;
-      stack.push_back({mid, it.depth + 1});
-      stack.push_back({it.len - mid, it.depth + 1});
-    }
+    uint64_t a, b;
+    kdtree_shape(n, &max_depth, &a, &b);
   }
   A3D_REQUIRE(max_depth < 26, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout");
   const uint64_t n_split = (1ull << max_depth) - 1, n_slots = (1ull << max_depth) * 16;
@@ -201,12 +211,35 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
   auto t = std::make_unique<a3d_kdtree>();
   t->ctx = ctx;
   t->n = (uint32_t)n;
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  const char* mode = getenv("A3D_KDTREE_BUILD");
+  if (!(mode && !strcmp(mode, "host"))) {  // device build: upload the points, sort level by level on the GPU
+    kdtree_shape(t->n, &t->max_depth, &t->n_leaves, &t->n_internal);
+    A3D_REQUIRE(t->max_depth < 26, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout");
+    t->n_split = (uint32_t)((1ull << t->max_depth) - 1);
+    t->n_leaf_slots = (1ull << t->max_depth) * 16;
+    float* d_points = nullptr;
+    A3D_HIP_TRY(hipMalloc((void**)&d_points, (size_t)n * 12));
+    a3d_status st = A3D_OK;
+    if (hipMemcpyAsync(d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+      set_error("a3d_kdtree_new: upload failed: %s", hipGetErrorString(hipGetLastError()));
+      st = A3D_HIP_ERROR;
+    }
+    if (st == A3D_OK) st = kdtree_build_device(t.get(), d_points);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_points);
+    if (st != A3D_OK) {
+      a3d_kdtree_free(t.release());
+      return st;
+    }
+    *out = t.release();
+    return A3D_OK;
+  }
   std::vector<float4> leaves;
   A3D_TRY(kdtree_build_host(points, t->n, &t->h_split, &leaves, &t->h_slot_of_point, &t->max_depth, &t->n_leaves,
                             &t->n_internal));
   t->n_split = (uint32_t)t->h_split.size();
   t->n_leaf_slots = leaves.size();
-  A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&t->d_split, std::max<size_t>(1, t->h_split.size()) * sizeof(float)));
   A3D_HIP_TRY(hipMalloc((void**)&t->d_leaves, leaves.size() * sizeof(float4)));
   if (!t->h_split.empty())
@@ -267,12 +300,25 @@ a3d_status a3d_kdtree_stats(a3d_kdtree* t, uint64_t out3[3]) {
   return A3D_OK;
 }
 
+a3d_status a3d_kdtree_download(a3d_kdtree* t, float* out_split, float* out_leaves, uint64_t out_counts[2]) {
+  A3D_REQUIRE(t && out_counts, A3D_INVALID_PARAMETER, "null argument");
+  out_counts[0] = t->n_split, out_counts[1] = t->n_leaf_slots;
+  hipStream_t s = t->ctx->stream;
+  if (out_split && t->n_split)
+    A3D_HIP_TRY(hipMemcpyAsync(out_split, t->d_split, (size_t)t->n_split * 4, hipMemcpyDeviceToHost, s));
+  if (out_leaves)
+    A3D_HIP_TRY(hipMemcpyAsync(out_leaves, t->d_leaves, t->n_leaf_slots * sizeof(float4), hipMemcpyDeviceToHost, s));
+  A3D_HIP_TRY(hipStreamSynchronize(s));
+  return A3D_OK;
+}
+
 a3d_status a3d_kdtree_free(a3d_kdtree* t) {
   if (!t) return A3D_OK;
   hipStreamSynchronize(t->ctx->stream);
   hipFree(t->d_split);
   hipFree(t->d_leaves);
   hipFree(t->d_leaf_normals);
+  hipFree(t->d_slot_of_point);
   delete t;
   return A3D_OK;
 }
@@ -286,7 +332,16 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
   A3D_TRY(a3d_kdtree_new(ctx, target->points, target->len, &icp->tree));
   a3d_kdtree* t = icp->tree;
   a3d_status st = A3D_OK;
-  if (target->normals) {  // scatter the target normals into the leaf slots of their points
+  if (target->normals && t->d_slot_of_point) {  // device build: scatter on the device
+    float* d_n = nullptr;
+    if (hipMalloc((void**)&d_n, (size_t)t->n * 12) != hipSuccess ||
+        hipMemcpyAsync(d_n, target->normals, (size_t)t->n * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      st = A3D_HIP_ERROR;
+    if (st == A3D_OK) st = kdtree_scatter_normals_device(t, d_n);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_n);
+    icp->target_has_normals = true;
+  } else if (target->normals) {  // scatter the target normals into the leaf slots of their points
     std::vector<float4> ln(t->n_leaf_slots, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < t->n; ++i)
       ln[t->h_slot_of_point[i]] =

@@ -17,7 +17,8 @@ struct a3d_kdtree {
   float* d_split = nullptr;    // [n_split] split values, heap order (root = 0, children 2i+1, 2i+2)
   float4* d_leaves = nullptr;  // [n_leaf_slots]
   float4* d_leaf_normals = nullptr;  // same slots: {nx, ny, nz, 0} (only for Icp targets)
-  // host copies of the build, kept for tests and for attaching normals
+  uint32_t* d_slot_of_point = nullptr;  // [n] leaf slot of each original point index (device build)
+  // host copies (host build only, A3D_KDTREE_BUILD=host), used for attaching normals
   std::vector<float> h_split;
   std::vector<uint32_t> h_slot_of_point;  // [n] leaf slot of each original point index
   uint64_t n_leaves = 0, n_internal = 0;
@@ -30,6 +31,15 @@ namespace a3d {
 a3d_status kdtree_build_host(const float* points, uint32_t n, std::vector<float>* split,
                              std::vector<float4>* leaves, std::vector<uint32_t>* slot_of_point,
                              uint32_t* max_depth, uint64_t* n_leaves, uint64_t* n_internal);
+
+// Shape of the tree for n points (data independent): depth of the deepest leaf, leaf and internal node counts.
+void kdtree_shape(uint32_t n, uint32_t* max_depth, uint64_t* n_leaves, uint64_t* n_internal);
+
+// Device build (kdtree_build.hip): one segmented stable radix sort per level; bit-identical to the host build.
+// Expects t->n, max_depth, n_split, n_leaf_slots set; fills d_split, d_leaves, d_slot_of_point.
+a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points);
+// leaf_normals[slot_of_point[i]] = normals[i] (device build)
+a3d_status kdtree_scatter_normals_device(a3d_kdtree* t, const float* d_normals);
 
 // Descent of R3dTree::nearest (src/kdtree.rs:69-105): returns the first slot of the leaf the query falls in.
 // `split_top` (nullable) is an LDS copy of the first `top_entries` heap entries of the split table.

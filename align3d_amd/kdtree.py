@@ -36,6 +36,15 @@ class R3dTree:
         _abi.check(self.ctx.lib.a3d_kdtree_stats(self.handle, s))
         return tuple(s)
 
+    def download(self):
+        """(split values in heap order, leaf slots [slots, 4] as raw u32 bits) — the tree as laid out in HBM."""
+        counts = (C.c_uint64 * 2)()
+        _abi.check(self.ctx.lib.a3d_kdtree_download(self.handle, None, None, counts))
+        split = np.empty(counts[0], np.float32)
+        leaves = np.empty((counts[1], 4), np.float32)
+        _abi.check(self.ctx.lib.a3d_kdtree_download(self.handle, _abi.ptr(split), _abi.ptr(leaves), counts))
+        return split.view(np.uint32), leaves.view(np.uint32)
+
     def free(self):
         if self.handle and self.ctx.handle:
             self.ctx.lib.a3d_kdtree_free(self.handle)

@@ -258,6 +258,10 @@ a3d_status a3d_kdtree_nearest_device(a3d_kdtree* tree, const void* d_queries, ui
 a3d_status a3d_kdtree_free(a3d_kdtree* tree);
 /* Instrumentation: tree shape {leaves, internal nodes, depth of the deepest leaf}. */
 a3d_status a3d_kdtree_stats(a3d_kdtree* tree, uint64_t out3[3]);
+/* Instrumentation: the tree as laid out in HBM.  out_split: [2^depth - 1] f32 split values in heap order;
+ * out_leaves: [2^depth * 16][4] f32 {x, y, z, index bits}, +inf in unused slots.  Either may be null; the
+ * element counts are returned in out_counts {splits, leaf slots} (call with null arrays to size the buffers). */
+a3d_status a3d_kdtree_download(a3d_kdtree* tree, float* out_split, float* out_leaves, uint64_t out_counts[2]);
 
 /* ---- Icp (src/icp/pcl_icp.rs:15-108) ------------------------------------------------------ */
 

@@ -91,3 +91,54 @@ def test_kdtree_full_size_500k_bit_exact(ctx):
     assert np.array_equal(sidx, np.arange(n, dtype=np.uint64)) and not sd.any()
     g2, d2 = tree.nearest(q)
     assert np.array_equal(g2, gidx) and np.array_equal(d2, gd)
+
+
+def _build(ctx, db, mode, monkeypatch, wide_len=None):
+    monkeypatch.setenv("A3D_KDTREE_BUILD", mode)
+    if wide_len is not None:
+        monkeypatch.setenv("A3D_KDTREE_WIDE_LEN", str(wide_len))
+    else:
+        monkeypatch.delenv("A3D_KDTREE_WIDE_LEN", raising=False)
+    return R3dTree.new(ctx, db)
+
+
+def _kd_cases():
+    rng = np.random.default_rng(17)
+    dup = rng.integers(-3, 4, size=(20000, 3)).astype(np.float32)
+    dup[::7, 0] = -0.0
+    dup[::5, 1] = 0.0
+    neg = (uniform01(3, 3 * 70001).reshape(-1, 3) - 0.5) * np.float32(1e3)
+    neg[::11] *= np.float32(1e-30)  # subnormal-range magnitudes keep their order too
+    return {"n1": uniform01(1, 3).reshape(1, 3), "n16": uniform01(2, 48).reshape(16, 3),
+            "n17": uniform01(2, 51).reshape(17, 3), "n33": uniform01(4, 99).reshape(33, 3),
+            "n1000": uniform01(5, 3000).reshape(1000, 3), "dup": dup, "neg": neg.astype(np.float32),
+            "n270213": uniform01(6, 3 * 270213).reshape(-1, 3)}
+
+
+@pytest.mark.parametrize("case", ["n1", "n16", "n17", "n33", "n1000", "dup", "neg", "n270213"])
+@pytest.mark.parametrize("wide_len", [None, 64, 1 << 30])
+def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, monkeypatch, case, wide_len):
+    """The device build (segmented / device-wide stable radix sorts) lays out exactly the tree of the host
+    build (std::stable_sort per node = R3dTree::new, src/kdtree.rs:28-58): split table and every leaf slot."""
+    db = _kd_cases()[case]
+    host = _build(ctx, db, "host", monkeypatch)
+    dev = _build(ctx, db, "device", monkeypatch, wide_len)
+    assert dev.stats() == host.stats()
+    hs, hl = host.download()
+    ds, dl = dev.download()
+    assert np.array_equal(ds, hs)
+    assert np.array_equal(dl, hl)
+
+
+def test_kdtree_device_build_nan_rules(ctx, monkeypatch):
+    """NaN in a coordinate that gets compared is the reference's panic; one that never is compared is not."""
+    for mode in ("host", "device"):
+        db = uniform01(1, 300).reshape(100, 3)
+        db[50, 2] = np.nan  # 100 points: depth 0 sorts x (100), depth 1 y (50), depth 2 z (25) -> compared
+        with pytest.raises(A3dError) as e:
+            _build(ctx, db, mode, monkeypatch)
+        assert e.value.status == 5
+        db = uniform01(1, 90).reshape(30, 3)
+        db[3, 2] = np.nan  # 30 points: x at depth 0, leaves of 15 afterwards: z never compared
+        t = _build(ctx, db, mode, monkeypatch)
+        assert t.stats() == (2, 1, 1)
