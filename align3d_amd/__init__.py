@@ -12,6 +12,7 @@ from .icp_params import IcpParams, MsIcpParams  # noqa: F401
 from .kdtree import R3dTree  # noqa: F401
 from .range_image import CameraIntrinsics, DeviceRangeImage, RangeImage, RangeImageBuilder  # noqa: F401
 from .transform import Transform  # noqa: F401
-from .dataset import SlamTbDataset, SyntheticDataset  # noqa: F401
+from .dataset import (DatasetError, IndoorLidarDataset, SlamTbDataset, SubsetDataset, SyntheticDataset,  # noqa: F401
+                      TumRgbdDataset, load_dataset)
 from .odometry import run_odometry  # noqa: F401
 from .trajectory import Trajectory, TrajectoryBuilder, TransformMetrics  # noqa: F401

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Counterpart of the reference's `odometry` example (examples/src/bin/odometry.rs):
-    python examples/odometry.py --format slamtb tests/golden/rgbd/sample1 [--max-frames N]
+    python examples/odometry.py --format tum    /data/rgbd_dataset_freiburg1_xyz [--max-frames N]
+    python examples/odometry.py --format ilrgbd /data/indoor_lidar/apartment     [--max-frames N]
+    python examples/odometry.py --format slamtb tests/golden/rgbd/sample1
     python examples/odometry.py --format synthetic 7 --max-frames 20      (seed 7, 20 frames)
 prints "Mean trajectory error: angle: X°, translation: Y" like the reference."""
 import argparse
@@ -8,14 +10,19 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from align3d_amd import Context, SlamTbDataset, SyntheticDataset, run_odometry  # noqa: E402
+from align3d_amd import Context, SubsetDataset, SyntheticDataset, load_dataset, run_odometry  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--format", choices=["slamtb", "synthetic"], required=True)
-ap.add_argument("dataset", help="dataset directory (slamtb) or seed (synthetic)")
+ap.add_argument("--format", choices=["ilrgbd", "tum", "slamtb", "synthetic"], required=True)
+ap.add_argument("dataset", help="dataset directory, or the seed for --format synthetic")
 ap.add_argument("--max-frames", type=int, default=None)
 args = ap.parse_args()
 ctx = Context(0)
-ds = SlamTbDataset.load(args.dataset) if args.format == "slamtb" else SyntheticDataset(int(args.dataset), args.max_frames or 20)
-pred, metrics = run_odometry(ctx, ds, max_frames=args.max_frames)
+if args.format == "synthetic":
+    ds = SyntheticDataset(int(args.dataset), args.max_frames or 20)
+else:
+    ds = load_dataset(args.format, args.dataset)
+    if args.max_frames is not None:  # odometry.rs:32-34
+        ds = SubsetDataset.new(ds, range(min(args.max_frames, ds.len())))
+pred, metrics = run_odometry(ctx, ds)
 print(f"Mean trajectory error: {metrics}")
