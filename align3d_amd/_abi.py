@@ -170,6 +170,7 @@ SIGNATURES = {
     "a3d_multiscale_batch_last_timing": (_ST, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "a3d_multiscale_batch_set_profiling": (_ST, [_P, C.c_int32]),
     "a3d_multiscale_batch_last_kernel_ms": (_ST, [_P, C.POINTER(C.c_float)]),
+    "a3d_multiscale_batch_concurrency": (_ST, [_P, C.POINTER(C.c_uint32)]),
     "a3d_kdtree_stats": (_ST, [_P, C.POINTER(C.c_uint64)]),
     "a3d_kdtree_download": (_ST, [_P, _P, _P, C.POINTER(C.c_uint64)]),
     "a3d_kdtree_new": (_ST, [_P, _P, C.c_uint64, _PP]),

@@ -577,6 +577,11 @@ struct a3d_multiscale_batch {
   bool profile_kernels = false;
   uint32_t resident_blocks = 1024;  // blocks of the per-pixel kernel the chip holds at once
   bool use_mfma = false;  // VALU accumulation measured faster on MI355X so far (kernel variants)
+  // Pair groups launched on separate streams: one group's launch ramp and last-block solve overlap the other
+  // groups' streaming (pairs are independent, so the groups never synchronise until the final read-out).
+  uint32_t n_streams = 1;
+  hipStream_t aux_streams[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   float last_total_ms = 0.f, last_kernel_ms = 0.f;
   uint64_t last_kernel_launches = 0;
 
@@ -592,6 +597,11 @@ struct a3d_multiscale_batch {
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
     for (auto e : kev) hipEventDestroy(e);
+    for (int i = 0; i < 3; ++i) {
+      if (aux_streams[i]) hipStreamDestroy(aux_streams[i]);
+      if (ev_join[i]) hipEventDestroy(ev_join[i]);
+    }
+    if (ev_fork) hipEventDestroy(ev_fork);
   }
 };
 
@@ -637,25 +647,29 @@ void choose_tiling(uint32_t n_pairs, uint32_t max_src_n, uint32_t resident_block
   *tiles = (max_src_n + 256 * *ppt - 1) / (256 * *ppt);
 }
 
-a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const SolveArgs& solve) {
-  dim3 grid(b->tiles[level], b->n_pairs), block(256);
-  const LevelDesc* descs = b->d_descs + (size_t)level * b->n_pairs;
-  hipStream_t s = b->ctx->stream;
+// Launches pairs [p0, p0 + count) of one level on stream `s`.
+a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const SolveArgs& solve, uint32_t p0,
+                               uint32_t count, hipStream_t s) {
+  dim3 grid(b->tiles[level], count), block(256);
+  const LevelDesc* descs = b->d_descs + (size_t)level * b->n_pairs + p0;
+  JobState* states = b->d_states + p0;
+  float* partials = b->d_partials + (size_t)p0 * b->tiles[level] * GN_PARTIAL;
+  unsigned* counters = b->d_counters + p0;
   const int ppt = (int)b->ppt[level];
   if (b->use_mfma) {
     if (b->group[level] == 2)
-      hipLaunchKernelGGL((image_icp_mfma_kernel<2>), grid, block, 0, s, descs, b->d_states, b->gates[level],
-                         b->d_partials, b->d_counters, solve, ppt);
+      hipLaunchKernelGGL((image_icp_mfma_kernel<2>), grid, block, 0, s, descs, states, b->gates[level],
+                         partials, counters, solve, ppt);
     else
-      hipLaunchKernelGGL((image_icp_mfma_kernel<1>), grid, block, 0, s, descs, b->d_states, b->gates[level],
-                         b->d_partials, b->d_counters, solve, ppt);
+      hipLaunchKernelGGL((image_icp_mfma_kernel<1>), grid, block, 0, s, descs, states, b->gates[level],
+                         partials, counters, solve, ppt);
   } else {
     if (b->group[level] == 2)
-      hipLaunchKernelGGL((image_icp_kernel<2>), grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials,
-                         b->d_counters, solve, ppt);
+      hipLaunchKernelGGL((image_icp_kernel<2>), grid, block, 0, s, descs, states, b->gates[level], partials,
+                         counters, solve, ppt);
     else
-      hipLaunchKernelGGL((image_icp_kernel<1>), grid, block, 0, s, descs, b->d_states, b->gates[level], b->d_partials,
-                         b->d_counters, solve, ppt);
+      hipLaunchKernelGGL((image_icp_kernel<1>), grid, block, 0, s, descs, states, b->gates[level], partials,
+                         counters, solve, ppt);
   }
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
@@ -671,7 +685,8 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     b->group[l] = 1;  // pixels per pipeline stage; 1 measured best on MI355X (kernel variants)
     // a batch fills the chip with exactly one round of blocks; a handful of pairs is latency-bound, and fewer,
     // fatter blocks shorten the last block's sum over the partials (measured: 0.82 vs 0.95 ms for one pair)
-    float waves = P >= 8 ? 1.0f : 0.25f;
+    // with three pair groups on separate streams, 1.5 rounds in total measured best (scripts/streams_sweep*.sh)
+    float waves = P >= 8 ? (b->n_streams > 2 ? 1.5f : 1.0f) : 0.25f;
     if (const char* env = getenv("A3D_ICP_WAVES")) waves = (float)atof(env);  // tuning knob
     if (const char* env = getenv("A3D_ICP_GROUP")) b->group[l] = atoi(env) == 2 ? 2 : 1;
     choose_tiling(P, max_n, b->resident_blocks, waves, b->group[l], &b->tiles[l], &b->ppt[l]);
@@ -720,6 +735,18 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   A3D_HIP_TRY(hipMalloc((void**)&b->d_epochs, n_pairs * sizeof(unsigned)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_poses, n_pairs * sizeof(Pose)));
   if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
+  // measured (scripts/streams_sweep*.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
+  // stream), 2 groups at 8 pairs (+21 %); a handful of pairs stays on one stream
+  b->n_streams = n_pairs >= 12 ? 3u : (n_pairs >= 8 ? 2u : 1u);
+  if (const char* env = getenv("A3D_ICP_STREAMS")) b->n_streams = (uint32_t)std::min(4, std::max(1, atoi(env)));
+  b->n_streams = b->use_level_kernel ? 1u : std::min(b->n_streams, n_pairs);
+  if (b->n_streams > 1) {
+    A3D_HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    for (uint32_t g = 1; g < b->n_streams; ++g) {
+      A3D_HIP_TRY(hipStreamCreateWithFlags(&b->aux_streams[g - 1], hipStreamNonBlocking));
+      A3D_HIP_TRY(hipEventCreateWithFlags(&b->ev_join[g - 1], hipEventDisableTiming));
+    }
+  }
   {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_level_kernel<1>, 256, 0) != hipSuccess)
@@ -744,7 +771,7 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   A3D_TRY(launch_job_init(s, b->d_states, d_init, (int)P));
   size_t kidx = 0;
   int trace_index = 0;
-  auto profile_begin = [&]() -> a3d_status {
+  auto profile_begin = [&](hipStream_t ps) -> a3d_status {
     if (!b->profile_kernels) return A3D_OK;
     if (b->kev.size() < 2 * (kidx + 1)) {
       hipEvent_t e0, e1;
@@ -753,11 +780,11 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
       b->kev.push_back(e0);
       b->kev.push_back(e1);
     }
-    A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx], s));
+    A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx], ps));
     return A3D_OK;
   };
-  auto profile_end = [&]() -> a3d_status {
-    if (b->profile_kernels) A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx + 1], s));
+  auto profile_end = [&](hipStream_t ps) -> a3d_status {
+    if (b->profile_kernels) A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx + 1], ps));
     ++kidx;
     return A3D_OK;
   };
@@ -766,6 +793,12 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   for (uint32_t l = 0; l < levels_to_run; ++l)
     level_kernel = level_kernel && (uint64_t)b->tiles[l] * P <= b->level_resident_blocks && b->group[l] == 1;
   if (level_kernel) A3D_HIP_TRY(hipMemsetAsync(b->d_epochs, 0, P * sizeof(unsigned), s));
+  // pair groups on separate streams (not with a trace: its rows are indexed by the pair number inside a launch)
+  const uint32_t S = (level_kernel || d_trace) ? 1u : b->n_streams;
+  if (S > 1) {
+    A3D_HIP_TRY(hipEventRecord(b->ev_fork, s));
+    for (uint32_t g = 1; g < S; ++g) A3D_HIP_TRY(hipStreamWaitEvent(b->aux_streams[g - 1], b->ev_fork, 0));
+  }
   uint32_t epoch_base = 0;
   for (uint32_t l = levels_to_run; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
     const a3d_icp_params& prm = b->params[l];
@@ -775,7 +808,7 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
     sa.trace = d_trace, sa.trace_stride = trace_stride;
     if (level_kernel) {
       if (prm.max_iterations == 0) continue;
-      A3D_TRY(profile_begin());
+      A3D_TRY(profile_begin(s));
       LevelPlan plan;
       plan.iterations = (uint32_t)prm.max_iterations;
       plan.epoch_base = epoch_base;
@@ -786,19 +819,27 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
                          b->d_descs + (size_t)l * P, b->d_states, b->gates[l], b->d_partials, b->d_counters, b->d_epochs,
                          sa, plan, (int)b->ppt[l]);
       A3D_HIP_TRY(hipGetLastError());
-      A3D_TRY(profile_end());
+      A3D_TRY(profile_end(s));
       epoch_base += plan.iterations;
       trace_index += (int)plan.iterations;
       continue;
     }
     for (uint64_t it = 0; it < prm.max_iterations; ++it) {
-      A3D_TRY(profile_begin());
       sa.first_in_level = it == 0, sa.last_in_level = it + 1 == prm.max_iterations;
       sa.trace_index = trace_index;
-      A3D_TRY(launch_pixel_kernel(b, l, sa));
-      A3D_TRY(profile_end());
+      for (uint32_t g = 0; g < S; ++g) {
+        const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
+        hipStream_t gs = g == 0 ? s : b->aux_streams[g - 1];
+        A3D_TRY(profile_begin(gs));
+        A3D_TRY(launch_pixel_kernel(b, l, sa, p0, p1 - p0, gs));
+        A3D_TRY(profile_end(gs));
+      }
       ++trace_index;
     }
+  }
+  for (uint32_t g = 1; g < S; ++g) {
+    A3D_HIP_TRY(hipEventRecord(b->ev_join[g - 1], b->aux_streams[g - 1]));
+    A3D_HIP_TRY(hipStreamWaitEvent(s, b->ev_join[g - 1], 0));
   }
   A3D_TRY(launch_job_finish(s, b->d_states, b->d_poses, b->d_status, d_matrices, (int)P));
   A3D_HIP_TRY(hipEventRecord(b->ev1, s));
@@ -916,7 +957,7 @@ a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* para
   if (st == A3D_OK) st = launch_job_init(s, b->d_states, d_pose, 1);
   SolveArgs none{};
   none.mode = SOLVE_NONE;
-  if (st == A3D_OK) st = launch_pixel_kernel(b.get(), 0, none);
+  if (st == A3D_OK) st = launch_pixel_kernel(b.get(), 0, none, 0, b->n_pairs, b->ctx->stream);
   if (st == A3D_OK) st = launch_gn_readback(s, b->d_partials, (int)b->tiles[0], b->d_readback);
   if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
     st = A3D_HIP_ERROR;
@@ -1013,6 +1054,12 @@ a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* b, float* o
   A3D_REQUIRE(b && out_kernel_ms, A3D_INVALID_PARAMETER, "null argument");
   A3D_TRY(batch_collect_timing(b));
   *out_kernel_ms = b->last_kernel_ms;
+  return A3D_OK;
+}
+
+a3d_status a3d_multiscale_batch_concurrency(a3d_multiscale_batch* b, uint32_t* out_streams) {
+  A3D_REQUIRE(b && out_streams, A3D_INVALID_PARAMETER, "null argument");
+  *out_streams = b->use_level_kernel ? 1u : b->n_streams;
   return A3D_OK;
 }
 

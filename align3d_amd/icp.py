@@ -156,6 +156,12 @@ class MultiscaleAlignBatch:
         _abi.check(self.ctx.lib.a3d_multiscale_batch_last_timing(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def concurrency(self):
+        """Number of pair groups whose launches run on separate streams at the same time."""
+        n = C.c_uint32()
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_concurrency(self.handle, C.byref(n)))
+        return n.value
+
     def last_kernel_ms(self):
         ms = C.c_float()
         _abi.check(self.ctx.lib.a3d_multiscale_batch_last_kernel_ms(self.handle, C.byref(ms)))

@@ -53,7 +53,7 @@ def build_stream_pyramids(ctx, seed, n_frames, width, height):
     return pyramids, poses, build_ms
 
 
-def measured_traffic(P, W, H):
+def measured_traffic(P, W, H, conc):
     """HBM bytes per launch of the ICP kernel from the committed PMC passes (scripts/traffic_pmc.sh; counters cannot
     be read from inside an unprofiled run).  Only a profile of this exact workload counts; otherwise null."""
     import glob
@@ -62,7 +62,7 @@ def measured_traffic(P, W, H):
             rec = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if rec.get("pairs_per_gpu") == P and (W, H) == (640, 480):
+        if rec.get("pairs_per_gpu") == P and rec.get("concurrent_launches", 1) == conc and (W, H) == (640, 480):
             return float(rec["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
     return None, None
 
@@ -310,26 +310,40 @@ def main():
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (image_icp_kernel), HIP events on the launch stream ----
+        # The batch runs `conc` pair groups on separate streams, so `conc` launches are in flight at once.
+        # per_launch: what one launch does (its own bytes / its own duration: what rocprofv3 --kernel-trace
+        # shows per kernel).  achieved: the chip-level figure = the step's algorithmic bytes / the device time of
+        # the whole launch sequence (first launch start -> last launch end, events on the context stream), i.e.
+        # the concurrent launches summed without double counting their overlap.
+        conc = batch.concurrency()
+        kernel_ms, region_ms, launches = [], [], 0
+        for _ in range(max(3, args.steps)):  # launch sequence as it runs in the timed steps (no per-launch events)
+            batch.enqueue()
+            ctx.synchronize()
+            region_ms.append(batch.last_timing()[0])
         batch.set_profiling(True)
-        kernel_ms, launches = [], 0
-        for _ in range(max(3, args.steps)):
+        for _ in range(max(3, args.steps)):  # per-launch durations, events around every launch on its stream
             batch.enqueue()
             ctx.synchronize()
             kernel_ms.append(batch.last_kernel_ms())
             launches = batch.last_timing()[1]
         batch.set_profiling(False)
-        kms = float(np.median(kernel_ms))
+        kms, rms = float(np.median(kernel_ms)), float(np.median(region_ms))
         iters = [int(p.max_iterations) for p in params]
         step_alg_bytes = P * sum(iters[l] * level_bytes(W >> l, H >> l) for l in range(3))
-        achieved = step_alg_bytes / (kms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(P, W, H)
+        bytes_per_launch = step_alg_bytes / max(1, launches)
+        avg_launch_ms = kms / max(1, launches)
+        achieved = step_alg_bytes / (rms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(P, W, H, conc)
         roofline = {
             "bound": "hbm", "kernel": "image_icp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
             "traffic_source": traffic_src,
-            "launches_per_step": int(launches), "avg_launch_us": kms * 1e3 / max(1, launches),
-            "algorithmic_bytes_per_launch": step_alg_bytes / max(1, launches),
-            "kernel_share_of_step": kms / ms_per_step,
+            "launches_per_step": int(launches), "concurrent_launches": conc,
+            "avg_launch_us": avg_launch_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "per_launch_GBs": bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9,
+            "launch_sequence_ms": rms,
+            "kernel_share_of_step": rms / ms_per_step,
         }
         poses, status = batch.align()
         extra = {"failed_pairs": int(np.count_nonzero(status))}

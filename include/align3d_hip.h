@@ -234,10 +234,13 @@ a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* batch, a3d_pose* out
                                       float* out_matrices_device, int32_t* out_status_host);
 a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* batch);
 /* Instrumentation: when on, every launch of the per-pixel kernel is bracketed by its own hipEvent pair
- * on the context stream, and a3d_multiscale_batch_last_kernel_ms returns the sum of those durations for
- * the most recent batch_align (divide by the launch count for the average launch). */
+ * on the stream it is launched on, and a3d_multiscale_batch_last_kernel_ms returns the sum of those durations
+ * for the most recent batch_align (divide by the launch count for the average launch).  A batch splits its
+ * pairs into a3d_multiscale_batch_concurrency() groups whose launches run on separate HIP streams at the same
+ * time, so that sum can exceed the wall time reported by a3d_multiscale_batch_last_timing. */
 a3d_status a3d_multiscale_batch_set_profiling(a3d_multiscale_batch* batch, int32_t on);
 a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* batch, float* out_kernel_ms);
+a3d_status a3d_multiscale_batch_concurrency(a3d_multiscale_batch* batch, uint32_t* out_streams);
 /* Time of the most recent batch_align on the device, between hipEvents recorded on the context
  * stream around its launches, and the share of it spent in the per-pixel kernel (sum of that
  * kernel's launches / number of launches). */

@@ -23,12 +23,13 @@ def per_launch(directory, counter):
 fetch = per_launch(sys.argv[1], "FETCH_SIZE")
 write = per_launch(sys.argv[2], "WRITE_SIZE")
 pairs = int(sys.argv[3])
+conc = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 assert fetch and len(fetch) == len(write), (len(fetch), len(write))
 n = len(fetch)
 fetch_b = sum(v for v, _ in fetch) * 1024.0 * 2.0 / n
 write_b = sum(v for v, _ in write) * 1024.0 / n
 print(json.dumps({
-    "kernel": KERNEL, "launches_averaged": n, "pairs_per_gpu": pairs,
+    "kernel": KERNEL, "launches_averaged": n, "pairs_per_gpu": pairs, "concurrent_launches": conc,
     "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
     "traffic_bytes_per_launch": fetch_b + write_b,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 2 --warmup 1; "
