@@ -106,34 +106,49 @@ __global__ void resize_pick_kernel(const float* __restrict__ src, const uint8_t*
 }
 
 // One tap table entry per output row / column: first tap, tap count, normalised weights.
+constexpr int MAX_TAPS = 14;  // ceil(in + 2 sigma) - floor(in - 2 sigma) <= 14  <=>  sigma <= 3
 struct TapRow {
   int32_t left, count;
-  float w[6];
+  float w[MAX_TAPS];
 };
 
-// vertical pass of the blur: u8 rgb -> f32, every row
-__global__ void blur_vertical_kernel(const uint8_t* __restrict__ rgb, uint32_t w, uint32_t h,
-                                     const TapRow* __restrict__ taps, float* __restrict__ tmp) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // over h * w * 3
-  if (i >= w * h * 3) return;
-  const uint32_t oy = i / (w * 3), rem = i % (w * 3);
-  const TapRow t = taps[oy];
+// imageops::blur + 2x subsample fused: the pyramid keeps only the even rows and columns of the blurred image,
+// so the vertical pass is evaluated at even rows only and never leaves the chip.  One block = one output row x
+// BLUR_TILE output columns: the vertical sums (u8 -> f32, the crate's f32 intermediate) of the source columns
+// this tile's horizontal taps touch go to LDS, then the horizontal pass, clamp and round-half-away (u8) read
+// them back.  Per output the additions run in tap order from 0.0f in both passes, as in the crate.
+constexpr uint32_t BLUR_TILE = 64;
+constexpr uint32_t BLUR_SPAN = 3 * (2 * BLUR_TILE + MAX_TAPS + 2);  // floats of vertical results a tile can need
+__global__ void __launch_bounds__(256)
+    blur_halve_kernel(const uint8_t* __restrict__ rgb, uint32_t w, uint32_t dw, const TapRow* __restrict__ taps_v,
+                      const TapRow* __restrict__ taps_h, uint8_t* __restrict__ out) {
+  __shared__ float s_v[BLUR_SPAN];
+  const uint32_t dy = blockIdx.y, dx0 = blockIdx.x * BLUR_TILE, dx1 = min(dx0 + BLUR_TILE, dw) - 1;
+  const TapRow* tv = taps_v + dy;  // row 2*dy of the source (table built with stride 2): block-uniform
+  const int32_t vleft = tv->left, vcount = tv->count;
+  const int32_t cmin = taps_h[dx0].left, cmax = taps_h[dx1].left + taps_h[dx1].count;  // source columns [cmin, cmax)
+  const uint32_t span = (uint32_t)(cmax - cmin) * 3u;
+  for (uint32_t e = threadIdx.x; e < span; e += 256) {
+    const uint8_t* col = rgb + (size_t)vleft * w * 3 + (size_t)cmin * 3 + e;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAX_TAPS; ++k)
+      if (k < vcount) acc += (float)col[(size_t)k * w * 3] * tv->w[k];
+    s_v[e] = acc;
+  }
+  __syncthreads();
+  const uint32_t o = threadIdx.x;  // over BLUR_TILE * 3 outputs
+  if (o >= BLUR_TILE * 3) return;
+  const uint32_t dx = dx0 + o / 3, ch = o % 3;
+  if (dx >= dw) return;
+  const TapRow* th = taps_h + dx;
+  const int32_t hleft = th->left - cmin, hcount = th->count;
   float acc = 0.0f;
-  for (int k = 0; k < t.count; ++k) acc += (float)rgb[(size_t)(t.left + k) * w * 3 + rem] * t.w[k];
-  tmp[i] = acc;
-}
-
-// horizontal pass at even rows / columns only, clamp, round to nearest (half away from zero), u8
-__global__ void blur_horizontal_halve_kernel(const float* __restrict__ tmp, uint32_t w, uint32_t dw, uint32_t dh,
-                                             const TapRow* __restrict__ taps, uint8_t* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // over dh * dw * 3
-  if (i >= dw * dh * 3) return;
-  const uint32_t ch = i % 3, dx = (i / 3) % dw, dy = i / (3 * dw);
-  const TapRow t = taps[dx];
-  float acc = 0.0f;
-  for (int k = 0; k < t.count; ++k) acc += tmp[((size_t)(2 * dy) * w + (uint32_t)(t.left + k)) * 3 + ch] * t.w[k];
+#pragma unroll
+  for (int k = 0; k < MAX_TAPS; ++k)
+    if (k < hcount) acc += s_v[(uint32_t)(hleft + k) * 3u + ch] * th->w[k];
   acc = fminf(fmaxf(acc, 0.0f), 255.0f);
-  out[i] = (uint8_t)roundf(acc);
+  out[((size_t)dy * dw + dx) * 3 + ch] = (uint8_t)roundf(acc);
 }
 
 // Tap tables of image::imageops::blur's sampling filter (support 2 sigma, weights renormalised over the
@@ -151,8 +166,8 @@ std::vector<TapRow> make_taps(uint32_t size, float sigma, uint32_t stride, uint3
     const float c = in - 0.5f;
     TapRow r{};
     r.left = (int32_t)left;
-    r.count = (int32_t)std::min<int64_t>(right - left, 6);
-    float sum = 0.0f, wv[6];
+    r.count = (int32_t)std::min<int64_t>(right - left, MAX_TAPS);  // callers reject sigma > 3 (more taps)
+    float sum = 0.0f, wv[MAX_TAPS];
     for (int i = 0; i < r.count; ++i) {
       const float x = (float)(left + i) - c;
       wv[i] = 1.0f / (std::sqrt(2.0f * 3.14159265358979323846f) * sigma) * std::exp(-(x * x) / (2.0f * sigma * sigma));
@@ -218,20 +233,17 @@ a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_i
   }
   if (src->colors) {
     if (sigma <= 0.0f) sigma = 1.0f;
-    const std::vector<TapRow> tv = make_taps(sh, sigma, 1, sh), th = make_taps(sw, sigma, 2, dw);
+    A3D_REQUIRE(sigma <= 3.0f, A3D_INVALID_PARAMETER, "blur_sigma above 3 is not supported by the device builder");
+    const std::vector<TapRow> tv = make_taps(sh, sigma, 2, dh), th = make_taps(sw, sigma, 2, dw);
     TapRow *d_tv = nullptr, *d_th = nullptr;
-    float* d_tmp = nullptr;
     A3D_TRY(scratch.take(&d_tv, tv.size()));
     A3D_TRY(scratch.take(&d_th, th.size()));
-    A3D_TRY(scratch.take(&d_tmp, (size_t)sw * sh * 3));
     A3D_TRY(arena.take(&dst->colors, (size_t)dn * 3));
     // pageable -> device async copies return once the host buffer has been staged, so the vectors may die
     A3D_HIP_TRY(hipMemcpyAsync(d_tv, tv.data(), tv.size() * sizeof(TapRow), hipMemcpyHostToDevice, s));
     A3D_HIP_TRY(hipMemcpyAsync(d_th, th.data(), th.size() * sizeof(TapRow), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(blur_vertical_kernel, grid_for((size_t)sw * sh * 3), dim3(256), 0, s, src->colors, sw, sh, d_tv,
-                       d_tmp);
-    hipLaunchKernelGGL(blur_horizontal_halve_kernel, grid_for((size_t)dn * 3), dim3(256), 0, s, d_tmp, sw, dw, dh, d_th,
-                       dst->colors);
+    hipLaunchKernelGGL(blur_halve_kernel, dim3((dw + BLUR_TILE - 1) / BLUR_TILE, dh), dim3(256), 0, s, src->colors, sw,
+                       dw, d_tv, d_th, dst->colors);
   }
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
@@ -270,7 +282,7 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
     arena_bytes += padded(nl * 12) + padded(nl) + padded(nl * 3);                 // points, mask, colors
     if (prm->with_normals) arena_bytes += padded(nl * 12);
     if (prm->with_intensity) arena_bytes += padded(nl) + padded((wl + 2) * (hl + 2) * 4);
-    if (l + 1 < L) scratch_bytes += padded(nl * 12) + padded(hl * sizeof(TapRow)) + padded((wl / 2) * sizeof(TapRow));
+    if (l + 1 < L) scratch_bytes += padded((hl / 2) * sizeof(TapRow)) + padded((wl / 2) * sizeof(TapRow));
   }
   DeviceArena* shared = new DeviceArena();
   if (hipMalloc(&shared->base, arena_bytes) != hipSuccess) {

@@ -127,3 +127,26 @@ def test_device_pyramid_builder_options_and_errors(ctx):
     assert int(ri.mask.sum()) == int((depth > 0).sum())
     with pytest.raises(A3dError):
         RangeImageBuilder(ctx).pyramid_levels(12).build_device(cam, depth, rgb, 0.001)  # too many levels for 640x480
+
+
+@pytest.mark.parametrize("w,h,sigma", [(150, 90, 1.0), (150, 90, 0.6), (262, 134, 2.0), (640, 480, 3.0), (66, 34, 1.7)])
+def test_device_pyramid_builder_ragged_sizes_and_blur_sigmas(ctx, w, h, sigma):
+    """The fused blur + halve kernel (even rows/columns only, vertical sums through LDS) against the oracle's full
+    two-pass blur: odd sizes, tiles that end inside the image, tap counts 3..14 (sigma up to 3)."""
+    from align3d_amd import A3dError, CameraIntrinsics, RangeImageBuilder
+
+    rng = np.random.default_rng(w * 1000 + h)
+    depth = rng.integers(400, 5000, size=(h, w), dtype=np.uint16)
+    depth[rng.random((h, w)) < 0.1] = 0
+    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    rgb[: h // 3] = 255  # saturated block: the clamp + round-half-away path
+    rgb[-(h // 4):, :, 1] = 0
+    fx = fy = 0.85 * w
+    cx, cy = w / 2.0, h / 2.0
+    ref = O.build_pyramid(depth, rgb, fx, fy, cx, cy, 0.001, levels=3, use_bilateral=False, sigma=sigma)
+    levels = RangeImageBuilder(ctx).blur_sigma(sigma).build_device(CameraIntrinsics(fx, fy, cx, cy, w, h), depth, rgb, 0.001)
+    for lv, r in zip(levels, ref):
+        _assert_same_level(lv, r)
+    with pytest.raises(A3dError) as e:
+        RangeImageBuilder(ctx).blur_sigma(3.5).build_device(CameraIntrinsics(fx, fy, cx, cy, w, h), depth, rgb, 0.001)
+    assert e.value.status == 1
