@@ -10,6 +10,14 @@ class Context:
         self.handle = C.c_void_p()
         _abi.check(self.lib.a3d_context_create(int(device_index), C.byref(self.handle)), "a3d_context_create")
         self.device_index = int(device_index)
+        self._sibling = None
+
+    def sibling(self):
+        """A second context on the same GPU (its own stream and scratch), created once and closed with this one:
+        the stream frame builds run on while this context aligns (align3d_amd.odometry)."""
+        if self._sibling is None:
+            self._sibling = Context(self.device_index)
+        return self._sibling
 
     def synchronize(self):
         _abi.check(self.lib.a3d_context_synchronize(self.handle))
@@ -40,6 +48,9 @@ class Context:
         return arr
 
     def close(self):
+        if self._sibling is not None:
+            self._sibling.close()
+            self._sibling = None
         if self.handle:
             self.lib.a3d_context_destroy(self.handle)
             self.handle = C.c_void_p()

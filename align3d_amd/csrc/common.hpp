@@ -2,10 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/align3d_hip.h"
@@ -74,6 +77,15 @@ struct a3d_context {
   // so successive calls may reuse them): [0] frame builder temporaries, [1] bilateral grids.
   void* scratch[2] = {nullptr, nullptr};
   size_t scratch_size[2] = {0, 0};
+  // Pyramid arenas handed back by a3d_range_image_free, kept for the next frame of the same size: a frame
+  // stream then costs no hipMalloc / hipFree (each of which synchronises the whole device) per frame.
+  // Guarded by a mutex because an image may be freed from another thread than the one building frames.
+  std::mutex pool_mutex;
+  std::vector<std::pair<void*, size_t>> arena_pool;
+  // The single-pair ICP engine (image_icp.hip) kept between calls: MultiscaleAlign::align and ImageIcp::align
+  // reuse its small device state instead of allocating and freeing it per alignment.
+  void* icp_engine = nullptr;
+  void (*icp_engine_free)(void*) = nullptr;
 };
 
 namespace a3d {
@@ -83,8 +95,13 @@ a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out);
 // One hipMalloc shared by the arrays of several device images (a pyramid); freed with its last user.
 struct DeviceArena {
   void* base = nullptr;
-  int refs = 0;
+  size_t bytes = 0;
+  std::atomic<int> refs{0};
 };
+// An arena of at least `bytes` from the context's pool, or a fresh hipMalloc; release returns it to the pool
+// (at most four are kept) or frees it.
+a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out);
+void ctx_arena_release(a3d_context* ctx, DeviceArena* arena);
 }  // namespace a3d
 
 // One RangeImage in HBM, in the reference's own standard layout (DESIGN.md "Data layout in HBM").

@@ -67,6 +67,36 @@ a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out) {
   return A3D_OK;
 }
 
+a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    for (size_t i = 0; i < ctx->arena_pool.size(); ++i) {
+      const size_t have = ctx->arena_pool[i].second;
+      if (have >= bytes && have <= bytes + bytes / 4) {
+        out->base = ctx->arena_pool[i].first;
+        out->bytes = have;
+        ctx->arena_pool.erase(ctx->arena_pool.begin() + (long)i);
+        return A3D_OK;
+      }
+    }
+  }
+  A3D_HIP_TRY(hipMalloc(&out->base, bytes));
+  out->bytes = bytes;
+  return A3D_OK;
+}
+
+void ctx_arena_release(a3d_context* ctx, DeviceArena* arena) {
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    if (ctx->arena_pool.size() < 4) {
+      ctx->arena_pool.emplace_back(arena->base, arena->bytes);
+      arena->base = nullptr;
+    }
+  }
+  if (arena->base) hipFree(arena->base);
+  arena->base = nullptr;
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -114,6 +144,8 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   if (!ctx) return A3D_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
+  for (auto& a : ctx->arena_pool) hipFree(a.first);
   hipFree(ctx->scratch[0]);
   hipFree(ctx->scratch[1]);
   hipEventDestroy(ctx->ev_start);

@@ -285,7 +285,7 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
     if (l + 1 < L) scratch_bytes += padded((hl / 2) * sizeof(TapRow)) + padded((wl / 2) * sizeof(TapRow));
   }
   DeviceArena* shared = new DeviceArena();
-  if (hipMalloc(&shared->base, arena_bytes) != hipSuccess) {
+  if (ctx_arena_acquire(ctx, arena_bytes, shared) != A3D_OK) {
     delete shared;
     set_error("a3d_range_image_build_pyramid: hipMalloc(%zu) failed", arena_bytes);
     return A3D_HIP_ERROR;
@@ -344,7 +344,7 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
     hipStreamSynchronize(s);
     for (a3d_device_image* lv : levels) a3d_range_image_free(lv);  // the last one releases the arena
     if (levels.empty()) {
-      hipFree(shared->base);
+      ctx_arena_release(ctx, shared);
       delete shared;
     }
     return st;

@@ -139,7 +139,7 @@ a3d_status a3d_range_image_free(a3d_device_image* im) {
   hipStreamSynchronize(im->ctx->stream);
   if (im->arena) {  // arrays live in a shared arena: release it with its last user
     if (--im->arena->refs == 0) {
-      hipFree(im->arena->base);
+      ctx_arena_release(im->ctx, im->arena);
       delete im->arena;
     }
   } else {

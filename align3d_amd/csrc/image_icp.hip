@@ -565,11 +565,13 @@ struct a3d_multiscale_batch {
   LevelDesc* d_descs = nullptr;
   JobState* d_states = nullptr;
   float* d_partials = nullptr;
+  size_t partials_capacity = 0;  // floats
   unsigned* d_counters = nullptr;  // per pair: blocks that have published their partial in this launch
   unsigned* d_epochs = nullptr;    // per pair: iterations completed (level kernel hand-off word)
   bool use_level_kernel = false;   // one launch per level when the whole grid is resident (A3D_ICP_PERSISTENT)
   uint32_t level_resident_blocks = 0;  // blocks of image_icp_level_kernel the chip holds at once
   Pose* d_poses = nullptr;
+  Pose* d_init = nullptr;  // per-pair initial transforms when the caller supplies them
   int32_t* d_status = nullptr;
   double* d_readback = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -592,6 +594,7 @@ struct a3d_multiscale_batch {
     hipFree(d_counters);
     hipFree(d_epochs);
     hipFree(d_poses);
+    hipFree(d_init);
     hipFree(d_status);
     hipFree(d_readback);
     if (ev0) hipEventDestroy(ev0);
@@ -700,9 +703,13 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     }
     max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
   }
-  if (b->d_partials) A3D_HIP_TRY(hipFree(b->d_partials));
-  b->d_partials = nullptr;
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_partials, max_partials * sizeof(float)));
+  if (b->partials_capacity < max_partials) {  // grow-only: a reused engine keeps its buffer
+    if (b->d_partials) A3D_HIP_TRY(hipFree(b->d_partials));
+    b->d_partials = nullptr;
+    b->partials_capacity = 0;
+    A3D_HIP_TRY(hipMalloc((void**)&b->d_partials, max_partials * sizeof(float)));
+    b->partials_capacity = max_partials;
+  }
   A3D_HIP_TRY(hipMemcpyAsync(b->d_descs, b->h_descs.data(), b->h_descs.size() * sizeof(LevelDesc),
                              hipMemcpyHostToDevice, b->ctx->stream));
   return A3D_OK;
@@ -734,6 +741,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_epochs, n_pairs * sizeof(unsigned)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_poses, n_pairs * sizeof(Pose)));
+  A3D_HIP_TRY(hipMalloc((void**)&b->d_init, n_pairs * sizeof(Pose)));
   if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
   // measured (scripts/streams_sweep*.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
   // stream), 2 groups at 8 pairs (+21 %); a handful of pairs stays on one stream
@@ -879,18 +887,45 @@ a3d_status read_results(a3d_multiscale_batch* b, a3d_pose* out_poses, int32_t* o
 }
 
 // One pair, any number of levels, host-synchronous: shared by image_icp_align and multiscale_align.
+// The context's single-pair engine: created on first use, kept until the context dies, re-parameterised per call
+// (an alignment then allocates nothing; hipMalloc / hipFree synchronise the whole device).
+a3d_status acquire_single_engine(a3d_context* ctx, const a3d_icp_params* params, uint32_t n_levels,
+                                 a3d_multiscale_batch** out) {
+  a3d_multiscale_batch* e = (a3d_multiscale_batch*)ctx->icp_engine;
+  if (e && e->n_levels != n_levels) {
+    A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    delete e;
+    e = nullptr;
+    ctx->icp_engine = nullptr;
+  }
+  if (!e) {
+    std::unique_ptr<a3d_multiscale_batch> b;
+    A3D_TRY(batch_create(ctx, params, n_levels, 1, &b));
+    e = b.release();
+    ctx->icp_engine = e;
+    ctx->icp_engine_free = [](void* p) { delete (a3d_multiscale_batch*)p; };
+  } else {
+    e->params.assign(params, params + n_levels);
+    for (uint32_t l = 0; l < n_levels; ++l) e->gates[l] = make_gates(params[l]);
+    // a run that died half-way may have left tickets behind
+    A3D_HIP_TRY(hipMemsetAsync(e->d_counters, 0, sizeof(unsigned), ctx->stream));
+  }
+  *out = e;
+  return A3D_OK;
+}
+
 a3d_status align_single(a3d_context* ctx, const a3d_icp_params* params, uint32_t n_levels,
                         const a3d_device_image* const* targets, const a3d_device_image* const* sources,
                         const a3d_pose* init, a3d_pose* out_pose, float* host_trace) {
-  std::unique_ptr<a3d_multiscale_batch> b;
-  A3D_TRY(batch_create(ctx, params, n_levels, 1, &b));
+  a3d_multiscale_batch* b = nullptr;
+  A3D_TRY(acquire_single_engine(ctx, params, n_levels, &b));
   for (uint32_t l = 0; l < n_levels; ++l) A3D_TRY(fill_desc(targets[l], sources[l], &b->h_descs[l]));
-  A3D_TRY(batch_commit_descs(b.get()));
+  A3D_TRY(batch_commit_descs(b));
   Pose* d_init = nullptr;
   Pose h_init;
   if (init) {
     h_init = pose_from_c(init);
-    A3D_HIP_TRY(hipMalloc((void**)&d_init, sizeof(Pose)));
+    d_init = b->d_init;
     A3D_HIP_TRY(hipMemcpyAsync(d_init, &h_init, sizeof(Pose), hipMemcpyHostToDevice, ctx->stream));
   }
   uint64_t total_iters = 0;
@@ -900,13 +935,12 @@ a3d_status align_single(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     A3D_HIP_TRY(hipMalloc((void**)&d_trace, total_iters * 8 * sizeof(float)));
     A3D_HIP_TRY(hipMemsetAsync(d_trace, 0, total_iters * 8 * sizeof(float), ctx->stream));
   }
-  a3d_status st = batch_enqueue(b.get(), d_init, n_levels, nullptr, d_trace, (int)total_iters);
+  a3d_status st = batch_enqueue(b, d_init, n_levels, nullptr, d_trace, (int)total_iters);
   a3d_status worst = A3D_OK;
-  if (st == A3D_OK) st = read_results(b.get(), out_pose, nullptr, &worst);
+  if (st == A3D_OK) st = read_results(b, out_pose, nullptr, &worst);
   if (st == A3D_OK && d_trace)
     if (hipMemcpy(host_trace, d_trace, total_iters * 8 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
       st = A3D_HIP_ERROR;
-  hipFree(d_init);
   hipFree(d_trace);
   if (st != A3D_OK) return st;
   if (worst == A3D_SOLVE_FAILED) set_error("GaussNewton::solve() returned None (count == 0 or Cholesky failed)");

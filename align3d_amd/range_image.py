@@ -318,6 +318,13 @@ class RangeImageBuilder:
         self._blur_sigma = s
         return self
 
+    def on_context(self, ctx):
+        """The same builder settings bound to another context (its own stream and scratch)."""
+        b = RangeImageBuilder(ctx)
+        b._with_normals, b._with_intensity = self._with_normals, self._with_intensity
+        b._bilateral_filter, b._pyramid_levels, b._blur_sigma = self._bilateral_filter, self._pyramid_levels, self._blur_sigma
+        return b
+
     def build_device(self, camera, depth_u16, rgb, depth_scale):
         """builder.rs:74-91 entirely on the GPU (a3d_range_image_build_pyramid): the frame crosses PCIe as
         u16 depth + u8 RGB and the pyramid levels stay resident.  Returns a list of DeviceRangeImage."""
