@@ -170,73 +170,83 @@ __device__ __forceinline__ void store_status(JobState* st, int v) {
 // same order per element, as nalgebra's left-looking loop), which keeps the solve out of the
 // accumulate kernel's register budget; the substitutions and the pose update are one lane.
 __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums, const SolveArgs& a, int job) {
-  __shared__ double L[36];
-  __shared__ double bvec[6];
-  __shared__ float s_residual;
-  __shared__ int s_ok;
+  __shared__ double Lm[36];
   const int tid = threadIdx.x;
+  if (tid >= 64) return;  // ONE wave finishes the iteration: everything below is wave-synchronous, no block barrier
   const int r = tid / 6, c = tid % 6;
+  const bool cell = tid < 36;  // lane (r, c) owns matrix element [r][c]
   const bool image_mode = a.mode == SOLVE_IMAGE_ICP;
-  if (tid < 36) {
+  double v = 0.0;
+  if (cell) {
     const int t = tri6(r < c ? r : c, r < c ? c : r);
     const float hg = (float)sums[t], hc = (float)sums[GN_ACC + t];
     // add_weighted: H = Hg w1^2 + Hc w2^2 ; weight(): H *= w^2   (all f32)
     const float h = image_mode ? hg * (a.weight * a.weight) + hc * (a.color_weight * a.color_weight)
                                : hg * (a.weight * a.weight);
-    L[tid] = (double)h;
-  } else if (tid >= 64 && tid < 70) {
-    const int k = tid - 64;
-    const float gg = (float)sums[21 + k], gc = (float)sums[GN_ACC + 21 + k];
-    bvec[k] = (double)(image_mode ? gg * a.weight + gc * a.color_weight : gg * a.weight);
-  } else if (tid == 128) {
+    v = (double)h;
+  }
+  A3D_STAMP(3);
+  // Cholesky, column by column, operands exchanged with wave shuffles: sqrt of the pivot, scale the column,
+  // rank-1 update of the trailing columns.
+  int ok = 1;
+  const int src_c = cell ? c * 6 : 0, src_r = cell ? r * 6 : 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double diag = __shfl(v, k * 7, 64);
+    if (diag == 0.0 || !(diag >= 0.0)) ok = 0;  // zero, negative or NaN pivot: Cholesky::new() == None (wave-uniform)
+    const double sq = sqrt(diag);
+    if (tid == k * 7) v = sq;
+    if (cell && c == k && r > k) v = v / sq;
+    const double lck = __shfl(v, src_c + k, 64), lrk = __shfl(v, src_r + k, 64);
+    if (cell && c > k && r >= c) v = (-lck) * lrk + v;
+  }
+  A3D_STAMP(4);
+  if (cell) Lm[tid] = v;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the LDS writes above are visible to lane 0 below
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (tid != 0) return;
+  float residual;
+  {
     const float ssq_g = (float)sums[27], ssq_c = (float)sums[GN_ACC + 27];
     const double cnt_g = sums[28], cnt_c = sums[GN_ACC + 28];
     // ImageIcp: weighted sum / combined count ; Icp: plain mean taken before weight()
     const double count = image_mode ? cnt_g + cnt_c : cnt_g;
     const float ssq = image_mode ? ssq_g * a.weight + ssq_c * a.color_weight : ssq_g;
-    s_residual = ssq / (float)count;
-    s_ok = count != 0.0;  // solve(): None if count == 0
+    residual = ssq / (float)count;
+    if (!(count != 0.0)) ok = 0;  // solve(): None if count == 0
   }
-  __syncthreads();
-  A3D_STAMP(3);
-  for (int k = 0; k < 6; ++k) {
-    if (tid == 0 && s_ok) {
-      const double diag = L[k * 6 + k];
-      if (diag == 0.0 || !(diag >= 0.0))
-        s_ok = 0;  // zero, negative or NaN pivot: Cholesky::new() == None
-      else
-        L[k * 6 + k] = sqrt(diag);
-    }
-    __syncthreads();
-    if (tid < 36 && s_ok && c == k && r > k) L[tid] /= L[k * 6 + k];
-    __syncthreads();
-    if (tid < 36 && s_ok && c > k && r >= c) L[tid] = (-L[c * 6 + k]) * L[r * 6 + k] + L[tid];
-    __syncthreads();
-  }
-  A3D_STAMP(4);
-  if (tid != 0) return;
-  const float residual = s_residual;
-  if (!s_ok) {  // the reference's unwrap() panics here
+  if (!ok) {  // the reference's unwrap() panics here
     st_coherent(&st->last_residual, residual);
     store_status(st, A3D_SOLVE_FAILED);
     return;
   }
-  // The substitutions work in place on the LDS vector, loops kept rolled: this single-lane code must
-  // not set the register budget of the accumulate kernel it is inlined into.
-#pragma unroll 1
-  for (int i = 0; i < 6; ++i) {  // solve_lower_triangular (column oriented)
-    const double coeff = bvec[i] / L[i * 6 + i];
-    bvec[i] = coeff;
-#pragma unroll 1
-    for (int rr = i + 1; rr < 6; ++rr) bvec[rr] = -coeff * L[rr * 6 + i] + bvec[rr];
+  // The two substitutions in registers on one lane (the accumulators are dead here, so this fits the kernel's
+  // register budget): 12 divisions and 45 multiply / add pairs in one dependent chain.
+  double Lr[21], bvec[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const float gg = (float)sums[21 + i], gc = (float)sums[GN_ACC + 21 + i];
+    bvec[i] = (double)(image_mode ? gg * a.weight + gc * a.color_weight : gg * a.weight);
+#pragma unroll
+    for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = Lm[i * 6 + j];  // lower triangle, row-major packed
   }
-#pragma unroll 1
+#define A3D_L(row, col) Lr[(row) * ((row) + 1) / 2 + (col)]
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {  // solve_lower_triangular (column oriented)
+    const double coeff = bvec[i] / A3D_L(i, i);
+    bvec[i] = coeff;
+#pragma unroll
+    for (int rr = i + 1; rr < 6; ++rr) bvec[rr] = -coeff * A3D_L(rr, i) + bvec[rr];
+  }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {  // ad_solve_lower_triangular: L^T x = b
     double d = 0.0;
-#pragma unroll 1
-    for (int rr = i + 1; rr < 6; ++rr) d += L[rr * 6 + i] * bvec[rr];
-    bvec[i] = (bvec[i] - d) / L[i * 6 + i];
+#pragma unroll
+    for (int rr = i + 1; rr < 6; ++rr) d += A3D_L(rr, i) * bvec[rr];
+    bvec[i] = (bvec[i] - d) / A3D_L(i, i);
   }
+#undef A3D_L
   float update[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) update[i] = (float)bvec[i];
