@@ -78,8 +78,15 @@ A3D_HD Quat qnormalize(Quat q) {
 A3D_HD float sin_f32(float x) { return sinf(x); }
 A3D_HD float cos_f32(float x) { return cosf(x); }
 
-// Transform::exp(&LieGroup::Se3(u)), u = [rho, omega]
-A3D_HD Pose exp_se3(const float u[6]) {
+// The four transcendental values Transform::exp needs: sin and cos of theta / 2 and of theta, theta = |omega|.
+struct Se3Trig {
+  float theta, sin_half, cos_half, sin_theta, cos_theta;
+};
+A3D_HD float se3_theta(const float u[6]) { return sqrtf(norm_squared(V3{u[3], u[4], u[5]})); }
+
+// Transform::exp(&LieGroup::Se3(u)), u = [rho, omega], with the transcendental values supplied by the caller
+// (the iteration tail evaluates sin/cos of theta/2 and theta on two lanes at once).
+A3D_HD Pose exp_se3_trig(const float u[6], const Se3Trig& tg) {
   const float EPS = 1e-8f;
   V3 omega{u[3], u[4], u[5]};
   float theta_sq0 = norm_squared(omega);
@@ -90,10 +97,9 @@ A3D_HD Pose exp_se3(const float u[6]) {
     imag = 0.5f - (1.0f / 48.0f) * theta_sq0 + (1.0f / 3840.0f) * po4;
     real = 1.0f - (1.0f / 8.0f) * theta_sq0 + (1.0f / 384.0f) * po4;
   } else {
-    theta = sqrtf(theta_sq0);
-    float half = 0.5f * theta;
-    imag = sin_f32(half) / theta;
-    real = cos_f32(half);
+    theta = tg.theta;
+    imag = tg.sin_half / theta;
+    real = tg.cos_half;
   }
   Quat q = qnormalize(Quat{imag * omega.x, imag * omega.y, imag * omega.z, real});
   float theta_sq = theta * theta;
@@ -112,8 +118,8 @@ A3D_HD Pose exp_se3(const float u[6]) {
         acc = W[r][2] * W[2][c] + acc;
         W2[r][c] = acc;
       }
-    float a = (1.0f - cos_f32(theta)) / theta_sq;
-    float b = (theta - sin_f32(theta)) / (theta_sq * theta);
+    float a = (1.0f - tg.cos_theta) / theta_sq;
+    float b = (theta - tg.sin_theta) / (theta_sq * theta);
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) V[r][c] = ((r == c ? 1.0f : 0.0f) + W[r][c] * a) + W2[r][c] * b;
   }
@@ -128,6 +134,15 @@ A3D_HD Pose exp_se3(const float u[6]) {
   p.t = {t[0], t[1], t[2]};
   p.q = q;
   return p;
+}
+
+A3D_HD Pose exp_se3(const float u[6]) {
+  Se3Trig tg;
+  tg.theta = se3_theta(u);
+  const float half = 0.5f * tg.theta;
+  tg.sin_half = sin_f32(half), tg.cos_half = cos_f32(half);
+  tg.sin_theta = sin_f32(tg.theta), tg.cos_theta = cos_f32(tg.theta);
+  return exp_se3_trig(u, tg);
 }
 
 // Isometry3 -> Matrix4 (row-major), UnitQuaternion::to_rotation_matrix

@@ -176,6 +176,8 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
   const int r = tid / 6, c = tid % 6;
   const bool cell = tid < 36;  // lane (r, c) owns matrix element [r][c]
   const bool image_mode = a.mode == SOLVE_IMAGE_ICP;
+  // the job state (pose 0..6, best 7..13, best_residual 14): one float per lane, in flight during the solve
+  const float state_word = tid < 15 ? ld_coherent((const float*)st + tid) : 0.0f;
   double v = 0.0;
   if (cell) {
     const int t = tri6(r < c ? r : c, r < c ? c : r);
@@ -205,7 +207,7 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the LDS writes above are visible to lane 0 below
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (tid != 0) return;
+  // From here on every lane computes the same values (all inputs are wave-uniform); only lane 0 stores.
   float residual;
   {
     const float ssq_g = (float)sums[27], ssq_c = (float)sums[GN_ACC + 27];
@@ -217,8 +219,10 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
     if (!(count != 0.0)) ok = 0;  // solve(): None if count == 0
   }
   if (!ok) {  // the reference's unwrap() panics here
-    st_coherent(&st->last_residual, residual);
-    store_status(st, A3D_SOLVE_FAILED);
+    if (tid == 0) {
+      st_coherent(&st->last_residual, residual);
+      store_status(st, A3D_SOLVE_FAILED);
+    }
     return;
   }
   // The two substitutions in registers on one lane (the accumulators are dead here, so this fits the kernel's
@@ -251,29 +255,60 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
 #pragma unroll
   for (int i = 0; i < 6; ++i) update[i] = (float)bvec[i];
   A3D_STAMP(5);
-  Pose pose = load_pose(&st->pose);
-  float best_residual = ld_coherent(&st->best_residual);
-  Pose best = load_pose(&st->best);
+  auto word = [&](int lane) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(state_word), lane));
+  };
+  Pose pose{{word(0), word(1), word(2)}, {word(3), word(4), word(5), word(6)}};
+  Pose best{{word(7), word(8), word(9)}, {word(10), word(11), word(12), word(13)}};
+  float best_residual = word(14);
   if (a.first_in_level) {  // ImageIcp::align starts every level with best = initial, +inf
     best_residual = __builtin_inff();
     best = pose;
   }
-  pose = compose(exp_se3(update), pose);  // Transform::exp(Se3(update)) * optim_transform
+  // sin and cos of theta / 2 (even lanes) and of theta (odd lanes) in one pass
+  Se3Trig tg;
+  tg.theta = se3_theta(update);
+  {
+    const float x = (tid & 1) ? tg.theta : 0.5f * tg.theta;
+    float sx, cx;
+    if (tg.theta <= 0.78539816f) {
+      // |x| <= pi/4 (every ICP update in practice): no range reduction needed, the single-precision minimax
+      // kernels of the Cephes library (sinf / cosf, < 1 ulp on this interval) — the device libm spends ~1 us of
+      // this single-lane tail in its general-argument path
+      const float z = x * x;
+      sx = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+      cx = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    } else {
+      sx = sin_f32(x), cx = cos_f32(x);
+    }
+    auto lane_of = [](float v, int lane) {
+      return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+    };
+    tg.sin_half = lane_of(sx, 0), tg.cos_half = lane_of(cx, 0);
+    tg.sin_theta = lane_of(sx, 1), tg.cos_theta = lane_of(cx, 1);
+  }
+  pose = compose(exp_se3_trig(update, tg), pose);  // Transform::exp(Se3(update)) * optim_transform
   if (residual < best_residual) {         // stores the transform AFTER the update (image_icp.rs:158-161)
     best_residual = residual;
     best = pose;
   }
-  if (a.trace) {
+  if (a.trace && tid == 0) {
     float* tr = a.trace + ((size_t)job * a.trace_stride + a.trace_index) * 8;
     tr[0] = residual;
     tr[1] = pose.t.x, tr[2] = pose.t.y, tr[3] = pose.t.z;
     tr[4] = pose.q.i, tr[5] = pose.q.j, tr[6] = pose.q.k, tr[7] = pose.q.w;
   }
   if (a.last_in_level) pose = best;  // align() returns best_transform; the next level starts from it
-  store_pose(&st->pose, pose);
-  store_pose(&st->best, best);
-  st_coherent(&st->best_residual, best_residual);
-  st_coherent(&st->last_residual, residual);
+  // one store instruction for the whole state: lane k writes float k of JobState (status, word 15, stays)
+  {
+    const float w[17] = {pose.t.x, pose.t.y, pose.t.z, pose.q.i, pose.q.j, pose.q.k, pose.q.w,
+                         best.t.x, best.t.y, best.t.z, best.q.i, best.q.j, best.q.k, best.q.w,
+                         best_residual, 0.0f, residual};
+    float mine = w[0];
+#pragma unroll
+    for (int k = 1; k < 17; ++k) mine = tid == k ? w[k] : mine;
+    if (tid < 17 && tid != 15) st_coherent((float*)st + tid, mine);
+  }
   A3D_STAMP(6);
 }
 

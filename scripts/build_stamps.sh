@@ -1,0 +1,11 @@
+# Diagnostic build of the library with s_memrealtime stamps in the iteration tail (read by scripts/tail_stamps.py).
+set -e
+cd "$(dirname "$0")/../align3d_amd/csrc"
+OUT=../../scripts/stampbuild
+mkdir -p $OUT
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -DA3D_TAIL_STAMPS"
+for f in context image frame icp_engine image_icp kdtree kdtree_build bilateral; do
+  /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OUT/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libalign3d_hip_stamps.so $OUT/*.o
