@@ -6,6 +6,7 @@
 // stay far below 2^53, so f64 addition is exact and the order of the adds cannot matter.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -84,6 +85,93 @@ __global__ void __launch_bounds__(256)
   o.x = (prev.x + next.x + 2.0 * cur.x) * 0.25;
   o.y = (prev.y + next.y + 2.0 * cur.y) * 0.25;
   out[cell] = o;
+}
+
+// ---- packed splat + fused blur (images below 2^24 pixels) ------------------------------------------------
+// Both sums of a cell are integers: the value sum is < pixels x 65535 < 2^40 and the count < 2^24, so a cell is
+// ONE u64 (value sum << 24 | count) and a pixel is ONE integer atomic instead of two f64 atomics; integer adds are
+// exact, so the cell holds exactly the reference's f64 sums.
+constexpr int PACK_SHIFT = 24;
+__global__ void __launch_bounds__(256)
+    splat_packed_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
+                        uint32_t color_min, GridDims g, unsigned long long* __restrict__ grid) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const uint32_t color = img[i];
+  if (color == 0) return;  // `color <= I::min_value()` (:67)
+  const uint32_t row = i / w, col = i % w;
+  const uint32_t grow = f64_as_usize((double)row * inv_ss + 0.5) + 2;
+  const uint32_t gcol = f64_as_usize((double)col * inv_ss + 0.5) + 2;
+  const uint32_t ch = f64_as_usize((double)(color - color_min) * inv_sc + 0.5) + 2;
+  atomicAdd(&grid[((size_t)grow * g.gw + gcol) * g.gd + ch], ((unsigned long long)color << PACK_SHIFT) + 1ull);
+}
+
+// The six blur passes (axis 0 twice, axis 1 twice, axis 2 twice; edge_aware_filter.rs:68-114) on one
+// (T+4)^3 tile held in LDS: each pass needs its neighbours along one axis only, so after the two passes of an axis
+// the two outermost layers of the tile along that axis are stale and the central T^3 cells are exactly what six
+// full-grid passes produce.  A pass writes rows 1..gh-2, cols 1..gw-2, channels 0..gd-2 and nothing else; every
+// other cell is zero in both of the reference's buffers forever, which is what `interior ? blur : 0` reproduces
+// (cells outside the grid count as such zeros).  One read of the packed grid, one write of the blurred grid:
+// 24 B of HBM traffic per cell instead of 6 x 32 B.
+constexpr int BT = 12, BR = BT + 4, BCELLS = BR * BR * BR;  // 4096 cells x 16 B = 64 KiB of LDS
+__global__ void __launch_bounds__(256)
+    blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double2* __restrict__ out) {
+  __shared__ double2 tile[BCELLS];
+  const int r0 = (int)blockIdx.z * BT - 2, c0 = (int)blockIdx.y * BT - 2, z0 = (int)blockIdx.x * BT - 2;
+  constexpr int PER = BCELLS / 256;
+  // cell k of this thread: local index it * 256 + tid -> (lr, lc, lz), lz fastest (the grid's contiguous axis)
+  bool interior[PER];
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    const int l = it * 256 + (int)threadIdx.x;
+    const int lz = l % BR, lc = (l / BR) % BR, lr = l / (BR * BR);
+    const int gr = r0 + lr, gc = c0 + lc, gz = z0 + lz;
+    const bool inside = gr >= 0 && gc >= 0 && gz >= 0 && gr < (int)g.gh && gc < (int)g.gw && gz < (int)g.gd;
+    interior[it] = inside && gr >= 1 && gr <= (int)g.gh - 2 && gc >= 1 && gc <= (int)g.gw - 2 && gz <= (int)g.gd - 2;
+    double2 v = make_double2(0.0, 0.0);
+    if (inside) {
+      const unsigned long long u = packed[((size_t)gr * g.gw + gc) * g.gd + gz];
+      v.x = (double)(u >> PACK_SHIFT);
+      v.y = (double)(u & ((1ull << PACK_SHIFT) - 1));
+    }
+    tile[l] = v;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int pass = 0; pass < 6; ++pass) {
+    const int axis = pass >> 1;
+    const int stride = axis == 0 ? BR * BR : (axis == 1 ? BR : 1);
+    double2 nv[PER];
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int l = it * 256 + (int)threadIdx.x;
+      const int lz = l % BR, lc = (l / BR) % BR, lr = l / (BR * BR);
+      const int la = axis == 0 ? lr : (axis == 1 ? lc : lz);
+      const double2 cur = tile[l];
+      const double2 next = la < BR - 1 ? tile[l + stride] : make_double2(0.0, 0.0);
+      // the reference's channel loop reads an aliased (always zero) cell as "previous" at channel 0
+      const bool no_prev = la == 0 || (axis == 2 && z0 + lz == 0);
+      const double2 prev = no_prev ? make_double2(0.0, 0.0) : tile[l - stride];
+      double2 o = make_double2(0.0, 0.0);
+      if (interior[it]) {
+        o.x = (prev.x + next.x + 2.0 * cur.x) * 0.25;
+        o.y = (prev.y + next.y + 2.0 * cur.y) * 0.25;
+      }
+      nv[it] = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PER; ++it) tile[it * 256 + (int)threadIdx.x] = nv[it];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    const int l = it * 256 + (int)threadIdx.x;
+    const int lz = l % BR, lc = (l / BR) % BR, lr = l / (BR * BR);
+    if (lr < 2 || lr >= BR - 2 || lc < 2 || lc >= BR - 2 || lz < 2 || lz >= BR - 2) continue;
+    const int gr = r0 + lr, gc = c0 + lc, gz = z0 + lz;
+    if (gr < (int)g.gh && gc < (int)g.gw && gz < (int)g.gd) out[((size_t)gr * g.gw + gc) * g.gd + gz] = tile[l];
+  }
 }
 
 __device__ __forceinline__ uint32_t clampu(uint32_t v, uint32_t hi) { return v > hi ? hi : v; }
@@ -167,6 +255,9 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
     if (out_grid_dims) out_grid_dims[0] = g.gh, out_grid_dims[1] = g.gw, out_grid_dims[2] = g.gd;
     const size_t cells = (size_t)g.gh * g.gw * g.gd;
     const size_t grid_bytes = ((cells * sizeof(double2) + 255) / 256) * 256;
+    // images below 2^24 pixels: packed integer splat + all six blur passes in one LDS-tiled kernel
+    const char* mode = getenv("A3D_BILATERAL");
+    const bool fused = n < (1u << PACK_SHIFT) && !(mode && !strcmp(mode, "unfused"));
     // (growing the region synchronises; the stream is idle here anyway after the min/max read-back)
     if (ctx_scratch(ctx, 1, 256 + 2 * grid_bytes, &scratch) != A3D_OK) {
       st = A3D_HIP_ERROR;
@@ -177,21 +268,31 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
       }
       d_a = (double2*)((char*)scratch + 256);
       d_b = (double2*)((char*)scratch + 256 + grid_bytes);
-      if (hipMemsetAsync(d_a, 0, 2 * grid_bytes, s) != hipSuccess) fail("grid clear");
+      // fused: d_b holds the packed u64 cells (cleared), d_a receives the blurred grid (every cell written)
+      if (fused ? hipMemsetAsync(d_b, 0, cells * 8, s) != hipSuccess : hipMemsetAsync(d_a, 0, 2 * grid_bytes, s) != hipSuccess)
+        fail("grid clear");
     }
     if (st == A3D_OK) {
       const double inv_ss = 1.0 / sigma_space, inv_sc = 1.0 / sigma_color;
-      hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
-                         (double*)d_a);
-      const uint64_t interior = (uint64_t)(g.gh - 2) * (g.gw - 2) * (g.gd - 1);
-      const uint32_t blocks = (uint32_t)((interior + 255) / 256);
-      double2 *src = d_a, *dst = d_b;
-      for (int axis = 0; axis < 3; ++axis)
-        for (int rep = 0; rep < 2; ++rep) {
-          hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, s, src, dst, g, axis);
-          std::swap(src, dst);
-        }
-      // six passes: the result is back in d_a (== src after the final swap)
+      double2* src = d_a;
+      if (fused) {
+        hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin,
+                           g, (unsigned long long*)d_b);
+        hipLaunchKernelGGL(blur_fused_kernel, dim3((g.gd + BT - 1) / BT, (g.gw + BT - 1) / BT, (g.gh + BT - 1) / BT),
+                           dim3(256), 0, s, (const unsigned long long*)d_b, g, d_a);
+      } else {
+        hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
+                           (double*)d_a);
+        const uint64_t interior = (uint64_t)(g.gh - 2) * (g.gw - 2) * (g.gd - 1);
+        const uint32_t blocks = (uint32_t)((interior + 255) / 256);
+        double2* dst = d_b;
+        for (int axis = 0; axis < 3; ++axis)
+          for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, s, src, dst, g, axis);
+            std::swap(src, dst);
+          }
+        // six passes: the result is back in d_a (== src after the final swap)
+      }
       hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
                          src, d_out, d_scal + 2);
       if (hipGetLastError() != hipSuccess) fail("kernel launch");

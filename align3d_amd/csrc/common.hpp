@@ -86,6 +86,12 @@ struct a3d_context {
   // reuse its small device state instead of allocating and freeing it per alignment.
   void* icp_engine = nullptr;
   void (*icp_engine_free)(void*) = nullptr;
+  // Small read-only tables uploaded once and kept (the blur tap tables of the pyramid builder), keyed by four words.
+  struct CachedTable {
+    uint32_t key[4];
+    void* d;
+  };
+  std::vector<CachedTable> tables;
 };
 
 namespace a3d {
@@ -98,6 +104,9 @@ struct DeviceArena {
   size_t bytes = 0;
   std::atomic<int> refs{0};
 };
+// Device copy of a small host table, uploaded on first use and kept until the context dies.
+a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void* host, size_t bytes, void** out);
+
 // An arena of at least `bytes` from the context's pool, or a fresh hipMalloc; release returns it to the pool
 // (at most four are kept) or frees it.
 a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out);

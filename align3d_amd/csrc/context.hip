@@ -67,6 +67,24 @@ a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out) {
   return A3D_OK;
 }
 
+a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void* host, size_t bytes, void** out) {
+  for (const auto& t : ctx->tables)
+    if (!memcmp(t.key, key, sizeof(t.key))) {
+      *out = t.d;
+      return A3D_OK;
+    }
+  void* d = nullptr;
+  A3D_HIP_TRY(hipMalloc(&d, bytes ? bytes : 1));
+  A3D_HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  a3d_context::CachedTable t;
+  memcpy(t.key, key, sizeof(t.key));
+  t.d = d;
+  ctx->tables.push_back(t);
+  *out = d;
+  return A3D_OK;
+}
+
 a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
   {
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
@@ -146,6 +164,7 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   hipStreamSynchronize(ctx->stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
   for (auto& a : ctx->arena_pool) hipFree(a.first);
+  for (auto& t : ctx->tables) hipFree(t.d);
   hipFree(ctx->scratch[0]);
   hipFree(ctx->scratch[1]);
   hipEventDestroy(ctx->ev_start);

@@ -234,14 +234,22 @@ a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_i
   if (src->colors) {
     if (sigma <= 0.0f) sigma = 1.0f;
     A3D_REQUIRE(sigma <= 3.0f, A3D_INVALID_PARAMETER, "blur_sigma above 3 is not supported by the device builder");
-    const std::vector<TapRow> tv = make_taps(sh, sigma, 2, dh), th = make_taps(sw, sigma, 2, dw);
+    // the tap tables depend on (size, sigma) only: computed and uploaded once per context, then reused
+    auto taps_for = [&](uint32_t size, uint32_t count, TapRow** out) -> a3d_status {
+      uint32_t key[4] = {0x54415053u /* 'TAPS' */, size, count, 0};
+      memcpy(&key[3], &sigma, 4);
+      for (const auto& t : ctx->tables)
+        if (!memcmp(t.key, key, sizeof(key))) {
+          *out = (TapRow*)t.d;
+          return A3D_OK;
+        }
+      const std::vector<TapRow> rows = make_taps(size, sigma, 2, count);
+      return ctx_cached_table(ctx, key, rows.data(), rows.size() * sizeof(TapRow), (void**)out);
+    };
     TapRow *d_tv = nullptr, *d_th = nullptr;
-    A3D_TRY(scratch.take(&d_tv, tv.size()));
-    A3D_TRY(scratch.take(&d_th, th.size()));
+    A3D_TRY(taps_for(sh, dh, &d_tv));
+    A3D_TRY(taps_for(sw, dw, &d_th));
     A3D_TRY(arena.take(&dst->colors, (size_t)dn * 3));
-    // pageable -> device async copies return once the host buffer has been staged, so the vectors may die
-    A3D_HIP_TRY(hipMemcpyAsync(d_tv, tv.data(), tv.size() * sizeof(TapRow), hipMemcpyHostToDevice, s));
-    A3D_HIP_TRY(hipMemcpyAsync(d_th, th.data(), th.size() * sizeof(TapRow), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(blur_halve_kernel, dim3((dw + BLUR_TILE - 1) / BLUR_TILE, dh), dim3(256), 0, s, src->colors, sw,
                        dw, d_tv, d_th, dst->colors);
   }
@@ -282,7 +290,6 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
     arena_bytes += padded(nl * 12) + padded(nl) + padded(nl * 3);                 // points, mask, colors
     if (prm->with_normals) arena_bytes += padded(nl * 12);
     if (prm->with_intensity) arena_bytes += padded(nl) + padded((wl + 2) * (hl + 2) * 4);
-    if (l + 1 < L) scratch_bytes += padded((hl / 2) * sizeof(TapRow)) + padded((wl / 2) * sizeof(TapRow));
   }
   DeviceArena* shared = new DeviceArena();
   if (ctx_arena_acquire(ctx, arena_bytes, shared) != A3D_OK) {

@@ -150,3 +150,22 @@ def test_device_pyramid_builder_ragged_sizes_and_blur_sigmas(ctx, w, h, sigma):
     with pytest.raises(A3dError) as e:
         RangeImageBuilder(ctx).blur_sigma(3.5).build_device(CameraIntrinsics(fx, fy, cx, cy, w, h), depth, rgb, 0.001)
     assert e.value.status == 1
+
+
+def test_bilateral_fused_and_unfused_paths_agree(ctx, monkeypatch):
+    """The packed-integer splat + LDS-tiled six-pass blur and the original pass-per-launch path are the same
+    function (and both are the oracle's): grids smaller than one tile, tiles cut by every grid face, deep grids."""
+    rng = np.random.default_rng(11)
+    cases = [(rng.integers(0, 65536, size=(97, 131)).astype(np.uint16), 3.0, 700.0),
+             (rng.integers(300, 9000, size=(480, 640)).astype(np.uint16), 4.5, 30.0),
+             (rng.integers(0, 3, size=(50, 60)).astype(np.uint16), 1.5, 0.7),
+             (np.full((13, 17), 40000, np.uint16), 20.0, 5.0)]
+    for img, ss, sc in cases:
+        st, ref, dims = O.bilateral(img, ss, sc)
+        outs = {}
+        for mode in ("fused", "unfused"):
+            monkeypatch.setenv("A3D_BILATERAL", mode)
+            f = BilateralFilter.new(ss, sc)
+            outs[mode] = f.filter(ctx, img)
+            assert f.last_grid_dims == dims
+        assert st == 0 and np.array_equal(outs["fused"], ref) and np.array_equal(outs["unfused"], ref)
