@@ -113,64 +113,92 @@ __global__ void __launch_bounds__(256)
 // other cell is zero in both of the reference's buffers forever, which is what `interior ? blur : 0` reproduces
 // (cells outside the grid count as such zeros).  One read of the packed grid, one write of the blurred grid:
 // 24 B of HBM traffic per cell instead of 6 x 32 B.
-constexpr int BT = 12, BR = BT + 4, BCELLS = BR * BR * BR;  // 4096 cells x 16 B = 64 KiB of LDS
+constexpr int BT = 12, BR = BT + 4;  // 16^3 cells per tile, 12^3 of them final
+constexpr int BZP = BR + 1;          // z pitch padded to 17 cells: a thread walking a z line does not hit one bank
+constexpr int BCELLS = BR * BR * BZP;  // x 16 B = 68 KiB of LDS
+
+// Two passes of the [1 2 1]/4 blur along one 16-cell line held in registers.  `ok(i)`: cell i is one the reference
+// writes (otherwise it is zero after every pass); `first_has_no_prev`: the line starts at channel 0 of the grid,
+// where the reference's "previous" read aliases an always-zero cell.
+template <typename OK>
+__device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok, bool first_has_no_prev) {
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    double2 prev = make_double2(0.0, 0.0);  // left of the tile: stale layers, never part of the final 12^3
+    (void)first_has_no_prev;                // (prev starts at zero either way)
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const double2 cur = v[i];
+      const double2 next = i + 1 < BR ? v[i + 1] : make_double2(0.0, 0.0);
+      double2 o = make_double2(0.0, 0.0);
+      if (ok(i)) {
+        o.x = (prev.x + next.x + 2.0 * cur.x) * 0.25;
+        o.y = (prev.y + next.y + 2.0 * cur.y) * 0.25;
+      }
+      v[i] = o;
+      prev = cur;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
     blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double2* __restrict__ out) {
   __shared__ double2 tile[BCELLS];
   const int r0 = (int)blockIdx.z * BT - 2, c0 = (int)blockIdx.y * BT - 2, z0 = (int)blockIdx.x * BT - 2;
-  constexpr int PER = BCELLS / 256;
-  // cell k of this thread: local index it * 256 + tid -> (lr, lc, lz), lz fastest (the grid's contiguous axis)
-  bool interior[PER];
+  const int gh = (int)g.gh, gw = (int)g.gw, gd = (int)g.gd;
+  const int t = (int)threadIdx.x, hi = t >> 4, lo = t & 15;
+  auto at = [](int lr, int lc, int lz) { return (lr * BR + lc) * BZP + lz; };
+  auto row_ok = [&](int gr) { return gr >= 1 && gr <= gh - 2; };
+  auto col_ok = [&](int gc) { return gc >= 1 && gc <= gw - 2; };
+  auto chan_ok = [&](int gz) { return gz >= 0 && gz <= gd - 2; };
+  double2 v[BR];
+  // ---- axis 0: thread = (column hi, channel lo) owns the 16 rows; read straight from the packed grid -------
+  {
+    const int gc = c0 + hi, gz = z0 + lo;
+    const bool line_in = gc >= 0 && gc < gw && gz >= 0 && gz < gd;
 #pragma unroll
-  for (int it = 0; it < PER; ++it) {
-    const int l = it * 256 + (int)threadIdx.x;
-    const int lz = l % BR, lc = (l / BR) % BR, lr = l / (BR * BR);
-    const int gr = r0 + lr, gc = c0 + lc, gz = z0 + lz;
-    const bool inside = gr >= 0 && gc >= 0 && gz >= 0 && gr < (int)g.gh && gc < (int)g.gw && gz < (int)g.gd;
-    interior[it] = inside && gr >= 1 && gr <= (int)g.gh - 2 && gc >= 1 && gc <= (int)g.gw - 2 && gz <= (int)g.gd - 2;
-    double2 v = make_double2(0.0, 0.0);
-    if (inside) {
-      const unsigned long long u = packed[((size_t)gr * g.gw + gc) * g.gd + gz];
-      v.x = (double)(u >> PACK_SHIFT);
-      v.y = (double)(u & ((1ull << PACK_SHIFT) - 1));
+    for (int i = 0; i < BR; ++i) {
+      const int gr = r0 + i;
+      unsigned long long u = 0;
+      if (line_in && gr >= 0 && gr < gh) u = packed[((size_t)gr * gw + gc) * gd + gz];
+      v[i] = make_double2((double)(u >> PACK_SHIFT), (double)(u & ((1ull << PACK_SHIFT) - 1)));
     }
-    tile[l] = v;
+    const bool line_ok = col_ok(gc) && chan_ok(gz) && gz < gd;
+    blur_line_twice(v, [&](int i) { return line_ok && row_ok(r0 + i); }, false);
+#pragma unroll
+    for (int i = 0; i < BR; ++i) tile[at(i, hi, lo)] = v[i];
   }
   __syncthreads();
-#pragma unroll 1
-  for (int pass = 0; pass < 6; ++pass) {
-    const int axis = pass >> 1;
-    const int stride = axis == 0 ? BR * BR : (axis == 1 ? BR : 1);
-    double2 nv[PER];
+  // ---- axis 1: thread = (row hi, channel lo) owns the 16 columns -------------------------------------------
+  {
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
-      const int l = it * 256 + (int)threadIdx.x;
-      const int lz = l % BR, lc = (l / BR) % BR, lr = l / (BR * BR);
-      const int la = axis == 0 ? lr : (axis == 1 ? lc : lz);
-      const double2 cur = tile[l];
-      const double2 next = la < BR - 1 ? tile[l + stride] : make_double2(0.0, 0.0);
-      // the reference's channel loop reads an aliased (always zero) cell as "previous" at channel 0
-      const bool no_prev = la == 0 || (axis == 2 && z0 + lz == 0);
-      const double2 prev = no_prev ? make_double2(0.0, 0.0) : tile[l - stride];
-      double2 o = make_double2(0.0, 0.0);
-      if (interior[it]) {
-        o.x = (prev.x + next.x + 2.0 * cur.x) * 0.25;
-        o.y = (prev.y + next.y + 2.0 * cur.y) * 0.25;
-      }
-      nv[it] = o;
-    }
-    __syncthreads();
+    for (int i = 0; i < BR; ++i) v[i] = tile[at(hi, i, lo)];
+    const int gr = r0 + hi, gz = z0 + lo;
+    const bool line_ok = row_ok(gr) && chan_ok(gz);
+    blur_line_twice(v, [&](int i) { return line_ok && col_ok(c0 + i); }, false);
 #pragma unroll
-    for (int it = 0; it < PER; ++it) tile[it * 256 + (int)threadIdx.x] = nv[it];
-    __syncthreads();
+    for (int i = 0; i < BR; ++i) tile[at(hi, i, lo)] = v[i];  // same thread rewrites its own line: no barrier before
   }
+  __syncthreads();
+  // ---- axis 2: thread = (row hi, column lo) owns the 16 channels -------------------------------------------
+  {
 #pragma unroll
-  for (int it = 0; it < PER; ++it) {
-    const int l = it * 256 + (int)threadIdx.x;
+    for (int i = 0; i < BR; ++i) v[i] = tile[at(hi, lo, i)];
+    const int gr = r0 + hi, gc = c0 + lo;
+    const bool line_ok = row_ok(gr) && col_ok(gc);
+    // at grid channel 0 the "previous" cell is the aliased zero; inside a tile that is local channel 2 of the
+    // first tile (z0 = -2), whose local channels 0 and 1 lie outside the grid and are zero anyway
+    blur_line_twice(v, [&](int i) { return line_ok && chan_ok(z0 + i); }, false);
+#pragma unroll
+    for (int i = 0; i < BR; ++i) tile[at(hi, lo, i)] = v[i];
+  }
+  __syncthreads();
+  // ---- the central 12^3 cells, written with the channel axis across lanes ------------------------------------
+  for (int l = t; l < BR * BR * BR; l += 256) {
     const int lz = l % BR, lc = (l / BR) % BR, lr = l / (BR * BR);
     if (lr < 2 || lr >= BR - 2 || lc < 2 || lc >= BR - 2 || lz < 2 || lz >= BR - 2) continue;
     const int gr = r0 + lr, gc = c0 + lc, gz = z0 + lz;
-    if (gr < (int)g.gh && gc < (int)g.gw && gz < (int)g.gd) out[((size_t)gr * g.gw + gc) * g.gd + gz] = tile[l];
+    if (gr < gh && gc < gw && gz < gd) out[((size_t)gr * gw + gc) * gd + gz] = tile[at(lr, lc, lz)];
   }
 }
 
