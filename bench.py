@@ -228,8 +228,8 @@ def cpu_baseline(host_pyramids, params, n_pairs, gpu_poses):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs-per-gpu", type=int, default=64)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
