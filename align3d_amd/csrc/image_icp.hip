@@ -692,6 +692,16 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     float waves = P >= 8 ? (b->n_streams > 2 ? 1.5f : 1.0f) : 0.25f;
     if (const char* env = getenv("A3D_ICP_WAVES")) waves = (float)atof(env);  // tuning knob
     if (const char* env = getenv("A3D_ICP_GROUP")) b->group[l] = atoi(env) == 2 ? 2 : 1;
+    if (const char* env = getenv("A3D_ICP_GROUP_LEVELS")) {  // tuning knob: per-level "g0,g1,g2"
+      unsigned gl[3] = {1, 1, 1};
+      sscanf(env, "%u,%u,%u", &gl[0], &gl[1], &gl[2]);
+      if (l < 3) b->group[l] = gl[l] == 2 ? 2 : 1;
+    }
+    if (const char* env = getenv("A3D_ICP_WAVES_LEVELS")) {  // tuning knob: per-level "w0,w1,w2"
+      float wl[3] = {waves, waves, waves};
+      sscanf(env, "%f,%f,%f", &wl[0], &wl[1], &wl[2]);
+      if (l < 3) waves = wl[l];
+    }
     choose_tiling(P, max_n, b->resident_blocks, waves, b->group[l], &b->tiles[l], &b->ppt[l]);
     if (const char* env = getenv("A3D_ICP_VARIANT")) {  // tuning knob: "ppt,g"
       unsigned ep = 0, eg = 0;

@@ -7,6 +7,7 @@
 //   icp::Icp                                src/icp/pcl_icp.rs:15-108
 //   kdtree::R3dTree                         src/kdtree.rs:19-106
 //   range_image::RangeImage (borrowed view) src/range_image/structure.rs:20-36
+//   range_image::RangeImageBuilder          src/range_image/builder.rs:7-92
 //   bilateral::BilateralFilter<u16>         src/bilateral/edge_aware_filter.rs:14-135
 //   transform::Transform                    src/transform.rs:18
 //
@@ -125,6 +126,18 @@ class RangeImage {
   RangeImage(const Context& ctx, const a3d_range_image_view& host_view) {
     check(a3d_range_image_upload(ctx.raw(), &host_view, &img_));
   }
+  /// Adopts a handle produced by the library (RangeImageBuilder::build).
+  explicit RangeImage(a3d_device_image* adopted) : img_(adopted) {}
+  uint64_t width() const {
+    uint64_t w, h;
+    check(a3d_range_image_size(img_, &w, &h));
+    return w;
+  }
+  uint64_t height() const {
+    uint64_t w, h;
+    check(a3d_range_image_size(img_, &w, &h));
+    return h;
+  }
   ~RangeImage() { a3d_range_image_free(img_); }
   RangeImage(RangeImage&& o) noexcept : img_(o.img_) { o.img_ = nullptr; }
   RangeImage(const RangeImage&) = delete;
@@ -146,6 +159,68 @@ inline std::vector<const a3d_device_image*> raw_pointers(const std::vector<Range
   for (const auto& r : v) out.push_back(r.raw());
   return out;
 }
+
+/// BilateralFilter::<u16>::{default, new}(sigma_space, sigma_color).filter(&image)
+class BilateralFilter {
+ public:
+  double sigma_space, sigma_color;
+  BilateralFilter() { a3d_bilateral_default_sigmas(&sigma_space, &sigma_color); }
+  BilateralFilter(double ss, double sc) : sigma_space(ss), sigma_color(sc) {}
+  std::vector<uint16_t> filter(const Context& ctx, const uint16_t* image, uint64_t width, uint64_t height) const {
+    std::vector<uint16_t> out(width * height);
+    check(a3d_bilateral_filter_u16(ctx.raw(), image, width, height, sigma_space, sigma_color, out.data(), nullptr));
+    return out;
+  }
+};
+
+/// CameraIntrinsics (src/camera.rs:9-22)
+struct CameraIntrinsics {
+  double fx, fy, cx, cy;
+  uint64_t width, height;
+};
+
+/// RangeImageBuilder::default().with_*(..).build(frame) -> Vec<RangeImage> (builder.rs:16-91), on the device:
+/// the frame crosses PCIe as u16 depth + u8 RGB and every pyramid level stays resident in HBM.
+class RangeImageBuilder {
+ public:
+  explicit RangeImageBuilder(const Context& ctx) : ctx_(ctx) { a3d_builder_params_default(&p_); }
+  RangeImageBuilder& with_normals(bool v) {
+    p_.with_normals = v;
+    return *this;
+  }
+  RangeImageBuilder& with_intensity(bool v) {
+    p_.with_intensity = v;
+    return *this;
+  }
+  RangeImageBuilder& with_bilateral_filter(const BilateralFilter* f) {  // Option<BilateralFilter>
+    p_.use_bilateral = f != nullptr;
+    if (f) p_.sigma_space = f->sigma_space, p_.sigma_color = f->sigma_color;
+    return *this;
+  }
+  RangeImageBuilder& pyramid_levels(uint64_t n) {
+    p_.pyramid_levels = n;
+    return *this;
+  }
+  RangeImageBuilder& blur_sigma(float s) {
+    p_.blur_sigma = s;
+    return *this;
+  }
+  /// depth: [height][width] u16; rgb: [height][width][3] u8; depth_scale as RgbdImage::depth_scale.
+  std::vector<RangeImage> build(const CameraIntrinsics& k, const uint16_t* depth, const uint8_t* rgb,
+                                double depth_scale) const {
+    std::vector<a3d_device_image*> raw(p_.pyramid_levels, nullptr);
+    check(a3d_range_image_build_pyramid(ctx_.raw(), &p_, depth, rgb, k.width, k.height, k.fx, k.fy, k.cx, k.cy,
+                                        depth_scale, raw.data()));
+    std::vector<RangeImage> out;
+    out.reserve(raw.size());
+    for (a3d_device_image* im : raw) out.emplace_back(im);
+    return out;
+  }
+
+ private:
+  const Context& ctx_;
+  a3d_builder_params p_;
+};
 
 /// ImageIcp::new(params, &target); initial_transform; align(&source)
 class ImageIcp {
@@ -227,17 +302,47 @@ class Icp {
   a3d_pcl_icp* icp_ = nullptr;
 };
 
-/// BilateralFilter::<u16>::{default, new}(sigma_space, sigma_color).filter(&image)
-class BilateralFilter {
+/// P independent MultiscaleAlign jobs in one launch sequence (the per-GPU shard of a batch of frame pairs):
+/// the same parameters for every pair, pyramids[pair][level]; align() returns one Transform per pair and
+/// throws Panic if any pair's solve failed (status() then tells which).
+class MultiscaleAlignBatch {
  public:
-  double sigma_space, sigma_color;
-  BilateralFilter() { a3d_bilateral_default_sigmas(&sigma_space, &sigma_color); }
-  BilateralFilter(double ss, double sc) : sigma_space(ss), sigma_color(sc) {}
-  std::vector<uint16_t> filter(const Context& ctx, const uint16_t* image, uint64_t width, uint64_t height) const {
-    std::vector<uint16_t> out(width * height);
-    check(a3d_bilateral_filter_u16(ctx.raw(), image, width, height, sigma_space, sigma_color, out.data(), nullptr));
+  MultiscaleAlignBatch(const Context& ctx, const MsIcpParams& params,
+                       const std::vector<const std::vector<RangeImage>*>& target_pyramids,
+                       const std::vector<const std::vector<RangeImage>*>& source_pyramids)
+      : n_pairs_(target_pyramids.size()) {
+    if (target_pyramids.size() != source_pyramids.size() || target_pyramids.empty())
+      throw InvalidParameter("A3D_INVALID_PARAMETER: one target and one source pyramid per pair are required");
+    const size_t levels = target_pyramids[0]->size();
+    std::vector<const a3d_device_image*> t, s;
+    for (size_t p = 0; p < n_pairs_; ++p) {
+      if (target_pyramids[p]->size() != levels || source_pyramids[p]->size() != levels)
+        throw InvalidParameter("A3D_INVALID_PARAMETER: every pyramid of a batch must have the same number of levels");
+      for (size_t l = 0; l < levels; ++l) {
+        t.push_back((*target_pyramids[p])[l].raw());
+        s.push_back((*source_pyramids[p])[l].raw());
+      }
+    }
+    auto prm = params.to_c();
+    check(a3d_multiscale_batch_new(ctx.raw(), prm.data(), prm.size(), n_pairs_, levels, t.data(), s.data(), &b_));
+  }
+  ~MultiscaleAlignBatch() { a3d_multiscale_batch_free(b_); }
+  MultiscaleAlignBatch(const MultiscaleAlignBatch&) = delete;
+  MultiscaleAlignBatch& operator=(const MultiscaleAlignBatch&) = delete;
+  std::vector<Transform> align() {
+    std::vector<a3d_pose> poses(n_pairs_);
+    status_.assign(n_pairs_, 0);
+    check(a3d_multiscale_batch_align(b_, poses.data(), nullptr, status_.data()));
+    std::vector<Transform> out;
+    for (const a3d_pose& p : poses) out.push_back(Transform::from_c(p));
     return out;
   }
+  const std::vector<int32_t>& status() const { return status_; }
+
+ private:
+  size_t n_pairs_;
+  a3d_multiscale_batch* b_ = nullptr;
+  std::vector<int32_t> status_;
 };
 
 }  // namespace align3d

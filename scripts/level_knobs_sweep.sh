@@ -1,0 +1,18 @@
+# per-level tuning: waves (rounds of resident blocks) and pipeline group per level, 64 pairs, 3 streams
+run() {
+  echo "== $*"
+  env "$@" python bench.py --steps 20 --warmup 5 --no-extras --cpu-pairs 0 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('value %.0f pairs/s  ms/step %.3f  failed %s' % (d['value'], d['ms_per_step'], d['extra'].get('failed_pairs')))"
+}
+run A3D_ICP_WAVES_LEVELS=1.5,1.5,1.5
+run A3D_ICP_WAVES_LEVELS=1.5,1.5,3
+run A3D_ICP_WAVES_LEVELS=1.5,1.5,6
+run A3D_ICP_WAVES_LEVELS=1.5,3,3
+run A3D_ICP_WAVES_LEVELS=1.5,3,6
+run A3D_ICP_WAVES_LEVELS=1.5,1.5,0.75
+run A3D_ICP_WAVES_LEVELS=1.5,0.75,0.75
+run A3D_ICP_GROUP_LEVELS=1,1,2
+run A3D_ICP_GROUP_LEVELS=1,2,2
+run A3D_ICP_GROUP_LEVELS=1,1,2 A3D_ICP_WAVES_LEVELS=1.5,1.5,3

@@ -1,7 +1,8 @@
 // Exercises include/align3d.hpp (the C++ host-side mirror of the reference API) against libalign3d_hip.so.
 //   ./host_mirror_test        CPU-only checks (parameters, error mapping without a GPU)
 //   ./host_mirror_test gpu    + the kd-tree KAT of src/kdtree.rs:121-139, MultiscaleAlign::new's length check
-//                             (src/icp/multiscale.rs:30-34) and one tiny ImageIcp on the device
+//                             (src/icp/multiscale.rs:30-34), one tiny ImageIcp, the device RangeImageBuilder and
+//                             a two-pair MultiscaleAlignBatch
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -74,6 +75,35 @@ int main(int argc, char** argv) {
   ImageIcp icp(ctx, one, target[0]);
   Transform T2 = icp.align(source[0]);
   EXPECT(std::fabs(T2.translation[0] - T.translation[0]) < 1e-6f);
+  {  // RangeImageBuilder on the device + MultiscaleAlignBatch: two identical synthetic frames, two pairs
+    const int BW = 64, BH = 48;
+    std::vector<uint16_t> depth(BW * BH);
+    std::vector<uint8_t> rgb(BW * BH * 3);
+    for (int r = 0; r < BH; ++r)
+      for (int c = 0; c < BW; ++c) {
+        depth[r * BW + c] = (uint16_t)(1500 + 4 * c + 3 * r + ((r * 7 + c * 13) % 5));
+        for (int k = 0; k < 3; ++k) rgb[(r * BW + c) * 3 + k] = (uint8_t)((c * 5 + r * 3 + 40 * k) & 255);
+      }
+    CameraIntrinsics k{60.0, 60.0, 32.0, 24.0, (uint64_t)BW, (uint64_t)BH};
+    BilateralFilter bf2;
+    RangeImageBuilder builder(ctx);
+    builder.with_bilateral_filter(&bf2).pyramid_levels(2);
+    std::vector<RangeImage> a = builder.build(k, depth.data(), rgb.data(), 0.001);
+    std::vector<RangeImage> b2 = builder.build(k, depth.data(), rgb.data(), 0.001);
+    EXPECT(a.size() == 2 && a[0].width() == 64 && a[0].height() == 48 && a[1].width() == 32 && a[1].height() == 24);
+    MsIcpParams prm = MsIcpParams::repeat(2, IcpParams().with_max_iterations(3));
+    Transform single = MultiscaleAlign(ctx, prm, a).align(b2);
+    MultiscaleAlignBatch batch(ctx, prm, {&a, &b2}, {&b2, &a});
+    std::vector<Transform> Ts = batch.align();
+    EXPECT(Ts.size() == 2 && batch.status()[0] == 0 && batch.status()[1] == 0);
+    for (int i = 0; i < 3; ++i) EXPECT(std::fabs(Ts[0].translation[i] - single.translation[i]) < 2e-6f);
+    for (int i = 0; i < 4; ++i) EXPECT(std::fabs(Ts[0].rotation_ijkw[i] - single.rotation_ijkw[i]) < 2e-6f);
+    try {
+      RangeImageBuilder(ctx).pyramid_levels(9).build(k, depth.data(), rgb.data(), 0.001);  // 64x48 has no 9 levels
+      EXPECT(false);
+    } catch (const InvalidParameter&) {
+    }
+  }
   std::printf("host mirror GPU checks OK\n");
   return 0;
 }
