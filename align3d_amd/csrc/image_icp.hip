@@ -566,6 +566,7 @@ struct a3d_multiscale_batch {
   JobState* d_states = nullptr;
   float* d_partials = nullptr;
   size_t partials_capacity = 0;  // floats
+  uint32_t max_tiles = 1;        // largest tiles[level]: the per-pair stride of a stream group's slice of d_partials
   unsigned* d_counters = nullptr;  // per pair: blocks that have published their partial in this launch
   unsigned* d_epochs = nullptr;    // per pair: iterations completed (level kernel hand-off word)
   bool use_level_kernel = false;   // one launch per level when the whole grid is resident (A3D_ICP_PERSISTENT)
@@ -656,7 +657,9 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
   dim3 grid(b->tiles[level], count), block(256);
   const LevelDesc* descs = b->d_descs + (size_t)level * b->n_pairs + p0;
   JobState* states = b->d_states + p0;
-  float* partials = b->d_partials + (size_t)p0 * b->tiles[level] * GN_PARTIAL;
+  // A group's slice starts at p0 x (the LARGEST tile count of any level): groups on different streams may be at
+  // different levels at the same time, so their slices must be disjoint for every combination of levels.
+  float* partials = b->d_partials + (size_t)p0 * b->max_tiles * GN_PARTIAL;
   unsigned* counters = b->d_counters + p0;
   const int ppt = (int)b->ppt[level];
   if (b->use_mfma) {
@@ -713,6 +716,7 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     }
     max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
   }
+  b->max_tiles = (uint32_t)(max_partials / ((size_t)P * GN_PARTIAL));
   if (b->partials_capacity < max_partials) {  // grow-only: a reused engine keeps its buffer
     if (b->d_partials) A3D_HIP_TRY(hipFree(b->d_partials));
     b->d_partials = nullptr;

@@ -249,3 +249,36 @@ def test_level_kernel_matches_per_iteration_launches(ctx, monkeypatch):
     p2, st2 = mixed.align()
     assert st2[0] == 3 and st2[1] == 0
     assert np.allclose(p2[1].t, ref_poses[1].t, atol=2e-6)
+
+
+def test_stream_groups_do_not_change_any_pair(ctx, monkeypatch):
+    """A batch of >= 12 pairs runs as three pair groups on three HIP streams.  With the tiling pinned, a pair's
+    arithmetic does not depend on which group it is in, so the poses must equal the one-stream run bit for bit —
+    on every repeat (the groups drift apart in time, so they must not share any scratch: regression test for
+    overlapping block-partial slices when two groups are at different pyramid levels)."""
+    prm = MsIcpParams.repeat(3, IcpParams.default())
+    base = [("sample1", 0, 1), ("sample1", 1, 4), ("sample1", 4, 5), ("sample2", 0, 1), ("sample2", 1, 4),
+            ("sample1", 5, 4), ("sample2", 4, 0)]
+    pairs = (base * 3)[:20]
+    tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs]
+    sps = [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in pairs]
+    monkeypatch.setenv("A3D_ICP_WAVES", "1.5")
+
+    def run(streams, repeats):
+        monkeypatch.setenv("A3D_ICP_STREAMS", str(streams))
+        batch = MultiscaleAlignBatch(ctx, prm, tps, sps)
+        assert batch.concurrency() == streams
+        outs = []
+        for _ in range(repeats):
+            poses, status = batch.align()
+            assert not status.any()
+            outs.append(np.array([np.concatenate([t.t, t.q]) for t in poses], np.float32).view(np.uint32))
+        batch.free()
+        return outs
+
+    one = run(1, 1)[0]
+    for o in run(3, 6) + run(2, 3):
+        assert np.array_equal(o, one)
+    # equal inputs give equal outputs wherever they sit in the batch
+    for k in range(7, 20):
+        assert np.array_equal(one[k], one[k % 7])
