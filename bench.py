@@ -166,6 +166,44 @@ def frame_prep_bench(ctx, host_pyramid_level0, depth_u16):
     }
 
 
+def named_shapes_bench(ctx, targets, sources):
+    """The other two ICP shapes BASELINE.md names, on the same resident pyramids: `bench10` = the reference's
+    published bench (benches/bench_image_icp.rs: one 640x480 level, IcpParams::default() with 10 iterations; README:
+    38.576 ms on 16 CPU threads) and `msdefault` = MsIcpParams::default() (20/20/30 iterations)."""
+    out = {}
+    P = len(targets)
+    for name, prm, levels in (("bench10", MsIcpParams.repeat(1, IcpParams(max_iterations=10)), 1),
+                              ("msdefault", MsIcpParams.default(), 3)):
+        tp = [t[:levels] for t in targets]
+        sp = [s[:levels] for s in sources]
+        batch = MultiscaleAlignBatch(ctx, prm, tp, sp)
+        for _ in range(3):
+            batch.enqueue()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            batch.enqueue()
+        ctx.synchronize()
+        batch_ms = (time.perf_counter() - t0) / 10 * 1e3
+        _, status = batch.align()
+        batch.free()
+        one = MultiscaleAlign.new(ctx, prm, tp[0])
+        for _ in range(2):
+            one.align(sp[0])
+        t0 = time.perf_counter()
+        for _ in range(5):
+            one.align(sp[0])
+        single_ms = (time.perf_counter() - t0) / 5 * 1e3
+        out[name] = {"pairs_per_s_batch_of_%d" % P: P / (batch_ms * 1e-3), "single_pair_latency_ms": single_ms,
+                     "failed_pairs": int(np.count_nonzero(status))}
+    pub_ms = 38.576  # README.md:130, i7-11800H x 16 threads
+    b10 = out["bench10"]
+    b10["published_cpu_ms"] = pub_ms
+    b10["x_vs_published_single_pair"] = pub_ms / b10["single_pair_latency_ms"]
+    b10["x_vs_published_batched"] = pub_ms * 1e-3 * b10["pairs_per_s_batch_of_%d" % P]
+    return out
+
+
 def odometry_bench(ctx, n_frames=20):
     """configs[3] shape: a 20-frame odometry stream (synthetic: no TUM / IL-RGBD data exists on the box), frames
     enter as u16 depth + u8 RGB, persistent device pyramids, MsIcpParams::default() (README usage)."""
@@ -372,7 +410,9 @@ def main():
             for _ in range(5):
                 ms1.align(sources[0])
             extra["single_pair_ms3x15_latency_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+            extra["named_shapes"] = named_shapes_bench(ctx, targets, sources)
             extra["kdtree"] = kdtree_bench(ctx)
+            extra["kdtree"]["x_vs_published_cpu_101.75ms"] = 101.75 / extra["kdtree"]["ms_per_500k_queries"]
             extra["pcl_icp"] = pcl_icp_bench(ctx)
             extra["odometry"] = odometry_bench(ctx)
             extra["frame_prep"] = frame_prep_bench(ctx, host_pyramids[0][0].download(), synth.frame_stream(1000, 1, W, H)[0][0][0])
