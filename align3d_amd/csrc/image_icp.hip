@@ -570,6 +570,7 @@ struct a3d_multiscale_batch {
   unsigned* d_counters = nullptr;  // per pair: blocks that have published their partial in this launch
   unsigned* d_epochs = nullptr;    // per pair: iterations completed (level kernel hand-off word)
   bool use_level_kernel = false;   // one launch per level when the whole grid is resident (A3D_ICP_PERSISTENT)
+  uint32_t level_mask = 0;         // bit l: level l runs as ONE launch per stream group (A3D_ICP_PERSISTENT_LEVELS)
   uint32_t level_resident_blocks = 0;  // blocks of image_icp_level_kernel the chip holds at once
   Pose* d_poses = nullptr;
   Pose* d_init = nullptr;  // per-pair initial transforms when the caller supplies them
@@ -706,6 +707,14 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
       if (l < 3) waves = wl[l];
     }
     choose_tiling(P, max_n, b->resident_blocks, waves, b->group[l], &b->tiles[l], &b->ppt[l]);
+    if ((b->level_mask >> l) & 1u) {  // every block of every group must be resident at once for this level
+      b->group[l] = 1;
+      choose_tiling(P, max_n, b->level_resident_blocks, 1.0f, 1, &b->tiles[l], &b->ppt[l]);
+      while ((uint64_t)b->tiles[l] * P > b->level_resident_blocks && b->tiles[l] > 1) {
+        ++b->ppt[l];
+        b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
+      }
+    }
     if (const char* env = getenv("A3D_ICP_VARIANT")) {  // tuning knob: "ppt,g"
       unsigned ep = 0, eg = 0;
       if (sscanf(env, "%u,%u", &ep, &eg) == 2 && ep && (eg == 1 || eg == 2)) {
@@ -757,6 +766,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   A3D_HIP_TRY(hipMalloc((void**)&b->d_poses, n_pairs * sizeof(Pose)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_init, n_pairs * sizeof(Pose)));
   if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
+  if (const char* env = getenv("A3D_ICP_PERSISTENT_LEVELS")) b->level_mask = (uint32_t)strtoul(env, nullptr, 0);
   // measured (scripts/streams_sweep*.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
   // stream), 2 groups at 8 pairs (+21 %); a handful of pairs stays on one stream
   b->n_streams = n_pairs >= 12 ? 3u : (n_pairs >= 8 ? 2u : 1u);
@@ -814,7 +824,13 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   bool level_kernel = b->use_level_kernel && !b->use_mfma && b->level_resident_blocks > 0;
   for (uint32_t l = 0; l < levels_to_run; ++l)
     level_kernel = level_kernel && (uint64_t)b->tiles[l] * P <= b->level_resident_blocks && b->group[l] == 1;
-  if (level_kernel) A3D_HIP_TRY(hipMemsetAsync(b->d_epochs, 0, P * sizeof(unsigned), s));
+  // hybrid: only the levels in level_mask run as one launch (per stream group); the others launch per iteration
+  uint32_t mask = 0;
+  if (!level_kernel && !b->use_mfma && !d_trace && b->level_resident_blocks > 0)
+    for (uint32_t l = 0; l < levels_to_run; ++l)
+      if (((b->level_mask >> l) & 1u) && (uint64_t)b->tiles[l] * P <= b->level_resident_blocks && b->group[l] == 1)
+        mask |= 1u << l;
+  if (level_kernel || mask) A3D_HIP_TRY(hipMemsetAsync(b->d_epochs, 0, P * sizeof(unsigned), s));
   // pair groups on separate streams (not with a trace: its rows are indexed by the pair number inside a launch)
   const uint32_t S = (level_kernel || d_trace) ? 1u : b->n_streams;
   if (S > 1) {
@@ -842,6 +858,29 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
                          sa, plan, (int)b->ppt[l]);
       A3D_HIP_TRY(hipGetLastError());
       A3D_TRY(profile_end(s));
+      epoch_base += plan.iterations;
+      trace_index += (int)plan.iterations;
+      continue;
+    }
+    if ((mask >> l) & 1u) {
+      if (prm.max_iterations == 0) continue;
+      LevelPlan plan;
+      plan.iterations = (uint32_t)prm.max_iterations;
+      plan.epoch_base = epoch_base;
+      plan.trace_base = trace_index;
+      sa.first_in_level = sa.last_in_level = 0;
+      sa.trace_index = 0;
+      for (uint32_t g = 0; g < S; ++g) {
+        const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
+        hipStream_t gs = g == 0 ? s : b->aux_streams[g - 1];
+        A3D_TRY(profile_begin(gs));
+        hipLaunchKernelGGL((image_icp_level_kernel<1>), dim3(b->tiles[l], p1 - p0), dim3(256), 0, gs,
+                           b->d_descs + (size_t)l * P + p0, b->d_states + p0, b->gates[l],
+                           b->d_partials + (size_t)p0 * b->max_tiles * GN_PARTIAL, b->d_counters + p0, b->d_epochs + p0,
+                           sa, plan, (int)b->ppt[l]);
+        A3D_HIP_TRY(hipGetLastError());
+        A3D_TRY(profile_end(gs));
+      }
       epoch_base += plan.iterations;
       trace_index += (int)plan.iterations;
       continue;

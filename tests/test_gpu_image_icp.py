@@ -239,6 +239,14 @@ def test_level_kernel_matches_per_iteration_launches(ctx, monkeypatch):
     for a, b, c in zip(poses, ref_poses, poses2):
         assert np.allclose(a.t, b.t, atol=2e-6) and np.allclose(a.q, b.q, atol=2e-6)
         assert np.array_equal(a.t, c.t) and np.array_equal(a.q, c.q)
+    # hybrid: only the coarsest level as one launch (A3D_ICP_PERSISTENT_LEVELS is a bit mask over levels)
+    monkeypatch.setenv("A3D_ICP_PERSISTENT_LEVELS", "4")
+    hybrid = MultiscaleAlignBatch(ctx, prm, tps, sps)
+    monkeypatch.delenv("A3D_ICP_PERSISTENT_LEVELS")
+    hposes, hstatus = hybrid.align()
+    assert not hstatus.any()
+    for a, b in zip(hposes, ref_poses):
+        assert np.allclose(a.t, b.t, atol=2e-6) and np.allclose(a.q, b.q, atol=2e-6)
     # a pair that fails (empty source) freezes without stalling the others
     empty = [to_range_image(f) for f in oracle_pyramid("sample1", 5)]
     for lv in empty:
