@@ -276,6 +276,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (gloo + --device 0 rehearses the multi-rank path on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for this rank (default: LOCAL_RANK)")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="run the N > 1 code path (process group, all-gather on the context stream) even with one "
+                         "rank: checks the RCCL path on a one-GPU box (launch under torchrun --nproc-per-node 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -284,7 +287,8 @@ def main():
     dist = torch = None
     device = local_rank if args.device is None else args.device
     use_nccl = args.backend == "nccl"
-    if world > 1:
+    multi = world > 1 or args.rehearse_collective  # the collective path
+    if multi:
         import torch
         import torch.distributed as dist
 
@@ -308,27 +312,27 @@ def main():
     batch = MultiscaleAlignBatch(ctx, params, targets, sources)
 
     d_mats = gathered = ext_stream = host_mats = None
-    if world > 1 and use_nccl:
+    if multi and use_nccl:
         mats = torch.zeros((P, 16), dtype=torch.float32, device="cuda")
         gathered = torch.zeros((world * P, 16), dtype=torch.float32, device="cuda")
         d_mats = C.c_void_p(mats.data_ptr())
         ext_stream = torch.cuda.ExternalStream(ctx.lib.a3d_context_stream(ctx.handle))
-    elif world > 1:  # gloo rehearsal: the poses go through host memory
+    elif multi:  # gloo rehearsal: the poses go through host memory
         d_mats = ctx.malloc(P * 64)
         host_mats = np.zeros((P, 16), np.float32)
         gathered = torch.zeros((world * P, 16), dtype=torch.float32)
 
     def step():
         batch.enqueue(matrices_device=d_mats)
-        if world > 1 and use_nccl:
+        if multi and use_nccl:
             with torch.cuda.stream(ext_stream):  # ordered after the kernels on the context stream
                 dist.all_gather_into_tensor(gathered, mats)
-        elif world > 1:
+        elif multi:
             ctx.to_host(d_mats, host_mats)
             dist.all_gather_into_tensor(gathered, torch.from_numpy(host_mats))
 
     def sync_all():
-        if world > 1:
+        if multi:
             dist.barrier()
             if use_nccl:
                 torch.cuda.synchronize()
@@ -342,7 +346,7 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_nccl else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -389,7 +393,7 @@ def main():
         }
         poses, status = batch.align()
         extra = {"failed_pairs": int(np.count_nonzero(status))}
-        if world > 1:  # the gathered buffer starts with this rank's own 4x4 poses
+        if multi:  # the gathered buffer starts with this rank's own 4x4 poses
             own = gathered[:P].cpu().numpy().reshape(P, 4, 4)
             extra["gather_matches_local_poses"] = bool(
                 all(np.allclose(own[p], poses[p].matrix(), atol=1e-6) for p in range(P)))
@@ -433,12 +437,12 @@ def main():
                                    "(configs[1] pair shape, batched as the per-GPU shard of configs[4])",
                        "pairs_per_gpu": P, "levels": 3, "iterations_per_level": iters,
                        "collective": (f"one all-gather of 16 f32 per pair per step ({'RCCL' if use_nccl else 'gloo rehearsal'})"
-                                      if world > 1 else "none")},
+                                      if multi else "none")},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
     sync_all()
     batch.free()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
