@@ -41,6 +41,13 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points);
 // leaf_normals[slot_of_point[i]] = normals[i] (device build)
 a3d_status kdtree_scatter_normals_device(a3d_kdtree* t, const float* d_normals);
 
+// The hand-written stable sorts of the device build (kdtree_sort.hip).
+size_t kdtree_sort_scratch_bytes(uint32_t n);
+a3d_status kdtree_radix_sort_pairs(hipStream_t s, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a,
+                                   uint32_t* vals_b, uint32_t n, int end_bit, uint32_t* hist, bool* in_b);
+a3d_status kdtree_sort_ranges(hipStream_t s, const float* points, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n,
+                              uint32_t level, int k, uint32_t cap_log2, uint32_t* nan_flag);
+
 // Descent of R3dTree::nearest (src/kdtree.rs:69-105): returns the first slot of the leaf the query falls in.
 // `split_top` (nullable) is an LDS copy of the first `top_entries` heap entries of the split table.
 __device__ __forceinline__ uint32_t kdtree_descend(const float* __restrict__ split, const float* split_top,

@@ -11,10 +11,10 @@
 // rocPRIM's segmented sort gives one workgroup to each range, which is right for the thousands of short ranges
 // of the deep levels but would leave the chip idle on the few long ranges at the top; those levels use ONE
 // device-wide stable radix sort instead, on 64-bit keys (range number << 32 | order-preserving key bits).
-// The sort primitive is rocPRIM's segmented_radix_sort_pairs (a stable LSD radix sort; ROCm ships it as a
-// header library); everything around it — key gather, NaN detection, range tables, split extraction, leaf
-// packing — is written here.  The result is bit-identical to the host build (kdtree.hip), which stays
-// available (A3D_KDTREE_BUILD=host) and is what the tests compare against.
+// The sorts are hand-written (kdtree_sort.hip); rocPRIM's stable radix sorts (a ROCm header library) stay behind
+// A3D_KDTREE_SORT=rocprim as a cross-check.  Key gather, NaN detection, range tables, split extraction and leaf
+// packing are written here.  The result is bit-identical to the host build (kdtree.hip), which stays available
+// (A3D_KDTREE_BUILD=host) and is what the tests compare against.
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
@@ -172,8 +172,12 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
   hipLaunchKernelGGL(fill_leaves_kernel, grid_for(n_slots), dim3(256), 0, s, t->d_leaves, n_slots);
 
   // Levels whose ranges are longer than this use the device-wide sort (no leaf can exist there: len > 16).
-  const uint32_t wide_len = getenv("A3D_KDTREE_WIDE_LEN") ? (uint32_t)atoi(getenv("A3D_KDTREE_WIDE_LEN")) : 4096u;
-  auto level_is_wide = [&](uint32_t level) { return (n >> level) > std::max(wide_len, 64u); };
+  const char* sort_env = getenv("A3D_KDTREE_SORT");
+  const bool use_rocprim = sort_env && !strcmp(sort_env, "rocprim");  // cross-check path; default: kdtree_sort.hip
+  uint32_t wide_len = getenv("A3D_KDTREE_WIDE_LEN") ? (uint32_t)atoi(getenv("A3D_KDTREE_WIDE_LEN")) : 4096u;
+  if (!use_rocprim) wide_len = std::min(wide_len, 4096u);  // the LDS sort holds at most 4096 points per range
+  auto max_len = [&](uint32_t level) { return (uint32_t)(((uint64_t)n + (1ull << level) - 1) >> level); };
+  auto level_is_wide = [&](uint32_t level) { return max_len(level) > std::max(wide_len, 64u); };
 
   // scratch: two index buffers, two key buffers, offsets for the widest level, NaN flag, rocPRIM storage
   const size_t max_nodes = D ? (1ull << (D - 1)) : 1;
@@ -188,7 +192,9 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
     sort_bytes = std::max(sort_bytes, wide_bytes);
   }
   auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
-  const size_t total = 2 * pad((size_t)n * 4) + 2 * pad((size_t)n * 8) + 2 * pad(max_nodes * 4) + 256 + pad(sort_bytes);
+  const size_t hist_bytes = pad(kdtree_sort_scratch_bytes(n));
+  const size_t total = 2 * pad((size_t)n * 4) + 2 * pad((size_t)n * 8) + 2 * pad(max_nodes * 4) + 256 +
+                       pad(sort_bytes) + hist_bytes;
   char* base = nullptr;
   A3D_HIP_TRY(hipMalloc((void**)&base, total));
   struct Free {
@@ -203,6 +209,7 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
   uint32_t* end = (uint32_t*)((char*)begin + pad(max_nodes * 4));
   uint32_t* nan_flag = (uint32_t*)((char*)end + pad(max_nodes * 4));
   void* sort_tmp = (char*)nan_flag + 256;
+  uint32_t* hist = (uint32_t*)((char*)sort_tmp + pad(sort_bytes));
 
   A3D_HIP_TRY(hipMemsetAsync(nan_flag, 0, 4, s));
   hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, s, idx_a, n);
@@ -211,6 +218,25 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
     const int k = (int)(level % 3);
     const uint32_t nodes = 1u << level;
     size_t bytes = sort_bytes;
+    if (!use_rocprim) {
+      bool sorted_in_nxt = true;
+      if (level_is_wide(level)) {
+        hipLaunchKernelGGL(gather_keys64_kernel, grid_for(n), dim3(256), 0, s, d_points, cur, n, level, k,
+                           (uint64_t*)keys_a, nan_flag);
+        A3D_TRY(kdtree_radix_sort_pairs(s, (uint64_t*)keys_a, (uint64_t*)keys_b, cur, nxt, n, 32 + (int)level, hist,
+                                        &sorted_in_nxt));
+      } else {
+        uint32_t cap_log2 = 5;
+        while ((1u << cap_log2) < max_len(level)) ++cap_log2;
+        // positions outside this level's ranges (already leaves) keep their order
+        A3D_HIP_TRY(hipMemcpyAsync(nxt, cur, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        A3D_TRY(kdtree_sort_ranges(s, d_points, cur, nxt, n, level, k, cap_log2, nan_flag));
+      }
+      if (sorted_in_nxt) std::swap(cur, nxt);
+      hipLaunchKernelGGL(extract_splits_kernel, grid_for(nodes), dim3(256), 0, s, d_points, cur, n, level, k,
+                         t->d_split);
+      continue;
+    }
     if (level_is_wide(level)) {
       hipLaunchKernelGGL(gather_keys64_kernel, grid_for(n), dim3(256), 0, s, d_points, cur, n, level, k,
                          (uint64_t*)keys_a, nan_flag);

@@ -93,8 +93,12 @@ def test_kdtree_full_size_500k_bit_exact(ctx):
     assert np.array_equal(g2, gidx) and np.array_equal(d2, gd)
 
 
-def _build(ctx, db, mode, monkeypatch, wide_len=None):
+def _build(ctx, db, mode, monkeypatch, wide_len=None, sort=None):
     monkeypatch.setenv("A3D_KDTREE_BUILD", mode)
+    if sort is not None:
+        monkeypatch.setenv("A3D_KDTREE_SORT", sort)
+    else:
+        monkeypatch.delenv("A3D_KDTREE_SORT", raising=False)
     if wide_len is not None:
         monkeypatch.setenv("A3D_KDTREE_WIDE_LEN", str(wide_len))
     else:
@@ -117,12 +121,15 @@ def _kd_cases():
 
 @pytest.mark.parametrize("case", ["n1", "n16", "n17", "n33", "n1000", "dup", "neg", "n270213"])
 @pytest.mark.parametrize("wide_len", [None, 64, 1 << 30])
-def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, monkeypatch, case, wide_len):
-    """The device build (segmented / device-wide stable radix sorts) lays out exactly the tree of the host
-    build (std::stable_sort per node = R3dTree::new, src/kdtree.rs:28-58): split table and every leaf slot."""
+@pytest.mark.parametrize("sort", [None, "rocprim"])
+def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, monkeypatch, case, wide_len, sort):
+    """The device build (hand-written device-wide radix sort for the long ranges + LDS bitonic sort on
+    (key, position) words for the short ones; rocPRIM's stable sorts as the cross-check) lays out exactly the tree
+    of the host build (std::stable_sort per node = R3dTree::new, src/kdtree.rs:28-58): split table and every leaf
+    slot."""
     db = _kd_cases()[case]
     host = _build(ctx, db, "host", monkeypatch)
-    dev = _build(ctx, db, "device", monkeypatch, wide_len)
+    dev = _build(ctx, db, "device", monkeypatch, wide_len, sort)
     assert dev.stats() == host.stats()
     hs, hl = host.download()
     ds, dl = dev.download()
