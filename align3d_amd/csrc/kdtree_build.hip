@@ -3,13 +3,13 @@
 // The reference sorts the index list of every node by one coordinate (stable sort, depth % 3), splits it at
 // len / 2 and recurses until len <= 16.  The shape of that recursion depends on N only, so level d of the
 // tree is a set of disjoint index ranges that is known without looking at the data; the device build runs
-// one SEGMENTED STABLE radix sort per level over all ranges of that level at once:
+// one SEGMENTED STABLE sort per level over all ranges of that level at once:
 //   keys   = coordinate (d % 3) of the point each index refers to, with -0.0 canonicalised to +0.0 so that
 //            the radix order equals `partial_cmp` (which calls the two zeros equal) and stability then keeps
 //            the parent's order among equal keys, exactly like `slice::sort_by`;
 //   values = the indices.
-// rocPRIM's segmented sort gives one workgroup to each range, which is right for the thousands of short ranges
-// of the deep levels but would leave the chip idle on the few long ranges at the top; those levels use ONE
+// One workgroup per range (or per handful of short ranges) is right for the thousands of short ranges of the
+// deep levels but would leave the chip idle on the few long ranges at the top; those levels use ONE
 // device-wide stable radix sort instead, on 64-bit keys (range number << 32 | order-preserving key bits).
 // The sorts are hand-written (kdtree_sort.hip); rocPRIM's stable radix sorts (a ROCm header library) stay behind
 // A3D_KDTREE_SORT=rocprim as a cross-check.  Key gather, NaN detection, range tables, split extraction and leaf
