@@ -233,6 +233,38 @@ __global__ void __launch_bounds__(256)
       const uint32_t i = base + (uint32_t)(k0 + g) * 256u;
       return stage_a(d, i, (k0 < PPT) && (i < d.src_n));
     };
+    if (G == 1) {
+      // Two pipeline steps per trip with the buffers swapping roles, so that the rotation cur <- nxt, s1 <- s2
+      // costs no register copies (a rolled loop spent ~30 v_mov per pixel on it; the kernel is VALU-issue bound).
+      SrcPx sa, sb;
+      ProjPx pa, pb;
+      float ia, ib;
+      {
+        const SrcPx s0 = src_at(0, 0);
+        sa = src_at(1, 0);
+        pa = stage_b(d, T, s0, twf, thf);
+        ia = s0.intensity;
+      }
+      // one step: `cur` holds the projected pixel k, `s_next` the source record of pixel k+1 (consumed here);
+      // leaves the projected pixel k+1 in `nxt` and the source record of pixel k+2 in `s_new`
+      auto step = [&](ProjPx& cur, float cur_i, ProjPx& nxt, float& nxt_i, const SrcPx& s_next, SrcPx& s_new, int k0) {
+        const SrcPx fresh = src_at(k0 + 2, 0);                      // issue source record k+2
+        const MapPx mp = stage_c(d, gt, cur, mw);                   // gathers(k) land; issue map cell(k)
+        nxt = stage_b(d, T, s_next, twf, thf);                      // issue gathers(k+1)
+        nxt_i = s_next.intensity;
+        s_new = fresh;
+        if (cur.live) {
+          const Terms t = stage_d(d, gt, cur, mp, cur_i, mw);
+          gn_step(acc, t.rg, t.Jg);  // the geometric term is accumulated even when the colour term is rejected
+          if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
+        }
+      };
+#pragma unroll 1
+      for (int k0 = 0; k0 < PPT; k0 += 2) {
+        step(pa, ia, pb, ib, sa, sb, k0);
+        if (k0 + 1 < PPT) step(pb, ib, pa, ia, sb, sa, k0 + 1);
+      }
+    } else {
     SrcPx s1[G];
     ProjPx cur[G];
     float cur_int[G];
@@ -269,6 +301,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int g = 0; g < G; ++g) cur[g] = nxt[g], cur_int[g] = nxt_int[g], s1[g] = s2[g];
     }
+    }  // G != 1
   }
   // a failed job stays frozen: its blocks contribute nothing and nobody runs its solve
   SolveArgs sa = solve;
