@@ -155,6 +155,7 @@ a3d_status a3d_range_image_free(a3d_device_image* im) {
 }
 
 a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
+  if (im) hipSetDevice(im->ctx->device);
   A3D_REQUIRE(im, A3D_INVALID_PARAMETER, "image is null");
   const size_t n = (size_t)im->width * im->height;
   A3D_REQUIRE(im->normals || !im->arena, A3D_INVALID_PARAMETER,
@@ -166,6 +167,7 @@ a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
 }
 
 a3d_status a3d_range_image_download_normals(a3d_device_image* im, float* out) {
+  if (im) hipSetDevice(im->ctx->device);
   A3D_REQUIRE(im && out, A3D_INVALID_PARAMETER, "null argument");
   A3D_REQUIRE(im->has_normals, A3D_MISSING_FIELD, "image has no normals");
   const size_t n = (size_t)im->width * im->height;

@@ -1003,6 +1003,7 @@ a3d_status acquire_single_engine(a3d_context* ctx, const a3d_icp_params* params,
 a3d_status align_single(a3d_context* ctx, const a3d_icp_params* params, uint32_t n_levels,
                         const a3d_device_image* const* targets, const a3d_device_image* const* sources,
                         const a3d_pose* init, a3d_pose* out_pose, float* host_trace) {
+  A3D_HIP_TRY(hipSetDevice(ctx->device));  // the caller's thread may have another device current
   a3d_multiscale_batch* b = nullptr;
   A3D_TRY(acquire_single_engine(ctx, params, n_levels, &b));
   for (uint32_t l = 0; l < n_levels; ++l) A3D_TRY(fill_desc(targets[l], sources[l], &b->h_descs[l]));
@@ -1146,6 +1147,7 @@ a3d_status a3d_multiscale_batch_new(a3d_context* ctx, const a3d_icp_params* para
 a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* b, a3d_pose* out_poses_host, float* out_matrices_device,
                                       int32_t* out_status_host) {
   A3D_REQUIRE(b, A3D_INVALID_PARAMETER, "batch is null");
+  A3D_HIP_TRY(hipSetDevice(b->ctx->device));
   A3D_TRY(batch_enqueue(b, nullptr, b->n_levels, out_matrices_device, nullptr, 0));
   if (!out_poses_host && !out_status_host) return A3D_OK;
   a3d_status worst;

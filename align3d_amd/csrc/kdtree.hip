@@ -257,6 +257,7 @@ a3d_status a3d_kdtree_nearest_device(a3d_kdtree* t, const void* d_queries, uint6
   A3D_REQUIRE(t && (m == 0 || (d_queries && d_indices && d_sqr)), A3D_INVALID_PARAMETER, "null argument");
   A3D_TRY(check_finite_query_count(m));
   if (m == 0) return A3D_OK;
+  A3D_HIP_TRY(hipSetDevice(t->ctx->device));
   // enough blocks to fill the chip, few enough that the 16 KiB LDS copy of the split table's top is amortised
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((m + 255) / 256, (uint64_t)std::max(1, t->ctx->num_cus) * 8);
   hipLaunchKernelGGL(kdtree_nearest_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, t->d_split, t->d_leaves, t->n,
@@ -271,6 +272,7 @@ a3d_status a3d_kdtree_nearest(a3d_kdtree* t, const float* queries, uint64_t m, u
   A3D_REQUIRE(t && (m == 0 || (queries && out_indices && out_sqr)), A3D_INVALID_PARAMETER, "null argument");
   A3D_TRY(check_finite_query_count(m));
   if (m == 0) return A3D_OK;
+  A3D_HIP_TRY(hipSetDevice(t->ctx->device));
   hipStream_t s = t->ctx->stream;
   float *d_q = nullptr, *d_d = nullptr;
   uint32_t* d_i = nullptr;
@@ -371,6 +373,7 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
 
 static a3d_status pcl_upload_source(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, float** d_pts,
                                     float** d_nrm) {
+  A3D_HIP_TRY(hipSetDevice(icp->ctx->device));
   // the reference `expect`s both normal sets at align time (pcl_icp.rs:50-58)
   A3D_REQUIRE(icp->target_has_normals, A3D_MISSING_FIELD, "Please, the target point cloud should have normals.");
   A3D_REQUIRE(source->normals, A3D_MISSING_FIELD, "Please, the source point cloud should have normals.");
