@@ -129,6 +129,8 @@ SIGNATURES = {
     "a3d_timer_start": (_ST, [_P]),
     "a3d_timer_stop": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_malloc": (_ST, [_P, C.c_size_t, _PP]),
+    "a3d_host_alloc": (_ST, [_P, C.c_size_t, _PP]),
+    "a3d_host_free": (_ST, [_P, _P]),
     "a3d_free": (_ST, [_P, _P]),
     "a3d_memcpy_h2d": (_ST, [_P, _P, _P, C.c_size_t]),
     "a3d_memcpy_d2h": (_ST, [_P, _P, _P, C.c_size_t]),
@@ -167,6 +169,7 @@ SIGNATURES = {
     ),
     "a3d_multiscale_batch_align": (_ST, [_P, C.POINTER(PoseC), _P, C.POINTER(C.c_int32)]),
     "a3d_multiscale_batch_free": (_ST, [_P]),
+    "a3d_multiscale_batch_rebind": (_ST, [_P, _P, _P]),
     "a3d_multiscale_batch_last_timing": (_ST, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "a3d_multiscale_batch_set_profiling": (_ST, [_P, C.c_int32]),
     "a3d_multiscale_batch_last_kernel_ms": (_ST, [_P, C.POINTER(C.c_float)]),

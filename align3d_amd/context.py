@@ -38,6 +38,23 @@ class Context:
     def free(self, p):
         _abi.check(self.lib.a3d_free(self.handle, p))
 
+    def pinned_empty(self, shape, dtype):
+        """A numpy array in page-locked host memory (a3d_host_alloc); frames built from it are uploaded by DMA.
+        The memory is released when the array (and every view of it) has been garbage collected."""
+        import numpy as np
+
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        _abi.check(self.lib.a3d_host_alloc(self.handle, n, C.byref(p)), "a3d_host_alloc")
+        buf = (C.c_char * max(1, n)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        lib, handle = self.lib, self.handle
+
+        import weakref
+        weakref.finalize(buf, lambda: lib.a3d_host_free(handle, p) if handle else None)
+        return arr
+
     def to_device(self, arr):
         p = self.malloc(arr.nbytes)
         _abi.check(self.lib.a3d_memcpy_h2d(self.handle, p, _abi.ptr(arr), arr.nbytes))

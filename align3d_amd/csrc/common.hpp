@@ -108,7 +108,7 @@ struct DeviceArena {
 a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void* host, size_t bytes, void** out);
 
 // An arena of at least `bytes` from the context's pool, or a fresh hipMalloc; release returns it to the pool
-// (at most four are kept) or frees it.
+// (up to 128 arenas / 4 GiB per context are kept) or frees it.
 a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out);
 void ctx_arena_release(a3d_context* ctx, DeviceArena* arena);
 }  // namespace a3d

@@ -107,7 +107,10 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
 void ctx_arena_release(a3d_context* ctx, DeviceArena* arena) {
   {
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
-    if (ctx->arena_pool.size() < 4) {
+    size_t pooled = 0;
+    for (const auto& a : ctx->arena_pool) pooled += a.second;
+    // keep up to 128 arenas / 4 GiB per context: a round of a frame stream is freed before the next is built
+    if (ctx->arena_pool.size() < 128 && pooled + arena->bytes <= (4ull << 30)) {
       ctx->arena_pool.emplace_back(arena->base, arena->bytes);
       arena->base = nullptr;
     }
@@ -211,6 +214,17 @@ a3d_status a3d_malloc(a3d_context* ctx, size_t bytes, void** out) {
 a3d_status a3d_free(a3d_context* ctx, void* p) {
   A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
   if (p) A3D_HIP_TRY(hipFree(p));
+  return A3D_OK;
+}
+a3d_status a3d_host_alloc(a3d_context* ctx, size_t bytes, void** out) {
+  A3D_REQUIRE(ctx && out, A3D_INVALID_PARAMETER, "null argument");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  A3D_HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return A3D_OK;
+}
+a3d_status a3d_host_free(a3d_context* ctx, void* p) {
+  A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
+  if (p) A3D_HIP_TRY(hipHostFree(p));
   return A3D_OK;
 }
 a3d_status a3d_memcpy_h2d(a3d_context* ctx, void* dst, const void* src, size_t bytes) {

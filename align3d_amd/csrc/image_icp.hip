@@ -1144,6 +1144,22 @@ a3d_status a3d_multiscale_batch_new(a3d_context* ctx, const a3d_icp_params* para
   return A3D_OK;
 }
 
+a3d_status a3d_multiscale_batch_rebind(a3d_multiscale_batch* b, const a3d_device_image* const* target_pyramids,
+                                       const a3d_device_image* const* source_pyramids) {
+  A3D_REQUIRE(b && target_pyramids && source_pyramids, A3D_INVALID_PARAMETER, "null argument");
+  A3D_HIP_TRY(hipSetDevice(b->ctx->device));
+  // the descriptors of the previous batch may still be in use by launches that have not run yet
+  A3D_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  const uint32_t P = b->n_pairs, L = b->n_levels;
+  for (uint32_t p = 0; p < P; ++p)
+    for (uint32_t l = 0; l < L; ++l)
+      A3D_TRY(fill_desc(target_pyramids[(size_t)p * L + l], source_pyramids[(size_t)p * L + l],
+                        &b->h_descs[(size_t)l * P + p]));
+  A3D_TRY(batch_commit_descs(b));
+  A3D_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  return A3D_OK;
+}
+
 a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* b, a3d_pose* out_poses_host, float* out_matrices_device,
                                       int32_t* out_status_host) {
   A3D_REQUIRE(b, A3D_INVALID_PARAMETER, "batch is null");

@@ -133,6 +133,19 @@ class MultiscaleAlignBatch:
             raise _abi.InvalidParameter(ctx.lib.a3d_last_error().decode())
         _abi.check(st, "a3d_multiscale_batch_new")
 
+    def rebind(self, target_pyramids, source_pyramids):
+        """The same batch object on other pyramids (same pair / level counts): nothing is allocated or freed."""
+        assert len(target_pyramids) == self.n_pairs and len(source_pyramids) == self.n_pairs
+        t_flat, s_flat = [], []
+        for tp, sp in zip(target_pyramids, source_pyramids):
+            assert len(tp) == self.n_levels and len(sp) == self.n_levels
+            t_flat += [_dev(self.ctx, t) for t in tp]
+            s_flat += [_dev(self.ctx, s) for s in sp]
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_rebind(self.handle, _handle_array(t_flat), _handle_array(s_flat)),
+                   "a3d_multiscale_batch_rebind")
+        self._keep = (t_flat, s_flat)
+        return self
+
     def align(self, matrices_device=None):
         """Runs all pairs; returns (list of Transform, int32 status array)."""
         poses = (_abi.PoseC * self.n_pairs)()

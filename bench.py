@@ -204,6 +204,69 @@ def named_shapes_bench(ctx, targets, sources):
     return out
 
 
+def streaming_bench(ctx, params, P, W, H, rounds=4, builders=4, pinned=True):
+    """End to end from host frames: every round, P + 1 NEW frames (u16 depth + u8 RGB in host memory) are uploaded
+    and built into resident pyramids by `builders` threads, each on its own context (HIP stream + scratch), while
+    the previous round's P frame pairs are being aligned on the main context.  Reports pairs/s with every frame
+    crossing PCIe and being filtered / back-projected / pyramided exactly once."""
+    import threading
+
+    frames, _ = synth.frame_stream(4242, P + 1, W, H)  # the same host frames every round: they are rebuilt each time
+    if pinned:  # page-locked host buffers: the upload is a DMA at the PCIe rate, not the pageable staging path
+        held = []
+        for d, rgb in frames:
+            pd, pr = ctx.pinned_empty(d.shape, d.dtype), ctx.pinned_empty(rgb.shape, rgb.dtype)
+            pd[...], pr[...] = d, rgb
+            held.append((pd, pr))
+        frames = held
+    cam = synth.camera(W, H)
+    ctxs = [Context(ctx.device_index) for _ in range(builders)]
+    bld = [RangeImageBuilder(c).with_bilateral_filter(BilateralFilter.default()) for c in ctxs]
+
+    def build_round():
+        out = [None] * (P + 1)
+
+        def work(k):
+            for i in range(k, P + 1, builders):
+                out[i] = bld[k].build_device(cam, frames[i][0], frames[i][1], synth.DEPTH_SCALE)
+            ctxs[k].synchronize()
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(builders)]
+        for t in ts:
+            t.start()
+        return out, ts
+
+    def free_round(pyr):
+        for lv in (lv for p in pyr for lv in p):
+            lv.free()
+
+    cur, ts = build_round()  # warm-up round (scratch, arena pools, code objects)
+    for t in ts:
+        t.join()
+    batch = MultiscaleAlignBatch(ctx, params, cur[:P], cur[1:])
+    batch.align()
+    t0 = time.perf_counter()
+    failed = 0
+    for _ in range(rounds):
+        nxt, ts = build_round()                      # builders work on the next round ...
+        batch.rebind(cur[:P], cur[1:])               # (one batch object for the whole stream: nothing allocated)
+        _, status = batch.align()                    # ... while this round is aligned
+        failed += int(np.count_nonzero(status))
+        for t in ts:
+            t.join()
+        free_round(cur)
+        cur = nxt
+    dt = time.perf_counter() - t0
+    batch.free()
+    free_round(cur)
+    for c in ctxs:
+        c.close()
+    return {"workload": f"{rounds} rounds of {P} pairs, {P + 1} new frames per round from "
+                        f"{'page-locked' if pinned else 'pageable'} host memory, "
+                        f"{builders} builder threads overlapping the alignment of the previous round",
+            "pairs_per_s": rounds * P / dt, "frames_built_per_s": rounds * (P + 1) / dt, "failed_pairs": failed}
+
+
 def odometry_bench(ctx, n_frames=20):
     """configs[3] shape: a 20-frame odometry stream (synthetic: no TUM / IL-RGBD data exists on the box), frames
     enter as u16 depth + u8 RGB, persistent device pyramids, MsIcpParams::default() (README usage)."""
@@ -424,6 +487,7 @@ def main():
             # back-projection, normals, pyramid, luma and intensity maps on the device
             extra["frame_build_ms_incl_pcie"] = build_ms
             extra["pairs_per_s_including_one_frame_build_per_pair"] = 1e3 / (build_ms + ms_per_step / P)
+            extra["streaming_from_host_frames"] = streaming_bench(ctx, params, P, W, H)
         cpu = None
         if world == 1 and args.cpu_pairs > 0:
             cpu = cpu_baseline(host_pyramids, params, min(args.cpu_pairs, P), poses)

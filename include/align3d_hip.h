@@ -131,6 +131,10 @@ a3d_status a3d_timer_stop(a3d_context* ctx, float* out_ms);
 /* Raw device memory on the context's GPU (bench / tests keep inputs resident with these). */
 a3d_status a3d_malloc(a3d_context* ctx, size_t bytes, void** out_device_ptr);
 a3d_status a3d_free(a3d_context* ctx, void* device_ptr);
+/* Page-locked host memory (hipHostMalloc): frames handed to a3d_range_image_build_pyramid from such a buffer are
+ * copied by DMA at the PCIe rate instead of through the runtime's pageable staging path. */
+a3d_status a3d_host_alloc(a3d_context* ctx, size_t bytes, void** out_host_ptr);
+a3d_status a3d_host_free(a3d_context* ctx, void* host_ptr);
 a3d_status a3d_memcpy_h2d(a3d_context* ctx, void* dst_device, const void* src_host, size_t bytes);
 a3d_status a3d_memcpy_d2h(a3d_context* ctx, void* dst_host, const void* src_device, size_t bytes);
 a3d_status a3d_memcpy_d2d(a3d_context* ctx, void* dst_device, const void* src_device, size_t bytes);
@@ -232,6 +236,10 @@ a3d_status a3d_multiscale_batch_new(a3d_context* ctx, const a3d_icp_params* para
  * out_poses_host == NULL and out_status_host == NULL the call only enqueues (no host sync). */
 a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* batch, a3d_pose* out_poses_host,
                                       float* out_matrices_device, int32_t* out_status_host);
+/* Points an existing batch at other pyramids (same pair and level counts, same layout as _new): the next
+ * batch_align runs on them.  A stream of batches reuses one object and allocates nothing per batch. */
+a3d_status a3d_multiscale_batch_rebind(a3d_multiscale_batch* batch, const a3d_device_image* const* target_pyramids,
+                                       const a3d_device_image* const* source_pyramids);
 a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* batch);
 /* Instrumentation: when on, every launch of the per-pixel kernel is bracketed by its own hipEvent pair
  * on the stream it is launched on, and a3d_multiscale_batch_last_kernel_ms returns the sum of those durations
