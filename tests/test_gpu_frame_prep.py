@@ -169,3 +169,21 @@ def test_bilateral_fused_and_unfused_paths_agree(ctx, monkeypatch):
             outs[mode] = f.filter(ctx, img)
             assert f.last_grid_dims == dims
         assert st == 0 and np.array_equal(outs["fused"], ref) and np.array_equal(outs["unfused"], ref)
+
+
+def test_frames_in_page_locked_host_memory_build_the_same_pyramid(ctx):
+    from align3d_amd import CameraIntrinsics, RangeImageBuilder
+
+    s = SlamTbSample("sample1")
+    depth, rgb = s.load(4)
+    cam = CameraIntrinsics(*s.intrinsics(4), 640, 480)
+    pd, pr = ctx.pinned_empty(depth.shape, depth.dtype), ctx.pinned_empty(rgb.shape, rgb.dtype)
+    pd[...], pr[...] = depth, rgb
+    b = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+    a_levels = b.build_device(cam, depth, rgb, s.depth_scale(4))
+    p_levels = b.build_device(cam, pd, pr, s.depth_scale(4))
+    for x, y in zip(a_levels, p_levels):
+        gx, gy = x.download(), y.download()
+        assert np.array_equal(_bits(gx.points), _bits(gy.points)) and np.array_equal(gx.mask, gy.mask)
+        assert np.array_equal(_bits(gx.normals), _bits(gy.normals)) and np.array_equal(gx.colors, gy.colors)
+        assert np.array_equal(_bits(gx.intensity_map), _bits(gy.intensity_map))

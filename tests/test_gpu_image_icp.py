@@ -290,3 +290,28 @@ def test_stream_groups_do_not_change_any_pair(ctx, monkeypatch):
     # equal inputs give equal outputs wherever they sit in the batch
     for k in range(7, 20):
         assert np.array_equal(one[k], one[k % 7])
+
+
+def test_batch_rebind_equals_a_new_batch(ctx):
+    """a3d_multiscale_batch_rebind: one batch object pointed at other pyramids gives what a fresh batch gives."""
+    prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 4))
+    first = [("sample1", 0, 5), ("sample1", 1, 4), ("sample2", 0, 4)]
+    second = [("sample2", 1, 0), ("sample1", 4, 0), ("sample1", 5, 1)]
+
+    def pyr(pairs):
+        return ([[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs],
+                [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in pairs])
+
+    t1, s1 = pyr(first)
+    t2, s2 = pyr(second)
+    batch = MultiscaleAlignBatch(ctx, prm, t1, s1)
+    batch.align()
+    got, status = batch.rebind(t2, s2).align()
+    want, wstatus = MultiscaleAlignBatch(ctx, prm, t2, s2).align()
+    assert not status.any() and not wstatus.any()
+    for a, b in zip(got, want):
+        assert np.array_equal(a.t, b.t) and np.array_equal(a.q, b.q)
+    back, _ = batch.rebind(t1, s1).align()
+    ref, _ = MultiscaleAlignBatch(ctx, prm, t1, s1).align()
+    for a, b in zip(back, ref):
+        assert np.array_equal(a.t, b.t) and np.array_equal(a.q, b.q)
