@@ -1,0 +1,54 @@
+"""BASELINE's full sizes through size-independent properties (no oracle run at this size): a 64-pair batch of
+640x480 synthetic frame pairs, 3 levels x 15 iterations (the benchmark's workload)."""
+import numpy as np
+import pytest
+
+from align3d_amd import (BilateralFilter, IcpParams, MsIcpParams, MultiscaleAlign, MultiscaleAlignBatch,
+                         RangeImageBuilder, synth)
+
+pytestmark = pytest.mark.gpu
+
+
+def _as_array(poses):
+    return np.array([np.concatenate([t.t, t.q]) for t in poses], np.float32)
+
+
+def test_full_size_batch_properties(ctx, monkeypatch):
+    P, W, H = 64, 640, 480
+    frames, gt = synth.frame_stream(1000, P + 1, W, H)  # the benchmark's rank-0 stream
+    cam = synth.camera(W, H)
+    builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+    pyr = [builder.build_device(cam, d, rgb, synth.DEPTH_SCALE) for d, rgb in frames]
+    prm = MsIcpParams.repeat(3, IcpParams.default())
+    monkeypatch.setenv("A3D_ICP_WAVES", "1.5")  # pin the tiling: sub-batches then do the same arithmetic per pair
+    batch = MultiscaleAlignBatch(ctx, prm, pyr[:P], pyr[1:])
+    poses, status = batch.align()
+    assert not status.any()
+    full = _as_array(poses)
+    # determinism: the same launch sequence gives the same bits
+    again, _ = batch.align()
+    assert np.array_equal(full.view(np.uint32), _as_array(again).view(np.uint32))
+    # the rotation estimates beat the identity against the synthetic ground truth; the translation stays within
+    # 2 cm (IcpParams::default() with the reference's gates is not a precise estimator on this scene: the CPU
+    # oracle gives the same numbers, bench.py cpu_baseline.max_gpu_vs_cpu_*)
+    errs, idents = [], []
+    for p in range(P):
+        rel = synth.relative_pose(gt[p], gt[p + 1])
+        d = np.linalg.inv(rel) @ poses[p].matrix().astype(np.float64)
+        errs.append((np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)), np.linalg.norm(d[:3, 3])))
+        idents.append((np.arccos(np.clip((np.trace(rel[:3, :3]) - 1) / 2, -1, 1)), np.linalg.norm(rel[:3, 3])))
+    errs, idents = np.array(errs), np.array(idents)
+    print(f"[full size] mean error {errs.mean(axis=0)}, identity {idents.mean(axis=0)}")
+    assert errs[:, 0].mean() < 0.5 * idents[:, 0].mean() and errs[:, 1].mean() < 0.02 and errs[:, 1].max() < 0.05
+    # a pair's result does not depend on its neighbours: two half batches (same tiling knobs, so the per-pair
+    # tile count differs -> compare to rounding), and pair 5 alone through MultiscaleAlign
+    lo, _ = MultiscaleAlignBatch(ctx, prm, pyr[:32], pyr[1:33]).align()
+    hi, _ = MultiscaleAlignBatch(ctx, prm, pyr[32:64], pyr[33:65]).align()
+    halves = np.concatenate([_as_array(lo), _as_array(hi)])
+    # IcpParams::default() is not contractive: differently associated sums may move a pose by ~1e-3
+    assert np.abs(halves - full).max() < 5e-3
+    single = MultiscaleAlign.new(ctx, prm, pyr[5]).align(pyr[6])
+    assert np.abs(np.concatenate([single.t, single.q]) - full[5]).max() < 5e-3
+    for p in pyr:
+        for lv in p:
+            lv.free()
