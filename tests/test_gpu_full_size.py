@@ -52,3 +52,38 @@ def test_full_size_batch_properties(ctx, monkeypatch):
     for p in pyr:
         for lv in p:
             lv.free()
+
+
+def test_full_size_point_cloud_icp_properties(ctx):
+    """configs[2] at its full size (500 000 target x 500 000 source points, 15 iterations): known-motion recovery,
+    determinism, and the fixed point of aligning a cloud with itself."""
+    from align3d_amd import Icp, PointCloud, RangeImage
+
+    frames, poses = synth.frame_stream(7, 2, 880, 660)
+    cam = synth.camera(880, 660)
+    clouds = []
+    for d, rgb in frames:
+        ri = RangeImage.from_rgbd_image(cam, d, rgb, synth.DEPTH_SCALE).compute_normals(ctx)
+        pc = PointCloud.from_range_image(ri)
+        assert pc.len() >= 500_000
+        clouds.append(PointCloud(pc.points[:500_000], pc.normals[:500_000]))
+    tgt, src = clouds
+    icp = Icp.new(ctx, IcpParams.default(), tgt)
+    T = icp.align(src)
+    T2 = icp.align(src)
+    assert np.array_equal(T.t, T2.t) and np.array_equal(T.q, T2.q)
+    rel = synth.relative_pose(poses[0], poses[1])
+    dm = np.linalg.inv(rel) @ T.matrix().astype(np.float64)
+    ang = np.arccos(np.clip((np.trace(dm[:3, :3]) - 1) / 2, -1, 1))
+    ident_ang = np.arccos(np.clip((np.trace(rel[:3, :3]) - 1) / 2, -1, 1))
+    assert ang < 0.2 * ident_ang + 1e-4 and np.linalg.norm(dm[:3, 3]) < 0.5 * np.linalg.norm(rel[:3, 3]) + 1e-3
+    # a cloud aligned to itself stays where it is: almost every point finds itself in its leaf (the leaf-only
+    # search misses the few that tie with a split value), so the residual is ~0 and the estimate the identity
+    self_icp = Icp.new(ctx, IcpParams.default(), src)
+    same = self_icp.accumulate(src, type(T).eye())
+    assert 0.98 * 500_000 < same["count"] <= 500_000 and float(same["ssq"]) / same["count"] < 1e-5
+    Ts = self_icp.align(src)
+    print(f"[self alignment] t={Ts.t} q={Ts.q}")
+    assert np.abs(Ts.t).max() < 1e-3 and np.abs(Ts.q[:3]).max() < 1e-3
+    self_icp.free()
+    icp.free()
