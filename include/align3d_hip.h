@@ -110,7 +110,14 @@ typedef struct a3d_multiscale_batch a3d_multiscale_batch; /* P independent Multi
 typedef struct a3d_kdtree a3d_kdtree;                   /* R3dTree */
 typedef struct a3d_pcl_icp a3d_pcl_icp;                 /* Icp */
 
-/* ---- library / context ------------------------------------------------------------------- */
+/* ---- library / context -------------------------------------------------------------------
+ * Threading: a context owns one HIP stream, its scratch regions, the pool of pyramid arenas and the cached
+ * single-pair ICP engine; calls that take the same context (directly or through a handle created on it) must not
+ * run concurrently.  Different contexts, also on the same GPU, may be used from different threads at the same time
+ * (this is how frame builds overlap alignments); freeing an image from another thread than the one using its
+ * context is allowed.  The reference's objects are re-entrant because they borrow host memory; here a thread that
+ * wants its own concurrent `align` creates its own context.  Results are complete when a call returns, except
+ * a3d_multiscale_batch_align with no host outputs, which only enqueues (a3d_context_synchronize waits). */
 
 uint32_t a3d_abi_version(void);
 /* Text of the most recent failure on the calling thread ("" if none). */
