@@ -82,6 +82,14 @@ __device__ __forceinline__ float div_by(float a, const DivBy d) {
 __device__ __forceinline__ bool div_den_ok(float z) { return fabsf(z) > 1e-9f && fabsf(z) < 1e9f; }
 __device__ __forceinline__ bool div_num_ok(float a) { return a == 0.0f || (fabsf(a) > 1e-20f && fabsf(a) < 1e9f); }
 
+// Byte offset of texel (row, col) in an f32 image `width` texels wide.  Written as a 24-bit multiply-add
+// (rows, columns and widths are far below 2^24): the generic 32-bit form compiles to v_mad_u64_u32 with a 64-bit
+// addend whose unused high half the register allocator parks on a register that still has a load in flight,
+// and the resulting s_waitcnt vmcnt(0) drains the whole software pipeline once per pixel.
+__device__ __forceinline__ uint32_t texel_offset(uint32_t row, uint32_t width, uint32_t col) {
+  return (__umul24(row, width) + col) * 4u;
+}
+
 // IntensityMap::bilinear (src/intensity_map.rs:150-169) from four already-loaded texels.
 __device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v11, float uf, float vf) {
   float u0 = v00 * (1.0f - uf) + v10 * uf;
@@ -90,7 +98,7 @@ __device__ __forceinline__ float bilerp(float v00, float v10, float v01, float v
 }
 __device__ __forceinline__ float bilinear_at(const float* imap, uint32_t mw, float u, float v) {
   const uint32_t ui = f32_as_usize(u), vi = f32_as_usize(v);
-  const uint32_t o = (vi * mw + ui) * 4u;
+  const uint32_t o = texel_offset(vi, mw, ui);
   const f32x2 a = ld<f32x2_u>(imap, o), b = ld<f32x2_u>(imap, o + mw * 4u);
   return bilerp(a.x, a.y, b.x, b.y, u - (float)ui, v - (float)vi);
 }
@@ -106,7 +114,10 @@ __device__ __forceinline__ SrcPx stage_a(const LevelDesc& d, uint32_t i, bool in
   SrcPx s;
   s.sp = ld_v3(d.src_points, ii);
   s.intensity = (float)ld<uint8_t>(d.src_intensities, ii);
-  s.live = in_range && (ld<uint8_t>(d.src_mask, ii) != 0);  // mask != 0 (image_icp.rs:102)
+  // the mask byte is loaded unconditionally: `in_range && load != 0` compiles to a branch around the load with an
+  // s_waitcnt vmcnt(0) behind it, which drains every load in flight (the whole software pipeline) once per pixel
+  const uint8_t mask = ld<uint8_t>(d.src_mask, ii);
+  s.live = in_range & (mask != 0);  // mask != 0 (image_icp.rs:102)
   return s;
 }
 
@@ -135,7 +146,7 @@ __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, con
   o.live = s.live && !(ur <= -1.0f || ur >= twf || vr <= -1.0f || vr >= thf);
   const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
   const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
-  const uint32_t tidx = o.live ? row * d.tw + col : 0u;
+  const uint32_t tidx = o.live ? __umul24(row, d.tw) + col : 0u;
   o.tp = ld_v3(d.tgt_points, tidx);
   o.tn = ld_v3(d.tgt_normals, tidx);
   o.tmask = ld<uint8_t>(d.tgt_mask, tidx);
@@ -156,7 +167,7 @@ __device__ __forceinline__ MapPx stage_c(const LevelDesc& d, const Gates& gt, Pr
   MapPx m;
   m.ui = px.live ? f32_as_usize(px.u) : 0u;
   m.vi = px.live ? f32_as_usize(px.v) : 0u;
-  const uint32_t o = (m.vi * mw + m.ui) * 4u;
+  const uint32_t o = texel_offset(m.vi, mw, m.ui);
   const f32x2 a = ld<f32x2_u>(d.imap, o), b = ld<f32x2_u>(d.imap, o + mw * 4u);
   m.t00 = a.x, m.t10 = a.y, m.t01 = b.x, m.t11 = b.y;
   return m;
