@@ -106,14 +106,15 @@ __device__ __forceinline__ float bilinear_at(const float* imap, uint32_t mw, flo
 // ---- the reference's pixel loop (image_icp.rs:101-139), in four stages -----------------------------------
 struct SrcPx {  // stage A: one source record
   V3 sp;
-  float intensity;  // u8 as f32 (exact)
+  uint8_t intensity;   // the raw byte; converted to f32 where it is used (stage D), two steps after its load,
+                       // so that the conversion does not wait for the load inside the step that issued it
   bool live;
 };
 __device__ __forceinline__ SrcPx stage_a(const LevelDesc& d, uint32_t i, bool in_range) {
   const uint32_t ii = in_range ? i : 0u;
   SrcPx s;
   s.sp = ld_v3(d.src_points, ii);
-  s.intensity = (float)ld<uint8_t>(d.src_intensities, ii);
+  s.intensity = ld<uint8_t>(d.src_intensities, ii);
   // the mask byte is loaded unconditionally: `in_range && load != 0` compiles to a branch around the load with an
   // s_waitcnt vmcnt(0) behind it, which drains every load in flight (the whole software pipeline) once per pixel
   const uint8_t mask = ld<uint8_t>(d.src_mask, ii);
@@ -179,7 +180,7 @@ struct Terms {  // stage D: the two residuals and Jacobians of a live pixel
   bool color;
 };
 __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, const ProjPx& px, const MapPx& m,
-                                         float intensity, uint32_t mw) {
+                                         uint8_t intensity, uint32_t mw) {
   Terms t;
   const V3 P = px.p, n = px.tn;
   {  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
@@ -199,7 +200,7 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
                                               : bilinear_at(d.imap, mw, px.u, v2);
   const float du = (uh - value) * H_INV;
   const float dv = (vh - value) * H_INV;
-  const float sc = intensity * 0.003921569f;  // image_icp.rs:131
+  const float sc = (float)intensity * 0.003921569f;  // image_icp.rs:131 (u8 -> f32 is exact)
   // CameraIntrinsics::project_grad (src/camera.rs:82-89): fx / z, -x fx / zz, fy / z, -y fy / zz
   const float z = P.z, zz = z * z;
   const float nxf = -P.x * d.fx, nyf = -P.y * d.fy;
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256)
       // costs no register copies (a rolled loop spent ~30 v_mov per pixel on it; the kernel is VALU-issue bound).
       SrcPx sa, sb;
       ProjPx pa, pb;
-      float ia, ib;
+      uint8_t ia, ib;
       {
         const SrcPx s0 = src_at(0, 0);
         sa = src_at(1, 0);
@@ -258,12 +259,11 @@ __global__ void __launch_bounds__(256)
       }
       // one step: `cur` holds the projected pixel k, `s_next` the source record of pixel k+1 (consumed here);
       // leaves the projected pixel k+1 in `nxt` and the source record of pixel k+2 in `s_new`
-      auto step = [&](ProjPx& cur, float cur_i, ProjPx& nxt, float& nxt_i, const SrcPx& s_next, SrcPx& s_new, int k0) {
-        const SrcPx fresh = src_at(k0 + 2, 0);                      // issue source record k+2
+      auto step = [&](ProjPx& cur, uint8_t cur_i, ProjPx& nxt, uint8_t& nxt_i, const SrcPx& s_next, SrcPx& s_new, int k0) {
+        s_new = src_at(k0 + 2, 0);                                  // issue source record k+2
         const MapPx mp = stage_c(d, gt, cur, mw);                   // gathers(k) land; issue map cell(k)
         nxt = stage_b(d, T, s_next, twf, thf);                      // issue gathers(k+1)
         nxt_i = s_next.intensity;
-        s_new = fresh;
         if (cur.live) {
           const Terms t = stage_d(d, gt, cur, mp, cur_i, mw);
           gn_step(acc, t.rg, t.Jg);  // the geometric term is accumulated even when the colour term is rejected
@@ -271,14 +271,14 @@ __global__ void __launch_bounds__(256)
         }
       };
 #pragma unroll 1
-      for (int k0 = 0; k0 < PPT; k0 += 2) {
+      for (int k0 = 0; k0 < PPT; k0 += 2) {  // PPT is even (batch_commit_descs); surplus pixels are out of range
         step(pa, ia, pb, ib, sa, sb, k0);
-        if (k0 + 1 < PPT) step(pb, ib, pa, ia, sb, sa, k0 + 1);
+        step(pb, ib, pa, ia, sb, sa, k0 + 1);
       }
     } else {
     SrcPx s1[G];
     ProjPx cur[G];
-    float cur_int[G];
+    uint8_t cur_int[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const SrcPx s0 = src_at(0, g);
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256)
       SrcPx s2[G];
       MapPx mp[G];
       ProjPx nxt[G];
-      float nxt_int[G];
+      uint8_t nxt_int[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) s2[g] = src_at(k0 + 2 * G, g);  // issue source records of batch k+2
 #pragma unroll
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256, 3)  // at most 168 VGPRs: three blocks pe
       };
       SrcPx s1[G];
       ProjPx cur[G];
-      float cur_int[G];
+      uint8_t cur_int[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const SrcPx s0 = src_at(0, g);
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256, 3)  // at most 168 VGPRs: three blocks pe
         SrcPx s2[G];
         MapPx mp[G];
         ProjPx nxt[G];
-        float nxt_int[G];
+        uint8_t nxt_int[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) s2[g] = src_at(k0 + 2 * G, g);
 #pragma unroll
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(256)
     };
     SrcPx s1[G];
     ProjPx cur[G];
-    float cur_int[G];
+    uint8_t cur_int[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const SrcPx s0 = src_at(0, g);
@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(256)
       SrcPx s2[G];
       MapPx mp[G];
       ProjPx nxt[G];
-      float nxt_int[G];
+      uint8_t nxt_int[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) s2[g] = src_at(k0 + 2 * G, g);
 #pragma unroll
@@ -751,6 +751,10 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
       if (l < 3) waves = wl[l];
     }
     choose_tiling(P, max_n, b->resident_blocks, waves, b->group[l], &b->tiles[l], &b->ppt[l]);
+    if (b->group[l] == 1 && !b->use_mfma && (b->ppt[l] & 1u)) {  // image_icp_kernel<1> takes two pipeline steps per trip
+      ++b->ppt[l];
+      b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
+    }
     if ((b->level_mask >> l) & 1u) {  // every block of every group must be resident at once for this level
       b->group[l] = 1;
       choose_tiling(P, max_n, b->level_resident_blocks, 1.0f, 1, &b->tiles[l], &b->ppt[l]);
