@@ -79,8 +79,9 @@ __device__ __forceinline__ float div_by(float a, const DivBy d) {
   const float r2 = __builtin_fmaf(d.negz, q1, a);
   return __builtin_fmaf(r2, d.y, q1);
 }
-__device__ __forceinline__ bool div_den_ok(float z) { return fabsf(z) > 1e-9f && fabsf(z) < 1e9f; }
-__device__ __forceinline__ bool div_num_ok(float a) { return a == 0.0f || (fabsf(a) > 1e-20f && fabsf(a) < 1e9f); }
+// (bitwise on purpose: short-circuit forms compile to a chain of exec-mask branches in the pixel loop)
+__device__ __forceinline__ bool div_den_ok(float z) { return (fabsf(z) > 1e-9f) & (fabsf(z) < 1e9f); }
+__device__ __forceinline__ bool div_num_ok(float a) { return (a == 0.0f) | ((fabsf(a) > 1e-20f) & (fabsf(a) < 1e9f)); }
 
 // Byte offset of texel (row, col) in an f32 image `width` texels wide.  Written as a 24-bit multiply-add
 // (rows, columns and widths are far below 2^24): the generic 32-bit form compiles to v_mad_u64_u32 with a 64-bit
@@ -138,7 +139,7 @@ __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, con
   float qu = div_by(au, dz), qv = div_by(av, dz);
   // rare: some lane is outside the fast range -> the whole wave takes the plain IEEE divide (same values
   // where both apply); a wave-uniform branch, so the slow sequence is not speculated into the hot path
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(div_den_ok(z) && div_num_ok(au) && div_num_ok(av))) != 0ull, 0))
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(div_den_ok(z) & div_num_ok(au) & div_num_ok(av))) != 0ull, 0))
     qu = au / z, qv = av / z;
   o.u = qu + d.cx;
   o.v = qv + d.cy;
@@ -206,8 +207,8 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
   const float nxf = -P.x * d.fx, nyf = -P.y * d.fy;
   const DivBy dz = div_prepare(z), dzz = div_prepare(zz);
   float dfx = div_by(d.fx, dz), dfy = div_by(d.fy, dz), dcx = div_by(nxf, dzz), dcy = div_by(nyf, dzz);
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(div_den_ok(z) && div_den_ok(zz) && div_num_ok(nxf) &&
-                                                     div_num_ok(nyf) && div_num_ok(d.fx) && div_num_ok(d.fy))) != 0ull,
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(div_den_ok(z) & div_den_ok(zz) & div_num_ok(nxf) &
+                                                     div_num_ok(nyf) & div_num_ok(d.fx) & div_num_ok(d.fy))) != 0ull,
                        0))
     dfx = d.fx / z, dfy = d.fy / z, dcx = nxf / zz, dcy = nyf / zz;  // rare: plain IEEE divide (wave-uniform)
   const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
