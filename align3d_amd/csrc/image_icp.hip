@@ -145,7 +145,7 @@ __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, con
   o.v = qv + d.cy;
   // (u + 0.5) as i32 -> as usize -> get_point bounds test: in range iff -1 < x < dim (NaN casts to 0)
   const float ur = o.u + 0.5f, vr = o.v + 0.5f;
-  o.live = s.live && !(ur <= -1.0f || ur >= twf || vr <= -1.0f || vr >= thf);
+  o.live = s.live & !((ur <= -1.0f) | (ur >= twf) | (vr <= -1.0f) | (vr >= thf));
   const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
   const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
   const uint32_t tidx = o.live ? __umul24(row, d.tw) + col : 0u;
@@ -194,11 +194,15 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
   const float value = bilerp(m.t00, m.t10, m.t01, m.t11, uf, vf);
   const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
   const float u2 = px.u + Hh, v2 = px.v + Hh;
-  // the shifted samples share the cell except within 0.005 of a texel boundary
-  const float uh = (f32_as_usize(u2) == m.ui) ? bilerp(m.t00, m.t10, m.t01, m.t11, u2 - (float)m.ui, vf)
-                                              : bilinear_at(d.imap, mw, u2, px.v);
-  const float vh = (f32_as_usize(v2) == m.vi) ? bilerp(m.t00, m.t10, m.t01, m.t11, uf, v2 - (float)m.vi)
-                                              : bilinear_at(d.imap, mw, px.u, v2);
+  // the shifted samples share the cell except within 0.005 of a texel boundary: those (rare) lanes resample
+  // from memory, behind ONE wave-uniform branch so that the common path has no per-lane branches
+  float uh = bilerp(m.t00, m.t10, m.t01, m.t11, u2 - (float)m.ui, vf);
+  float vh = bilerp(m.t00, m.t10, m.t01, m.t11, uf, v2 - (float)m.vi);
+  const bool u_leaves = f32_as_usize(u2) != m.ui, v_leaves = f32_as_usize(v2) != m.vi;
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(u_leaves | v_leaves) != 0ull, 0)) {
+    if (u_leaves) uh = bilinear_at(d.imap, mw, u2, px.v);
+    if (v_leaves) vh = bilinear_at(d.imap, mw, px.u, v2);
+  }
   const float du = (uh - value) * H_INV;
   const float dv = (vh - value) * H_INV;
   const float sc = (float)intensity * 0.003921569f;  // image_icp.rs:131 (u8 -> f32 is exact)
