@@ -720,7 +720,10 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
       hipLaunchKernelGGL((image_icp_mfma_kernel<1>), grid, block, 0, s, descs, states, b->gates[level],
                          partials, counters, solve, ppt);
   } else {
-    if (b->group[level] == 2)
+    if (b->group[level] == 4)
+      hipLaunchKernelGGL((image_icp_kernel<4>), grid, block, 0, s, descs, states, b->gates[level], partials,
+                         counters, solve, ppt);
+    else if (b->group[level] == 2)
       hipLaunchKernelGGL((image_icp_kernel<2>), grid, block, 0, s, descs, states, b->gates[level], partials,
                          counters, solve, ppt);
     else
@@ -748,7 +751,7 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     if (const char* env = getenv("A3D_ICP_GROUP_LEVELS")) {  // tuning knob: per-level "g0,g1,g2"
       unsigned gl[3] = {1, 1, 1};
       sscanf(env, "%u,%u,%u", &gl[0], &gl[1], &gl[2]);
-      if (l < 3) b->group[l] = gl[l] == 2 ? 2 : 1;
+      if (l < 3) b->group[l] = (gl[l] == 2 || gl[l] == 4) ? gl[l] : 1;
     }
     if (const char* env = getenv("A3D_ICP_WAVES_LEVELS")) {  // tuning knob: per-level "w0,w1,w2"
       float wl[3] = {waves, waves, waves};
