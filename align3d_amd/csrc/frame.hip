@@ -276,6 +276,8 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
                                          double cx, double cy, double depth_scale, a3d_device_image** out_levels) {
   A3D_REQUIRE(ctx && prm && depth && rgb && out_levels, A3D_INVALID_PARAMETER, "null argument");
   A3D_REQUIRE(width > 0 && height > 0 && width * height < (1ull << 28), A3D_INVALID_PARAMETER, "bad image size");
+  // the kernels form texel offsets with 24-bit multiplies
+  A3D_REQUIRE(width < (1ull << 23) && height < (1ull << 23), A3D_INVALID_PARAMETER, "image side too long");
   A3D_REQUIRE(prm->pyramid_levels >= 1 && prm->pyramid_levels <= 16, A3D_INVALID_PARAMETER, "bad pyramid_levels");
   A3D_REQUIRE((width >> (prm->pyramid_levels - 1)) >= 2 && (height >> (prm->pyramid_levels - 1)) >= 2,
               A3D_INVALID_PARAMETER, "image too small for this many pyramid levels");

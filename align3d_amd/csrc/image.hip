@@ -100,6 +100,8 @@ a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* 
   A3D_REQUIRE(v->points && v->mask, A3D_INVALID_PARAMETER, "RangeImage needs points and mask");
   A3D_REQUIRE(v->width > 0 && v->height > 0 && v->width * v->height < (1ull << 28), A3D_INVALID_PARAMETER,
               "bad image size (at most 2^28 pixels: the kernels address the arrays with 32-bit byte offsets)");
+  // the kernels form texel offsets with 24-bit multiplies
+  A3D_REQUIRE(v->width < (1ull << 23) && v->height < (1ull << 23), A3D_INVALID_PARAMETER, "image side too long");
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   a3d_device_image* im = new a3d_device_image();
   im->ctx = ctx;
