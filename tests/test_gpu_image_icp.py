@@ -348,3 +348,35 @@ def test_ragged_small_images_per_iteration(ctx, w, h):
         st, T_ref, _ = O.image_icp_align(prm3.to_c(), ft, fs)
         ang, tr = transform_diff(T_gpu, T_ref)
         assert st == 0 and ang <= ROT_TOL and tr <= TRANS_TOL
+
+
+@pytest.mark.parametrize("knobs", [
+    {"A3D_ICP_ACCUM": "mfma"},
+    {"A3D_ICP_GROUP": "2"},
+    {"A3D_ICP_GROUP_LEVELS": "1,2,4"},
+    {"A3D_ICP_WAVES": "3"},
+    {"A3D_ICP_WAVES": "0.1"},
+    {"A3D_ICP_VARIANT": "7,1"},
+    {"A3D_ICP_STREAMS": "2", "A3D_ICP_WAVES_LEVELS": "2,1,0.5"},
+])
+def test_opt_in_kernel_variants_keep_parity(ctx, monkeypatch, knobs):
+    """The tuning knobs select other kernels / tilings (MFMA accumulation, 2 or 4 pixels per pipeline step, odd
+    pixel counts per thread, more or fewer blocks): none may change what is computed beyond the association of
+    the f32 sums."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    ft, fs = oracle_frame("sample1", 0, False), oracle_frame("sample1", 5, False)
+    _check_accumulators(ctx, MsIcpParams.default()[0], ft, fs, small_pose(1))
+    prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 5))
+    pairs = [("sample1", 0, 5), ("sample2", 0, 4)] * 7  # 14 pairs: the stream groups are in play
+    tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs]
+    sps = [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in pairs]
+    poses, status = MultiscaleAlignBatch(ctx, prm, tps, sps).align()
+    assert not status.any()
+    for k in range(2):
+        s, a, b = pairs[k]
+        st, T_ref = O.multiscale_align(prm.to_c_array(), 3, oracle_pyramid(s, a), oracle_pyramid(s, b), threads=4)
+        ang, tr = transform_diff(poses[k], T_ref)
+        assert st == 0 and ang <= ROT_TOL and tr <= TRANS_TOL
+    for k in range(2, 14):  # equal inputs, equal outputs wherever the pair sits
+        assert np.array_equal(poses[k].t, poses[k % 2].t) and np.array_equal(poses[k].q, poses[k % 2].q)
