@@ -1,7 +1,7 @@
 // ImageIcp::align (src/icp/image_icp.rs:43-164) and MultiscaleAlign (src/icp/multiscale.rs:26-67)
-// for P independent frame pairs at once: per iteration one per-pixel kernel (grid = tiles x pairs)
-// and one solve kernel (grid = pairs); the whole coarse-to-fine sequence is enqueued without a host
-// round trip.
+// for P independent frame pairs at once: per iteration ONE kernel per stream group of pairs (grid = tiles x
+// pairs) whose last block per pair also runs the Gauss-Newton solve and the pose update (icp_engine.hpp); the
+// whole coarse-to-fine sequence is enqueued without a host round trip.
 #include <cstdlib>
 #include <memory>
 
@@ -223,11 +223,13 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
   return t;
 }
 
-// grid = (tiles, pairs); block = 256.  A thread visits PPT source pixels, 256 apart (coalesced), G at a
-// time: the G target gathers are issued together, then the G map cells, so each dependent memory round
-// trip is paid once per G pixels; the source records run one batch ahead; only the accumulation sits
-// under the per-pixel gates.  ACCUM = 0: 58 per-thread f32 accumulators + wave reduce-scatter;
-// ACCUM = 1: X^T X on the matrix pipe (below).
+// grid = (tiles, pairs); block = 256.  A thread visits PPT source pixels, 256 apart (coalesced), through a
+// three-deep software pipeline: the source record of pixel k+2, the target gathers of pixel k+1 and the map cell of
+// pixel k are in flight while pixel k is accumulated (58 per-thread f32 accumulators, wave reduce-scatter at the
+// end).  G = 1 (the default) unrolls the pipeline by two with the buffers swapping roles; G = 2 / 4 handle G pixels
+// per step (tuning options).  Reading the loop's s_waitcnt's in the ISA is part of maintaining this kernel: a
+// short-circuit `&&` around a load, a u8 -> f32 conversion next to its load or a 64-bit multiply-add with a
+// don't-care high half each cost a full drain of the pipeline per pixel before they were found.
 template <int G>
 __global__ void __launch_bounds__(256)
     image_icp_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
