@@ -84,3 +84,19 @@ def test_synthetic_dataset_is_seeded():
     assert np.array_equal(a.get(1)[1], b.get(1)[1]) and np.array_equal(a.get(1)[2], b.get(1)[2])
     rel = a.trajectory().get_relative_transform(1, 0)
     assert 0.0005 < TransformMetrics.new(Transform.eye(), rel).angle < 0.02
+
+
+def test_bench_reads_the_committed_traffic_profile():
+    """roofline.traffic comes from the committed PMC passes of exactly the benchmark's workload, or is null."""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    traffic, src = bench.measured_traffic(64, 640, 480, 3)
+    assert src and src.startswith("profiles/") and 5e7 < traffic < 2e8  # ~1e8 bytes per launch of 21-22 pairs
+    assert bench.measured_traffic(64, 640, 480, 1) == (None, None)      # no profile of a one-stream run is committed
+    assert bench.measured_traffic(48, 640, 480, 3) == (None, None)
+    assert bench.level_bytes(640, 480) == 13218576 and bench.level_bytes(160, 120) == 827856  # SURVEY 8(d)
