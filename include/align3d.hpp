@@ -329,6 +329,19 @@ class MultiscaleAlignBatch {
   ~MultiscaleAlignBatch() { a3d_multiscale_batch_free(b_); }
   MultiscaleAlignBatch(const MultiscaleAlignBatch&) = delete;
   MultiscaleAlignBatch& operator=(const MultiscaleAlignBatch&) = delete;
+  /// The same batch object on other pyramids (same pair and level counts): nothing is allocated or freed.
+  void rebind(const std::vector<const std::vector<RangeImage>*>& target_pyramids,
+              const std::vector<const std::vector<RangeImage>*>& source_pyramids) {
+    if (target_pyramids.size() != n_pairs_ || source_pyramids.size() != n_pairs_)
+      throw InvalidParameter("A3D_INVALID_PARAMETER: rebind needs the batch's own number of pairs");
+    std::vector<const a3d_device_image*> t, s;
+    for (size_t p = 0; p < n_pairs_; ++p) {
+      for (const auto& r : *target_pyramids[p]) t.push_back(r.raw());
+      for (const auto& r : *source_pyramids[p]) s.push_back(r.raw());
+    }
+    if (t.size() != s.size() || t.size() % n_pairs_) throw InvalidParameter("A3D_INVALID_PARAMETER: ragged pyramids");
+    check(a3d_multiscale_batch_rebind(b_, t.data(), s.data()));
+  }
   std::vector<Transform> align() {
     std::vector<a3d_pose> poses(n_pairs_);
     status_.assign(n_pairs_, 0);

@@ -98,6 +98,9 @@ int main(int argc, char** argv) {
     EXPECT(Ts.size() == 2 && batch.status()[0] == 0 && batch.status()[1] == 0);
     for (int i = 0; i < 3; ++i) EXPECT(std::fabs(Ts[0].translation[i] - single.translation[i]) < 2e-6f);
     for (int i = 0; i < 4; ++i) EXPECT(std::fabs(Ts[0].rotation_ijkw[i] - single.rotation_ijkw[i]) < 2e-6f);
+    batch.rebind({&b2, &a}, {&a, &b2});  // swapped roles: pair 0 now is what pair 1 was
+    std::vector<Transform> Tr = batch.align();
+    for (int i = 0; i < 3; ++i) EXPECT(Tr[0].translation[i] == Ts[1].translation[i] && Tr[1].translation[i] == Ts[0].translation[i]);
     try {
       RangeImageBuilder(ctx).pyramid_levels(9).build(k, depth.data(), rgb.data(), 0.001);  // 64x48 has no 9 levels
       EXPECT(false);
