@@ -107,9 +107,35 @@ __global__ void __launch_bounds__(256)
 // ONE u64 (value sum << 24 | count) and a pixel is ONE integer atomic instead of two f64 atomics; integer adds are
 // exact, so the cell holds exactly the reference's f64 sums.
 constexpr int PACK_SHIFT = 24;
+
+// Device-side scalars of one filter call (the head of the context's grid scratch region).  When a kernel gets a
+// non-null `dyn` pointer, the grid dimensions and the colour minimum come from there instead of from its arguments:
+// the host then enqueues the whole filter without the min/max round trip (bilateral_filter_device_async).
+enum { SC_MIN = 0, SC_MAX = 1, SC_OVERFLOW = 2, SC_GH = 4, SC_GW = 5, SC_GD = 6, SC_TOO_BIG = 7, SC_WORDS = 8 };
+__device__ __forceinline__ bool dyn_dims(const uint32_t* __restrict__ dyn, GridDims* g, uint32_t* color_min) {
+  if (!dyn) return true;
+  if (dyn[SC_TOO_BIG]) return false;  // the grid does not fit the scratch region: the host grows it and repeats
+  *g = GridDims{dyn[SC_GH], dyn[SC_GW], dyn[SC_GD]};
+  if (color_min) *color_min = dyn[SC_MIN];
+  return true;
+}
+
+// grid.rs:37-56 on the device (same f64 arithmetic as the host path), plus the capacity check
+__global__ void dims_kernel(uint32_t* __restrict__ sc, uint32_t w, uint32_t h, double sigma_space, double sigma_color,
+                            unsigned long long capacity_cells) {
+  const uint32_t cmin = sc[SC_MIN], cmax = sc[SC_MAX];
+  const uint32_t gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4;
+  const uint32_t gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
+  const uint32_t gd = (uint32_t)((double)(cmax - cmin) / sigma_color) + 1 + 4;
+  sc[SC_GH] = gh, sc[SC_GW] = gw, sc[SC_GD] = gd;
+  sc[SC_TOO_BIG] = (unsigned long long)gh * gw * gd > capacity_cells ? 1u : 0u;
+}
+
 __global__ void __launch_bounds__(256)
     splat_packed_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
-                        uint32_t color_min, GridDims g, unsigned long long* __restrict__ grid) {
+                        uint32_t color_min, GridDims g, unsigned long long* __restrict__ grid,
+                        const uint32_t* __restrict__ dyn) {
+  if (!dyn_dims(dyn, &g, &color_min)) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w * h) return;
   const uint32_t color = img[i];
@@ -157,9 +183,15 @@ __device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok, bool fi
 }
 
 __global__ void __launch_bounds__(256)
-    blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double2* __restrict__ out) {
+    blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double2* __restrict__ out,
+                      const uint32_t* __restrict__ dyn) {
   __shared__ double2 tile[BCELLS];
-  const int r0 = (int)blockIdx.z * BT - 2, c0 = (int)blockIdx.y * BT - 2, z0 = (int)blockIdx.x * BT - 2;
+  if (!dyn_dims(dyn, &g, nullptr)) return;
+  // 1-D launch (the host may not know the dimensions): block -> tile (row, column, channel), channel fastest
+  const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
+  if (blockIdx.x >= tx * ty * tz) return;
+  const int r0 = (int)(blockIdx.x / (ty * tz)) * BT - 2, c0 = (int)((blockIdx.x / tz) % ty) * BT - 2,
+            z0 = (int)(blockIdx.x % tz) * BT - 2;
   const int gh = (int)g.gh, gw = (int)g.gw, gd = (int)g.gd;
   const int t = (int)threadIdx.x, hi = t >> 4, lo = t & 15;
   auto at = [](int lr, int lc, int lz) { return (lr * BR + lc) * BZP + lz; };
@@ -230,7 +262,8 @@ __device__ __forceinline__ double cell_value(const double2* __restrict__ grid, G
 __global__ void __launch_bounds__(256)
     slice_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
                  uint32_t color_min, GridDims g, const double2* __restrict__ grid, uint16_t* __restrict__ out,
-                 uint32_t* __restrict__ overflow_flag) {
+                 uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ dyn) {
+  if (!dyn_dims(dyn, &g, &color_min)) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w * h) return;
   const uint32_t r = i / w, c = i % w;
@@ -320,9 +353,10 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
       double2* src = d_a;
       if (fused) {
         hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin,
-                           g, (unsigned long long*)d_b);
-        hipLaunchKernelGGL(blur_fused_kernel, dim3((g.gd + BT - 1) / BT, (g.gw + BT - 1) / BT, (g.gh + BT - 1) / BT),
-                           dim3(256), 0, s, (const unsigned long long*)d_b, g, d_a);
+                           g, (unsigned long long*)d_b, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(blur_fused_kernel,
+                           dim3(((g.gd + BT - 1) / BT) * ((g.gw + BT - 1) / BT) * ((g.gh + BT - 1) / BT)), dim3(256), 0, s,
+                           (const unsigned long long*)d_b, g, d_a, (const uint32_t*)nullptr);
       } else {
         hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
                            (double*)d_a);
@@ -337,7 +371,7 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
         // six passes: the result is back in d_a (== src after the final swap)
       }
       hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
-                         src, d_out, d_scal + 2);
+                         src, d_out, d_scal + 2, (const uint32_t*)nullptr);
       if (hipGetLastError() != hipSuccess) fail("kernel launch");
     }
     if (st == A3D_OK && (hipMemcpyAsync(h_scal + 2, d_scal + 2, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -346,6 +380,69 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
   }
   if (st != A3D_OK) return st;
   if (h_scal[2]) {
+    set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
+    return A3D_CAST_OVERFLOW;
+  }
+  return A3D_OK;
+}
+
+// The fused filter enqueued WITHOUT a host round trip: min/max, the grid dimensions and the capacity check stay on
+// the device, the kernels read them from the scratch region's scalar block, launch sizes come from the capacity.
+// Only possible when the context's grid scratch region already exists (its size bounds the grid): the first filter
+// on a context goes through bilateral_filter_device, which sizes the region.  `result` (page-locked, SC_WORDS words)
+// receives the scalar block by an asynchronous copy; after the caller's own stream synchronisation
+// bilateral_async_status() tells whether the output is valid.  *enqueued = false: nothing was done, use the
+// synchronous path.
+a3d_status bilateral_filter_device_async(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w,
+                                         uint32_t h, double sigma_space, double sigma_color, uint32_t* result,
+                                         bool* enqueued) {
+  *enqueued = false;
+  const uint32_t n = w * h;
+  const char* mode = getenv("A3D_BILATERAL");
+  if (n >= (1u << PACK_SHIFT) || (mode && (!strcmp(mode, "unfused") || !strcmp(mode, "sync")))) return A3D_OK;
+  if (!ctx->scratch[1] || ctx->scratch_size[1] < (1u << 20)) return A3D_OK;
+  hipStream_t s = ctx->stream;
+  // scratch layout: [256 B scalars][capacity x 8 B packed cells][capacity x 16 B blurred cells]
+  const unsigned long long capacity = (ctx->scratch_size[1] - 256 - 512) / 24;
+  uint32_t* d_scal = (uint32_t*)ctx->scratch[1];
+  unsigned long long* d_packed = (unsigned long long*)((char*)ctx->scratch[1] + 256);
+  double2* d_blur = (double2*)((char*)d_packed + ((capacity * 8 + 255) / 256) * 256);
+  const uint32_t init[SC_WORDS] = {0xFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  memcpy(result, init, sizeof(init));  // `result` is page-locked: the copy below reads it asynchronously
+  A3D_HIP_TRY(hipMemcpyAsync(d_scal, result, sizeof(init), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64)), dim3(256), 0, s, d_img, n, d_scal);
+  hipLaunchKernelGGL(dims_kernel, dim3(1), dim3(1), 0, s, d_scal, w, h, sigma_space, sigma_color, capacity);
+  A3D_HIP_TRY(hipMemsetAsync(d_packed, 0, capacity * 8, s));
+  const double inv_ss = 1.0 / sigma_space, inv_sc = 1.0 / sigma_color;
+  const GridDims none{0, 0, 0};
+  hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, 0u, none,
+                     d_packed, (const uint32_t*)d_scal);
+  // any grid of `capacity` cells has at most this many 12^3 tiles (each axis rounds up: <= cells/1728 + slack)
+  const uint32_t max_tiles = (uint32_t)std::min<unsigned long long>(capacity / 64 + 64, 1u << 30);
+  const uint32_t gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4, gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
+  const unsigned long long plane_tiles = (unsigned long long)((gh + BT - 1) / BT) * ((gw + BT - 1) / BT);
+  const unsigned long long max_gd = capacity / ((unsigned long long)gh * gw) + 1;
+  const uint32_t tiles = (uint32_t)std::min<unsigned long long>(plane_tiles * ((max_gd + BT - 1) / BT), max_tiles + plane_tiles);
+  hipLaunchKernelGGL(blur_fused_kernel, dim3(std::max(1u, tiles)), dim3(256), 0, s, (const unsigned long long*)d_packed,
+                     none, d_blur, (const uint32_t*)d_scal);
+  hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, 0u, none,
+                     (const double2*)d_blur, d_out, d_scal + SC_OVERFLOW, (const uint32_t*)d_scal);
+  A3D_HIP_TRY(hipGetLastError());
+  A3D_HIP_TRY(hipMemcpyAsync(result, d_scal, SC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  *enqueued = true;
+  return A3D_OK;
+}
+
+// After the stream has been synchronised: A3D_OK (output valid), A3D_CAST_OVERFLOW, or *needs_bytes > 0 when the
+// grid did not fit the scratch region (grow it to *needs_bytes and run the filter again).
+a3d_status bilateral_async_status(const uint32_t* result, size_t* needs_bytes) {
+  *needs_bytes = 0;
+  if (result[SC_TOO_BIG]) {
+    const size_t cells = (size_t)result[SC_GH] * result[SC_GW] * result[SC_GD];
+    *needs_bytes = 256 + 512 + cells * 24 + cells * 6;  // 25 % head room for the next frames
+    return A3D_OK;
+  }
+  if (result[SC_OVERFLOW]) {
     set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
     return A3D_CAST_OVERFLOW;
   }

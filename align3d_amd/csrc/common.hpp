@@ -63,6 +63,11 @@ namespace a3d {
 // BilateralFilter::filter on device-resident u16 images (bilateral.hip).
 a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w, uint32_t h,
                                    double sigma_space, double sigma_color, uint64_t out_grid_dims[3]);
+// The same filter enqueued without the min/max host round trip (see bilateral.hip); `result`: 8 page-locked words.
+a3d_status bilateral_filter_device_async(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w,
+                                         uint32_t h, double sigma_space, double sigma_color, uint32_t* result,
+                                         bool* enqueued);
+a3d_status bilateral_async_status(const uint32_t* result, size_t* needs_bytes);
 // RangeImage::compute_normals on device-resident arrays (image.hip).
 a3d_status compute_normals_device(a3d_context* ctx, const float* d_points, const uint8_t* d_mask, float* d_normals,
                                   uint32_t w, uint32_t h);
@@ -86,6 +91,7 @@ struct a3d_context {
   // reuse its small device state instead of allocating and freeing it per alignment.
   void* icp_engine = nullptr;
   void (*icp_engine_free)(void*) = nullptr;
+  uint32_t* pinned_words = nullptr;  // 16 page-locked words: scalar results copied back asynchronously
   // Small read-only tables uploaded once and kept (the blur tap tables of the pyramid builder), keyed by four words.
   struct CachedTable {
     uint32_t key[4];

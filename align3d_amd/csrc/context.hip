@@ -164,6 +164,7 @@ a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx) {
   A3D_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_start));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_stop));
+  A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, 16 * sizeof(uint32_t), hipHostMallocDefault));
   *out_ctx = ctx;
   return A3D_OK;
 }
@@ -175,6 +176,7 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
   for (auto& a : ctx->arena_pool) hipFree(a.first);
   for (auto& t : ctx->tables) hipFree(t.d);
+  if (ctx->pinned_words) hipHostFree(ctx->pinned_words);
   hipFree(ctx->scratch[0]);
   hipFree(ctx->scratch[1]);
   hipEventDestroy(ctx->ev_start);

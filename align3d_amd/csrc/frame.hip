@@ -309,6 +309,8 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
     levels.push_back(im);
     return im;
   };
+  bool async_bilateral = false;
+  size_t retry_scratch_bytes = 0;
   auto build = [&]() -> a3d_status {
     void* scratch_base = nullptr;
     A3D_TRY(ctx_scratch(ctx, 0, scratch_bytes, &scratch_base));
@@ -327,7 +329,11 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
     A3D_HIP_TRY(hipMemcpyAsync(l0->colors, rgb, (size_t)n * 3, hipMemcpyHostToDevice, s));
     const uint16_t* d_use = d_depth;
     if (prm->use_bilateral) {  // builder.rs:75-77
-      A3D_TRY(bilateral_filter_device(ctx, d_depth, d_filtered, w, h, prm->sigma_space, prm->sigma_color, nullptr));
+      // without a host round trip when the context's grid scratch already exists (every frame but the first)
+      A3D_TRY(bilateral_filter_device_async(ctx, d_depth, d_filtered, w, h, prm->sigma_space, prm->sigma_color,
+                                            ctx->pinned_words, &async_bilateral));
+      if (!async_bilateral)
+        A3D_TRY(bilateral_filter_device(ctx, d_depth, d_filtered, w, h, prm->sigma_space, prm->sigma_color, nullptr));
       d_use = d_filtered;
     }
     hipLaunchKernelGGL(backproject_kernel, grid_for(n), dim3(256), 0, s, d_use, w, h, l0->fx, l0->fy, l0->cx, l0->cy,
@@ -346,6 +352,10 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
       for (a3d_device_image* lv : levels) A3D_TRY(add_intensity(lv, arena));
     A3D_HIP_TRY(hipGetLastError());
     A3D_HIP_TRY(hipStreamSynchronize(s));
+    if (async_bilateral) {  // the filter's scalars arrived with the synchronisation above
+      A3D_TRY(bilateral_async_status(ctx->pinned_words, &retry_scratch_bytes));
+      if (retry_scratch_bytes) return A3D_HIP_ERROR;  // (not an error: handled below by growing the region)
+    }
     return A3D_OK;
   };
   const a3d_status st = build();
@@ -355,6 +365,12 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
     if (levels.empty()) {
       ctx_arena_release(ctx, shared);
       delete shared;
+    }
+    if (retry_scratch_bytes) {  // this frame's bilateral grid outgrew the scratch region: grow it, build again
+      void* unused = nullptr;
+      A3D_TRY(ctx_scratch(ctx, 1, retry_scratch_bytes, &unused));
+      return a3d_range_image_build_pyramid(ctx, prm, depth, rgb, width, height, fx, fy, cx, cy, depth_scale,
+                                           out_levels);
     }
     return st;
   }

@@ -187,3 +187,36 @@ def test_frames_in_page_locked_host_memory_build_the_same_pyramid(ctx):
         assert np.array_equal(_bits(gx.points), _bits(gy.points)) and np.array_equal(gx.mask, gy.mask)
         assert np.array_equal(_bits(gx.normals), _bits(gy.normals)) and np.array_equal(gx.colors, gy.colors)
         assert np.array_equal(_bits(gx.intensity_map), _bits(gy.intensity_map))
+
+
+def test_device_builder_without_minmax_round_trip_and_scratch_regrow():
+    """From the second frame on a context the builder enqueues the bilateral filter without reading min/max back
+    (grid dimensions, capacity check and launch bounds live on the device).  A later frame whose depth range needs
+    a larger grid than the scratch region holds is detected on the device and rebuilt after growing the region.
+    All pyramids equal the oracle's bit for bit."""
+    from align3d_amd import CameraIntrinsics, Context, RangeImageBuilder
+
+    rng = np.random.default_rng(5)
+    w, h = 320, 240
+    cam = CameraIntrinsics(300.0, 300.0, w / 2.0, h / 2.0, w, h)
+    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    base = (1000 + 400 * np.sin(np.linspace(0, 6, w))[None, :] + 300 * np.cos(np.linspace(0, 4, h))[:, None])
+    frames = [
+        (base + rng.integers(0, 30, size=(h, w))).astype(np.uint16),            # first frame: synchronous path
+        (base * 1.1 + rng.integers(0, 30, size=(h, w))).astype(np.uint16),      # fits: asynchronous path
+        (base * 9.0 + rng.integers(0, 3000, size=(h, w))).astype(np.uint16),    # far larger depth range: regrow
+        (base * 0.5 + rng.integers(0, 10, size=(h, w))).astype(np.uint16),      # small again, large region
+    ]
+    frames[1][10:40, 20:90] = 0
+    own = Context(0)
+    try:
+        b = RangeImageBuilder(own).with_bilateral_filter(BilateralFilter.default())
+        for depth in frames:
+            ref = O.build_pyramid(depth, rgb, cam.fx, cam.fy, cam.cx, cam.cy, 0.001, levels=3, use_bilateral=True)
+            levels = b.build_device(cam, depth, rgb, 0.001)
+            for lv, r in zip(levels, ref):
+                _assert_same_level(lv, r)
+            for lv in levels:
+                lv.free()
+    finally:
+        own.close()
