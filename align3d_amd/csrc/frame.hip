@@ -67,42 +67,54 @@ __global__ void intensity_map_kernel(const uint8_t* __restrict__ luma, uint32_t 
 // get_neighborhood_mean_point over every 2x2 block (src/range_image/resize.rs:4-40): among the entries
 // whose SOURCE mask is 1, the one nearest to their mean (strict <, first wins).  Used for points
 // (writes the destination mask) and for normals (mask output null).
-__global__ void resize_pick_kernel(const float* __restrict__ src, const uint8_t* __restrict__ src_mask, uint32_t sw,
-                                   uint32_t sh, uint32_t dw, uint32_t dh, float* __restrict__ dst,
-                                   uint8_t* __restrict__ dst_mask) {
+// blockIdx.y = 0 picks the points (and writes the destination mask), blockIdx.y = 1 the normals (if any): one
+// launch per level.  The four candidates stay in registers (no dynamically indexed private array).
+__global__ void __launch_bounds__(256)
+    resize_pick_kernel(const float* __restrict__ src_points, const float* __restrict__ src_normals,
+                       const uint8_t* __restrict__ src_mask, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
+                       float* __restrict__ dst_points, float* __restrict__ dst_normals,
+                       uint8_t* __restrict__ dst_mask) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= dw * dh) return;
+  const bool normals = blockIdx.y == 1;
+  const float* __restrict__ src = normals ? src_normals : src_points;
+  float* __restrict__ dst = normals ? dst_normals : dst_points;
   const uint32_t dv = i / dw, du = i % dw;
   const float hr = (float)sh / (float)dh, wr = (float)sw / (float)dw;
   const uint32_t sv = (uint32_t)((float)dv * hr), su = (uint32_t)((float)du * wr);
-  V3 local[4];
+  V3 cand[4];
+  bool ok[4];
   int n = 0;
 #pragma unroll
   for (uint32_t a = 0; a < 2; ++a)
 #pragma unroll
     for (uint32_t b = 0; b < 2; ++b) {
-      const uint32_t r = sv + a, c = su + b;
-      if (r < sh && c < sw && src_mask[r * sw + c] == 1) {
-        const uint32_t k = r * sw + c;
-        local[n++] = V3{src[3 * k], src[3 * k + 1], src[3 * k + 2]};
-      }
+      const uint32_t r = sv + a, c = su + b, q = a * 2 + b;
+      const bool in = r < sh && c < sw;
+      const uint32_t k = in ? r * sw + c : 0u;
+      ok[q] = in && src_mask[k] == 1;
+      cand[q] = V3{src[3 * k], src[3 * k + 1], src[3 * k + 2]};
+      n += ok[q] ? 1 : 0;
     }
   V3 nearest{0.f, 0.f, 0.f};
   if (n > 0) {
-    V3 sum{0.f, 0.f, 0.f};
-    for (int k = 0; k < n; ++k) sum = sum + local[k];
+    V3 sum{0.f, 0.f, 0.f};  // valid entries in block order, as the reference's `local` list
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ok[q]) sum = sum + cand[q];
     const V3 mean = sum / (float)n;
     float min_dist = 3.402823466e+38f;
-    for (int k = 0; k < n; ++k) {
-      const float d = norm_squared(local[k] - mean);
-      if (d < min_dist) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float d = norm_squared(cand[q] - mean);
+      if (ok[q] && d < min_dist) {  // strict <: the first minimum wins
         min_dist = d;
-        nearest = local[k];
+        nearest = cand[q];
       }
     }
   }
   dst[3 * i] = nearest.x, dst[3 * i + 1] = nearest.y, dst[3 * i + 2] = nearest.z;
-  if (dst_mask) dst_mask[i] = n > 0 ? 1 : 0;
+  if (!normals) dst_mask[i] = n > 0 ? 1 : 0;
 }
 
 // One tap table entry per output row / column: first tap, tap count, normalised weights.
@@ -223,14 +235,12 @@ a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_i
   dst->fx = (float)dst->fx64, dst->fy = (float)dst->fy64, dst->cx = (float)dst->cx64, dst->cy = (float)dst->cy64;
   A3D_TRY(arena.take(&dst->points, (size_t)dn * 3));
   A3D_TRY(arena.take(&dst->mask, dn));
-  hipLaunchKernelGGL(resize_pick_kernel, grid_for(dn), dim3(256), 0, s, src->points, src->mask, sw, sh, dw, dh,
-                     dst->points, dst->mask);
   if (src->has_normals) {
     A3D_TRY(arena.take(&dst->normals, (size_t)dn * 3));
-    hipLaunchKernelGGL(resize_pick_kernel, grid_for(dn), dim3(256), 0, s, src->normals, src->mask, sw, sh, dw, dh,
-                       dst->normals, (uint8_t*)nullptr);
     dst->has_normals = true;
   }
+  hipLaunchKernelGGL(resize_pick_kernel, dim3((dn + 255) / 256, src->has_normals ? 2 : 1), dim3(256), 0, s, src->points,
+                     src->normals, src->mask, sw, sh, dw, dh, dst->points, dst->normals, dst->mask);
   if (src->colors) {
     if (sigma <= 0.0f) sigma = 1.0f;
     A3D_REQUIRE(sigma <= 3.0f, A3D_INVALID_PARAMETER, "blur_sigma above 3 is not supported by the device builder");
