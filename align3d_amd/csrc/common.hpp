@@ -87,6 +87,11 @@ struct a3d_context {
   // Guarded by a mutex because an image may be freed from another thread than the one building frames.
   std::mutex pool_mutex;
   std::vector<std::pair<void*, size_t>> arena_pool;
+  // Arenas are carved out of slabs of SLAB_ARENAS at a time (one hipMalloc, i.e. one device-wide synchronisation,
+  // per 16 frames instead of per frame); slices return to the pool and the slabs live as long as the context.
+  std::vector<void*> arena_slabs;
+  std::vector<size_t> slab_sizes;
+  size_t slab_bytes_total = 0;
   // The single-pair ICP engine (image_icp.hip) kept between calls: MultiscaleAlign::align and ImageIcp::align
   // reuse its small device state instead of allocating and freeing it per alignment.
   void* icp_engine = nullptr;
@@ -108,6 +113,7 @@ a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out);
 struct DeviceArena {
   void* base = nullptr;
   size_t bytes = 0;
+  bool slab_slice = false;  // carved out of a context slab: goes back to the pool, never to hipFree
   std::atomic<int> refs{0};
 };
 // Device copy of a small host table, uploaded on first use and kept until the context dies.

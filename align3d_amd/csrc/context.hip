@@ -86,21 +86,45 @@ a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void*
   return A3D_OK;
 }
 
+// Pool entries: (base, bytes); slab slices are recognised by address (inside one of the context's slabs).
+static bool in_slab(const a3d_context* ctx, const void* p, size_t slab_stride_unused = 0) {
+  (void)slab_stride_unused;
+  for (size_t i = 0; i < ctx->arena_slabs.size(); ++i) {
+    const char* b = (const char*)ctx->arena_slabs[i];
+    if ((const char*)p >= b && (const char*)p < b + ctx->slab_sizes[i]) return true;
+  }
+  return false;
+}
+
 a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
-  {
-    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
-    for (size_t i = 0; i < ctx->arena_pool.size(); ++i) {
-      const size_t have = ctx->arena_pool[i].second;
-      if (have >= bytes && have <= bytes + bytes / 4) {
-        out->base = ctx->arena_pool[i].first;
-        out->bytes = have;
-        ctx->arena_pool.erase(ctx->arena_pool.begin() + (long)i);
-        return A3D_OK;
-      }
+  constexpr size_t SLAB_ARENAS = 16, SLAB_BUDGET = 8ull << 30;
+  const size_t padded = ((bytes + 255) / 256) * 256;
+  std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+  for (size_t i = 0; i < ctx->arena_pool.size(); ++i) {
+    const size_t have = ctx->arena_pool[i].second;
+    if (have >= bytes && have <= bytes + bytes / 4) {
+      out->base = ctx->arena_pool[i].first;
+      out->bytes = have;
+      out->slab_slice = in_slab(ctx, out->base);
+      ctx->arena_pool.erase(ctx->arena_pool.begin() + (long)i);
+      return A3D_OK;
     }
+  }
+  if (ctx->slab_bytes_total + SLAB_ARENAS * padded <= SLAB_BUDGET) {  // a new slab: this arena + 15 for the pool
+    void* slab = nullptr;
+    if (hipMalloc(&slab, SLAB_ARENAS * padded) == hipSuccess) {
+      ctx->arena_slabs.push_back(slab);
+      ctx->slab_sizes.push_back(SLAB_ARENAS * padded);
+      ctx->slab_bytes_total += SLAB_ARENAS * padded;
+      for (size_t k = 1; k < SLAB_ARENAS; ++k) ctx->arena_pool.emplace_back((char*)slab + k * padded, padded);
+      out->base = slab, out->bytes = padded, out->slab_slice = true;
+      return A3D_OK;
+    }
+    (void)hipGetLastError();  // fall back to a single allocation
   }
   A3D_HIP_TRY(hipMalloc(&out->base, bytes));
   out->bytes = bytes;
+  out->slab_slice = false;
   return A3D_OK;
 }
 
@@ -109,8 +133,8 @@ void ctx_arena_release(a3d_context* ctx, DeviceArena* arena) {
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     size_t pooled = 0;
     for (const auto& a : ctx->arena_pool) pooled += a.second;
-    // keep up to 128 arenas / 4 GiB per context: a round of a frame stream is freed before the next is built
-    if (ctx->arena_pool.size() < 128 && pooled + arena->bytes <= (4ull << 30)) {
+    // slab slices always return to the pool; single allocations are kept up to 128 arenas / 4 GiB per context
+    if (arena->slab_slice || (ctx->arena_pool.size() < 128 && pooled + arena->bytes <= (4ull << 30))) {
       ctx->arena_pool.emplace_back(arena->base, arena->bytes);
       arena->base = nullptr;
     }
@@ -174,7 +198,9 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
-  for (auto& a : ctx->arena_pool) hipFree(a.first);
+  for (auto& a : ctx->arena_pool)
+    if (!in_slab(ctx, a.first)) hipFree(a.first);
+  for (void* slab : ctx->arena_slabs) hipFree(slab);
   for (auto& t : ctx->tables) hipFree(t.d);
   if (ctx->pinned_words) hipHostFree(ctx->pinned_words);
   hipFree(ctx->scratch[0]);
