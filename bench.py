@@ -100,13 +100,13 @@ def kdtree_bench(ctx, n=500_000, reps=20):
 
 def pcl_icp_bench(ctx, n=500_000):
     """configs[2]: Icp (kd-tree point-to-plane) on 500k target x 500k source points, IcpParams::default()."""
-    from align3d_amd import Icp, PointCloud, RangeImage
+    from align3d_amd import Icp, PointCloud, RangeImageBuilder
 
     frames, poses = synth.frame_stream(7, 2, 880, 660)
     cam = synth.camera(880, 660)
     clouds = []
     for d, rgb in frames:
-        ri = RangeImage.from_rgbd_image(cam, d, rgb, synth.DEPTH_SCALE).compute_normals(ctx)
+        ri = RangeImageBuilder(ctx).pyramid_levels(1).with_intensity(False).build(cam, d, rgb, synth.DEPTH_SCALE)[0].download(intensity=False)
         pc = PointCloud.from_range_image(ri)
         clouds.append(PointCloud(pc.points[:n], pc.normals[:n]))
     tgt, src = clouds

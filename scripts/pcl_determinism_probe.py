@@ -2,14 +2,14 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from align3d_amd import Context, Icp, IcpParams, MsIcpParams, MultiscaleAlignBatch, PointCloud, RangeImage, synth
+from align3d_amd import Context, Icp, IcpParams, MsIcpParams, MultiscaleAlignBatch, PointCloud, RangeImageBuilder, synth
 from bench import build_stream_pyramids
 ctx = Context(0)
 frames, poses = synth.frame_stream(7, 2, 880, 660)
 cam = synth.camera(880, 660)
 clouds = []
 for d, rgb in frames:
-    ri = RangeImage.from_rgbd_image(cam, d, rgb, synth.DEPTH_SCALE).compute_normals(ctx)
+    ri = RangeImageBuilder(ctx).pyramid_levels(1).with_intensity(False).build(cam, d, rgb, synth.DEPTH_SCALE)[0].download(intensity=False)
     pc = PointCloud.from_range_image(ri)
     clouds.append(PointCloud(pc.points[:500000], pc.normals[:500000]))
 icp = Icp.new(ctx, IcpParams.default(), clouds[0])

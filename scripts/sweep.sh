@@ -1,0 +1,18 @@
+# One parameterised tuning sweep over bench.py (replaces the round-1 variants*/streams_sweep*/level_knobs*/
+# hybrid/waves/pairs scripts).  Each argument is one configuration: environment assignments, optionally followed
+# by "--" and extra bench.py flags.  Run on an MI355X from the repository root, e.g.
+#   bash scripts/sweep.sh "A3D_ICP_STREAMS=1" "A3D_ICP_STREAMS=3 A3D_ICP_WAVES=1.5" "A3D_ICP_STREAMS=3 -- --pairs-per-gpu 128"
+#   bash scripts/sweep.sh "A3D_ICP_VARIANT=8,1" "A3D_ICP_ACCUM=mfma A3D_ICP_VARIANT=16,2" "A3D_ICP_PERSISTENT_LEVELS=4"
+STEPS=${STEPS:-20}
+WARMUP=${WARMUP:-5}
+for cfg in "$@"; do
+  envs="${cfg%%--*}"
+  extra=""
+  case "$cfg" in *--*) extra="${cfg#*--}";; esac
+  echo "== $cfg"
+  env $envs timeout -k 10 300 python3 bench.py --steps $STEPS --warmup $WARMUP --no-extras --cpu-pairs 0 $extra 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+r=d['roofline']
+print('value %.0f pairs/s  ms/step %.3f  avg_launch_us %.1f  frac %.3f  failed %s' % (d['value'], d['ms_per_step'], r.get('avg_launch_us', 0), r['frac'], d['extra'].get('failed_pairs')))"
+done

@@ -10,7 +10,7 @@ import pytest
 import oracle_lib as O
 from align3d_amd import _abi
 from align3d_amd import IcpParams, MsIcpParams, RangeImage, CameraIntrinsics
-from align3d_amd.range_image import intensity_map_from_luma, rgb_to_luma_u8, _resize_pick, blur_rgb_and_halve
+from host_frame_prep import (intensity_map_from_luma, rgb_to_luma_u8, _resize_pick, blur_rgb_and_halve, from_rgbd_image)
 from data_util import SlamTbSample
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,7 +78,7 @@ def test_host_frame_preparation_matches_oracle():
     depth, rgb = s.load(0)
     fx, fy, cx, cy = s.intrinsics(0)
     fr = O.build_frame(depth, rgb, fx, fy, cx, cy, s.depth_scale(0))
-    ri = RangeImage.from_rgbd_image(CameraIntrinsics(fx, fy, cx, cy, 640, 480), depth, rgb, s.depth_scale(0))
+    ri = from_rgbd_image(CameraIntrinsics(fx, fy, cx, cy, 640, 480), depth, rgb, s.depth_scale(0))
     assert np.array_equal(ri.mask, fr.mask) and ri.valid_points_count() == 270213
     assert np.array_equal(ri.points.view(np.uint32), fr.points.view(np.uint32))
     luma = rgb_to_luma_u8(rgb)

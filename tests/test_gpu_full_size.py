@@ -57,13 +57,13 @@ def test_full_size_batch_properties(ctx, monkeypatch):
 def test_full_size_point_cloud_icp_properties(ctx):
     """configs[2] at its full size (500 000 target x 500 000 source points, 15 iterations): known-motion recovery,
     determinism, and the fixed point of aligning a cloud with itself."""
-    from align3d_amd import Icp, PointCloud, RangeImage
+    from align3d_amd import Icp, PointCloud, RangeImageBuilder
 
     frames, poses = synth.frame_stream(7, 2, 880, 660)
     cam = synth.camera(880, 660)
     clouds = []
     for d, rgb in frames:
-        ri = RangeImage.from_rgbd_image(cam, d, rgb, synth.DEPTH_SCALE).compute_normals(ctx)
+        ri = RangeImageBuilder(ctx).pyramid_levels(1).with_intensity(False).build(cam, d, rgb, synth.DEPTH_SCALE)[0].download(intensity=False)
         pc = PointCloud.from_range_image(ri)
         assert pc.len() >= 500_000
         clouds.append(PointCloud(pc.points[:500_000], pc.normals[:500_000]))
