@@ -44,6 +44,11 @@ void orc_intensity_map_bilinear_grad(const float* map, uint64_t width, uint64_t 
 a3d_status orc_image_icp_accumulate(const a3d_icp_params* params, const a3d_range_image_view* target,
                                     const a3d_range_image_view* source, const a3d_pose* pose,
                                     int32_t accum_f64, a3d_gn_state* out_geom, a3d_gn_state* out_color);
+/* Order in which the following passes ON THE CALLING THREAD merge their 4096-pixel chunks: 0 (default) = chunk
+ * order; any other value seeds a fresh pseudo-random permutation per pass.  The reference merges in whatever order
+ * rayon's par_bridge() delivered the chunks (image_icp.rs:96,143-148), so every permutation is a legitimate
+ * reference result; tests use this to measure the reference's own run-to-run envelope. */
+void orc_set_chunk_merge_order(uint64_t seed);
 /* ImageIcp::align.  threads >= 1 spreads the 4096-pixel chunks over threads (merge stays in chunk
  * order).  trace (nullable) receives per iteration [residual, t(3), q(4)] = 8 floats of the
  * transform after that iteration's update. */

@@ -141,6 +141,19 @@ a3d_status check_image_inputs(const a3d_range_image_view* target, const a3d_rang
 
 constexpr uint64_t BATCH_SIZE = 4096;  // image_icp.rs:74
 
+// Chunk merge order.  The reference collects the per-chunk sub-optimisers through rayon's `par_bridge()`
+// (image_icp.rs:96,143), which does NOT preserve the order of the chunks, and then adds them in the order of that
+// Vec (:145-148): any permutation of the chunks is a result the reference can produce.  0 = chunk order; any
+// other value seeds one permutation per pass (splitmix64 Fisher-Yates), advanced after every pass.
+thread_local uint64_t g_merge_order_state = 0;
+
+inline uint64_t splitmix64_next(uint64_t& x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
 // One full pass: chunk sub-optimisers (image_icp.rs:76-143) merged in chunk order (:145-148).
 template <typename Acc>
 void image_icp_pass(const a3d_icp_params& prm, const a3d_range_image_view& tgt,
@@ -165,9 +178,13 @@ void image_icp_pass(const a3d_icp_params& prm, const a3d_range_image_view& tgt,
     }
     for (auto& th : pool) th.join();
   }
-  for (uint64_t c = 0; c < n_chunks; ++c) {
-    color.add(sub_color[c]);
-    geom.add(sub_geom[c]);
+  std::vector<uint64_t> order(n_chunks);
+  for (uint64_t c = 0; c < n_chunks; ++c) order[c] = c;
+  if (g_merge_order_state != 0)
+    for (uint64_t c = n_chunks; c > 1; --c) std::swap(order[c - 1], order[splitmix64_next(g_merge_order_state) % c]);
+  for (uint64_t k = 0; k < n_chunks; ++k) {
+    color.add(sub_color[order[k]]);
+    geom.add(sub_geom[order[k]]);
   }
 }
 
@@ -326,6 +343,8 @@ void orc_intensity_map_bilinear_grad(const float* map, uint64_t w, uint64_t h, f
                                      float out3[3]) {
   bilinear_grad(map, w + 2, h + 2, u, v, &out3[0], &out3[1], &out3[2]);
 }
+
+void orc_set_chunk_merge_order(uint64_t seed) { g_merge_order_state = seed; }
 
 a3d_status orc_image_icp_accumulate(const a3d_icp_params* prm, const a3d_range_image_view* target,
                                     const a3d_range_image_view* source, const a3d_pose* pose,

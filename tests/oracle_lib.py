@@ -35,6 +35,7 @@ def load():
     lib.orc_intensity_map_bilinear_grad.argtypes = [_P, C.c_uint64, C.c_uint64, C.c_float, C.c_float, _P]
     lib.orc_image_icp_accumulate.argtypes = [_P, _P, _P, _P, C.c_int32, _P, _P]
     lib.orc_image_icp_align.argtypes = [_P, _P, _P, _P, C.c_int32, _P, _P]
+    lib.orc_set_chunk_merge_order.argtypes = [C.c_uint64]
     lib.orc_multiscale_align.argtypes = [_P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, C.c_int32, _P]
     lib.orc_kdtree_new.argtypes = [_P, C.c_uint64, C.POINTER(_P)]
     lib.orc_kdtree_nearest.argtypes = [_P, _P, C.c_uint64, _P, _P]
@@ -240,6 +241,12 @@ def image_icp_align(prm, target, source, init=None, threads=1, want_trace=False)
                                     C.byref(init) if init is not None else None, threads, C.byref(out),
                                     ptr(trace))
     return st, out, trace
+
+
+def set_chunk_merge_order(seed):
+    """0 = chunk order; otherwise the following passes on this thread merge their chunks in seeded permutations
+    (the orders rayon's par_bridge() may deliver, image_icp.rs:96,143-148)."""
+    load().orc_set_chunk_merge_order(int(seed))
 
 
 def multiscale_align(prm_arr, n_params, target_pyr, source_pyr, threads=1):

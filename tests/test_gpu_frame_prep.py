@@ -77,6 +77,20 @@ def test_bilateral_bit_exact_synthetic_and_edges(ctx):
         assert np.array_equal(out, ref)
 
 
+def test_bilateral_bit_exact_on_the_reference_known_answer_image(ctx):
+    """The image of the reference's own bilateral KAT (bloei.jpg -> luma16 / 13, src/unit_test/images.rs:28-40,
+    grid 138 x 104 x 173 of src/bilateral/grid.rs:183-185; the oracle is near-pinned on it in test_oracle_kat.py):
+    the device filter at the KAT's sigmas equals the oracle bit for bit on all 600 x 450 pixels."""
+    from test_oracle_kat import bloei_luma16
+
+    img = bloei_luma16()
+    st, ref, dims = O.bilateral(img, 4.5, 30.0)
+    f = BilateralFilter.new(4.5, 30.0)
+    out = f.filter(ctx, img)
+    assert st == 0 and dims == (138, 104, 173) and f.last_grid_dims == dims
+    assert np.array_equal(out, ref)
+
+
 def _assert_same_level(dev_level, ref):
     got = dev_level.download()
     assert got.mask.shape == ref.mask.shape

@@ -380,3 +380,63 @@ def test_opt_in_kernel_variants_keep_parity(ctx, monkeypatch, knobs):
         assert st == 0 and ang <= ROT_TOL and tr <= TRANS_TOL
     for k in range(2, 14):  # equal inputs, equal outputs wherever the pair sits
         assert np.array_equal(poses[k].t, poses[k % 2].t) and np.array_equal(poses[k].q, poses[k % 2].q)
+
+
+def test_bench10_lies_inside_the_reference_nondeterminism_envelope(ctx):
+    """bench10 (benches/bench_image_icp.rs: sample1 0 <- 5, IcpParams::default(), 10 iterations) is not contractive
+    (SURVEY §10.1), and the reference itself is not reproducible on it: rayon's par_bridge() (image_icp.rs:96) hands
+    the 75 chunk accumulators to `collect` in arbitrary order and they are then added in that order (:145-148).  The
+    oracle replays that freedom (a seeded permutation of the chunk merge order per pass).  The GPU result has to be
+    no farther from the oracle's results than those are from each other."""
+    ft, fs = oracle_frame("sample1", 0), oracle_frame("sample1", 5)
+    prm = IcpParams(max_iterations=10)
+    runs = []
+    try:
+        for seed in range(13):  # seed 0 = chunk order
+            O.set_chunk_merge_order(seed)
+            st, T, _ = O.image_icp_align(prm.to_c(), ft, fs, threads=4)
+            assert st == 0
+            runs.append(T)
+    finally:
+        O.set_chunk_merge_order(0)
+    pair = np.array([[O.transform_metrics(a, b) for b in runs] for a in runs])
+    spread_ang, spread_tr = float(pair[..., 0].max()), float(pair[..., 1].max())
+    T_gpu = ImageIcp.new(ctx, prm, to_range_image(ft)).align(to_range_image(fs))
+    to_gpu = np.array([transform_diff(T_gpu, r) for r in runs])
+    print(f"[bench10 envelope] oracle vs oracle over 13 merge orders: max {spread_ang:.3e} rad {spread_tr:.3e} m, "
+          f"median {np.median(pair[..., 0]):.3e} rad;  GPU vs oracle runs: min {to_gpu[:, 0].min():.3e} rad "
+          f"{to_gpu[:, 1].min():.3e} m, max {to_gpu[:, 0].max():.3e} rad {to_gpu[:, 1].max():.3e} m")
+    assert spread_ang > ROT_TOL  # the reference's own envelope is wider than the north-star tolerance on this shape
+    assert to_gpu[:, 0].min() <= spread_ang and to_gpu[:, 1].min() <= spread_tr
+    assert to_gpu[:, 0].max() <= 2 * spread_ang and to_gpu[:, 1].max() <= 2 * spread_tr
+
+
+def test_ms3x15_end_to_end_on_benchmark_pairs(ctx):
+    """The headline workload itself (bench.py: seed-1000 synthetic 640x480 stream, device-built pyramids,
+    MsIcpParams::repeat(3, IcpParams::default()) = ms3x15): the batched GPU poses against the oracle run on the very
+    arrays the kernels read, <= 1e-4 rad / 1e-4 m (the synthetic texture keeps the default parameters contractive)."""
+    import bench
+
+    P = 6
+    pyr, _, _ = bench.build_stream_pyramids(ctx, 1000, P + 1, 640, 480)
+    prm = MsIcpParams.repeat(3, IcpParams.default())
+    batch = MultiscaleAlignBatch(ctx, prm, pyr[:P], pyr[1:])
+    poses, status = batch.align()
+    batch.free()
+    assert not np.any(status)
+
+    def frame(dev_level):
+        ri = dev_level.download(colors=False)
+        k = ri.intrinsics
+        return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
+
+    host = [[frame(lv) for lv in p] for p in pyr]
+    worst = (0.0, 0.0)
+    for p in range(P):
+        st, T_ref = O.multiscale_align(prm.to_c_array(), 3, host[p], host[p + 1], threads=8)
+        ang, tr = transform_diff(poses[p], T_ref)
+        worst = (max(worst[0], ang), max(worst[1], tr))
+        assert st == 0 and ang <= ROT_TOL and tr <= TRANS_TOL, (p, ang, tr)
+    print(f"[ms3x15 on the benchmark's pairs] worst d_angle={worst[0]:.3e} rad d_trans={worst[1]:.3e} m")
+    for lv in (lv for p in pyr for lv in p):
+        lv.free()

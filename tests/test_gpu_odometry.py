@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 def test_real_consecutive_pairs_follow_ground_truth(ctx):
     """sample1 frames 0 -> 1 and 4 -> 5 (the consecutive pairs among the fixtures): device builder + default
     MsIcpParams; the estimate must beat the identity against the dataset's ground truth and equal the oracle."""
-    ds = SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1"))  # fixture frames 0, 1, 4, 5
+    ds = SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1"))  # fixture frames 0..19
     gt = ds.trajectory()
     builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
-    for a, b, ids in ((0, 1, (0, 1)), (2, 3, (4, 5))):
+    for a, b, ids in ((0, 1, (0, 1)), (4, 5, (4, 5))):
         target = builder.build_device(*ds.get(a))
         source = builder.build_device(*ds.get(b))
         T = MultiscaleAlign.new(ctx, MsIcpParams.default(), target).align(source)
@@ -32,6 +32,64 @@ def test_real_consecutive_pairs_follow_ground_truth(ctx):
                                        oracle_pyramid("sample1", ids[1]), threads=4)
         ang, tr = transform_diff(T, T_ref)
         assert st == 0 and ang <= 1e-4 and tr <= 1e-4
+
+
+def test_sample1_20_frame_odometry_against_oracle_and_ground_truth(ctx):
+    """configs[3] on real data: the 20-frame odometry loop of examples/src/bin/odometry.rs:38-56 (README.md:79-116) on
+    the reference's own sample1 sequence (no TUM / IL-RGBD data exists in the image): RangeImageBuilder::default() +
+    BilateralFilter::default(), MsIcpParams::default(), frame i-1 the target and frame i the source.  Every one of the
+    19 alignments is held to the oracle's (<= 1e-4 rad / 1e-4 m), so is every accumulated pose, and the
+    mean trajectory error against the dataset's ground truth is reported and must equal the oracle's."""
+    from align3d_amd import Trajectory, Transform, TrajectoryBuilder
+
+    ds = SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1"))
+    n = 20
+    assert ds.len() == n
+    pred, metrics = run_odometry(ctx, ds)
+    assert pred.len() == n
+    # the same loop without the prefetch worker, keeping every per-pair transform
+    builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+    prm = MsIcpParams.default()
+    last = builder.build(*ds.get(0))
+    tb = TrajectoryBuilder.with_start(Transform.eye(), 0.0)
+    ref_poses = [Transform.eye()]
+    ref_last = O.pose()  # oracle-side TrajectoryBuilder::accumulate (trajectory.rs:164-168): last = T * last
+    worst_pair = worst_acc = (0.0, 0.0)
+    for i in range(1, n):
+        cur = builder.build(*ds.get(i))
+        T = MultiscaleAlign.new(ctx, prm, last).align(cur)
+        tb.accumulate(T, float(i))
+        st, T_ref = O.multiscale_align(prm.to_c_array(), 3, oracle_pyramid("sample1", i - 1), oracle_pyramid("sample1", i),
+                                       threads=8)
+        assert st == 0
+        ang, tr = transform_diff(T, T_ref)
+        assert ang <= 1e-4 and tr <= 1e-4, (i, ang, tr)
+        worst_pair = (max(worst_pair[0], ang), max(worst_pair[1], tr))
+        ref_last = O.compose(T_ref, ref_last)
+        ref_poses.append(Transform.from_c(ref_last))
+        ang, tr = transform_diff(tb.build()[i], ref_last)
+        assert ang <= 1e-4 and tr <= 1e-4, ("accumulated", i, ang, tr)
+        worst_acc = (max(worst_acc[0], ang), max(worst_acc[1], tr))
+        for lv in last:
+            lv.free()
+        last = cur
+    for lv in last:
+        lv.free()
+    seq = tb.build()
+    for a, b in zip(pred.camera_to_world, seq.camera_to_world):  # the pipelined loop = the sequential loop
+        assert np.array_equal(a.t, b.t) and np.array_equal(a.q, b.q)
+    gt = ds.trajectory().slice(0, n).first_frame_at_origin()
+    still, ref_traj = Trajectory(), Trajectory()
+    for i in range(n):
+        still.push(Transform.eye(), float(i))
+        ref_traj.push(ref_poses[i], float(i))
+    m_still = TransformMetrics.mean_trajectory_error(still, gt)
+    m_ref = TransformMetrics.mean_trajectory_error(ref_traj, gt)
+    print(f"[sample1 20-frame odometry] Mean trajectory error: {metrics} (oracle: {m_ref}; camera held still: {m_still}); "
+          f"worst pair vs oracle {worst_pair[0]:.2e} rad {worst_pair[1]:.2e} m; worst accumulated pose vs oracle "
+          f"{worst_acc[0]:.2e} rad {worst_acc[1]:.2e} m")
+    assert abs(metrics.angle - m_ref.angle) <= 1e-4 and abs(metrics.translation - m_ref.translation) <= 1e-4
+    assert metrics.total() < m_still.total()  # the estimate tracks the ground truth better than no motion at all
 
 
 def test_synthetic_stream_odometry(ctx):

@@ -69,7 +69,7 @@ def test_trajectory_builder_semantics():
 # src/io/dataset/slamtb.rs:161-173
 def test_slamtb_reader():
     ds = SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1"))
-    assert ds.len() == 4
+    assert ds.len() == 20
     cam, depth, rgb, scale = ds.get(0)
     assert (cam.fx, cam.fy, cam.cx, cam.cy) == (544.4732666015625, 544.4732666015625, 320.0, 240.0)
     assert depth.shape == (480, 640) and depth.dtype == np.uint16 and rgb.shape == (480, 640, 3) and scale == 0.001

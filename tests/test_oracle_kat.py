@@ -1,13 +1,14 @@
 """Pins the CPU oracle against every known-answer test the reference holds for the hot path
 (SURVEY.md §4 / §8c).  Runs on CPU."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 import oracle_lib as O
 from align3d_amd._abi import GnStateC, PoseC, ptr
-from data_util import SlamTbSample
+from data_util import GOLDEN, SlamTbSample
 
 
 # src/optim/gaussnewton.rs:141-167
@@ -227,3 +228,26 @@ def test_multiscale_new_length_mismatch_and_smoke():
         prm[i].max_iterations = 3
     st, T = O.multiscale_align(prm, 3, tp, sp, threads=4)
     assert st == 0 and np.all(np.isfinite(O.pose_tuple(T)[0]))
+
+
+def bloei_luma16():
+    """unit_test/images.rs:28-40: bloei.jpg -> into_luma16() -> v /= u16::MAX / 5000.  The JPEG is decoded by Pillow
+    here and by the `image` crate's jpeg-decoder 0.3.0 in the reference (IDCT rounding may differ by one grey level);
+    image-0.24.7's Rgb8 -> Luma16 is (2126 r + 7152 g + 722 b) / 10000 in integers, then x 257."""
+    from PIL import Image
+
+    rgb = np.array(Image.open(os.path.join(GOLDEN, "images", "bloei.jpg")).convert("RGB"), np.uint32)
+    l8 = (2126 * rgb[..., 0] + 7152 * rgb[..., 1] + 722 * rgb[..., 2]) // 10000
+    return ((l8 * 257).astype(np.uint16) // np.uint16(65535 // 5000)).astype(np.uint16)
+
+
+# src/bilateral/grid.rs:183-194: the one value-level known answer the reference holds for the bilateral grid
+def test_bilateral_grid_slice_known_answer_near_pin():
+    img = bloei_luma16()
+    assert img.shape == (600, 450)
+    st, out, dims = O.bilateral(img, 4.5, 30.0, blur=False)  # BilateralGrid::from_image + normalize + slice
+    assert st == 0 and dims == (138, 104, 173)               # verify_grid_creation: dim() == (138, 104, 173, 2)
+    assert out.shape == (600, 450)
+    # verify_slice: dest_image[(421, 123)] == 2266 with the reference's JPEG decoder; Pillow's decode of the same
+    # file differs by at most one grey level per channel, which moves this value by at most one count (2265 here)
+    assert abs(int(out[421, 123]) - 2266) <= 1
