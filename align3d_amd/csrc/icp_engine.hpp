@@ -101,9 +101,8 @@ __device__ __forceinline__ float wave_reduce_scatter(const float (&acc)[N]) {
 }
 
 // Wave reduce-scatter + LDS across the block's 4 waves -> one block partial of N floats.
-template <int N, bool WRITE_THROUGH = false>
+template <int N, bool WRITE_THROUGH = false, int WAVES = 4>
 __device__ __forceinline__ void block_reduce_store(const float (&acc)[N], float* __restrict__ out) {
-  constexpr int WAVES = 4;  // 256-thread blocks
   __shared__ float red[WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   red[wave][lane] = wave_reduce_scatter<N>(acc);
@@ -324,12 +323,12 @@ __device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job
                                                          unsigned* __restrict__ counter, JobState* st,
                                                          const SolveArgs& args, int job);
 
-template <int N>
+template <int N, int WAVES = 4>
 __device__ __forceinline__ void block_finish(const float (&acc)[N], float* __restrict__ job_partials, uint32_t tile,
                                              uint32_t tiles, unsigned* __restrict__ counter, JobState* st,
                                              const SolveArgs& args, int job) {
   float* out = job_partials + (size_t)tile * GN_PARTIAL;
-  block_reduce_store<N, true>(acc, out);
+  block_reduce_store<N, true, WAVES>(acc, out);
   if (N < GN_PARTIAL && threadIdx.x >= N && threadIdx.x < GN_PARTIAL)
     __hip_atomic_store((unsigned*)out + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   block_publish_and_finish(job_partials, tiles, counter, st, args, job);
@@ -360,7 +359,7 @@ __device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job
   {
     const int cg = threadIdx.x & 31, slice = threadIdx.x >> 5;
     double sum0 = 0.0, sum1 = 0.0;
-    if (cg < GN_PARTIAL / 2) {
+    if (cg < GN_PARTIAL / 2 && slice < 8) {  // the first 256 threads of the block (blocks may be larger)
       const unsigned long long* base = (const unsigned long long*)job_partials + cg;
       uint32_t t = slice;
       for (; t + 56 < tiles; t += 64) {

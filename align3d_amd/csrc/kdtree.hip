@@ -43,7 +43,7 @@ a3d_status kdtree_build_host(const float* points, uint32_t n, std::vector<float>
     uint64_t a, b;
     kdtree_shape(n, &max_depth, &a, &b);
   }
-  A3D_REQUIRE(max_depth < 26, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout");
+  A3D_REQUIRE(max_depth <= 23, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout (leaf byte offsets are 32-bit)");
   const uint64_t n_split = (1ull << max_depth) - 1, n_slots = (1ull << max_depth) * 16;
   split->assign(n_split, 0.0f);
   const float inf = std::numeric_limits<float>::infinity();
@@ -95,32 +95,69 @@ a3d_status kdtree_build_host(const float* points, uint32_t n, std::vector<float>
 
 namespace {
 
-constexpr uint32_t KD_TOP = 4095;  // heap entries of the split table kept in LDS (levels 0..11, 16 KiB)
+// Launch geometry of the two query kernels.  The split table's top `lds_levels` heap levels are staged in LDS by
+// every block (2^levels - 1 floats), so fat blocks amortise the staging.  Default: one 1024-thread block per CU with
+// 15 levels (128 KiB of the CU's 160 KiB): a 500k-point tree then descends entirely out of LDS, and each thread
+// serves two or more queries, which staggers the waves' descent and scan phases (measured on MI355X, 500k x 500k:
+// 17.3 us against 19.4 us for 512 threads / 12 levels / 4 blocks per CU; scripts/kd_sweep.sh).
+struct KdLaunch {
+  uint32_t block, lds_levels, blocks;
+  size_t lds_bytes;
+};
 
-__global__ void __launch_bounds__(256)
+KdLaunch kd_launch_config(const a3d_kdtree* t, uint64_t m, const char* env_prefix, uint32_t def_block,
+                          uint32_t def_levels, uint32_t blocks_per_cu_cap) {
+  auto env_u = [&](const char* suffix, uint32_t def) {
+    std::string name = std::string(env_prefix) + suffix;
+    const char* v = getenv(name.c_str());
+    return v ? (uint32_t)atoi(v) : def;
+  };
+  KdLaunch L;
+  L.block = env_u("_BLOCK", def_block);
+  if (L.block != 256 && L.block != 512 && L.block != 1024) L.block = def_block;
+  L.lds_levels = std::min<uint32_t>(env_u("_LDS_LEVELS", def_levels), 15u);  // 15 levels = 128 KiB of the CU's 160
+  L.lds_levels = std::min<uint32_t>(L.lds_levels, t->max_depth);             // deeper levels do not exist
+  const uint64_t want = (1ull << L.lds_levels) - 1;
+  L.lds_bytes = (size_t)std::min<uint64_t>(want, t->n_split) * sizeof(float);
+  const uint32_t per_cu = std::max<uint32_t>(1, env_u("_BLOCKS_PER_CU", blocks_per_cu_cap));
+  L.blocks = (uint32_t)std::min<uint64_t>((m + L.block - 1) / L.block, (uint64_t)std::max(1, t->ctx->num_cus) * per_cu);
+  L.blocks = std::max<uint32_t>(1, L.blocks);
+  return L;
+}
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
     kdtree_nearest_kernel(const float* __restrict__ split, const float4* __restrict__ leaves, uint32_t n,
-                          uint32_t n_split, uint32_t max_depth, const float* __restrict__ queries, uint32_t m,
-                          uint32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
-  __shared__ float split_top[KD_TOP];
-  const uint32_t top = n_split < KD_TOP ? n_split : KD_TOP;
-  for (uint32_t k = threadIdx.x; k < top; k += blockDim.x) split_top[k] = split[k];
-  __syncthreads();
+                          uint32_t n_split, uint32_t max_depth, uint32_t lds_levels,
+                          const float* __restrict__ queries, uint32_t m, uint32_t* __restrict__ out_idx,
+                          float* __restrict__ out_dist) {
+  extern __shared__ __attribute__((aligned(16))) float kd_lds[];
+  typedef float f32x3 __attribute__((ext_vector_type(3)));
+  typedef f32x3 __attribute__((aligned(4))) f32x3_u;
+  kd_stage_splits(split, n_split, lds_levels, kd_lds);
+  const KdSplits sp{split, kd_lds, lds_levels};
   // grid-stride over queries; every lane stays in the loop (the cooperative scan needs the whole wave)
-  const uint32_t rounds = (m + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+  const uint32_t rounds = (m + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
   for (uint32_t r = 0; r < rounds; ++r) {
-    const uint32_t i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint32_t i = (r * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
     const uint32_t ii = i < m ? i : m - 1;
-    typedef float f32x3 __attribute__((ext_vector_type(3)));
-    typedef f32x3 __attribute__((aligned(4))) f32x3_u;
     const f32x3 qv = *(const f32x3_u*)(queries + 3 * (size_t)ii);  // one dwordx3
     const V3 q{qv.x, qv.y, qv.z};
-    const uint32_t base = kdtree_descend(split, split_top, top, n, max_depth, q);
+#if defined(A3D_KD_PROBE) && A3D_KD_PROBE == 2  // phase probe (scripts/build_variant.sh): scan only, pseudo-random leaf
+    const uint32_t base = ((i * 2654435761u) >> (32u - max_depth)) * 16u;
+#else
+    const uint32_t base = kdtree_descend(sp, n, max_depth, q);
+#endif
+#if defined(A3D_KD_PROBE) && A3D_KD_PROBE == 1  // phase probe: descent only
+    if (i < m) out_idx[i] = base, out_dist[i] = 0.0f;
+    continue;
+#endif
     uint32_t slot;
     float dist;
-    float4 win;
-    kdtree_scan_leaves_coop(leaves, base, q, &slot, &dist, &win);
+    kdtree_scan_leaves_coop(leaves, base, q, &slot, &dist);
+    const uint32_t idx = ((const uint32_t*)leaves)[(size_t)slot * 4 + 3];  // the winner's original index
     if (i < m) {
-      out_idx[i] = __float_as_uint(win.w);
+      out_idx[i] = idx;
       out_dist[i] = dist;
     }
   }
@@ -131,54 +168,62 @@ struct PclGates {
   float dot_reject_max;  // reject iff -1 <= sn.tn <= dot_reject_max  (== acos(sn.tn).abs() > max_normal_angle)
 };
 
-// The body of Icp::align's point loop (src/icp/pcl_icp.rs:68-92); grid-stride, 256 threads.
-__global__ void __launch_bounds__(256)
+// The body of Icp::align's point loop (src/icp/pcl_icp.rs:68-92); grid-stride.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
     pcl_icp_kernel(const float* __restrict__ split, const float4* __restrict__ leaves,
-                   const float4* __restrict__ leaf_normals, uint32_t n, uint32_t max_depth,
+                   const float4* __restrict__ leaf_normals, uint32_t n, uint32_t max_depth, uint32_t lds_levels,
                    const float* __restrict__ src_points, const float* __restrict__ src_normals, uint32_t m,
                    JobState* __restrict__ states, PclGates gates, float* __restrict__ partials,
                    unsigned* __restrict__ counter, SolveArgs solve) {
-  __shared__ float split_top[KD_TOP];
+  extern __shared__ __attribute__((aligned(16))) float kd_lds[];
   const uint32_t n_split = (1u << max_depth) - 1u;
-  const uint32_t top = n_split < KD_TOP ? n_split : KD_TOP;
-  for (uint32_t k = threadIdx.x; k < top; k += blockDim.x) split_top[k] = split[k];
-  __syncthreads();
+  kd_stage_splits(split, n_split, lds_levels, kd_lds);
+  const KdSplits sp{split, kd_lds, lds_levels};
   float acc[GN_ACC];
 #pragma unroll
   for (int k = 0; k < GN_ACC; ++k) acc[k] = 0.0f;
-  if (states->status == A3D_OK) {
+  const int status = states->status;
+  if (status == A3D_OK) {
     const Pose T = states->pose;
     typedef float f32x3 __attribute__((ext_vector_type(3)));
     typedef f32x3 __attribute__((aligned(4))) f32x3_u;
     // every lane stays in the loop: the cooperative leaf scan needs the whole wave
-    const uint32_t rounds = (m + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    const uint32_t rounds = (m + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
     for (uint32_t r = 0; r < rounds; ++r) {
-      const uint32_t i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+      const uint32_t i = (r * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
       const uint32_t ii = i < m ? i : m - 1;
       const f32x3 pv = *(const f32x3_u*)(src_points + 3 * (size_t)ii), nv = *(const f32x3_u*)(src_normals + 3 * (size_t)ii);
-      const V3 sp = transform_vector(T, V3{pv.x, pv.y, pv.z});
-      const V3 sn = transform_normal(T, V3{nv.x, nv.y, nv.z});
-      const uint32_t base = kdtree_descend(split, split_top, top, n, max_depth, sp);
+      const V3 p = transform_vector(T, V3{pv.x, pv.y, pv.z});
+      const uint32_t base = kdtree_descend(sp, n, max_depth, p);
       uint32_t slot;
       float d2;
-      float4 win;
-      kdtree_scan_leaves_coop(leaves, base, sp, &slot, &d2, &win);
-      if (i >= m) continue;
-      if (d2 > gates.max_distance_sqr) continue;
-      const float4 tn4 = leaf_normals[slot];
+      kdtree_scan_leaves_coop(leaves, base, p, &slot, &d2);
+      // the winner's record and its normal: one 16-byte gather each (the point's line was just scanned)
+      const float4 win = leaves[slot], tn4 = leaf_normals[slot];
+      const V3 sn = transform_normal(T, V3{nv.x, nv.y, nv.z});
       const V3 tn{tn4.x, tn4.y, tn4.z};
       const float c = dot(sn, tn);
-      if (c >= -1.0f && c <= gates.dot_reject_max) continue;
-      const V3 tp{win.x, win.y, win.z};
-      const float rr = dot(tp - sp, tn);
-      const V3 tw = cross(sp, tn);
-      const float J[6] = {tn.x, tn.y, tn.z, tw.x, tw.y, tw.z};
-      gn_step(acc, rr, J);
+      const bool keep = i < m && !(d2 > gates.max_distance_sqr) && !(c >= -1.0f && c <= gates.dot_reject_max);
+      if (keep) {
+        const V3 tp{win.x, win.y, win.z};
+        const float rr = dot(tp - p, tn);
+        const V3 tw = cross(p, tn);
+        const float J[6] = {tn.x, tn.y, tn.z, tw.x, tw.y, tw.z};
+        gn_step(acc, rr, J);
+      }
     }
   }
   SolveArgs sa = solve;
-  if (states->status != A3D_OK) sa.mode = SOLVE_NONE;
-  block_finish<GN_ACC>(acc, partials, blockIdx.x, gridDim.x, counter, states, sa, 0);  // no colour term
+  if (status != A3D_OK) sa.mode = SOLVE_NONE;
+  block_finish<GN_ACC, BLOCK / 64>(acc, partials, blockIdx.x, gridDim.x, counter, states, sa, 0);  // no colour term
+}
+
+template <typename K>
+a3d_status kd_allow_big_lds(K kernel, size_t lds_bytes) {
+  if (lds_bytes > 48 * 1024)
+    A3D_HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  return A3D_OK;
 }
 
 a3d_status check_finite_query_count(uint64_t m) {
@@ -193,7 +238,8 @@ struct a3d_pcl_icp {
   a3d_icp_params params;
   a3d_kdtree* tree = nullptr;
   bool target_has_normals = false;
-  uint32_t blocks = 0;
+  uint32_t blocks = 0;  // block partials (= grid size of the iteration kernel)
+  KdLaunch launch{};
   JobState* d_state = nullptr;
   float* d_partials = nullptr;
   unsigned* d_counter = nullptr;
@@ -215,7 +261,7 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
   const char* mode = getenv("A3D_KDTREE_BUILD");
   if (!(mode && !strcmp(mode, "host"))) {  // device build: upload the points, sort level by level on the GPU
     kdtree_shape(t->n, &t->max_depth, &t->n_leaves, &t->n_internal);
-    A3D_REQUIRE(t->max_depth < 26, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout");
+    A3D_REQUIRE(t->max_depth <= 23, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout (leaf byte offsets are 32-bit)");
     t->n_split = (uint32_t)((1ull << t->max_depth) - 1);
     t->n_leaf_slots = (1ull << t->max_depth) * 16;
     float* d_points = nullptr;
@@ -258,11 +304,16 @@ a3d_status a3d_kdtree_nearest_device(a3d_kdtree* t, const void* d_queries, uint6
   A3D_TRY(check_finite_query_count(m));
   if (m == 0) return A3D_OK;
   A3D_HIP_TRY(hipSetDevice(t->ctx->device));
-  // enough blocks to fill the chip, few enough that the 16 KiB LDS copy of the split table's top is amortised
-  const uint32_t blocks = (uint32_t)std::min<uint64_t>((m + 255) / 256, (uint64_t)std::max(1, t->ctx->num_cus) * 8);
-  hipLaunchKernelGGL(kdtree_nearest_kernel, dim3(blocks), dim3(256), 0, t->ctx->stream, t->d_split, t->d_leaves, t->n,
-                     t->n_split, t->max_depth, (const float*)d_queries, (uint32_t)m, (uint32_t*)d_indices,
-                     (float*)d_sqr);
+  const KdLaunch L = kd_launch_config(t, m, "A3D_KD", 1024, 15, 1);
+#define A3D_KD_LAUNCH(B)                                                                                      \
+  {                                                                                                           \
+    A3D_TRY(kd_allow_big_lds(kdtree_nearest_kernel<B>, L.lds_bytes));                                         \
+    hipLaunchKernelGGL(kdtree_nearest_kernel<B>, dim3(L.blocks), dim3(B), L.lds_bytes, t->ctx->stream, t->d_split, \
+                       t->d_leaves, t->n, t->n_split, t->max_depth, L.lds_levels, (const float*)d_queries,   \
+                       (uint32_t)m, (uint32_t*)d_indices, (float*)d_sqr);                                     \
+  }
+  if (L.block == 256) A3D_KD_LAUNCH(256) else if (L.block == 512) A3D_KD_LAUNCH(512) else A3D_KD_LAUNCH(1024)
+#undef A3D_KD_LAUNCH
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }
@@ -353,8 +404,10 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
       st = A3D_HIP_ERROR;
     icp->target_has_normals = true;
   }
-  // few, fat blocks: the last block sums one partial per block, so the tail grows with the block count
-  icp->blocks = (uint32_t)std::max(1, ctx->num_cus * (getenv("A3D_PCL_BLOCKS_PER_CU") ? atoi(getenv("A3D_PCL_BLOCKS_PER_CU")) : 4));
+  // few, fat blocks: the last block sums one partial per block, so the tail grows with the block count; the grid
+  // is fixed per Icp object (sized for a source cloud as large as the target) so the partials buffer is too
+  icp->launch = kd_launch_config(t, 1ull << 31, "A3D_PCL", 1024, 15, 1);
+  icp->blocks = icp->launch.blocks;
   if (st == A3D_OK &&
       (hipMalloc((void**)&icp->d_state, sizeof(JobState)) != hipSuccess ||
        hipMalloc((void**)&icp->d_partials, (size_t)icp->blocks * GN_PARTIAL * sizeof(float)) != hipSuccess ||
@@ -393,9 +446,16 @@ static a3d_status pcl_launch_pass(a3d_pcl_icp* icp, const float* d_pts, const fl
   g.max_distance_sqr = icp->params.max_distance * icp->params.max_distance;
   g.dot_reject_max = acos_gate_threshold(icp->params.max_normal_angle, /*strict=*/true);
   a3d_kdtree* t = icp->tree;
-  hipLaunchKernelGGL(pcl_icp_kernel, dim3(icp->blocks), dim3(256), 0, icp->ctx->stream, t->d_split, t->d_leaves,
-                     t->d_leaf_normals, t->n, t->max_depth, d_pts, d_nrm, m, icp->d_state, g, icp->d_partials,
-                     icp->d_counter, solve);
+  const KdLaunch& L = icp->launch;
+#define A3D_PCL_LAUNCH(B)                                                                                      \
+  {                                                                                                            \
+    A3D_TRY(kd_allow_big_lds(pcl_icp_kernel<B>, L.lds_bytes));                                                 \
+    hipLaunchKernelGGL(pcl_icp_kernel<B>, dim3(L.blocks), dim3(B), L.lds_bytes, icp->ctx->stream, t->d_split,  \
+                       t->d_leaves, t->d_leaf_normals, t->n, t->max_depth, L.lds_levels, d_pts, d_nrm, m,      \
+                       icp->d_state, g, icp->d_partials, icp->d_counter, solve);                               \
+  }
+  if (L.block == 256) A3D_PCL_LAUNCH(256) else if (L.block == 512) A3D_PCL_LAUNCH(512) else A3D_PCL_LAUNCH(1024)
+#undef A3D_PCL_LAUNCH
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }

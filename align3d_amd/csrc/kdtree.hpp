@@ -48,60 +48,140 @@ a3d_status kdtree_radix_sort_pairs(hipStream_t s, uint64_t* keys_a, uint64_t* ke
 a3d_status kdtree_sort_ranges(hipStream_t s, const float* points, const uint32_t* idx_in, uint32_t* idx_out, uint32_t n,
                               uint32_t level, int k, uint32_t cap_log2, uint32_t* nan_flag);
 
-// Descent of R3dTree::nearest (src/kdtree.rs:69-105): returns the first slot of the leaf the query falls in.
-// `split_top` (nullable) is an LDS copy of the first `top_entries` heap entries of the split table.
-__device__ __forceinline__ uint32_t kdtree_descend(const float* __restrict__ split, const float* split_top,
-                                                   uint32_t top_entries, uint32_t n, uint32_t max_depth, V3 q) {
-  uint32_t len = n, node = 0, path = 0, depth = 0;
-  int dim = 0;
-  while (len > 16) {
-    const float sv = node < top_entries ? split_top[node] : split[node];
-    const float qd = dim == 0 ? q.x : (dim == 1 ? q.y : q.z);
-    const uint32_t right = (qd < sv) ? 0u : 1u;  // `point[dim] < mid` goes left; NaN goes right
-    const uint32_t mid = len >> 1;
-    len = right ? len - mid : mid;
-    node = 2 * node + 1 + right;
-    path = 2 * path + right;
-    ++depth;
-    dim = dim == 2 ? 0 : dim + 1;
-  }
-  return (path << (max_depth - depth)) * 16u;
+// ---- device side of R3dTree::nearest (src/kdtree.rs:69-105) -----------------------------------------------------
+//
+// Shape facts the kernels rely on (checked on the host for every n by kdtree_shape_check, tests/test_abi_cpu.py):
+//  * the node reached by descent path `path` at depth d holds  len = (n + bitrev_d(path)) >> d  points
+//    (left child = floor(len / 2), right child = ceil(len / 2));
+//  * every leaf sits at depth max_depth - 1 or max_depth.
+// So a descent is max_depth - 1 unconditional steps plus one conditional step, the coordinate tested at depth d is
+// d % 3, and neither `len` nor `path` has to be carried along: node = heap index, path = node + 1 - 2^depth.
+
+// One descent step: `point[dim] < mid` goes left, everything else (NaN included) goes right (kdtree.rs:80-88).
+__device__ __forceinline__ uint32_t kd_step(uint32_t node, float qd, float sv) {
+  return 2u * node + ((qd < sv) ? 1u : 2u);
 }
 
-// The 16-slot scan of one lane's own leaf (used where a lane works alone: the Icp kernel).
-__device__ __forceinline__ uint32_t kdtree_scan_leaf(const float4* __restrict__ leaves, uint32_t base, V3 q,
-                                                     float* out_dist, float4* out_point) {
-  float4 pts[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) pts[s] = leaves[base + s];
-  float min_dist = 3.402823466e+38f;  // f32::MAX
-  uint32_t min_slot = 0;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    // (point - leaf_point).norm_squared() = (dx^2 + dy^2) + dz^2, no contraction
-    const float dist = norm_squared(q - V3{pts[s].x, pts[s].y, pts[s].z});
-    if (dist < min_dist) {  // strict <: the first minimum wins (kdtree.rs:96)
-      min_dist = dist;
-      min_slot = s;
+// Split table: heap levels [0, lds_levels) come from the block's LDS copy, deeper ones from global memory.
+struct KdSplits {
+  const float* __restrict__ global;
+  const float* lds;
+  uint32_t lds_levels;
+};
+
+// Copies the first min(2^levels - 1, n_split) heap entries of the split table into LDS (all threads of the block;
+// `lds` 16-byte aligned).  16-byte loads, four in flight per thread before the first LDS write: the copy costs one or
+// two memory round trips instead of one per 4 bytes and thread.
+__device__ __forceinline__ void kd_stage_splits(const float* __restrict__ split, uint32_t n_split, uint32_t levels,
+                                                float* lds) {
+  const uint32_t want = (1u << levels) - 1u, top = n_split < want ? n_split : want;
+  const float4* s4 = (const float4*)split;
+  float4* l4 = (float4*)lds;
+  const uint32_t n4 = top >> 2, B = blockDim.x;
+  uint32_t k = threadIdx.x;
+  for (; k + 3 * B < n4; k += 4 * B) {
+    const float4 a = s4[k], b = s4[k + B], c = s4[k + 2 * B], d = s4[k + 3 * B];
+    l4[k] = a, l4[k + B] = b, l4[k + 2 * B] = c, l4[k + 3 * B] = d;
+  }
+  for (; k < n4; k += B) l4[k] = s4[k];
+  for (k = 4 * n4 + threadIdx.x; k < top; k += B) lds[k] = split[k];
+  __syncthreads();
+}
+
+// `count` unconditional descent steps through the LDS table, the first on coordinate a, then b, c, a, ...
+__device__ __forceinline__ uint32_t kd_walk(const float* tab, uint32_t node, uint32_t count, float a, float b, float c) {
+  uint32_t k = 0;
+  for (; k + 3 <= count; k += 3) {  // dim = depth % 3 without a select
+    node = kd_step(node, a, tab[node]);
+    node = kd_step(node, b, tab[node]);
+    node = kd_step(node, c, tab[node]);
+  }
+  if (k < count) {
+    node = kd_step(node, a, tab[node]);
+    if (k + 1 < count) node = kd_step(node, b, tab[node]);
+  }
+  return node;
+}
+
+// (x, y, z) rotated left by r (wave-uniform r in 0..2): the coordinate tested at depth d is rot(q, d % 3).x
+__device__ __forceinline__ V3 kd_rot(V3 q, uint32_t r) {
+  return r == 0 ? q : (r == 1 ? V3{q.y, q.z, q.x} : V3{q.z, q.x, q.y});
+}
+
+typedef float kd_f32x2 __attribute__((ext_vector_type(2)));
+typedef float kd_f32x4 __attribute__((ext_vector_type(4)));
+typedef kd_f32x2 __attribute__((aligned(4))) kd_f32x2_u;
+typedef kd_f32x4 __attribute__((aligned(4))) kd_f32x4_u;
+
+// Three heap levels below `node` fetched in ONE memory round trip: the node's split value, its two children's
+// (adjacent heap entries 2n+1, 2n+2) and its four grandchildren's (4n+3 .. 4n+6); the two decisions then pick the
+// values that a level-by-level descent would have read.
+struct KdTriple {
+  float s0;
+  kd_f32x2 s1;
+  kd_f32x4 s2;
+};
+__device__ __forceinline__ KdTriple kd_fetch3(const float* __restrict__ tab, uint32_t node) {
+  KdTriple t;
+  t.s0 = tab[node];
+  t.s1 = *(const kd_f32x2_u*)(tab + 2u * (size_t)node + 1u);
+  t.s2 = *(const kd_f32x4_u*)(tab + 4u * (size_t)node + 3u);
+  return t;
+}
+
+// Returns the first slot of the leaf the query falls in.
+__device__ __forceinline__ uint32_t kdtree_descend(const KdSplits& sp, uint32_t n, uint32_t max_depth, V3 q) {
+  if (max_depth == 0) return 0u;
+  const uint32_t last = max_depth - 1;  // depth of the conditional step
+  // the heap entry of a node at depth `last` always exists (the table has 2^max_depth - 1 entries; a leaf's entry
+  // holds 0 and is ignored), so the last split value is read unconditionally, from whichever table holds that level
+  uint32_t node;  // the node reached at depth `last`
+  float sv;       // its split value
+  if (last < sp.lds_levels) {  // wave-uniform: the whole descent runs out of LDS
+    node = kd_walk(sp.lds, 0u, last, q.x, q.y, q.z);
+    sv = sp.lds[node];
+  } else {
+    node = kd_walk(sp.lds, 0u, sp.lds_levels, q.x, q.y, q.z);
+    uint32_t level = sp.lds_levels;
+    const float* __restrict__ tab = sp.global;
+    for (; level + 3 <= last; level += 3) {  // three unconditional levels per round trip
+      const V3 c = kd_rot(q, level % 3u);
+      const KdTriple t = kd_fetch3(tab, node);
+      const uint32_t r0 = (c.x < t.s0) ? 0u : 1u;
+      const uint32_t r1 = (c.y < (r0 ? t.s1.y : t.s1.x)) ? 0u : 1u;
+      const uint32_t g = 2u * r0 + r1;
+      const float s2 = g == 0 ? t.s2.x : (g == 1 ? t.s2.y : (g == 2 ? t.s2.z : t.s2.w));
+      node = 8u * node + 7u + 4u * r0 + 2u * r1 + ((c.z < s2) ? 0u : 1u);
+    }
+    const V3 c = kd_rot(q, level % 3u);
+    const uint32_t rest = last - level;  // unconditional levels left before the one at depth `last`: 0, 1 or 2
+    if (rest == 0) {
+      sv = tab[node];
+    } else if (rest == 1) {
+      const float s0 = tab[node];
+      const kd_f32x2 s1 = *(const kd_f32x2_u*)(tab + 2u * (size_t)node + 1u);
+      const uint32_t r0 = (c.x < s0) ? 0u : 1u;
+      node = 2u * node + 1u + r0;
+      sv = r0 ? s1.y : s1.x;
+    } else {
+      const KdTriple t = kd_fetch3(tab, node);
+      const uint32_t r0 = (c.x < t.s0) ? 0u : 1u;
+      const uint32_t r1 = (c.y < (r0 ? t.s1.y : t.s1.x)) ? 0u : 1u;
+      const uint32_t g = 2u * r0 + r1;
+      node = 4u * node + 3u + g;
+      sv = g == 0 ? t.s2.x : (g == 1 ? t.s2.y : (g == 2 ? t.s2.z : t.s2.w));
     }
   }
-  *out_dist = min_dist;
-  *out_point = leaves[base + min_slot];  // L1-resident re-read instead of a 16-way register select
-  return base + min_slot;
+  // depth `last`: leaf iff len <= 16
+  const uint32_t path = node + 1u - (1u << last);
+  const uint32_t rev = last ? (__brev(path) >> (32u - last)) : 0u;
+  const uint32_t len = (n + rev) >> last;
+  const float qd = kd_rot(q, last % 3u).x;
+  const bool inner = len > 16u;
+  const uint32_t child = kd_step(node, qd, sv) + 1u - (2u << last);  // path at depth max_depth
+  return (inner ? child : (path << 1)) * 16u;
 }
 
-__device__ __forceinline__ uint32_t kdtree_nearest_slot(const float* __restrict__ split,
-                                                        const float4* __restrict__ leaves, uint32_t n,
-                                                        uint32_t max_depth, V3 q, float* out_dist,
-                                                        float4* out_point) {
-  return kdtree_scan_leaf(leaves, kdtree_descend(split, nullptr, 0, n, max_depth, q), q, out_dist, out_point);
-}
-
-// Cooperative leaf scan: the 64 queries of a wave are served 4 at a time, 16 lanes per query, one leaf
-// slot per lane, so a wave-wide load touches 4 leaves = 8 cache lines instead of 64 lanes x 1 line each
-// (the per-lane scan makes ~1000 L1 tag lookups per wave; this makes 128).  Within the 16 lanes the
-// minimum of (distance, slot) in lexicographic order is the reference's "first strict minimum".
-// In: base/q of THIS lane's query.  Out: this lane's winner (slot index, distance, leaf record).
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
@@ -110,63 +190,73 @@ template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
+// Lane J of every row of 16 lanes, broadcast to the whole row (DPP row_newbcast, gfx90a+): one VALU move, no LDS.
+template <int J>
+__device__ __forceinline__ float row_bcast_f(float v) { return dpp_f<0x150 + J>(v); }
+template <int J>
+__device__ __forceinline__ unsigned row_bcast_u(unsigned v) { return dpp_u<0x150 + J>(v); }
 
+constexpr float KD_F32_MAX = 3.402823466e+38f;  // f32::MAX, the scan's initial min_dist (kdtree.rs:91)
+
+// One round of the cooperative leaf scan: the row's 16 lanes hold the 16 slots of the leaf of the query owned by
+// lane J of the row; `d` is this lane's candidate distance as its bit pattern (distances are sums of squares, i.e.
+// never negative and never -0.0, so unsigned order = float order; NaN / +inf / f32::MAX already mapped to +inf).
+// Returns in every lane of the row the row minimum and the FIRST slot that attains it: the reference's
+// `dist < min_dist` scan in stored order keeps exactly that one (kdtree.rs:93-100).
+__device__ __forceinline__ void kd_row_argmin(unsigned d, unsigned row_shift, unsigned* out_min, unsigned* out_slot) {
+  unsigned m = d;
+  m = min(m, dpp_u<0x128>(m));  // lane ^ 8 (row_ror:8)
+  m = min(m, dpp_u<0x141>(m));  // 7 - lane within each 8 (row_half_mirror)
+  m = min(m, dpp_u<0x4E>(m));   // lane ^ 2
+  m = min(m, dpp_u<0xB1>(m));   // lane ^ 1
+  const unsigned long long eq = __ballot(d == m);  // never empty within a row
+  *out_min = m;
+  *out_slot = (unsigned)__builtin_ctz((unsigned)(eq >> row_shift));  // lowest lane of MY row (rows above only add higher bits)
+}
+
+// Cooperative leaf scan: the 64 queries of a wave are served 4 at a time, 16 lanes per query, one leaf slot per
+// lane, so a wave-wide load touches 4 leaves = 8 cache lines instead of 64 lanes x 1 line each.
+// In: base/q of THIS lane's query (leaf byte offsets fit 32 bits: max_depth <= 23 is checked on the host).
+// Out: this lane's winner (slot index, distance); the caller re-reads the winning record where it needs it.
+// Every lane of the wave must be active.
 __device__ __forceinline__ void kdtree_scan_leaves_coop(const float4* __restrict__ leaves, uint32_t base, V3 q,
-                                                        uint32_t* out_slot, float* out_dist, float4* out_point) {
+                                                        uint32_t* out_slot, float* out_dist) {
   const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const unsigned sub = lane & 15u, grp16 = lane & 48u;
-  float my_d = 3.402823466e+38f;
-  unsigned my_slot = 0;
-  float4 my_pt = make_float4(0.f, 0.f, 0.f, 0.f);
-  // eight rounds at a time: all eight loads are in flight before the first reduction
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    float4 p[8];
-    float qx[8], qy[8], qz[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int j = half * 8 + r;
-      const int src = (int)(grp16 | (unsigned)j);  // the lane of this 16-group whose query is served in round j
-      const uint32_t b = (uint32_t)__shfl((int)base, src, 64);
-      qx[r] = __shfl(q.x, src, 64), qy[r] = __shfl(q.y, src, 64), qz[r] = __shfl(q.z, src, 64);
-      p[r] = leaves[b + sub];
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int j = half * 8 + r;
-      float d = norm_squared(V3{qx[r], qy[r], qz[r]} - V3{p[r].x, p[r].y, p[r].z});
-      // `dist < min_dist` with min_dist starting at f32::MAX: NaN and +inf can never win; rank them last
-      if (!(d < 3.402823466e+38f)) d = __builtin_inff();
-      unsigned s = sub;
-      float4 w = p[r];
-#define A3D_ARGMIN_STEP(CTRL)                                                             \
-  {                                                                                       \
-    const float od = dpp_f<CTRL>(d);                                                      \
-    const unsigned os = dpp_u<CTRL>(s);                                                   \
-    const float ox = dpp_f<CTRL>(w.x), oy = dpp_f<CTRL>(w.y), oz = dpp_f<CTRL>(w.z), ow = dpp_f<CTRL>(w.w); \
-    const bool take = od < d || (od == d && os < s);                                      \
-    d = take ? od : d, s = take ? os : s;                                                 \
-    w.x = take ? ox : w.x, w.y = take ? oy : w.y, w.z = take ? oz : w.z, w.w = take ? ow : w.w; \
+  const unsigned sub = lane & 15u, row_shift = lane & 48u;
+  const unsigned base_off = base * 16u, sub_off = sub * 16u;  // bytes
+  const unsigned f32_max = __float_as_uint(KD_F32_MAX), f32_inf = 0x7F800000u;
+  unsigned my_d = f32_max, my_slot = 0;
+  const char* lbase = (const char*)leaves;
+#define A3D_KD_ROUND(J, P)                                                                          \
+  {                                                                                                 \
+    const V3 c{P.x, P.y, P.z};                                                                      \
+    const float df = norm_squared(V3{row_bcast_f<J>(q.x), row_bcast_f<J>(q.y), row_bcast_f<J>(q.z)} - c); \
+    /* `dist < min_dist` from f32::MAX: NaN, +inf and f32::MAX itself can never win; rank them last */ \
+    const unsigned d = (df < KD_F32_MAX) ? __float_as_uint(df) : f32_inf;                           \
+    unsigned m, s;                                                                                  \
+    kd_row_argmin(d, row_shift, &m, &s);                                                            \
+    const bool mine = sub == (unsigned)(J);                                                         \
+    /* all 16 candidates lost: the reference returns slot 0 and f32::MAX (ctz gave 0 already) */    \
+    my_d = mine ? min(m, f32_max) : my_d;                                                           \
+    my_slot = mine ? s : my_slot;                                                                   \
   }
-      A3D_ARGMIN_STEP(0x128)  // lane ^ 8 (row_ror:8)
-      A3D_ARGMIN_STEP(0x141)  // 7 - lane within each 8 (row_half_mirror)
-      A3D_ARGMIN_STEP(0x4E)   // lane ^ 2 (quad_perm [2,3,0,1])
-      A3D_ARGMIN_STEP(0xB1)   // lane ^ 1 (quad_perm [1,0,3,2])
-#undef A3D_ARGMIN_STEP
-      if (sub == (unsigned)j) {
-        // all 16 candidates lost (every distance NaN / inf): the reference returns slot 0 and f32::MAX
-        const bool none = !(d < 3.402823466e+38f);
-        my_d = none ? 3.402823466e+38f : d;
-        my_slot = none ? 0u : s;
-        my_pt = w;
-      }
-    }
+#define A3D_KD_LOAD(J) (*(const float4*)(lbase + (size_t)(row_bcast_u<J>(base_off) + sub_off)))
+  {  // eight rounds at a time: all eight loads are in flight before the first reduction
+    const float4 p0 = A3D_KD_LOAD(0), p1 = A3D_KD_LOAD(1), p2 = A3D_KD_LOAD(2), p3 = A3D_KD_LOAD(3);
+    const float4 p4 = A3D_KD_LOAD(4), p5 = A3D_KD_LOAD(5), p6 = A3D_KD_LOAD(6), p7 = A3D_KD_LOAD(7);
+    A3D_KD_ROUND(0, p0) A3D_KD_ROUND(1, p1) A3D_KD_ROUND(2, p2) A3D_KD_ROUND(3, p3)
+    A3D_KD_ROUND(4, p4) A3D_KD_ROUND(5, p5) A3D_KD_ROUND(6, p6) A3D_KD_ROUND(7, p7)
   }
-  // `none` case: w is whichever record the argmin kept; the reference returns leaf entry 0 -> re-read it
-  if (my_slot == 0u && !(my_d < 3.402823466e+38f)) my_pt = leaves[base];
+  {
+    const float4 p0 = A3D_KD_LOAD(8), p1 = A3D_KD_LOAD(9), p2 = A3D_KD_LOAD(10), p3 = A3D_KD_LOAD(11);
+    const float4 p4 = A3D_KD_LOAD(12), p5 = A3D_KD_LOAD(13), p6 = A3D_KD_LOAD(14), p7 = A3D_KD_LOAD(15);
+    A3D_KD_ROUND(8, p0) A3D_KD_ROUND(9, p1) A3D_KD_ROUND(10, p2) A3D_KD_ROUND(11, p3)
+    A3D_KD_ROUND(12, p4) A3D_KD_ROUND(13, p5) A3D_KD_ROUND(14, p6) A3D_KD_ROUND(15, p7)
+  }
+#undef A3D_KD_LOAD
+#undef A3D_KD_ROUND
   *out_slot = base + my_slot;
-  *out_dist = my_d;
-  *out_point = my_pt;
+  *out_dist = __uint_as_float(my_d);
 }
 
 }  // namespace a3d
