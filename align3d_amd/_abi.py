@@ -147,6 +147,11 @@ SIGNATURES = {
         [_P, C.POINTER(BuilderParamsC), _P, _P, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double,
          C.c_double, C.c_double, _PP],
     ),
+    "a3d_range_image_build_pyramids": (
+        _ST,
+        [_P, C.POINTER(BuilderParamsC), C.c_uint64, _PP, _PP, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double,
+         C.c_double, C.c_double, _PP],
+    ),
     "a3d_range_image_size": (_ST, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "a3d_range_image_download": (_ST, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double)]),
     "a3d_compute_normals": (_ST, [_P, _P, _P, C.c_uint64, C.c_uint64, _P]),

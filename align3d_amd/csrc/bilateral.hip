@@ -8,22 +8,17 @@
 #include <cmath>
 #include <cstdlib>
 
-#include "common.hpp"
+#include "bilateral.hpp"
 
 using namespace a3d;
 
 namespace {
 
-struct GridDims {
-  uint32_t gh, gw, gd;
-};
-
-// `x as usize` for a non-negative finite f64
-__device__ __forceinline__ uint32_t f64_as_usize(double x) { return x > 0.0 ? (uint32_t)x : 0u; }
-
 // min / max over ALL pixels, zeros included (src/bilateral/grid.rs:41-49)
 __global__ void __launch_bounds__(256)
-    minmax_u16_kernel(const uint16_t* __restrict__ img, uint32_t n, uint32_t* __restrict__ out_minmax) {
+    minmax_u16_kernel(const uint16_t* __restrict__ img, uint32_t n, uint32_t* __restrict__ out_minmax, bool min_inverted) {
+  img += (size_t)blockIdx.y * n;  // blockIdx.y = frame of a batch ([frames][n] pixels, SC_STRIDE words of scalars each)
+  out_minmax += blockIdx.y * SC_STRIDE;
   uint32_t mi = 0xFFFFu, ma = 0u;
   // eight pixels per 16-byte load when the image is 16-byte aligned (it is when it comes from the library's own
   // allocations), the remainder and unaligned images one by one
@@ -53,7 +48,11 @@ __global__ void __launch_bounds__(256)
   if ((threadIdx.x & 63) == 0) s_mi[threadIdx.x >> 6] = mi, s_ma[threadIdx.x >> 6] = ma;
   __syncthreads();
   if (threadIdx.x == 0) {  // one atomic pair per block: 64 blocks, not thousands of waves, meet on the two words
-    atomicMin(&out_minmax[0], min(min(s_mi[0], s_mi[1]), min(s_mi[2], s_mi[3])));
+    const uint32_t bmin = min(min(s_mi[0], s_mi[1]), min(s_mi[2], s_mi[3]));
+    // batches clear their scalar blocks with one memset to zero: the minimum is then kept as 0xFFFF - min (dims_kernel
+    // turns it back), so that zero is the neutral start for both words
+    if (min_inverted) atomicMax(&out_minmax[0], 0xFFFFu - bmin);
+    else atomicMin(&out_minmax[0], bmin);
     atomicMax(&out_minmax[1], max(max(s_ma[0], s_ma[1]), max(s_ma[2], s_ma[3])));
   }
 }
@@ -108,22 +107,14 @@ __global__ void __launch_bounds__(256)
 // exact, so the cell holds exactly the reference's f64 sums.
 constexpr int PACK_SHIFT = 24;
 
-// Device-side scalars of one filter call (the head of the context's grid scratch region).  When a kernel gets a
-// non-null `dyn` pointer, the grid dimensions and the colour minimum come from there instead of from its arguments:
-// the host then enqueues the whole filter without the min/max round trip (bilateral_filter_device_async).
-enum { SC_MIN = 0, SC_MAX = 1, SC_OVERFLOW = 2, SC_GH = 4, SC_GW = 5, SC_GD = 6, SC_TOO_BIG = 7, SC_WORDS = 8 };
-__device__ __forceinline__ bool dyn_dims(const uint32_t* __restrict__ dyn, GridDims* g, uint32_t* color_min) {
-  if (!dyn) return true;
-  if (dyn[SC_TOO_BIG]) return false;  // the grid does not fit the scratch region: the host grows it and repeats
-  *g = GridDims{dyn[SC_GH], dyn[SC_GW], dyn[SC_GD]};
-  if (color_min) *color_min = dyn[SC_MIN];
-  return true;
-}
-
 // grid.rs:37-56 on the device (same f64 arithmetic as the host path), plus the capacity check
-__global__ void dims_kernel(uint32_t* __restrict__ sc, uint32_t w, uint32_t h, double sigma_space, double sigma_color,
-                            unsigned long long capacity_cells) {
-  const uint32_t cmin = sc[SC_MIN], cmax = sc[SC_MAX];
+__global__ void dims_kernel(uint32_t* __restrict__ sc, uint32_t n_frames, uint32_t w, uint32_t h, double sigma_space,
+                            double sigma_color, unsigned long long capacity_cells) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_frames) return;
+  sc += f * SC_STRIDE;
+  const uint32_t cmin = 0xFFFFu - sc[SC_MIN], cmax = sc[SC_MAX];  // (see minmax_u16_kernel: kept inverted until here)
+  sc[SC_MIN] = cmin;
   const uint32_t gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4;
   const uint32_t gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
   const uint32_t gd = (uint32_t)((double)(cmax - cmin) / sigma_color) + 1 + 4;
@@ -131,10 +122,27 @@ __global__ void dims_kernel(uint32_t* __restrict__ sc, uint32_t w, uint32_t h, d
   sc[SC_TOO_BIG] = (unsigned long long)gh * gw * gd > capacity_cells ? 1u : 0u;
 }
 
+// Clears the cells of each frame's packed grid that its dimensions actually use (a batch's grids are `capacity`
+// cells apart; clearing whole capacities would move several times the bytes).
+__global__ void __launch_bounds__(256)
+    clear_packed_kernel(unsigned long long* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity) {
+  dyn += blockIdx.y * SC_STRIDE;
+  grid += blockIdx.y * capacity;
+  GridDims g;
+  if (!dyn_dims(dyn, &g, nullptr)) return;
+  const unsigned long long cells = (unsigned long long)g.gh * g.gw * g.gd;
+  ulonglong2* g2 = (ulonglong2*)grid;  // capacity offsets keep 16-byte alignment when capacity is even (it is)
+  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < (cells + 1) / 2; i += gridDim.x * 256ull)
+    g2[i] = make_ulonglong2(0ull, 0ull);
+}
+
 __global__ void __launch_bounds__(256)
     splat_packed_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
                         uint32_t color_min, GridDims g, unsigned long long* __restrict__ grid,
-                        const uint32_t* __restrict__ dyn) {
+                        const uint32_t* __restrict__ dyn, unsigned long long capacity) {
+  if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
+  img += (size_t)blockIdx.y * w * h;
+  grid += blockIdx.y * capacity;
   if (!dyn_dims(dyn, &g, &color_min)) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w * h) return;
@@ -184,8 +192,11 @@ __device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok, bool fi
 
 __global__ void __launch_bounds__(256)
     blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double2* __restrict__ out,
-                      const uint32_t* __restrict__ dyn) {
+                      const uint32_t* __restrict__ dyn, unsigned long long capacity) {
   __shared__ double2 tile[BCELLS];
+  if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
+  packed += blockIdx.y * capacity;
+  out += blockIdx.y * capacity;
   if (!dyn_dims(dyn, &g, nullptr)) return;
   // 1-D launch (the host may not know the dimensions): block -> tile (row, column, channel), channel fastest
   const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
@@ -249,15 +260,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-__device__ __forceinline__ uint32_t clampu(uint32_t v, uint32_t hi) { return v > hi ? hi : v; }
-
-// BilateralGrid::normalize (grid.rs:90-104) folded into the read, then trilinear (grid.rs:132-162)
-__device__ __forceinline__ double cell_value(const double2* __restrict__ grid, GridDims g, uint32_t r, uint32_t c,
-                                             uint32_t z) {
-  const double2 v = grid[((size_t)r * g.gw + c) * g.gd + z];
-  return v.y > 0.0 ? v.x / v.y : v.x;
-}
-
 // BilateralGrid::slice (grid.rs:106-130): every pixel, zeros included; num::cast::<f64,u16>
 __global__ void __launch_bounds__(256)
     slice_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
@@ -266,30 +268,10 @@ __global__ void __launch_bounds__(256)
   if (!dyn_dims(dyn, &g, &color_min)) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w * h) return;
-  const uint32_t r = i / w, c = i % w;
-  const double row = (double)r * inv_ss + 2.0;
-  const double col = (double)c * inv_ss + 2.0;
-  const double channel = (double)((uint32_t)img[i] - color_min) * inv_sc + 2.0;
-  const uint32_t z = clampu(f64_as_usize(channel), g.gd - 1), zz = clampu(f64_as_usize(channel + 1.0), g.gd - 1);
-  const double za = channel - (double)z;
-  const uint32_t y = clampu(f64_as_usize(row), g.gh - 1), yy = clampu(f64_as_usize(row + 1.0), g.gh - 1);
-  const double ya = row - (double)y;
-  const uint32_t x = clampu(f64_as_usize(col), g.gw - 1), xx = clampu(f64_as_usize(col + 1.0), g.gw - 1);
-  const double xa = col - (double)x;
-  const double value = (1.0 - ya) * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, y, x, z) +
-                       (1.0 - ya) * xa * (1.0 - za) * cell_value(grid, g, y, xx, z) +
-                       ya * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, yy, x, z) +
-                       ya * xa * (1.0 - za) * cell_value(grid, g, yy, xx, z) +
-                       (1.0 - ya) * (1.0 - xa) * za * cell_value(grid, g, y, x, zz) +
-                       (1.0 - ya) * xa * za * cell_value(grid, g, y, xx, zz) +
-                       ya * (1.0 - xa) * za * cell_value(grid, g, yy, x, zz) +
-                       ya * xa * za * cell_value(grid, g, yy, xx, zz);
-  if (value > -1.0 && value < 65536.0) {
-    out[i] = (uint16_t)value;  // truncation toward zero
-  } else {
-    out[i] = 0;
+  uint16_t v;
+  if (!slice_pixel(img[i], i / w, i % w, inv_ss, inv_sc, color_min, g, grid, &v))
     atomicOr(overflow_flag, 1u);  // the reference's .unwrap() would panic
-  }
+  out[i] = v;
 }
 
 }  // namespace
@@ -316,7 +298,7 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
   if (hipMemcpyAsync(d_scal, h_scal, 12, hipMemcpyHostToDevice, s) != hipSuccess) fail("upload");
   if (st == A3D_OK) {
     hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64)), dim3(256), 0, s, d_img, n,
-                       d_scal);
+                       d_scal, false);
     if (hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
       fail("min/max");
@@ -353,10 +335,10 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
       double2* src = d_a;
       if (fused) {
         hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin,
-                           g, (unsigned long long*)d_b, (const uint32_t*)nullptr);
+                           g, (unsigned long long*)d_b, (const uint32_t*)nullptr, 0ull);
         hipLaunchKernelGGL(blur_fused_kernel,
                            dim3(((g.gd + BT - 1) / BT) * ((g.gw + BT - 1) / BT) * ((g.gh + BT - 1) / BT)), dim3(256), 0, s,
-                           (const unsigned long long*)d_b, g, d_a, (const uint32_t*)nullptr);
+                           (const unsigned long long*)d_b, g, d_a, (const uint32_t*)nullptr, 0ull);
       } else {
         hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
                            (double*)d_a);
@@ -386,66 +368,48 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
   return A3D_OK;
 }
 
-// The fused filter enqueued WITHOUT a host round trip: min/max, the grid dimensions and the capacity check stay on
-// the device, the kernels read them from the scratch region's scalar block, launch sizes come from the capacity.
-// Only possible when the context's grid scratch region already exists (its size bounds the grid): the first filter
-// on a context goes through bilateral_filter_device, which sizes the region.  `result` (page-locked, SC_WORDS words)
-// receives the scalar block by an asynchronous copy; after the caller's own stream synchronisation
-// bilateral_async_status() tells whether the output is valid.  *enqueued = false: nothing was done, use the
-// synchronous path.
-a3d_status bilateral_filter_device_async(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w,
-                                         uint32_t h, double sigma_space, double sigma_color, uint32_t* result,
-                                         bool* enqueued) {
-  *enqueued = false;
+unsigned long long bilateral_grid_cells(uint32_t w, uint32_t h, double sigma_space, double sigma_color, uint32_t depth_span) {
+  const unsigned long long gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4, gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
+  const unsigned long long gd = (uint32_t)((double)depth_span / sigma_color) + 1 + 4;
+  return gh * gw * gd;
+}
+
+// The grids of a batch of frames enqueued WITHOUT a host round trip: min/max, the grid dimensions and the capacity
+// check stay on the device, the kernels read them from each frame's scalar block, launch sizes come from the capacity.
+a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, uint32_t n_frames, uint32_t w, uint32_t h,
+                                   double sigma_space, double sigma_color, unsigned long long capacity, GridBatch* out) {
   const uint32_t n = w * h;
-  const char* mode = getenv("A3D_BILATERAL");
-  if (n >= (1u << PACK_SHIFT) || (mode && (!strcmp(mode, "unfused") || !strcmp(mode, "sync")))) return A3D_OK;
-  if (!ctx->scratch[1] || ctx->scratch_size[1] < (1u << 20)) return A3D_OK;
+  A3D_REQUIRE(n < (1u << PACK_SHIFT), A3D_INVALID_PARAMETER,
+              "the device frame builder's bilateral filter handles images below 2^24 pixels");
   hipStream_t s = ctx->stream;
-  // scratch layout: [256 B scalars][capacity x 8 B packed cells][capacity x 16 B blurred cells]
-  const unsigned long long capacity = (ctx->scratch_size[1] - 256 - 512) / 24;
-  uint32_t* d_scal = (uint32_t*)ctx->scratch[1];
-  unsigned long long* d_packed = (unsigned long long*)((char*)ctx->scratch[1] + 256);
-  double2* d_blur = (double2*)((char*)d_packed + ((capacity * 8 + 255) / 256) * 256);
-  const uint32_t init[SC_WORDS] = {0xFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  memcpy(result, init, sizeof(init));  // `result` is page-locked: the copy below reads it asynchronously
-  A3D_HIP_TRY(hipMemcpyAsync(d_scal, result, sizeof(init), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64)), dim3(256), 0, s, d_img, n, d_scal);
-  hipLaunchKernelGGL(dims_kernel, dim3(1), dim3(1), 0, s, d_scal, w, h, sigma_space, sigma_color, capacity);
-  A3D_HIP_TRY(hipMemsetAsync(d_packed, 0, capacity * 8, s));
+  const size_t scal_bytes = (((size_t)n_frames * SC_STRIDE * 4 + 255) / 256) * 256;
+  capacity += capacity & 1;  // even: every frame's packed grid starts 16-byte aligned
+  const size_t packed_bytes = (((size_t)n_frames * capacity * 8 + 255) / 256) * 256;
+  void* region = nullptr;
+  A3D_TRY(ctx_scratch(ctx, 1, scal_bytes + packed_bytes + (size_t)n_frames * capacity * 16 + 256, &region));
+  out->scal = (uint32_t*)region;
+  out->packed = (unsigned long long*)((char*)region + scal_bytes);
+  out->blurred = (double2*)((char*)out->packed + packed_bytes);
+  out->capacity = capacity;
+  A3D_HIP_TRY(hipMemsetAsync(region, 0, scal_bytes, s));
+  hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64), n_frames), dim3(256), 0, s, d_depth, n,
+                     out->scal, true);
+  hipLaunchKernelGGL(dims_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s, out->scal, n_frames, w, h, sigma_space,
+                     sigma_color, capacity);
+  hipLaunchKernelGGL(clear_packed_kernel, dim3(256, n_frames), dim3(256), 0, s, out->packed, (const uint32_t*)out->scal,
+                     capacity);
   const double inv_ss = 1.0 / sigma_space, inv_sc = 1.0 / sigma_color;
   const GridDims none{0, 0, 0};
-  hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, 0u, none,
-                     d_packed, (const uint32_t*)d_scal);
-  // any grid of `capacity` cells has at most this many 12^3 tiles (each axis rounds up: <= cells/1728 + slack)
-  const uint32_t max_tiles = (uint32_t)std::min<unsigned long long>(capacity / 64 + 64, 1u << 30);
+  hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 255) / 256, n_frames), dim3(256), 0, s, d_depth, w, h, inv_ss, inv_sc, 0u,
+                     none, out->packed, (const uint32_t*)out->scal, capacity);
+  // any grid of `capacity` cells with this image's row / column extents has at most this many 12^3 tiles
   const uint32_t gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4, gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
   const unsigned long long plane_tiles = (unsigned long long)((gh + BT - 1) / BT) * ((gw + BT - 1) / BT);
   const unsigned long long max_gd = capacity / ((unsigned long long)gh * gw) + 1;
-  const uint32_t tiles = (uint32_t)std::min<unsigned long long>(plane_tiles * ((max_gd + BT - 1) / BT), max_tiles + plane_tiles);
-  hipLaunchKernelGGL(blur_fused_kernel, dim3(std::max(1u, tiles)), dim3(256), 0, s, (const unsigned long long*)d_packed,
-                     none, d_blur, (const uint32_t*)d_scal);
-  hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, 0u, none,
-                     (const double2*)d_blur, d_out, d_scal + SC_OVERFLOW, (const uint32_t*)d_scal);
+  const uint32_t tiles = (uint32_t)std::min<unsigned long long>(plane_tiles * ((max_gd + BT - 1) / BT), 1u << 30);
+  hipLaunchKernelGGL(blur_fused_kernel, dim3(std::max(1u, tiles), n_frames), dim3(256), 0, s,
+                     (const unsigned long long*)out->packed, none, out->blurred, (const uint32_t*)out->scal, capacity);
   A3D_HIP_TRY(hipGetLastError());
-  A3D_HIP_TRY(hipMemcpyAsync(result, d_scal, SC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  *enqueued = true;
-  return A3D_OK;
-}
-
-// After the stream has been synchronised: A3D_OK (output valid), A3D_CAST_OVERFLOW, or *needs_bytes > 0 when the
-// grid did not fit the scratch region (grow it to *needs_bytes and run the filter again).
-a3d_status bilateral_async_status(const uint32_t* result, size_t* needs_bytes) {
-  *needs_bytes = 0;
-  if (result[SC_TOO_BIG]) {
-    const size_t cells = (size_t)result[SC_GH] * result[SC_GW] * result[SC_GD];
-    *needs_bytes = 256 + 512 + cells * 24 + cells * 6;  // 25 % head room for the next frames
-    return A3D_OK;
-  }
-  if (result[SC_OVERFLOW]) {
-    set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
-    return A3D_CAST_OVERFLOW;
-  }
   return A3D_OK;
 }
 

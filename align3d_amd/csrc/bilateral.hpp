@@ -1,0 +1,87 @@
+// Device-side pieces of BilateralGrid shared by bilateral.hip (the filter) and frame.hip (the frame builder, which
+// slices the blurred grid inside its back-projection kernel): src/bilateral/grid.rs:90-162.
+#pragma once
+#include "common.hpp"
+
+namespace a3d {
+
+struct GridDims {
+  uint32_t gh, gw, gd;
+};
+
+// `x as usize` for a non-negative finite f64
+__device__ __forceinline__ uint32_t f64_as_usize(double x) { return x > 0.0 ? (uint32_t)x : 0u; }
+
+// Device-side scalars of one filter call.  When a kernel gets a non-null `dyn` pointer, the grid dimensions and the
+// colour minimum come from there instead of from its arguments: the host then enqueues the whole filter without
+// the min/max round trip.  A batch of frames has one block of SC_STRIDE words per frame.
+enum { SC_MIN = 0, SC_MAX = 1, SC_OVERFLOW = 2, SC_GH = 4, SC_GW = 5, SC_GD = 6, SC_TOO_BIG = 7, SC_WORDS = 8 };
+constexpr uint32_t SC_STRIDE = 16;  // words between the scalar blocks of consecutive frames (64 B: one per line)
+
+__device__ __forceinline__ bool dyn_dims(const uint32_t* __restrict__ dyn, GridDims* g, uint32_t* color_min) {
+  if (!dyn) return true;
+  if (dyn[SC_TOO_BIG]) return false;  // the grid does not fit the scratch region: the host grows it and repeats
+  *g = GridDims{dyn[SC_GH], dyn[SC_GW], dyn[SC_GD]};
+  if (color_min) *color_min = dyn[SC_MIN];
+  return true;
+}
+
+__device__ __forceinline__ uint32_t clampu(uint32_t v, uint32_t hi) { return v > hi ? hi : v; }
+
+// BilateralGrid::normalize (grid.rs:90-104) folded into the read, then trilinear (grid.rs:132-162)
+__device__ __forceinline__ double cell_value(const double2* __restrict__ grid, GridDims g, uint32_t r, uint32_t c,
+                                             uint32_t z) {
+  const double2 v = grid[((size_t)r * g.gw + c) * g.gd + z];
+  return v.y > 0.0 ? v.x / v.y : v.x;
+}
+
+// BilateralGrid::slice for one pixel (grid.rs:106-130, trilinear :132-162): every pixel, zeros included.
+// Returns false when the value is not representable as u16 (num::cast::<f64,u16>().unwrap() would panic).
+__device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t c, double inv_ss, double inv_sc,
+                                            uint32_t color_min, GridDims g, const double2* __restrict__ grid,
+                                            uint16_t* out) {
+  const double row = (double)r * inv_ss + 2.0;
+  const double col = (double)c * inv_ss + 2.0;
+  const double channel = (double)(color - color_min) * inv_sc + 2.0;
+  const uint32_t z = clampu(f64_as_usize(channel), g.gd - 1), zz = clampu(f64_as_usize(channel + 1.0), g.gd - 1);
+  const double za = channel - (double)z;
+  const uint32_t y = clampu(f64_as_usize(row), g.gh - 1), yy = clampu(f64_as_usize(row + 1.0), g.gh - 1);
+  const double ya = row - (double)y;
+  const uint32_t x = clampu(f64_as_usize(col), g.gw - 1), xx = clampu(f64_as_usize(col + 1.0), g.gw - 1);
+  const double xa = col - (double)x;
+  const double value = (1.0 - ya) * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, y, x, z) +
+                       (1.0 - ya) * xa * (1.0 - za) * cell_value(grid, g, y, xx, z) +
+                       ya * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, yy, x, z) +
+                       ya * xa * (1.0 - za) * cell_value(grid, g, yy, xx, z) +
+                       (1.0 - ya) * (1.0 - xa) * za * cell_value(grid, g, y, x, zz) +
+                       (1.0 - ya) * xa * za * cell_value(grid, g, y, xx, zz) +
+                       ya * (1.0 - xa) * za * cell_value(grid, g, yy, x, zz) +
+                       ya * xa * za * cell_value(grid, g, yy, xx, zz);
+  if (value > -1.0 && value < 65536.0) {
+    *out = (uint16_t)value;  // truncation toward zero
+    return true;
+  }
+  *out = 0;
+  return false;
+}
+
+// Where the blurred grids of a batch of frames live (the context's grid scratch region):
+// [n_frames x SC_STRIDE words of scalars][n_frames x capacity packed u64 cells][n_frames x capacity double2 cells]
+struct GridBatch {
+  uint32_t* scal = nullptr;
+  unsigned long long* packed = nullptr;
+  double2* blurred = nullptr;
+  unsigned long long capacity = 0;  // cells per frame
+};
+
+// Enqueues min/max, grid sizing, splat and the fused blur for `n_frames` depth images ([n_frames][h][w] u16,
+// device) on the context's stream WITHOUT a host round trip; afterwards out->blurred + f * capacity is frame f's
+// blurred grid and out->scal + f * SC_STRIDE its scalars (dimensions, colour minimum, SC_TOO_BIG when its grid did
+// not fit `capacity` cells: the caller checks that after its own synchronisation and calls again with more room).
+a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, uint32_t n_frames, uint32_t w, uint32_t h,
+                                   double sigma_space, double sigma_color, unsigned long long capacity_cells,
+                                   GridBatch* out);
+// Cells a frame's grid needs: enough for a depth range of `depth_span` units (BilateralGrid::from_image, grid.rs:37-56)
+unsigned long long bilateral_grid_cells(uint32_t w, uint32_t h, double sigma_space, double sigma_color, uint32_t depth_span);
+
+}  // namespace a3d

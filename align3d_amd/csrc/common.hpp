@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <memory>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -63,11 +64,6 @@ namespace a3d {
 // BilateralFilter::filter on device-resident u16 images (bilateral.hip).
 a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w, uint32_t h,
                                    double sigma_space, double sigma_color, uint64_t out_grid_dims[3]);
-// The same filter enqueued without the min/max host round trip (see bilateral.hip); `result`: 8 page-locked words.
-a3d_status bilateral_filter_device_async(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w,
-                                         uint32_t h, double sigma_space, double sigma_color, uint32_t* result,
-                                         bool* enqueued);
-a3d_status bilateral_async_status(const uint32_t* result, size_t* needs_bytes);
 // RangeImage::compute_normals on device-resident arrays (image.hip).
 a3d_status compute_normals_device(a3d_context* ctx, const float* d_points, const uint8_t* d_mask, float* d_normals,
                                   uint32_t w, uint32_t h);
@@ -96,7 +92,12 @@ struct a3d_context {
   // reuse its small device state instead of allocating and freeing it per alignment.
   void* icp_engine = nullptr;
   void (*icp_engine_free)(void*) = nullptr;
-  uint32_t* pinned_words = nullptr;  // 16 page-locked words: scalar results copied back asynchronously
+  uint32_t* pinned_words = nullptr;  // PINNED_WORDS page-locked words: scalar results copied back asynchronously
+  static constexpr size_t PINNED_WORDS = 1024;
+  // Cells per frame the bilateral grids of the frame builder are given in the grid scratch region (grown on demand).
+  unsigned long long grid_capacity = 0;
+  // How often each arena size has been asked for: a slab is only taken for a size that keeps coming back.
+  std::vector<std::pair<size_t, uint32_t>> arena_requests;
   // Small read-only tables uploaded once and kept (the blur tap tables of the pyramid builder), keyed by four words.
   struct CachedTable {
     uint32_t key[4];
@@ -115,6 +116,37 @@ struct DeviceArena {
   size_t bytes = 0;
   bool slab_slice = false;  // carved out of a context slab: goes back to the pool, never to hipFree
   std::atomic<int> refs{0};
+  // Consumers on OTHER streams that may still be reading this arena after their host call returned (a batch
+  // alignment enqueued without host outputs): the arena waits for them before it is recycled.
+  std::mutex fence_mutex;
+  std::vector<std::shared_ptr<struct UseFence>> fences;
+};
+
+// "Everything enqueued so far by this consumer": an event the consumer re-records after each enqueue.
+struct UseFence {
+  std::mutex m;
+  hipEvent_t ev = nullptr;
+  bool recorded = false;
+  void record(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(m);
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      ev = nullptr;
+      return;
+    }
+    recorded = hipEventRecord(ev, s) == hipSuccess;
+  }
+  void wait() {  // host wait: the arena is about to be handed to another stream's build
+    std::lock_guard<std::mutex> lock(m);
+    if (ev && recorded) hipEventSynchronize(ev);
+  }
+  void retire() {  // the consumer is gone (it synchronised its streams first)
+    std::lock_guard<std::mutex> lock(m);
+    if (ev) hipEventDestroy(ev);
+    ev = nullptr, recorded = false;
+  }
+  ~UseFence() {
+    if (ev) hipEventDestroy(ev);
+  }
 };
 // Device copy of a small host table, uploaded on first use and kept until the context dies.
 a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void* host, size_t bytes, void** out);

@@ -1,4 +1,5 @@
 // Context, error text, raw device memory, timers and the host-only parameter helpers of the C ABI.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -96,8 +97,30 @@ static bool in_slab(const a3d_context* ctx, const void* p, size_t slab_stride_un
   return false;
 }
 
+// Frees every pooled arena that is a single allocation (slab slices stay): called when a hipMalloc fails, so that
+// memory parked in the pool is not the reason for an out-of-memory status.
+static void trim_pool_locked(a3d_context* ctx) {
+  for (size_t i = 0; i < ctx->arena_pool.size();) {
+    if (!in_slab(ctx, ctx->arena_pool[i].first)) {
+      hipFree(ctx->arena_pool[i].first);
+      ctx->arena_pool.erase(ctx->arena_pool.begin() + (long)i);
+    } else {
+      ++i;
+    }
+  }
+}
+
 a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
+  // A slab (several arenas from one hipMalloc, i.e. one device-wide synchronisation) is only taken for a size that
+  // has been asked for SLAB_AFTER times — one-shot builds and odd sizes pay for exactly what they use — and is capped
+  // at A3D_ARENA_SLAB_MB (default 512 MiB; 0 disables slabs): a 640x480 pyramid then gets 16-arena slabs of 216 MB,
+  // a 4K frame none.
   constexpr size_t SLAB_ARENAS = 16, SLAB_BUDGET = 8ull << 30;
+  constexpr uint32_t SLAB_AFTER = 3;
+  static const size_t slab_cap = [] {
+    const char* v = getenv("A3D_ARENA_SLAB_MB");
+    return (size_t)(v ? std::max(0, atoi(v)) : 512) << 20;
+  }();
   const size_t padded = ((bytes + 255) / 256) * 256;
   std::lock_guard<std::mutex> lock(ctx->pool_mutex);
   for (size_t i = 0; i < ctx->arena_pool.size(); ++i) {
@@ -110,25 +133,39 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
       return A3D_OK;
     }
   }
-  if (ctx->slab_bytes_total + SLAB_ARENAS * padded <= SLAB_BUDGET) {  // a new slab: this arena + 15 for the pool
+  uint32_t asked = 0;
+  for (auto& r : ctx->arena_requests)
+    if (r.first == padded) asked = ++r.second;
+  if (!asked) ctx->arena_requests.emplace_back(padded, asked = 1);
+  const size_t per_slab = std::min(SLAB_ARENAS, padded ? slab_cap / padded : 0);
+  if (asked > SLAB_AFTER && per_slab >= 2 && ctx->slab_bytes_total + per_slab * padded <= SLAB_BUDGET) {
     void* slab = nullptr;
-    if (hipMalloc(&slab, SLAB_ARENAS * padded) == hipSuccess) {
+    if (hipMalloc(&slab, per_slab * padded) == hipSuccess) {
       ctx->arena_slabs.push_back(slab);
-      ctx->slab_sizes.push_back(SLAB_ARENAS * padded);
-      ctx->slab_bytes_total += SLAB_ARENAS * padded;
-      for (size_t k = 1; k < SLAB_ARENAS; ++k) ctx->arena_pool.emplace_back((char*)slab + k * padded, padded);
+      ctx->slab_sizes.push_back(per_slab * padded);
+      ctx->slab_bytes_total += per_slab * padded;
+      for (size_t k = 1; k < per_slab; ++k) ctx->arena_pool.emplace_back((char*)slab + k * padded, padded);
       out->base = slab, out->bytes = padded, out->slab_slice = true;
       return A3D_OK;
     }
     (void)hipGetLastError();  // fall back to a single allocation
   }
-  A3D_HIP_TRY(hipMalloc(&out->base, bytes));
+  if (hipMalloc(&out->base, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    trim_pool_locked(ctx);  // give back what the pool holds, then try once more
+    A3D_HIP_TRY(hipMalloc(&out->base, bytes));
+  }
   out->bytes = bytes;
   out->slab_slice = false;
   return A3D_OK;
 }
 
 void ctx_arena_release(a3d_context* ctx, DeviceArena* arena) {
+  {  // consumers on other streams that were enqueued without a host synchronisation must be done with the arena
+    std::lock_guard<std::mutex> lock(arena->fence_mutex);
+    for (auto& f : arena->fences) f->wait();
+    arena->fences.clear();
+  }
   {
     std::lock_guard<std::mutex> lock(ctx->pool_mutex);
     size_t pooled = 0;
@@ -188,7 +225,7 @@ a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx) {
   A3D_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_start));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_stop));
-  A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, 16 * sizeof(uint32_t), hipHostMallocDefault));
+  A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, a3d_context::PINNED_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   *out_ctx = ctx;
   return A3D_OK;
 }

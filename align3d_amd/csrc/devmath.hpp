@@ -194,4 +194,33 @@ A3D_HD bool gn_solve6(const float H[36], const float g[6], float out[6]) {
 // Index of (r, c), r <= c, in the packed upper triangle of a symmetric 6x6 (21 entries).
 A3D_HD constexpr int tri6(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
 
+// The per-pixel body of RangeImage::compute_normals (src/range_image/structure.rs:207-257): neighbours that are
+// out of range or masked out arrive as (0,0,0); ratio comparisons with NaN / inf are false like the reference's.
+A3D_HD V3 normal_from_neighbours(V3 center, V3 left, V3 right, V3 top, V3 bottom) {
+  const float thr_sq = 2.0f * 2.0f;
+  float ld = norm_squared(left - center), rd = norm_squared(right - center);
+  float lr_ratio = ld / rd;
+  V3 left_to_right;
+  if (lr_ratio < thr_sq && lr_ratio > 1.0f / thr_sq)
+    left_to_right = right - left;
+  else if (ld < rd)
+    left_to_right = center - left;
+  else
+    left_to_right = right - center;
+  float bd = norm_squared(bottom - center), td = norm_squared(top - center);
+  float bt_ratio = bd / td;
+  V3 bottom_to_top;
+  if (bt_ratio < thr_sq && bt_ratio > 1.0f / thr_sq)
+    bottom_to_top = top - bottom;
+  else if (bd < td)
+    bottom_to_top = center - bottom;
+  else
+    bottom_to_top = top - center;
+  V3 n = cross(left_to_right, bottom_to_top);
+  float mag = sqrtf(norm_squared(n));
+  V3 out{0.f, 0.f, 0.f};
+  if (mag > 1e-6f) out = n / mag;
+  return out;
+}
+
 }  // namespace a3d

@@ -1,84 +1,149 @@
-// RangeImageBuilder::build (src/range_image/builder.rs:74-91) entirely on the device: a frame enters
-// HBM as u16 depth + u8 RGB (1.5 MB for 640x480 instead of ~12 MB of f32 pyramid levels) and leaves as a
-// resident pyramid:
-//   bilateral filter                 src/bilateral/edge_aware_filter.rs:126-135   (bilateral.hip)
+// RangeImageBuilder::build (src/range_image/builder.rs:74-91) entirely on the device, for a BATCH of frames: the
+// frames enter HBM as u16 depth + u8 RGB (1.5 MB per 640x480 frame instead of ~12 MB of f32 pyramid levels) and
+// leave as resident pyramids:
+//   bilateral filter                 src/bilateral/edge_aware_filter.rs:126-135   (grids: bilateral.hip)
 //   RangeImage::from_rgbd_image      src/range_image/structure.rs:56-95
-//   RangeImage::compute_normals      src/range_image/structure.rs:184-262        (image.hip)
+//   RangeImage::compute_normals      src/range_image/structure.rs:184-262
 //   RangeImage::pyr_scale_down       src/range_image/structure.rs:309-340, src/range_image/resize.rs:4-104
 //   compute_intensity / _map         src/range_image/structure.rs:266-297, src/image/luma.rs:81-83,
 //                                    src/intensity_map.rs:37-92
+// Every kernel has a frame dimension (blockIdx.z, or .y where noted), so up to MAX_BATCH frames cost the same
+// ~12 launches as one frame; the per-frame arenas are laid out identically, so a kernel needs one base pointer per
+// frame (FrameBases, passed by value) plus array offsets that are the same for all frames.
 // The RGB blur of the pyramid (image 0.24.7 imageops::blur) is restated from its published algorithm
 // like the oracle's: PARITY UNPINNED (no reference test pins its values).
 #include <cmath>
 #include <memory>
 
-#include "common.hpp"
+#include "bilateral.hpp"
 
 using namespace a3d;
 
 namespace {
 
-// CameraIntrinsics::backproject (src/camera.rs:101-107) over a depth image; mask = depth > 0.
-__global__ void backproject_kernel(const uint16_t* __restrict__ depth, uint32_t w, uint32_t h, float fx, float fy,
-                                   float cx, float cy, float scale, float* __restrict__ points,
-                                   uint8_t* __restrict__ mask) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w * h) return;
-  const uint32_t y = i / w, x = i % w;
-  const uint16_t d = depth[i];
+constexpr uint32_t MAX_BATCH = 16;  // frames per launch sequence
+struct FrameBases {
+  char* arena[MAX_BATCH];
+};
+
+// ---- level 0: bilateral slice + back-projection + normals in one pass ---------------------------------------
+// A block stages the points of a 32 x 16 patch (the 30 x 14 pixels it owns plus a one-pixel halo) in LDS: every
+// staged pixel's filtered depth (BilateralGrid::slice, grid.rs:106-162 — same f64 arithmetic as slice_kernel) is
+// back-projected (CameraIntrinsics::backproject, camera.rs:101-107; mask = depth > 0, structure.rs:56-95) by the
+// thread that staged it; the owned pixels then take their normals from the staged neighbours
+// (structure.rs:184-262).  The filtered depth image never exists in memory, points and mask are written once and
+// the normals need no second read of them.  Halo pixels are sliced twice (22 % more slices) — cheaper than a
+// round trip of the filtered image through HBM and two more launches.
+constexpr int ST_W = 32, ST_H = 16, OWN_W = ST_W - 2, OWN_H = ST_H - 2;
+
+template <bool FILTER>
+__global__ void __launch_bounds__(ST_W* ST_H)
+    level0_kernel(const uint16_t* __restrict__ depth, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
+                  const double2* __restrict__ grids, unsigned long long capacity, uint32_t* __restrict__ scal, float fx,
+                  float fy, float cx, float cy, float scale, FrameBases bases, size_t off_points, size_t off_mask,
+                  size_t off_normals, bool with_normals) {
+  __shared__ float sp[3][ST_H][ST_W + 1];
+  const uint32_t f = blockIdx.z;
+  const int lx = threadIdx.x % ST_W, ly = threadIdx.x / ST_W;
+  const int col = (int)blockIdx.x * OWN_W + lx - 1, row = (int)blockIdx.y * OWN_H + ly - 1;
+  const bool in = col >= 0 && col < (int)w && row >= 0 && row < (int)h;
   float px = 0.f, py = 0.f, pz = 0.f;
-  if (d > 0) {
-    pz = (float)d * scale;
-    px = ((float)x - cx) * pz / fx;
-    py = ((float)y - cy) * pz / fy;
+  uint32_t d = 0;
+  if (in) {
+    d = depth[(size_t)f * w * h + (size_t)row * w + col];
+    if (FILTER) {
+      uint32_t* sc = scal + f * SC_STRIDE;
+      GridDims g;
+      uint32_t cmin;
+      if (dyn_dims(sc, &g, &cmin)) {  // (false: this frame's grid did not fit; the host grows the region and repeats)
+        uint16_t v;
+        if (!slice_pixel(d, (uint32_t)row, (uint32_t)col, inv_ss, inv_sc, cmin, g, grids + f * capacity, &v))
+          atomicOr(&sc[SC_OVERFLOW], 1u);  // the reference's .unwrap() would panic
+        d = v;
+      }
+    }
+    if (d > 0) {
+      pz = (float)d * scale;
+      px = ((float)col - cx) * pz / fx;
+      py = ((float)row - cy) * pz / fy;
+    }
   }
-  points[3 * i] = px, points[3 * i + 1] = py, points[3 * i + 2] = pz;
-  mask[i] = d > 0 ? 1 : 0;
+  sp[0][ly][lx] = px, sp[1][ly][lx] = py, sp[2][ly][lx] = pz;
+  __syncthreads();
+  if (!in || lx == 0 || lx == ST_W - 1 || ly == 0 || ly == ST_H - 1) return;  // halo
+  char* base = bases.arena[f];
+  const size_t idx = (size_t)row * w + col;
+  float* points = (float*)(base + off_points);
+  points[3 * idx] = px, points[3 * idx + 1] = py, points[3 * idx + 2] = pz;
+  ((uint8_t*)(base + off_mask))[idx] = d > 0 ? 1 : 0;
+  if (!with_normals) return;
+  // an invalid neighbour's point is (0,0,0) already (= get_point(...).unwrap_or_else(zeros)); so is everything
+  // outside the image; the centre is used as stored, its mask is NOT checked (structure.rs:207)
+  auto at = [&](int y, int x) { return V3{sp[0][y][x], sp[1][y][x], sp[2][y][x]}; };
+  const V3 nrm = normal_from_neighbours(V3{px, py, pz}, at(ly, lx - 1), at(ly, lx + 1), at(ly - 1, lx), at(ly + 1, lx));
+  float* normals = (float*)(base + off_normals);
+  normals[3 * idx] = nrm.x, normals[3 * idx + 1] = nrm.y, normals[3 * idx + 2] = nrm.z;
 }
 
 // rgb_to_luma_u8 (src/image/luma.rs:81-83): (r*0.3 + g*0.59 + b*0.11) as u8 (saturating truncation)
-__global__ void luma_kernel(const uint8_t* __restrict__ rgb, uint32_t n, uint8_t* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ uint8_t luma_u8(const uint8_t* __restrict__ rgb, uint32_t i) {
   const float l = (float)rgb[3 * i] * 0.3f + (float)rgb[3 * i + 1] * 0.59f + (float)rgb[3 * i + 2] * 0.11f;
-  out[i] = l >= 255.0f ? 255 : (l <= 0.0f ? 0 : (uint8_t)l);
+  return l >= 255.0f ? 255 : (l <= 0.0f ? 0 : (uint8_t)l);
 }
 
-// IntensityMap::from_luma_image (src/intensity_map.rs:37-92), one thread per cell of the (h+2) x (w+2) map,
-// including the incomplete border: rows h, h+1 copy row h-1 for cols < w-1; cols w, w+1 copy col w-1 for
-// rows < h-1; (h, w) and (h+1, w+1) take the last pixel; the other border cells stay 0.
-__global__ void intensity_map_kernel(const uint8_t* __restrict__ luma, uint32_t w, uint32_t h, float* __restrict__ map) {
+// One pyramid level as the kernels see it: size and the byte offsets of its arrays inside a frame's arena.
+struct LevelLayout {
+  uint32_t w, h;
+  size_t points, mask, normals, colors, intensities, imap;
+};
+constexpr uint32_t MAX_LEVELS = 16;
+struct PyramidLayout {
+  LevelLayout lv[MAX_LEVELS];
+};
+
+// compute_intensity + compute_intensity_map (structure.rs:266-297) for every level of every frame in one launch:
+// blockIdx.y = level, blockIdx.z = frame, one thread per cell of the (h+2) x (w+2) map.
+// IntensityMap::from_luma_image (src/intensity_map.rs:37-92) including the incomplete border: rows h, h+1 copy row
+// h-1 for cols < w-1; cols w, w+1 copy col w-1 for rows < h-1; (h, w) and (h+1, w+1) take the last pixel; the other
+// border cells stay 0.  The luma of a cell's pixel is computed from the level's colours on the fly; interior cells
+// also store it as the level's `intensities`.
+__global__ void __launch_bounds__(256) luma_imap_kernel(PyramidLayout layout, FrameBases bases) {
+  const LevelLayout L = layout.lv[blockIdx.y];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t mw = w + 2, mh = h + 2;
+  const uint32_t w = L.w, h = L.h, mw = w + 2, mh = h + 2;
   if (i >= mw * mh) return;
+  char* base = bases.arena[blockIdx.z];
+  const uint8_t* __restrict__ rgb = (const uint8_t*)(base + L.colors);
   const uint32_t r = i / mw, c = i % mw;
   float v = 0.0f;
-  if (r < h && c < w)
-    v = (float)luma[r * w + c] / 255.0f;
-  else if (r >= h && c + 1 < w)
-    v = (float)luma[(h - 1) * w + c] / 255.0f;
-  else if (c >= w && r + 1 < h)
-    v = (float)luma[r * w + (w - 1)] / 255.0f;
-  else if ((r == h && c == w) || (r == h + 1 && c == w + 1))
-    v = (float)luma[(h - 1) * w + (w - 1)] / 255.0f;
-  map[i] = v;
+  if (r < h && c < w) {
+    const uint8_t l = luma_u8(rgb, r * w + c);
+    ((uint8_t*)(base + L.intensities))[r * w + c] = l;
+    v = (float)l / 255.0f;
+  } else if (r >= h && c + 1 < w) {
+    v = (float)luma_u8(rgb, (h - 1) * w + c) / 255.0f;
+  } else if (c >= w && r + 1 < h) {
+    v = (float)luma_u8(rgb, r * w + (w - 1)) / 255.0f;
+  } else if ((r == h && c == w) || (r == h + 1 && c == w + 1)) {
+    v = (float)luma_u8(rgb, (h - 1) * w + (w - 1)) / 255.0f;
+  }
+  ((float*)(base + L.imap))[i] = v;
 }
 
 // get_neighborhood_mean_point over every 2x2 block (src/range_image/resize.rs:4-40): among the entries
 // whose SOURCE mask is 1, the one nearest to their mean (strict <, first wins).  Used for points
 // (writes the destination mask) and for normals (mask output null).
-// blockIdx.y = 0 picks the points (and writes the destination mask), blockIdx.y = 1 the normals (if any): one
-// launch per level.  The four candidates stay in registers (no dynamically indexed private array).
-__global__ void __launch_bounds__(256)
-    resize_pick_kernel(const float* __restrict__ src_points, const float* __restrict__ src_normals,
-                       const uint8_t* __restrict__ src_mask, uint32_t sw, uint32_t sh, uint32_t dw, uint32_t dh,
-                       float* __restrict__ dst_points, float* __restrict__ dst_normals,
-                       uint8_t* __restrict__ dst_mask) {
+// blockIdx.y = 0 picks the points (and writes the destination mask), blockIdx.y = 1 the normals (if any);
+// blockIdx.z = frame.  The four candidates stay in registers (no dynamically indexed private array).
+__global__ void __launch_bounds__(256) resize_pick_kernel(LevelLayout S, LevelLayout D, FrameBases bases) {
+  const uint32_t sw = S.w, sh = S.h, dw = D.w, dh = D.h;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= dw * dh) return;
+  char* base = bases.arena[blockIdx.z];
   const bool normals = blockIdx.y == 1;
-  const float* __restrict__ src = normals ? src_normals : src_points;
-  float* __restrict__ dst = normals ? dst_normals : dst_points;
+  const float* __restrict__ src = (const float*)(base + (normals ? S.normals : S.points));
+  float* __restrict__ dst = (float*)(base + (normals ? D.normals : D.points));
+  const uint8_t* __restrict__ src_mask = (const uint8_t*)(base + S.mask);
   const uint32_t dv = i / dw, du = i % dw;
   const float hr = (float)sh / (float)dh, wr = (float)sw / (float)dw;
   const uint32_t sv = (uint32_t)((float)dv * hr), su = (uint32_t)((float)du * wr);
@@ -114,7 +179,7 @@ __global__ void __launch_bounds__(256)
     }
   }
   dst[3 * i] = nearest.x, dst[3 * i + 1] = nearest.y, dst[3 * i + 2] = nearest.z;
-  if (!normals) dst_mask[i] = n > 0 ? 1 : 0;
+  if (!normals) ((uint8_t*)(base + D.mask))[i] = n > 0 ? 1 : 0;
 }
 
 // One tap table entry per output row / column: first tap, tap count, normalised weights.
@@ -132,9 +197,11 @@ struct TapRow {
 constexpr uint32_t BLUR_TILE = 64;
 constexpr uint32_t BLUR_SPAN = 3 * (2 * BLUR_TILE + MAX_TAPS + 2);  // floats of vertical results a tile can need
 __global__ void __launch_bounds__(256)
-    blur_halve_kernel(const uint8_t* __restrict__ rgb, uint32_t w, uint32_t dw, const TapRow* __restrict__ taps_v,
-                      const TapRow* __restrict__ taps_h, uint8_t* __restrict__ out) {
+    blur_halve_kernel(size_t off_src, uint32_t w, uint32_t dw, const TapRow* __restrict__ taps_v,
+                      const TapRow* __restrict__ taps_h, size_t off_dst, FrameBases bases) {
   __shared__ float s_v[BLUR_SPAN];
+  const uint8_t* __restrict__ rgb = (const uint8_t*)(bases.arena[blockIdx.z] + off_src);  // blockIdx.z = frame
+  uint8_t* __restrict__ out = (uint8_t*)(bases.arena[blockIdx.z] + off_dst);
   const uint32_t dy = blockIdx.y, dx0 = blockIdx.x * BLUR_TILE, dx1 = min(dx0 + BLUR_TILE, dw) - 1;
   const TapRow* tv = taps_v + dy;  // row 2*dy of the source (table built with stride 2): block-uniform
   const int32_t vleft = tv->left, vcount = tv->count;
@@ -191,79 +258,170 @@ std::vector<TapRow> make_taps(uint32_t size, float sigma, uint32_t stride, uint3
   return rows;
 }
 
-// Bump allocator over one region (256-byte aligned pieces): the pyramid's arrays share one arena, the
-// temporaries share the context's scratch region, so a frame costs one hipMalloc instead of ~40.
-struct Carver {
-  char* base = nullptr;
-  size_t used = 0, capacity = 0;
-  template <typename T>
-  a3d_status take(T** p, size_t count) {
-    const size_t bytes = ((std::max<size_t>(1, count) * sizeof(T) + 255) / 256) * 256;
-    A3D_REQUIRE(used + bytes <= capacity, A3D_INVALID_PARAMETER, "internal: arena too small");
-    *p = (T*)(base + used);
-    used += bytes;
-    return A3D_OK;
-  }
-};
 inline size_t padded(size_t bytes) { return ((std::max<size_t>(1, bytes) + 255) / 256) * 256; }
 
-inline dim3 grid_for(size_t n) { return dim3((uint32_t)((n + 255) / 256)); }
+// Where each array of each level lives inside a frame's arena (256-byte aligned pieces, same for every frame).
+struct ArenaPlan {
+  PyramidLayout layout{};
+  size_t bytes = 0;
+};
+ArenaPlan plan_arena(uint32_t w, uint32_t h, const a3d_builder_params* prm) {
+  ArenaPlan p;
+  auto take = [&](size_t bytes) {
+    const size_t at = p.bytes;
+    p.bytes += padded(bytes);
+    return at;
+  };
+  for (uint64_t l = 0; l < prm->pyramid_levels; ++l) {
+    LevelLayout& L = p.layout.lv[l];
+    L.w = w >> l, L.h = h >> l;
+    const size_t n = (size_t)L.w * L.h;
+    L.colors = take(n * 3);
+    L.points = take(n * 12);
+    L.mask = take(n);
+    L.normals = prm->with_normals ? take(n * 12) : 0;
+    L.intensities = prm->with_intensity ? take(n) : 0;
+    L.imap = prm->with_intensity ? take((size_t)(L.w + 2) * (L.h + 2) * 4) : 0;
+  }
+  return p;
+}
 
-// compute_intensity + compute_intensity_map on a resident level that has colours
-a3d_status add_intensity(a3d_device_image* im, Carver& arena) {
-  const uint32_t w = im->width, h = im->height, n = w * h;
-  hipStream_t s = im->ctx->stream;
-  A3D_TRY(arena.take(&im->intensities, n));
-  A3D_TRY(arena.take(&im->imap, (size_t)(w + 2) * (h + 2)));
-  hipLaunchKernelGGL(luma_kernel, grid_for(n), dim3(256), 0, s, im->colors, n, im->intensities);
-  hipLaunchKernelGGL(intensity_map_kernel, grid_for((size_t)(w + 2) * (h + 2)), dim3(256), 0, s, im->intensities, w, h,
-                     im->imap);
+// The tap tables depend on (size, sigma) only: computed and uploaded once per context, then reused.
+a3d_status taps_for(a3d_context* ctx, uint32_t size, uint32_t count, float sigma, TapRow** out) {
+  uint32_t key[4] = {0x54415053u /* 'TAPS' */, size, count, 0};
+  memcpy(&key[3], &sigma, 4);
+  for (const auto& t : ctx->tables)
+    if (!memcmp(t.key, key, sizeof(key))) {
+      *out = (TapRow*)t.d;
+      return A3D_OK;
+    }
+  const std::vector<TapRow> rows = make_taps(size, sigma, 2, count);
+  return ctx_cached_table(ctx, key, rows.data(), rows.size() * sizeof(TapRow), (void**)out);
+}
+
+// Everything after the uploads for up to MAX_BATCH frames whose depth images sit at d_depth ([F][h][w]) and whose
+// colours are already in their arenas.  Enqueue only; the caller synchronises and then reads `result`.
+a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32_t F, const uint16_t* d_depth, uint32_t w,
+                         uint32_t h, float fx, float fy, float cx, float cy, float depth_scale, const ArenaPlan& plan,
+                         const FrameBases& bases, uint32_t* result) {
+  hipStream_t s = ctx->stream;
+  const PyramidLayout& P = plan.layout;
+  const LevelLayout& L0 = P.lv[0];
+  const dim3 grid0((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F);
+  if (prm->use_bilateral) {  // builder.rs:75-77
+    GridBatch gb;
+    A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb));
+    hipLaunchKernelGGL(level0_kernel<true>, grid0, dim3(ST_W * ST_H), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
+                       1.0 / prm->sigma_color, (const double2*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
+                       bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0);
+    A3D_HIP_TRY(hipMemcpyAsync(result, gb.scal, (size_t)F * SC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  } else {
+    hipLaunchKernelGGL(level0_kernel<false>, grid0, dim3(ST_W * ST_H), 0, s, d_depth, w, h, 0.0, 0.0,
+                       (const double2*)nullptr, 0ull, (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points,
+                       L0.mask, L0.normals, prm->with_normals != 0);
+  }
+  // RangeImage::pyramid (structure.rs:342-351): normals exist at level 0 only (builder.rs:79-82), coarser levels
+  // inherit picked normals; colours are blurred and halved level by level
+  float sigma = prm->blur_sigma;
+  if (sigma <= 0.0f) sigma = 1.0f;
+  for (uint64_t l = 1; l < prm->pyramid_levels; ++l) {
+    const LevelLayout &S = P.lv[l - 1], &D = P.lv[l];
+    hipLaunchKernelGGL(resize_pick_kernel, dim3((D.w * D.h + 255) / 256, prm->with_normals ? 2 : 1, F), dim3(256), 0, s, S, D,
+                       bases);
+    TapRow *d_tv = nullptr, *d_th = nullptr;
+    A3D_TRY(taps_for(ctx, S.h, D.h, sigma, &d_tv));
+    A3D_TRY(taps_for(ctx, S.w, D.w, sigma, &d_th));
+    hipLaunchKernelGGL(blur_halve_kernel, dim3((D.w + BLUR_TILE - 1) / BLUR_TILE, D.h, F), dim3(256), 0, s, S.colors, S.w,
+                       D.w, d_tv, d_th, D.colors, bases);
+  }
+  if (prm->with_intensity)
+    hipLaunchKernelGGL(luma_imap_kernel, dim3(((w + 2) * (h + 2) + 255) / 256, (uint32_t)prm->pyramid_levels, F), dim3(256),
+                       0, s, P, bases);
   A3D_HIP_TRY(hipGetLastError());
-  im->has_intensities = im->has_imap = true;
   return A3D_OK;
 }
 
-// RangeImage::pyr_scale_down(sigma) (structure.rs:309-340)
-a3d_status pyr_scale_down(const a3d_device_image* src, float sigma, a3d_device_image* dst, Carver& arena,
-                          Carver& scratch) {
-  a3d_context* ctx = src->ctx;
+a3d_status build_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32_t F, const uint16_t* const* depth,
+                       const uint8_t* const* rgb, uint32_t w, uint32_t h, double fx, double fy, double cx, double cy,
+                       double depth_scale, a3d_device_image** out_levels) {
   hipStream_t s = ctx->stream;
-  const uint32_t sw = src->width, sh = src->height, dw = sw / 2, dh = sh / 2, dn = dw * dh;
-  dst->ctx = ctx;
-  dst->width = dw, dst->height = dh;
-  dst->fx64 = src->fx64 * 0.5, dst->fy64 = src->fy64 * 0.5, dst->cx64 = src->cx64 * 0.5, dst->cy64 = src->cy64 * 0.5;
-  dst->fx = (float)dst->fx64, dst->fy = (float)dst->fy64, dst->cx = (float)dst->cx64, dst->cy = (float)dst->cy64;
-  A3D_TRY(arena.take(&dst->points, (size_t)dn * 3));
-  A3D_TRY(arena.take(&dst->mask, dn));
-  if (src->has_normals) {
-    A3D_TRY(arena.take(&dst->normals, (size_t)dn * 3));
-    dst->has_normals = true;
+  const size_t n = (size_t)w * h;
+  const uint64_t L = prm->pyramid_levels;
+  const ArenaPlan plan = plan_arena(w, h, prm);
+  FrameBases bases{};
+  std::vector<a3d_device_image*> images;  // [F][L], filled as the arenas are acquired
+  auto fail = [&](a3d_status st) {
+    hipStreamSynchronize(s);
+    for (a3d_device_image* im : images) a3d_range_image_free(im);  // a frame's last level releases its arena
+    return st;
+  };
+  for (uint32_t f = 0; f < F; ++f) {
+    DeviceArena* arena = new DeviceArena();
+    if (ctx_arena_acquire(ctx, plan.bytes, arena) != A3D_OK) {
+      delete arena;
+      set_error("a3d_range_image_build_pyramids: hipMalloc(%zu) failed", plan.bytes);
+      return fail(A3D_HIP_ERROR);
+    }
+    bases.arena[f] = (char*)arena->base;
+    for (uint64_t l = 0; l < L; ++l) {
+      const LevelLayout& Y = plan.layout.lv[l];
+      a3d_device_image* im = new a3d_device_image();
+      im->ctx = ctx, im->arena = arena;
+      ++arena->refs;
+      im->width = Y.w, im->height = Y.h;
+      const double k = std::ldexp(1.0, -(int)l);  // CameraIntrinsics::scale(0.5) per level (camera.rs:119-127): exact
+      im->fx64 = fx * k, im->fy64 = fy * k, im->cx64 = cx * k, im->cy64 = cy * k;
+      im->fx = (float)im->fx64, im->fy = (float)im->fy64, im->cx = (float)im->cx64, im->cy = (float)im->cy64;
+      char* b = (char*)arena->base;
+      im->colors = (uint8_t*)(b + Y.colors), im->points = (float*)(b + Y.points), im->mask = (uint8_t*)(b + Y.mask);
+      if (prm->with_normals) im->normals = (float*)(b + Y.normals), im->has_normals = true;
+      if (prm->with_intensity) {
+        im->intensities = (uint8_t*)(b + Y.intensities), im->imap = (float*)(b + Y.imap);
+        im->has_intensities = im->has_imap = true;
+      }
+      images.push_back(im);
+    }
   }
-  hipLaunchKernelGGL(resize_pick_kernel, dim3((dn + 255) / 256, src->has_normals ? 2 : 1), dim3(256), 0, s, src->points,
-                     src->normals, src->mask, sw, sh, dw, dh, dst->points, dst->normals, dst->mask);
-  if (src->colors) {
-    if (sigma <= 0.0f) sigma = 1.0f;
-    A3D_REQUIRE(sigma <= 3.0f, A3D_INVALID_PARAMETER, "blur_sigma above 3 is not supported by the device builder");
-    // the tap tables depend on (size, sigma) only: computed and uploaded once per context, then reused
-    auto taps_for = [&](uint32_t size, uint32_t count, TapRow** out) -> a3d_status {
-      uint32_t key[4] = {0x54415053u /* 'TAPS' */, size, count, 0};
-      memcpy(&key[3], &sigma, 4);
-      for (const auto& t : ctx->tables)
-        if (!memcmp(t.key, key, sizeof(key))) {
-          *out = (TapRow*)t.d;
-          return A3D_OK;
-        }
-      const std::vector<TapRow> rows = make_taps(size, sigma, 2, count);
-      return ctx_cached_table(ctx, key, rows.data(), rows.size() * sizeof(TapRow), (void**)out);
-    };
-    TapRow *d_tv = nullptr, *d_th = nullptr;
-    A3D_TRY(taps_for(sh, dh, &d_tv));
-    A3D_TRY(taps_for(sw, dw, &d_th));
-    A3D_TRY(arena.take(&dst->colors, (size_t)dn * 3));
-    hipLaunchKernelGGL(blur_halve_kernel, dim3((dw + BLUR_TILE - 1) / BLUR_TILE, dh), dim3(256), 0, s, src->colors, sw,
-                       dw, d_tv, d_th, dst->colors);
+  void* scratch = nullptr;
+  if (ctx_scratch(ctx, 0, (size_t)F * padded(n * 2), &scratch) != A3D_OK) return fail(A3D_HIP_ERROR);
+  uint16_t* d_depth = (uint16_t*)scratch;
+  // kernels index the batch's depth images as [F][n]: n * 2 bytes apart (no padding between frames)
+  for (uint32_t f = 0; f < F; ++f) {
+    if (hipMemcpyAsync(d_depth + (size_t)f * n, depth[f], n * 2, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(bases.arena[f] + plan.layout.lv[0].colors, rgb[f], n * 3, hipMemcpyHostToDevice, s) != hipSuccess) {
+      set_error("a3d_range_image_build_pyramids: upload failed: %s", hipGetErrorString(hipGetLastError()));
+      return fail(A3D_HIP_ERROR);
+    }
   }
-  A3D_HIP_TRY(hipGetLastError());
+  if (prm->use_bilateral && ctx->grid_capacity == 0)  // first guess: a depth span of 4096 units (4 m at 1 mm)
+    ctx->grid_capacity = bilateral_grid_cells(w, h, prm->sigma_space, prm->sigma_color, 4096);
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    a3d_status st = enqueue_chunk(ctx, prm, F, d_depth, w, h, (float)fx, (float)fy, (float)cx, (float)cy, (float)depth_scale,
+                                  plan, bases, ctx->pinned_words);
+    if (st != A3D_OK) return fail(st);
+    if (hipStreamSynchronize(s) != hipSuccess) {
+      set_error("a3d_range_image_build_pyramids: %s", hipGetErrorString(hipGetLastError()));
+      return fail(A3D_HIP_ERROR);
+    }
+    if (!prm->use_bilateral) break;
+    unsigned long long need = 0;
+    bool overflow = false;
+    for (uint32_t f = 0; f < F; ++f) {  // the filter's scalars arrived with the synchronisation above
+      const uint32_t* r = ctx->pinned_words + f * SC_STRIDE;
+      if (r[SC_TOO_BIG]) need = std::max<unsigned long long>(need, (unsigned long long)r[SC_GH] * r[SC_GW] * r[SC_GD]);
+      overflow |= r[SC_OVERFLOW] != 0;
+    }
+    if (need) {  // a frame's bilateral grid outgrew the scratch region: grow it (25 % head room) and run the chunk again
+      ctx->grid_capacity = need + need / 4;
+      continue;
+    }
+    if (overflow) {
+      set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
+      return fail(A3D_CAST_OVERFLOW);
+    }
+    break;
+  }
+  for (size_t k = 0; k < images.size(); ++k) out_levels[k] = images[k];
   return A3D_OK;
 }
 
@@ -281,111 +439,55 @@ void a3d_builder_params_default(a3d_builder_params* out) {
   out->blur_sigma = 1.0f;
 }
 
-a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_params* prm, const uint16_t* depth,
-                                         const uint8_t* rgb, uint64_t width, uint64_t height, double fx, double fy,
-                                         double cx, double cy, double depth_scale, a3d_device_image** out_levels) {
-  A3D_REQUIRE(ctx && prm && depth && rgb && out_levels, A3D_INVALID_PARAMETER, "null argument");
+a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_params* prm, uint64_t n_frames,
+                                          const uint16_t* const* depth_frames, const uint8_t* const* rgb_frames,
+                                          uint64_t width, uint64_t height, double fx, double fy, double cx, double cy,
+                                          double depth_scale, a3d_device_image** out_levels) {
+  A3D_REQUIRE(ctx && prm && depth_frames && rgb_frames && out_levels, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(n_frames >= 1 && n_frames <= (1u << 20), A3D_INVALID_PARAMETER, "bad frame count");
+  for (uint64_t f = 0; f < n_frames; ++f)
+    A3D_REQUIRE(depth_frames[f] && rgb_frames[f], A3D_INVALID_PARAMETER, "null frame pointer");
   A3D_REQUIRE(width > 0 && height > 0 && width * height < (1ull << 28), A3D_INVALID_PARAMETER, "bad image size");
   // the kernels form texel offsets with 24-bit multiplies
   A3D_REQUIRE(width < (1ull << 23) && height < (1ull << 23), A3D_INVALID_PARAMETER, "image side too long");
-  A3D_REQUIRE(prm->pyramid_levels >= 1 && prm->pyramid_levels <= 16, A3D_INVALID_PARAMETER, "bad pyramid_levels");
+  A3D_REQUIRE(prm->pyramid_levels >= 1 && prm->pyramid_levels <= MAX_LEVELS, A3D_INVALID_PARAMETER, "bad pyramid_levels");
   A3D_REQUIRE((width >> (prm->pyramid_levels - 1)) >= 2 && (height >> (prm->pyramid_levels - 1)) >= 2,
               A3D_INVALID_PARAMETER, "image too small for this many pyramid levels");
+  // BilateralFilter::new takes any sigma; a non-positive or non-finite one would size the grid by a division by zero
+  A3D_REQUIRE(!prm->use_bilateral || (prm->sigma_space > 0.0 && prm->sigma_color > 0.0 && std::isfinite(prm->sigma_space) &&
+                                      std::isfinite(prm->sigma_color)),
+              A3D_INVALID_PARAMETER, "bilateral sigmas must be positive and finite");
+  A3D_REQUIRE(std::isfinite(prm->blur_sigma), A3D_INVALID_PARAMETER, "blur_sigma must be finite");
+  A3D_REQUIRE(prm->pyramid_levels == 1 || prm->blur_sigma <= 3.0f, A3D_INVALID_PARAMETER,
+              "blur_sigma above 3 is not supported by the device builder");
+  A3D_REQUIRE(!prm->use_bilateral || width * height < (1ull << 24), A3D_INVALID_PARAMETER,
+              "the device frame builder's bilateral filter handles images below 2^24 pixels");
   A3D_HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const uint32_t w = (uint32_t)width, h = (uint32_t)height, n = w * h;
-  // ---- sizes: one arena for everything that stays resident, the context's scratch for the temporaries ----
   const uint64_t L = prm->pyramid_levels;
-  size_t arena_bytes = 0, scratch_bytes = 2 * padded((size_t)n * 2);
-  for (uint64_t l = 0; l < L; ++l) {
-    const size_t wl = w >> l, hl = h >> l, nl = wl * hl;
-    arena_bytes += padded(nl * 12) + padded(nl) + padded(nl * 3);                 // points, mask, colors
-    if (prm->with_normals) arena_bytes += padded(nl * 12);
-    if (prm->with_intensity) arena_bytes += padded(nl) + padded((wl + 2) * (hl + 2) * 4);
+  // frames per launch sequence: at most MAX_BATCH, and few enough that their bilateral grids fit ~1 GiB of scratch
+  uint64_t chunk = MAX_BATCH;
+  if (prm->use_bilateral) {
+    const unsigned long long cap = ctx->grid_capacity ? ctx->grid_capacity
+                                                      : bilateral_grid_cells((uint32_t)width, (uint32_t)height, prm->sigma_space,
+                                                                             prm->sigma_color, 4096);
+    chunk = std::max<uint64_t>(1, std::min<uint64_t>(MAX_BATCH, (1ull << 30) / (cap * 24 + 1)));
   }
-  DeviceArena* shared = new DeviceArena();
-  if (ctx_arena_acquire(ctx, arena_bytes, shared) != A3D_OK) {
-    delete shared;
-    set_error("a3d_range_image_build_pyramid: hipMalloc(%zu) failed", arena_bytes);
-    return A3D_HIP_ERROR;
+  for (uint64_t f0 = 0; f0 < n_frames; f0 += chunk) {
+    const uint32_t F = (uint32_t)std::min<uint64_t>(chunk, n_frames - f0);
+    const a3d_status st = build_chunk(ctx, prm, F, depth_frames + f0, rgb_frames + f0, (uint32_t)width, (uint32_t)height, fx, fy,
+                                      cx, cy, depth_scale, out_levels + f0 * L);
+    if (st != A3D_OK) {  // the caller gets all the pyramids or none
+      for (uint64_t k = 0; k < f0 * L; ++k) a3d_range_image_free(out_levels[k]);
+      return st;
+    }
   }
-  Carver arena{(char*)shared->base, 0, arena_bytes};
-  std::vector<a3d_device_image*> levels;
-  auto new_level = [&]() {
-    a3d_device_image* im = new a3d_device_image();
-    im->ctx = ctx;
-    im->arena = shared;
-    ++shared->refs;
-    levels.push_back(im);
-    return im;
-  };
-  bool async_bilateral = false;
-  size_t retry_scratch_bytes = 0;
-  auto build = [&]() -> a3d_status {
-    void* scratch_base = nullptr;
-    A3D_TRY(ctx_scratch(ctx, 0, scratch_bytes, &scratch_base));
-    Carver scratch{(char*)scratch_base, 0, scratch_bytes};
-    uint16_t *d_depth = nullptr, *d_filtered = nullptr;
-    a3d_device_image* l0 = new_level();
-    l0->width = w, l0->height = h;
-    l0->fx64 = fx, l0->fy64 = fy, l0->cx64 = cx, l0->cy64 = cy;
-    l0->fx = (float)fx, l0->fy = (float)fy, l0->cx = (float)cx, l0->cy = (float)cy;
-    A3D_TRY(scratch.take(&d_depth, n));
-    A3D_TRY(scratch.take(&d_filtered, n));
-    A3D_TRY(arena.take(&l0->colors, (size_t)n * 3));
-    A3D_TRY(arena.take(&l0->points, (size_t)n * 3));
-    A3D_TRY(arena.take(&l0->mask, n));
-    A3D_HIP_TRY(hipMemcpyAsync(d_depth, depth, (size_t)n * 2, hipMemcpyHostToDevice, s));
-    A3D_HIP_TRY(hipMemcpyAsync(l0->colors, rgb, (size_t)n * 3, hipMemcpyHostToDevice, s));
-    const uint16_t* d_use = d_depth;
-    if (prm->use_bilateral) {  // builder.rs:75-77
-      // without a host round trip when the context's grid scratch already exists (every frame but the first)
-      A3D_TRY(bilateral_filter_device_async(ctx, d_depth, d_filtered, w, h, prm->sigma_space, prm->sigma_color,
-                                            ctx->pinned_words, &async_bilateral));
-      if (!async_bilateral)
-        A3D_TRY(bilateral_filter_device(ctx, d_depth, d_filtered, w, h, prm->sigma_space, prm->sigma_color, nullptr));
-      d_use = d_filtered;
-    }
-    hipLaunchKernelGGL(backproject_kernel, grid_for(n), dim3(256), 0, s, d_use, w, h, l0->fx, l0->fy, l0->cx, l0->cy,
-                       (float)depth_scale, l0->points, l0->mask);
-    if (prm->with_normals) {  // level 0 only (builder.rs:79-82); coarser levels inherit picked normals
-      A3D_TRY(arena.take(&l0->normals, (size_t)n * 3));
-      A3D_TRY(compute_normals_device(ctx, l0->points, l0->mask, l0->normals, w, h));
-      l0->has_normals = true;
-    }
-    for (uint64_t l = 1; l < L; ++l) {  // RangeImage::pyramid (structure.rs:342-351)
-      a3d_device_image* prev = levels.back();
-      a3d_device_image* next = new_level();
-      A3D_TRY(pyr_scale_down(prev, prm->blur_sigma, next, arena, scratch));
-    }
-    if (prm->with_intensity)
-      for (a3d_device_image* lv : levels) A3D_TRY(add_intensity(lv, arena));
-    A3D_HIP_TRY(hipGetLastError());
-    A3D_HIP_TRY(hipStreamSynchronize(s));
-    if (async_bilateral) {  // the filter's scalars arrived with the synchronisation above
-      A3D_TRY(bilateral_async_status(ctx->pinned_words, &retry_scratch_bytes));
-      if (retry_scratch_bytes) return A3D_HIP_ERROR;  // (not an error: handled below by growing the region)
-    }
-    return A3D_OK;
-  };
-  const a3d_status st = build();
-  if (st != A3D_OK) {
-    hipStreamSynchronize(s);
-    for (a3d_device_image* lv : levels) a3d_range_image_free(lv);  // the last one releases the arena
-    if (levels.empty()) {
-      ctx_arena_release(ctx, shared);
-      delete shared;
-    }
-    if (retry_scratch_bytes) {  // this frame's bilateral grid outgrew the scratch region: grow it, build again
-      void* unused = nullptr;
-      A3D_TRY(ctx_scratch(ctx, 1, retry_scratch_bytes, &unused));
-      return a3d_range_image_build_pyramid(ctx, prm, depth, rgb, width, height, fx, fy, cx, cy, depth_scale,
-                                           out_levels);
-    }
-    return st;
-  }
-  for (size_t l = 0; l < levels.size(); ++l) out_levels[l] = levels[l];
   return A3D_OK;
+}
+
+a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_params* prm, const uint16_t* depth,
+                                         const uint8_t* rgb, uint64_t width, uint64_t height, double fx, double fy,
+                                         double cx, double cy, double depth_scale, a3d_device_image** out_levels) {
+  return a3d_range_image_build_pyramids(ctx, prm, 1, &depth, &rgb, width, height, fx, fy, cx, cy, depth_scale, out_levels);
 }
 
 a3d_status a3d_range_image_size(const a3d_device_image* im, uint64_t* out_width, uint64_t* out_height) {

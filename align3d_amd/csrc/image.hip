@@ -40,29 +40,7 @@ __global__ void __launch_bounds__(TILE_W* TILE_H)
   auto at = [&](int ly, int lx) { return V3{tile[0][ly][lx], tile[1][ly][lx], tile[2][ly][lx]}; };
   V3 left = at(ty + 1, tx), right = at(ty + 1, tx + 2);
   V3 top = at(ty, tx + 1), bottom = at(ty + 2, tx + 1);
-  const float thr_sq = 2.0f * 2.0f;
-  float ld = norm_squared(left - center), rd = norm_squared(right - center);
-  float lr_ratio = ld / rd;
-  V3 left_to_right;
-  if (lr_ratio < thr_sq && lr_ratio > 1.0f / thr_sq)
-    left_to_right = right - left;
-  else if (ld < rd)
-    left_to_right = center - left;
-  else
-    left_to_right = right - center;
-  float bd = norm_squared(bottom - center), td = norm_squared(top - center);
-  float bt_ratio = bd / td;
-  V3 bottom_to_top;
-  if (bt_ratio < thr_sq && bt_ratio > 1.0f / thr_sq)
-    bottom_to_top = top - bottom;
-  else if (bd < td)
-    bottom_to_top = center - bottom;
-  else
-    bottom_to_top = top - center;
-  V3 n = cross(left_to_right, bottom_to_top);
-  float mag = sqrtf(norm_squared(n));
-  V3 out{0.f, 0.f, 0.f};
-  if (mag > 1e-6f) out = n / mag;
+  const V3 out = normal_from_neighbours(center, left, right, top, bottom);
   normals[3 * idx] = out.x;
   normals[3 * idx + 1] = out.y;
   normals[3 * idx + 2] = out.z;

@@ -639,8 +639,12 @@ struct a3d_multiscale_batch {
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   float last_total_ms = 0.f, last_kernel_ms = 0.f;
   uint64_t last_kernel_launches = 0;
+  // "every launch this batch has enqueued so far": registered with the arenas of the images the batch reads, so
+  // that an image freed after an enqueue-only align (no host synchronisation) is not recycled under the kernels
+  std::shared_ptr<UseFence> fence = std::make_shared<UseFence>();
 
   ~a3d_multiscale_batch() {
+    fence->retire();
     hipFree(d_descs);
     hipFree(d_states);
     hipFree(d_partials);
@@ -679,6 +683,16 @@ a3d_status fill_desc(const a3d_device_image* target, const a3d_device_image* sou
   d->fx = target->fx, d->fy = target->fy, d->cx = target->cx, d->cy = target->cy;
   d->pad = 0;
   return A3D_OK;
+}
+
+// The image's arena (if it has one) will wait for this batch's launches before it is recycled.
+void attach_fence(const a3d_device_image* im, const std::shared_ptr<UseFence>& fence) {
+  DeviceArena* a = im ? im->arena : nullptr;
+  if (!a) return;  // individually allocated arrays are released with hipFree, which synchronises the device
+  std::lock_guard<std::mutex> lock(a->fence_mutex);
+  for (const auto& f : a->fences)
+    if (f == fence) return;
+  a->fences.push_back(fence);
 }
 
 Gates make_gates(const a3d_icp_params& p) {
@@ -1163,6 +1177,8 @@ a3d_status a3d_multiscale_batch_new(a3d_context* ctx, const a3d_icp_params* para
     for (uint32_t l = 0; l < n_levels; ++l)
       A3D_TRY(fill_desc(target_pyramids[(size_t)p * n_levels + l], source_pyramids[(size_t)p * n_levels + l],
                         &b->h_descs[(size_t)l * n_pairs + p]));
+  for (size_t k = 0; k < (size_t)n_pairs * n_levels; ++k)
+    attach_fence(target_pyramids[k], b->fence), attach_fence(source_pyramids[k], b->fence);
   A3D_TRY(batch_commit_descs(b.get()));
   A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
   *out = b.release();
@@ -1180,6 +1196,7 @@ a3d_status a3d_multiscale_batch_rebind(a3d_multiscale_batch* b, const a3d_device
     for (uint32_t l = 0; l < L; ++l)
       A3D_TRY(fill_desc(target_pyramids[(size_t)p * L + l], source_pyramids[(size_t)p * L + l],
                         &b->h_descs[(size_t)l * P + p]));
+  for (size_t k = 0; k < (size_t)P * L; ++k) attach_fence(target_pyramids[k], b->fence), attach_fence(source_pyramids[k], b->fence);
   A3D_TRY(batch_commit_descs(b));
   A3D_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
   return A3D_OK;
@@ -1190,6 +1207,7 @@ a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* b, a3d_pose* out_pos
   A3D_REQUIRE(b, A3D_INVALID_PARAMETER, "batch is null");
   A3D_HIP_TRY(hipSetDevice(b->ctx->device));
   A3D_TRY(batch_enqueue(b, nullptr, b->n_levels, out_matrices_device, nullptr, 0));
+  b->fence->record(b->ctx->stream);  // the aux streams have been joined into the context stream by now
   if (!out_poses_host && !out_status_host) return A3D_OK;
   a3d_status worst;
   A3D_TRY(read_results(b, out_poses_host, out_status_host, &worst));

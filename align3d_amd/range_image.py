@@ -171,17 +171,7 @@ class RangeImageBuilder:
         b._bilateral_filter, b._pyramid_levels, b._blur_sigma = self._bilateral_filter, self._pyramid_levels, self._blur_sigma
         return b
 
-    def build(self, camera, depth_u16, rgb, depth_scale):
-        """RangeImageBuilder::build (builder.rs:74-91) entirely on the GPU (a3d_range_image_build_pyramid): the frame
-        crosses PCIe as u16 depth + u8 RGB and the pyramid levels stay resident.  Returns a list of
-        DeviceRangeImage, index 0 = full resolution (`.download()` gives the host arrays)."""
-        depth_u16 = np.ascontiguousarray(depth_u16, np.uint16)
-        rgb = np.ascontiguousarray(rgb, np.uint8)
-        if depth_u16.ndim != 2 or rgb.shape != depth_u16.shape + (3,):
-            # the C ABI receives bare pointers: this is the only place a size mismatch can be caught
-            raise _abi.InvalidParameter(
-                f"depth must be [h][w] u16 and rgb [h][w][3] u8 of the same size (got {depth_u16.shape} and {rgb.shape})")
-        h, w = depth_u16.shape
+    def _params(self):
         p = _abi.BuilderParamsC()
         self.ctx.lib.a3d_builder_params_default(C.byref(p))
         p.with_normals = 1 if self._with_normals else 0
@@ -192,12 +182,41 @@ class RangeImageBuilder:
             p.use_bilateral = 1
             p.sigma_space = self._bilateral_filter.sigma_space
             p.sigma_color = self._bilateral_filter.sigma_color
-        out = (C.c_void_p * self._pyramid_levels)()
+        return p
+
+    def build_many(self, camera, frames, depth_scale):
+        """RangeImageBuilder::build (builder.rs:74-91) for a list of (depth_u16, rgb) frames of one stream (same size
+        and camera) in one launch sequence on the GPU (a3d_range_image_build_pyramids): each frame crosses PCIe as
+        u16 depth + u8 RGB and its pyramid levels stay resident.  Returns one list of DeviceRangeImage per frame,
+        index 0 = full resolution (`.download()` gives the host arrays)."""
+        if not frames:
+            return []
+        held = []  # keeps converted copies alive until the call returns
+        h, w = np.asarray(frames[0][0]).shape[:2]
+        for depth_u16, rgb in frames:
+            depth_u16 = np.ascontiguousarray(depth_u16, np.uint16)
+            rgb = np.ascontiguousarray(rgb, np.uint8)
+            if depth_u16.shape != (h, w) or rgb.shape != (h, w, 3):
+                # the C ABI receives bare pointers: this is the only place a size mismatch can be caught
+                raise _abi.InvalidParameter(
+                    f"depth must be [h][w] u16 and rgb [h][w][3] u8, every frame {h}x{w} (got {depth_u16.shape} and {rgb.shape})")
+            held.append((depth_u16, rgb))
+        n, L = len(held), self._pyramid_levels
+        p = self._params()
+        dptr = (C.c_void_p * n)(*[_abi.ptr(d) for d, _ in held])
+        cptr = (C.c_void_p * n)(*[_abi.ptr(c) for _, c in held])
+        out = (C.c_void_p * (n * L))()
         _abi.check(
-            self.ctx.lib.a3d_range_image_build_pyramid(self.ctx.handle, C.byref(p), _abi.ptr(depth_u16), _abi.ptr(rgb), w, h,
-                                                       camera.fx, camera.fy, camera.cx, camera.cy, float(depth_scale), out),
-            "a3d_range_image_build_pyramid",
+            self.ctx.lib.a3d_range_image_build_pyramids(self.ctx.handle, C.byref(p), n, dptr, cptr, w, h, camera.fx, camera.fy,
+                                                        camera.cx, camera.cy, float(depth_scale), out),
+            "a3d_range_image_build_pyramids",
         )
-        return [DeviceRangeImage(self.ctx, handle=C.c_void_p(out[i])) for i in range(self._pyramid_levels)]
+        return [[DeviceRangeImage(self.ctx, handle=C.c_void_p(out[f * L + l])) for l in range(L)] for f in range(n)]
+
+    def build(self, camera, depth_u16, rgb, depth_scale):
+        """RangeImageBuilder::build (builder.rs:74-91) entirely on the GPU: see build_many."""
+        if np.asarray(depth_u16).ndim != 2:
+            raise _abi.InvalidParameter(f"depth must be [h][w] u16 (got shape {np.asarray(depth_u16).shape})")
+        return self.build_many(camera, [(depth_u16, rgb)], depth_scale)[0]
 
     build_device = build  # round-1 name

@@ -117,7 +117,11 @@ typedef struct a3d_pcl_icp a3d_pcl_icp;                 /* Icp */
  * (this is how frame builds overlap alignments); freeing an image from another thread than the one using its
  * context is allowed.  The reference's objects are re-entrant because they borrow host memory; here a thread that
  * wants its own concurrent `align` creates its own context.  Results are complete when a call returns, except
- * a3d_multiscale_batch_align with no host outputs, which only enqueues (a3d_context_synchronize waits). */
+ * a3d_multiscale_batch_align with no host outputs, which only enqueues (a3d_context_synchronize waits).
+ * Lifetime of images: the objects that read images (a3d_multiscale, a3d_multiscale_batch) borrow them like the
+ * reference's `&'a Vec<RangeImage>`; an image must not be freed while a host-synchronous call on it is running.
+ * After an enqueue-only batch_align the images MAY be freed right away: a3d_range_image_free waits for the batch's
+ * launches (also when batch and image live on different contexts / streams) before the memory is recycled. */
 
 uint32_t a3d_abi_version(void);
 /* Text of the most recent failure on the calling thread ("" if none). */
@@ -178,6 +182,15 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
                                          const uint16_t* depth, const uint8_t* rgb, uint64_t width,
                                          uint64_t height, double fx, double fy, double cx, double cy,
                                          double depth_scale, a3d_device_image** out_levels);
+/* The same for n_frames frames of one stream (same size, intrinsics and depth scale) in ONE launch sequence: every
+ * kernel of the builder has a frame dimension, so 16 frames cost the ~12 launches one frame costs (a frame stream is
+ * launch-bound otherwise).  depth_frames / rgb_frames: n_frames host pointers (page-locked buffers from a3d_host_alloc
+ * are copied by DMA).  out_levels: [n_frames][params->pyramid_levels] handles, frame-major.  All or nothing: on
+ * failure no handle is returned.  The call returns when every pyramid is complete. */
+a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_params* params, uint64_t n_frames,
+                                          const uint16_t* const* depth_frames, const uint8_t* const* rgb_frames,
+                                          uint64_t width, uint64_t height, double fx, double fy, double cx, double cy,
+                                          double depth_scale, a3d_device_image** out_levels);
 a3d_status a3d_range_image_size(const a3d_device_image* image, uint64_t* out_width, uint64_t* out_height);
 /* Reads resident arrays back (each pointer nullable): points [h][w][3], mask [h][w], normals [h][w][3],
  * intensities [h*w], intensity_map [(h+2)][(w+2)], colors [h][w][3] u8, intrinsics fx fy cx cy. */

@@ -234,3 +234,72 @@ def test_device_builder_without_minmax_round_trip_and_scratch_regrow():
                 lv.free()
     finally:
         own.close()
+
+
+def test_batched_builder_equals_oracle_and_single_builds(ctx):
+    """a3d_range_image_build_pyramids: 20 real frames in two launch sequences (16 + 4) — every level of every frame
+    equals the single-frame build bit for bit, and the oracle's pyramid on the frames checked against it; frames with
+    very different depth ranges (= bilateral grids of different sizes, one of which outgrows the scratch region and
+    forces the chunk to run again) share a batch."""
+    from align3d_amd import CameraIntrinsics, Context, RangeImageBuilder
+    from gpu_util import oracle_pyramid
+
+    s = SlamTbSample("sample1")
+    cam = CameraIntrinsics(*s.intrinsics(0), 640, 480)
+    frames = [s.load(i) for i in range(20)]
+    own = Context(0)  # its own scratch region: the capacity guess and the regrow path are exercised from scratch
+    try:
+        b = RangeImageBuilder(own).with_bilateral_filter(BilateralFilter.default())
+        many = b.build_many(cam, frames, s.depth_scale(0))
+        assert len(many) == 20 and all(len(p) == 3 for p in many)
+        for i in (0, 1, 7, 15, 16, 19):  # both chunks, first and last slot of each
+            for lv, r in zip(many[i], oracle_pyramid("sample1", i)):
+                _assert_same_level(lv, r)
+        for i in (3, 12, 18):
+            single = b.build(cam, *frames[i], s.depth_scale(0))
+            for lv, one in zip(many[i], single):
+                a, c = lv.download(), one.download()
+                for name in ("points", "mask", "normals", "colors", "intensities", "intensity_map"):
+                    assert np.array_equal(getattr(a, name), getattr(c, name), equal_nan=True), (i, name)
+            for lv in single:
+                lv.free()
+        for lv in (lv for p in many for lv in p):
+            lv.free()
+        # mixed depth ranges in one batch: frame 1's grid is ~9x deeper than the others'
+        rng = np.random.default_rng(5)
+        w, h = 262, 134
+        cam2 = CameraIntrinsics(300.0, 300.0, w / 2.0, h / 2.0, w, h)
+        rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        base = (1000 + 400 * np.sin(np.linspace(0, 6, w))[None, :] + 300 * np.cos(np.linspace(0, 4, h))[:, None])
+        depths = [(base + rng.integers(0, 30, size=(h, w))).astype(np.uint16),
+                  (base * 30.0 + rng.integers(0, 9000, size=(h, w))).astype(np.uint16),
+                  np.zeros((h, w), np.uint16),
+                  (base * 0.5).astype(np.uint16)]
+        depths[0][10:40, 20:90] = 0
+        mixed = b.build_many(cam2, [(d, rgb) for d in depths], 0.001)
+        for d, pyr in zip(depths, mixed):
+            ref = O.build_pyramid(d, rgb, cam2.fx, cam2.fy, cam2.cx, cam2.cy, 0.001, levels=3, use_bilateral=True)
+            for lv, r in zip(pyr, ref):
+                _assert_same_level(lv, r)
+    finally:
+        own.close()
+
+
+def test_builder_rejects_bad_sigmas_and_mismatched_frames(ctx):
+    from align3d_amd import A3dError, CameraIntrinsics, InvalidParameter, RangeImageBuilder
+
+    cam = CameraIntrinsics(300.0, 300.0, 32.0, 24.0, 64, 48)
+    depth = np.full((48, 64), 1000, np.uint16)
+    rgb = np.zeros((48, 64, 3), np.uint8)
+    for ss, sc in ((0.0, 30.0), (4.5, -1.0), (float("nan"), 30.0), (4.5, float("inf"))):
+        with pytest.raises(A3dError) as e:
+            RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.new(ss, sc)).build(cam, depth, rgb, 0.001)
+        assert e.value.status == 1
+    with pytest.raises(A3dError):
+        RangeImageBuilder(ctx).blur_sigma(float("nan")).build(cam, depth, rgb, 0.001)
+    with pytest.raises(InvalidParameter):
+        RangeImageBuilder(ctx).build(cam, depth, rgb[:40], 0.001)          # rgb smaller than depth
+    with pytest.raises(InvalidParameter):
+        RangeImageBuilder(ctx).build(cam, depth.reshape(-1), rgb, 0.001)   # depth not 2-D
+    with pytest.raises(InvalidParameter):
+        RangeImageBuilder(ctx).build_many(cam, [(depth, rgb), (depth[:24], rgb[:24])], 0.001)  # frames of two sizes

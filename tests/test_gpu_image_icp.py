@@ -440,3 +440,47 @@ def test_ms3x15_end_to_end_on_benchmark_pairs(ctx):
     print(f"[ms3x15 on the benchmark's pairs] worst d_angle={worst[0]:.3e} rad d_trans={worst[1]:.3e} m")
     for lv in (lv for p in pyr for lv in p):
         lv.free()
+
+
+def test_images_may_be_freed_right_after_an_enqueue_only_align():
+    """Lifetime rule of include/align3d_hip.h: a batch aligned WITHOUT host outputs only enqueues; freeing its images
+    right away (they live on a builder context, the batch on another: two streams) and rebuilding other frames into
+    the recycled arenas must not disturb the alignments still in flight — a3d_range_image_free waits for them."""
+    from align3d_amd import BilateralFilter, Context, RangeImageBuilder, synth
+
+    main, side = Context(0), Context(0)
+    try:
+        P = 12
+        frames, _ = synth.frame_stream(321, P + 1, 640, 480)
+        other, _ = synth.frame_stream(999, P + 1, 640, 480)
+        cam = synth.camera(640, 480)
+        b = RangeImageBuilder(side).with_bilateral_filter(BilateralFilter.default())
+        prm = MsIcpParams.repeat(3, IcpParams.default())
+        warm = b.build_many(cam, frames, synth.DEPTH_SCALE)   # fills the arena pool (slabs appear on the 4th request)
+        for lv in (lv for p in warm for lv in p):
+            lv.free()
+        pyr = b.build_many(cam, frames, synth.DEPTH_SCALE)
+        batch = MultiscaleAlignBatch(main, prm, pyr[:P], pyr[1:])
+        d_mats = main.malloc(P * 64)
+        _, status = batch.align(matrices_device=d_mats)      # host-synchronous reference result
+        assert not np.any(status)
+        want = main.to_host(d_mats, np.zeros((P, 16), np.float32)).copy()
+        for trial in range(3):
+            batch.enqueue(matrices_device=d_mats)             # enqueue only: ~3 ms of kernels now in flight
+            for lv in (lv for p in pyr for lv in p):
+                lv.free()                                     # must wait for the batch, then recycle the arenas
+            junk = b.build_many(cam, other, synth.DEPTH_SCALE)  # lands in the arenas just released
+            main.synchronize()
+            got = main.to_host(d_mats, np.zeros((P, 16), np.float32))
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), trial
+            for lv in (lv for q in junk for lv in q):
+                lv.free()
+            pyr = b.build_many(cam, frames, synth.DEPTH_SCALE)
+            batch.rebind(pyr[:P], pyr[1:])
+        main.free(d_mats)
+        batch.free()
+        for lv in (lv for p in pyr for lv in p):
+            lv.free()
+    finally:
+        side.close()
+        main.close()
