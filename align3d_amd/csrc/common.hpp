@@ -93,7 +93,10 @@ struct a3d_context {
   void* icp_engine = nullptr;
   void (*icp_engine_free)(void*) = nullptr;
   uint32_t* pinned_words = nullptr;  // PINNED_WORDS page-locked words: scalar results copied back asynchronously
-  static constexpr size_t PINNED_WORDS = 1024;
+  static constexpr size_t PINNED_WORDS = 16384;
+  // Second stream of the frame builder: the uploads of chunk k + 1 run under the kernels of chunk k.
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> copy_events;
   // Cells per frame the bilateral grids of the frame builder are given in the grid scratch region (grown on demand).
   unsigned long long grid_capacity = 0;
   // How often each arena size has been asked for: a slab is only taken for a size that keeps coming back.

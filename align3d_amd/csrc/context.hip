@@ -223,6 +223,7 @@ a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx) {
   A3D_HIP_TRY(hipGetDeviceProperties(&prop, device_index));
   ctx->num_cus = prop.multiProcessorCount;
   A3D_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  A3D_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_start));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_stop));
   A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, a3d_context::PINNED_WORDS * sizeof(uint32_t), hipHostMallocDefault));
@@ -234,6 +235,9 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   if (!ctx) return A3D_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  hipStreamSynchronize(ctx->copy_stream);
+  for (hipEvent_t e : ctx->copy_events) hipEventDestroy(e);
+  hipStreamDestroy(ctx->copy_stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
   for (auto& a : ctx->arena_pool)
     if (!in_slab(ctx, a.first)) hipFree(a.first);

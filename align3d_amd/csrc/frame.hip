@@ -341,28 +341,30 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   return A3D_OK;
 }
 
-a3d_status build_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32_t F, const uint16_t* const* depth,
-                       const uint8_t* const* rgb, uint32_t w, uint32_t h, double fx, double fy, double cx, double cy,
-                       double depth_scale, a3d_device_image** out_levels) {
-  hipStream_t s = ctx->stream;
+// One chunk of a batched build: up to MAX_BATCH frames that share a launch sequence.
+struct Chunk {
+  uint32_t F = 0;
+  FrameBases bases{};
+  uint16_t* d_depth = nullptr;            // [F][h][w] in the context's staging region
+  std::vector<a3d_device_image*> images;  // [F][L]
+  uint32_t* result = nullptr;             // this chunk's page-locked scalar blocks
+};
+
+// Arenas and image handles of a chunk; its uploads go to the copy stream (they only touch memory no kernel of an
+// earlier chunk reads), followed by an event the compute stream waits for.
+a3d_status chunk_prepare(a3d_context* ctx, const a3d_builder_params* prm, const ArenaPlan& plan, Chunk& c,
+                         const uint16_t* const* depth, const uint8_t* const* rgb, uint32_t w, uint32_t h, double fx,
+                         double fy, double cx, double cy, hipEvent_t uploaded) {
   const size_t n = (size_t)w * h;
   const uint64_t L = prm->pyramid_levels;
-  const ArenaPlan plan = plan_arena(w, h, prm);
-  FrameBases bases{};
-  std::vector<a3d_device_image*> images;  // [F][L], filled as the arenas are acquired
-  auto fail = [&](a3d_status st) {
-    hipStreamSynchronize(s);
-    for (a3d_device_image* im : images) a3d_range_image_free(im);  // a frame's last level releases its arena
-    return st;
-  };
-  for (uint32_t f = 0; f < F; ++f) {
+  for (uint32_t f = 0; f < c.F; ++f) {
     DeviceArena* arena = new DeviceArena();
     if (ctx_arena_acquire(ctx, plan.bytes, arena) != A3D_OK) {
       delete arena;
       set_error("a3d_range_image_build_pyramids: hipMalloc(%zu) failed", plan.bytes);
-      return fail(A3D_HIP_ERROR);
+      return A3D_HIP_ERROR;
     }
-    bases.arena[f] = (char*)arena->base;
+    c.bases.arena[f] = (char*)arena->base;
     for (uint64_t l = 0; l < L; ++l) {
       const LevelLayout& Y = plan.layout.lv[l];
       a3d_device_image* im = new a3d_device_image();
@@ -379,49 +381,104 @@ a3d_status build_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32_t
         im->intensities = (uint8_t*)(b + Y.intensities), im->imap = (float*)(b + Y.imap);
         im->has_intensities = im->has_imap = true;
       }
-      images.push_back(im);
+      c.images.push_back(im);
     }
   }
-  void* scratch = nullptr;
-  if (ctx_scratch(ctx, 0, (size_t)F * padded(n * 2), &scratch) != A3D_OK) return fail(A3D_HIP_ERROR);
-  uint16_t* d_depth = (uint16_t*)scratch;
-  // kernels index the batch's depth images as [F][n]: n * 2 bytes apart (no padding between frames)
-  for (uint32_t f = 0; f < F; ++f) {
-    if (hipMemcpyAsync(d_depth + (size_t)f * n, depth[f], n * 2, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(bases.arena[f] + plan.layout.lv[0].colors, rgb[f], n * 3, hipMemcpyHostToDevice, s) != hipSuccess) {
+  // kernels index the chunk's depth images as [F][n]: n * 2 bytes apart (no padding between frames)
+  for (uint32_t f = 0; f < c.F; ++f) {
+    if (hipMemcpyAsync(c.d_depth + (size_t)f * n, depth[f], n * 2, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+        hipMemcpyAsync(c.bases.arena[f] + plan.layout.lv[0].colors, rgb[f], n * 3, hipMemcpyHostToDevice,
+                       ctx->copy_stream) != hipSuccess) {
       set_error("a3d_range_image_build_pyramids: upload failed: %s", hipGetErrorString(hipGetLastError()));
-      return fail(A3D_HIP_ERROR);
+      return A3D_HIP_ERROR;
     }
+  }
+  A3D_HIP_TRY(hipEventRecord(uploaded, ctx->copy_stream));
+  return A3D_OK;
+}
+
+// Up to PINNED_WORDS / (MAX_BATCH * SC_STRIDE) chunks in one pipelined pass: all uploads are queued on the copy
+// stream first, the chunks' kernels follow on the context stream as their uploads land, ONE synchronisation at the end.
+a3d_status build_frames(a3d_context* ctx, const a3d_builder_params* prm, uint64_t n_frames, uint64_t chunk_frames,
+                        const uint16_t* const* depth, const uint8_t* const* rgb, uint32_t w, uint32_t h, double fx,
+                        double fy, double cx, double cy, double depth_scale, a3d_device_image** out_levels) {
+  hipStream_t s = ctx->stream;
+  const size_t n = (size_t)w * h;
+  const ArenaPlan plan = plan_arena(w, h, prm);
+  const size_t n_chunks = (size_t)((n_frames + chunk_frames - 1) / chunk_frames);
+  std::vector<Chunk> chunks(n_chunks);
+  auto fail = [&](a3d_status st) {
+    hipStreamSynchronize(ctx->copy_stream);
+    hipStreamSynchronize(s);
+    for (Chunk& c : chunks)
+      for (a3d_device_image* im : c.images) a3d_range_image_free(im);  // a frame's last level releases its arena
+    return st;
+  };
+  void* staging = nullptr;
+  if (ctx_scratch(ctx, 0, (size_t)n_frames * n * 2 + 256, &staging) != A3D_OK) return A3D_HIP_ERROR;
+  while (ctx->copy_events.size() < n_chunks) {
+    hipEvent_t e;
+    A3D_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->copy_events.push_back(e);
   }
   if (prm->use_bilateral && ctx->grid_capacity == 0)  // first guess: a depth span of 4096 units (4 m at 1 mm)
     ctx->grid_capacity = bilateral_grid_cells(w, h, prm->sigma_space, prm->sigma_color, 4096);
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    a3d_status st = enqueue_chunk(ctx, prm, F, d_depth, w, h, (float)fx, (float)fy, (float)cx, (float)cy, (float)depth_scale,
-                                  plan, bases, ctx->pinned_words);
+  // the staging region may have moved (ctx_scratch synchronised the context stream then); nothing older is in flight
+  for (size_t k = 0; k < n_chunks; ++k) {
+    Chunk& c = chunks[k];
+    const uint64_t f0 = k * chunk_frames;
+    c.F = (uint32_t)std::min<uint64_t>(chunk_frames, n_frames - f0);
+    c.d_depth = (uint16_t*)staging + f0 * n;
+    c.result = ctx->pinned_words + k * (MAX_BATCH * SC_STRIDE);
+    const a3d_status st = chunk_prepare(ctx, prm, plan, c, depth + f0, rgb + f0, w, h, fx, fy, cx, cy, ctx->copy_events[k]);
     if (st != A3D_OK) return fail(st);
+  }
+  std::vector<size_t> todo(n_chunks);
+  for (size_t k = 0; k < n_chunks; ++k) todo[k] = k;
+  for (int attempt = 0; attempt < 3 && !todo.empty(); ++attempt) {
+    for (size_t k : todo) {
+      Chunk& c = chunks[k];
+      if (attempt == 0 && hipStreamWaitEvent(s, ctx->copy_events[k], 0) != hipSuccess) return fail(A3D_HIP_ERROR);
+      const a3d_status st = enqueue_chunk(ctx, prm, c.F, c.d_depth, w, h, (float)fx, (float)fy, (float)cx, (float)cy,
+                                          (float)depth_scale, plan, c.bases, c.result);
+      if (st != A3D_OK) return fail(st);
+    }
     if (hipStreamSynchronize(s) != hipSuccess) {
       set_error("a3d_range_image_build_pyramids: %s", hipGetErrorString(hipGetLastError()));
       return fail(A3D_HIP_ERROR);
     }
-    if (!prm->use_bilateral) break;
+    if (!prm->use_bilateral) {
+      todo.clear();
+      break;
+    }
     unsigned long long need = 0;
     bool overflow = false;
-    for (uint32_t f = 0; f < F; ++f) {  // the filter's scalars arrived with the synchronisation above
-      const uint32_t* r = ctx->pinned_words + f * SC_STRIDE;
-      if (r[SC_TOO_BIG]) need = std::max<unsigned long long>(need, (unsigned long long)r[SC_GH] * r[SC_GW] * r[SC_GD]);
-      overflow |= r[SC_OVERFLOW] != 0;
-    }
-    if (need) {  // a frame's bilateral grid outgrew the scratch region: grow it (25 % head room) and run the chunk again
-      ctx->grid_capacity = need + need / 4;
-      continue;
+    std::vector<size_t> again;
+    for (size_t k : todo) {  // the filter's scalars arrived with the synchronisation above
+      bool redo = false;
+      for (uint32_t f = 0; f < chunks[k].F; ++f) {
+        const uint32_t* r = chunks[k].result + f * SC_STRIDE;
+        if (r[SC_TOO_BIG]) need = std::max<unsigned long long>(need, (unsigned long long)r[SC_GH] * r[SC_GW] * r[SC_GD]), redo = true;
+        overflow |= r[SC_OVERFLOW] != 0 && !r[SC_TOO_BIG];
+      }
+      if (redo) again.push_back(k);
     }
     if (overflow) {
       set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
       return fail(A3D_CAST_OVERFLOW);
     }
-    break;
+    // a frame's bilateral grid outgrew the scratch region: grow it (25 % head room) and run those chunks again (their
+    // inputs are still resident)
+    if (need) ctx->grid_capacity = need + need / 4;
+    todo.swap(again);
   }
-  for (size_t k = 0; k < images.size(); ++k) out_levels[k] = images[k];
+  if (!todo.empty()) {
+    set_error("a3d_range_image_build_pyramids: the bilateral grid kept outgrowing its scratch region");
+    return fail(A3D_HIP_ERROR);
+  }
+  size_t o = 0;
+  for (Chunk& c : chunks)
+    for (a3d_device_image* im : c.images) out_levels[o++] = im;
   return A3D_OK;
 }
 
@@ -464,18 +521,20 @@ a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_pa
               "the device frame builder's bilateral filter handles images below 2^24 pixels");
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   const uint64_t L = prm->pyramid_levels;
-  // frames per launch sequence: at most MAX_BATCH, and few enough that their bilateral grids fit ~1 GiB of scratch
+  // frames per launch sequence: at most MAX_BATCH, and few enough that their bilateral grids fit ~2 GiB of scratch
   uint64_t chunk = MAX_BATCH;
   if (prm->use_bilateral) {
     const unsigned long long cap = ctx->grid_capacity ? ctx->grid_capacity
                                                       : bilateral_grid_cells((uint32_t)width, (uint32_t)height, prm->sigma_space,
                                                                              prm->sigma_color, 4096);
-    chunk = std::max<uint64_t>(1, std::min<uint64_t>(MAX_BATCH, (1ull << 30) / (cap * 24 + 1)));
+    chunk = std::max<uint64_t>(1, std::min<uint64_t>(MAX_BATCH, (2ull << 30) / (cap * 24 + 1)));
   }
-  for (uint64_t f0 = 0; f0 < n_frames; f0 += chunk) {
-    const uint32_t F = (uint32_t)std::min<uint64_t>(chunk, n_frames - f0);
-    const a3d_status st = build_chunk(ctx, prm, F, depth_frames + f0, rgb_frames + f0, (uint32_t)width, (uint32_t)height, fx, fy,
-                                      cx, cy, depth_scale, out_levels + f0 * L);
+  // frames per pipelined pass: as many chunks as the page-locked result area has scalar blocks for
+  const uint64_t pass = chunk * (a3d_context::PINNED_WORDS / (MAX_BATCH * SC_STRIDE));
+  for (uint64_t f0 = 0; f0 < n_frames; f0 += pass) {
+    const uint64_t F = std::min<uint64_t>(pass, n_frames - f0);
+    const a3d_status st = build_frames(ctx, prm, F, chunk, depth_frames + f0, rgb_frames + f0, (uint32_t)width, (uint32_t)height,
+                                       fx, fy, cx, cy, depth_scale, out_levels + f0 * L);
     if (st != A3D_OK) {  // the caller gets all the pyramids or none
       for (uint64_t k = 0; k < f0 * L; ++k) a3d_range_image_free(out_levels[k]);
       return st;

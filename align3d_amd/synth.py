@@ -132,9 +132,12 @@ def camera(width=640, height=480):
     return CameraIntrinsics(fx, fy, cx, cy, width, height)
 
 
-def frame_stream(seed, n_frames, width=640, height=480):
-    """n_frames (depth u16, rgb u8) of one scene along one trajectory + the camera-to-world poses."""
+def frame_stream(seed, n_frames, width=640, height=480, first=0, count=None):
+    """Frames [first, first + count) (default: all) of the n_frames-long stream `seed`: (depth u16, rgb u8) of one
+    scene along one trajectory + the camera-to-world poses of those frames.  A frame depends on (seed, its index)
+    only, so ranks that render disjoint slices of one stream agree on every frame."""
     scene = Scene(seed)
-    poses = trajectory(seed, n_frames)
-    frames = [scene.render(R, t, width, height, noise_seed=k) for k, (R, t) in enumerate(poses)]
+    count = n_frames - first if count is None else count
+    poses = trajectory(seed, n_frames)[first:first + count]
+    frames = [scene.render(R, t, width, height, noise_seed=first + k) for k, (R, t) in enumerate(poses)]
     return frames, poses

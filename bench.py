@@ -4,18 +4,23 @@
 One "step" = one pass of MultiscaleAlign over a batch of independent synthetic 640x480 frame pairs
 that are already resident in HBM (`ms3x15`: 3 pyramid levels, IcpParams::default() = 15 iterations
 per level — the shape BASELINE.json's metric is quoted on).  Per GPU the batch is 64 pairs (the
-per-GPU shard of configs[4]: 512 pairs over 8 GPUs); with N > 1 ranks every rank aligns its own
-pairs and one RCCL all-gather collects the 4x4 poses (weak scaling).
+per-GPU shard of configs[4]: 512 pairs over 8 GPUs).  With N > 1 ranks ONE global list of 64 N pairs is
+sharded in contiguous blocks (align3d_amd.distributed.shard_range), every rank aligns its own block and one
+RCCL all-gather collects the 4x4 poses in global pair order (gather_poses) — weak scaling.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 600 --warmup 20
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the round instructions) with `roofline` for the dominant
-kernel (the per-pixel kernel) and `cpu_baseline` (the CPU oracle timed on a bounded sample)."""
+kernel (the per-pixel kernel) and `cpu_baseline` (the CPU oracle timed on a bounded sample); `extra` holds the
+secondary workloads (kd-tree, Icp, frame preparation, odometry, streaming), each with its own roofline and CPU
+baseline, and the min / median / max of repeated timings."""
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,8 +31,11 @@ sys.path.insert(0, ROOT)
 
 from align3d_amd import (BilateralFilter, Context, IcpParams, MsIcpParams, MultiscaleAlign,  # noqa: E402
                          MultiscaleAlignBatch, R3dTree, RangeImageBuilder, synth)
+from align3d_amd.distributed import gather_poses, shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PAIRS_PER_STREAM = 64  # the global pair list is a concatenation of 65-frame streams (seed 1000 + stream)
+
 
 # algorithmic bytes of one ImageIcp iteration at each level of a 640x480 pyramid:
 # source 14 B/px + target 25 B/px + the (H+2)(W+2) f32 intensity map.
@@ -39,99 +47,130 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def build_stream_pyramids(ctx, seed, n_frames, width, height):
-    """Synthetic frame stream -> resident pyramids, built on the device (bilateral filter, back-projection,
-    normals, pyramid, luma, intensity maps: a3d_range_image_build_pyramid).  Returns the device pyramids, the
-    ground-truth camera poses and the per-frame build time (depth + RGB upload included)."""
-    frames, poses = synth.frame_stream(seed, n_frames, width, height)
-    builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
-    cam = synth.camera(width, height)
-    t0 = time.perf_counter()
-    pyramids = [builder.build_device(cam, d, rgb, synth.DEPTH_SCALE) for d, rgb in frames]
-    ctx.synchronize()
-    build_ms = (time.perf_counter() - t0) / n_frames * 1e3
-    return pyramids, poses, build_ms
+def stats(samples):
+    a = np.asarray(samples, np.float64)
+    return {"min": float(a.min()), "median": float(np.median(a)), "max": float(a.max()), "repeats": int(a.size)}
 
 
-def measured_traffic(P, W, H, conc):
-    """HBM bytes per launch of the ICP kernel from the committed PMC passes (scripts/traffic_pmc.sh; counters cannot
-    be read from inside an unprofiled run).  Only a profile of this exact workload counts; otherwise null."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_hbm_traffic.json")), reverse=True):
+def roofline(alg_bytes, ms, traffic=None, traffic_src=None, **more):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+         "algorithmic_bytes_per_launch": alg_bytes}
+    r.update(more)
+    return r
+
+
+def measured_traffic(name, **match):
+    """HBM bytes per launch of a workload's dominant kernel from the committed PMC passes (scripts/traffic_pmc.sh;
+    counters cannot be read from inside an unprofiled run).  Only a profile whose recorded workload keys equal
+    `match` counts; otherwise (None, None)."""
+    names = [f"round*_{name}_traffic.json"] + (["round*_hbm_traffic.json"] if name == "bench" else [])
+    files = sorted((f for n in names for f in glob.glob(os.path.join(ROOT, "profiles", n))), reverse=True)
+    for f in files:
         try:
             rec = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if rec.get("pairs_per_gpu") == P and rec.get("concurrent_launches", 1) == conc and (W, H) == (640, 480):
+        if all(rec.get(k) == v for k, v in match.items()):
             return float(rec["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
     return None, None
 
 
-def kdtree_bench(ctx, n=500_000, reps=20):
+def build_stream_pyramids(ctx, seed, n_frames, width, height, first=0, total=None):
+    """Synthetic frame stream -> resident pyramids, built on the device in batches (bilateral filter,
+    back-projection, normals, pyramid, luma, intensity maps: a3d_range_image_build_pyramids).  Returns the device
+    pyramids, the ground-truth camera poses and the per-frame build time (depth + RGB upload included)."""
+    frames, poses = synth.frame_stream(seed, total or n_frames, width, height, first=first, count=n_frames)
+    builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+    cam = synth.camera(width, height)
+    for lv in builder.build(cam, *frames[0], synth.DEPTH_SCALE):  # first use of the context: scratch, tap tables
+        lv.free()
+    t0 = time.perf_counter()
+    pyramids = builder.build_many(cam, frames, synth.DEPTH_SCALE)
+    build_ms = (time.perf_counter() - t0) / n_frames * 1e3
+    return pyramids, poses, build_ms
+
+
+def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
     db = synth.uniform01_f32(10, 3 * n).reshape(n, 3)
     q = synth.uniform01_f32(11, 3 * n).reshape(n, 3)
     R3dTree.new(ctx, db).free()  # first call pays the one-off code-object load of the sort kernels
-    t0 = time.perf_counter()
+    builds = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        tree = R3dTree.new(ctx, db)
+        builds.append((time.perf_counter() - t0) * 1e3)
+        tree.free()
     tree = R3dTree.new(ctx, db)
-    build_ms = (time.perf_counter() - t0) * 1e3
     d_q = ctx.to_device(q)
     d_i, d_d = ctx.malloc(4 * n), ctx.malloc(4 * n)
     for _ in range(3):
         tree.nearest_device(d_q, n, d_i, d_d)
-    ctx.timer_start()
-    for _ in range(reps):
-        tree.nearest_device(d_q, n, d_i, d_d)
-    ms = ctx.timer_stop() / reps
+    per = []
+    for _ in range(groups):
+        ctx.timer_start()
+        for _ in range(reps):
+            tree.nearest_device(d_q, n, d_i, d_d)
+        per.append(ctx.timer_stop() / reps)
+    ms = float(np.median(per))
     for p in (d_q, d_i, d_d):
         ctx.free(p)
     leaves, internal, depth = tree.stats()
     tree.free()
     alg_bytes = 216 * n + 4 * internal  # SURVEY §8(d): 216 B/query + the split table once
+    traffic, src = measured_traffic("kdtree", queries=n, points=n)
     return {
         "metric": "kdtree 500k queries/s (500k database, uniform [0,1)^3)",
-        "value": n / (ms * 1e-3),
-        "unit": "queries/s",
-        "ms_per_500k_queries": ms,
-        "build_ms_incl_pcie": build_ms,  # R3dTree::new from host points: upload + 15 device sort levels
-        "roofline": {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        "value": n / (ms * 1e-3), "unit": "queries/s", "ms_per_500k_queries": ms,
+        "ms_per_500k_queries_stats": stats(per),
+        "build_ms_incl_pcie": float(np.median(builds)),  # R3dTree::new from host points: upload + device sort levels
+        "roofline": roofline(alg_bytes, ms, traffic, src, kernel="kdtree_nearest_kernel"),
     }
 
 
-def pcl_icp_bench(ctx, n=500_000):
-    """configs[2]: Icp (kd-tree point-to-plane) on 500k target x 500k source points, IcpParams::default()."""
-    from align3d_amd import Icp, PointCloud, RangeImageBuilder
+def pcl_clouds(ctx, n=500_000):
+    from align3d_amd import PointCloud
 
     frames, poses = synth.frame_stream(7, 2, 880, 660)
     cam = synth.camera(880, 660)
     clouds = []
     for d, rgb in frames:
-        ri = RangeImageBuilder(ctx).pyramid_levels(1).with_intensity(False).build(cam, d, rgb, synth.DEPTH_SCALE)[0].download(intensity=False)
-        pc = PointCloud.from_range_image(ri)
+        lv = RangeImageBuilder(ctx).pyramid_levels(1).with_intensity(False).build(cam, d, rgb, synth.DEPTH_SCALE)[0]
+        pc = PointCloud.from_range_image(lv.download(intensity=False))
+        lv.free()
         clouds.append(PointCloud(pc.points[:n], pc.normals[:n]))
-    tgt, src = clouds
+    return clouds, poses
+
+
+def pcl_icp_bench(ctx, n=500_000):
+    """configs[2]: Icp (kd-tree point-to-plane) on 500k target x 500k source points, IcpParams::default()."""
+    from align3d_amd import Icp
+
+    (tgt, src), poses = pcl_clouds(ctx, n)
     t0 = time.perf_counter()
     icp = Icp.new(ctx, IcpParams.default(), tgt)
     build_ms = (time.perf_counter() - t0) * 1e3
     icp.align(src)
     times = []
-    for _ in range(3):
+    for _ in range(7):
         T = icp.align(src)
         times.append(icp.last_device_ms())
     ms = float(np.median(times))
     iters = 15
-    alg = 252 * src.len() * iters  # SURVEY §8(d): 252 B per source point per iteration
+    alg = 252 * src.len()  # SURVEY §8(d): 252 B per source point per iteration
     gt = synth.relative_pose(poses[0], poses[1])
     dm = np.linalg.inv(gt) @ T.matrix().astype(np.float64)
     icp.free()
+    traffic, tsrc = measured_traffic("pcl_icp", source_points=src.len(), target_points=tgt.len())
     return {
         "workload": f"Icp::align, {tgt.len()} target x {src.len()} source points, 15 iterations (configs[2])",
-        "device_ms_per_align": ms, "aligns_per_s": 1e3 / ms, "icp_new_ms_incl_pcie": build_ms,
+        "device_ms_per_align": ms, "device_ms_per_align_stats": stats(times), "aligns_per_s": 1e3 / ms,
+        "us_per_iteration": ms * 1e3 / iters, "icp_new_ms_incl_pcie": build_ms,
         "error_vs_synthetic_gt": {"angle_rad": float(np.arccos(np.clip((np.trace(dm[:3, :3]) - 1) / 2, -1, 1))),
                                   "translation_m": float(np.linalg.norm(dm[:3, 3]))},
-        "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
-    }
+        "roofline": roofline(alg, ms / iters, traffic, tsrc, kernel="pcl_icp_kernel", launches_per_align=iters),
+    }, (tgt, src)
 
 
 def frame_prep_bench(ctx, host_pyramid_level0, depth_u16):
@@ -145,24 +184,30 @@ def frame_prep_bench(ctx, host_pyramid_level0, depth_u16):
     for _ in range(3):
         dev.compute_normals()
     ctx.synchronize()
-    ctx.timer_start()
-    for _ in range(20):
-        dev.compute_normals()
-    n_ms = ctx.timer_stop() / 20  # includes the re-pack of the 32-byte target records after each call
+    per = []
+    for _ in range(7):
+        ctx.timer_start()
+        for _ in range(20):
+            dev.compute_normals()
+        per.append(ctx.timer_stop() / 20)
+    n_ms = float(np.median(per))
     dev.free()
     f = BilateralFilter.default()
     f.filter(ctx, depth_u16)
-    t0 = time.perf_counter()
-    for _ in range(5):
+    b = []
+    for _ in range(7):
+        t0 = time.perf_counter()
         f.filter(ctx, depth_u16)
-    b_ms = (time.perf_counter() - t0) / 5 * 1e3
+        b.append((time.perf_counter() - t0) * 1e3)
+    b_ms = float(np.median(b))
     n_px = depth_u16.size
     cells = int(np.prod(f.last_grid_dims))
     return {
-        "compute_normals_ms": n_ms,
-        "compute_normals_frac_of_8TBs": 25 * n_px / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "bilateral_filter_ms_host_to_host": b_ms, "bilateral_grid_dims": list(f.last_grid_dims),
-        "bilateral_algorithmic_MB": (72 * n_px + 192 * cells) / 1e6,
+        "compute_normals_ms": n_ms, "compute_normals_ms_stats": stats(per),
+        "compute_normals_roofline": roofline(25 * n_px, n_ms, kernel="compute_normals_kernel"),
+        "bilateral_filter_ms_host_to_host": b_ms, "bilateral_filter_ms_stats": stats(b),
+        "bilateral_grid_dims": list(f.last_grid_dims),
+        "bilateral_roofline": roofline(72 * n_px + 192 * cells, b_ms, kernel="bilateral filter (all kernels + PCIe)"),
     }
 
 
@@ -180,21 +225,30 @@ def named_shapes_bench(ctx, targets, sources):
         for _ in range(3):
             batch.enqueue()
         ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            batch.enqueue()
-        ctx.synchronize()
-        batch_ms = (time.perf_counter() - t0) / 10 * 1e3
+        per = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                batch.enqueue()
+            ctx.synchronize()
+            per.append((time.perf_counter() - t0) / 10 * 1e3)
+        batch_ms = float(np.median(per))
         _, status = batch.align()
         batch.free()
         one = MultiscaleAlign.new(ctx, prm, tp[0])
         for _ in range(2):
             one.align(sp[0])
-        t0 = time.perf_counter()
-        for _ in range(5):
+        lat = []
+        for _ in range(9):
+            t0 = time.perf_counter()
             one.align(sp[0])
-        single_ms = (time.perf_counter() - t0) / 5 * 1e3
-        out[name] = {"pairs_per_s_batch_of_%d" % P: P / (batch_ms * 1e-3), "single_pair_latency_ms": single_ms,
+            lat.append((time.perf_counter() - t0) * 1e3)
+        iters = [int(p.max_iterations) for p in prm]
+        alg = sum(iters[l] * level_bytes(640 >> l, 480 >> l) for l in range(levels))
+        out[name] = {"pairs_per_s_batch_of_%d" % P: P / (batch_ms * 1e-3), "batch_ms_stats": stats(per),
+                     "single_pair_latency_ms": float(np.median(lat)), "single_pair_latency_ms_stats": stats(lat),
+                     "algorithmic_bytes_per_pair": alg,
+                     "frac_of_8TBs_batched": alg * P / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "failed_pairs": int(np.count_nonzero(status))}
     pub_ms = 38.576  # README.md:130, i7-11800H x 16 threads
     b10 = out["bench10"]
@@ -204,11 +258,12 @@ def named_shapes_bench(ctx, targets, sources):
     return out
 
 
-def streaming_bench(ctx, params, P, W, H, rounds=4, builders=4, pinned=True):
+def streaming_bench(ctx, params, P, W, H, rounds=6, builders=1, pinned=True):
     """End to end from host frames: every round, P + 1 NEW frames (u16 depth + u8 RGB in host memory) are uploaded
-    and built into resident pyramids by `builders` threads, each on its own context (HIP stream + scratch), while
-    the previous round's P frame pairs are being aligned on the main context.  Reports pairs/s with every frame
-    crossing PCIe and being filtered / back-projected / pyramided exactly once."""
+    and built into resident pyramids by `builders` threads, each on its own context (HIP stream + scratch) with ONE
+    batched build call for its share of the frames, while the previous round's P frame pairs are being aligned on the
+    main context.  Reports pairs/s with every frame crossing PCIe and being filtered / back-projected / pyramided
+    exactly once."""
     import threading
 
     frames, _ = synth.frame_stream(4242, P + 1, W, H)  # the same host frames every round: they are rebuilt each time
@@ -226,10 +281,9 @@ def streaming_bench(ctx, params, P, W, H, rounds=4, builders=4, pinned=True):
     def build_round():
         out = [None] * (P + 1)
 
-        def work(k):
-            for i in range(k, P + 1, builders):
-                out[i] = bld[k].build_device(cam, frames[i][0], frames[i][1], synth.DEPTH_SCALE)
-            ctxs[k].synchronize()
+        def work(k):  # a contiguous share of the round's frames, ~12 launches per 16 frames
+            lo, hi = (P + 1) * k // builders, (P + 1) * (k + 1) // builders
+            out[lo:hi] = bld[k].build_many(cam, frames[lo:hi], synth.DEPTH_SCALE)
 
         ts = [threading.Thread(target=work, args=(k,)) for k in range(builders)]
         for t in ts:
@@ -263,37 +317,75 @@ def streaming_bench(ctx, params, P, W, H, rounds=4, builders=4, pinned=True):
         c.close()
     return {"workload": f"{rounds} rounds of {P} pairs, {P + 1} new frames per round from "
                         f"{'page-locked' if pinned else 'pageable'} host memory, "
-                        f"{builders} builder threads overlapping the alignment of the previous round",
+                        f"{builders} builder threads (one batched build call each) overlapping the alignment of the "
+                        f"previous round",
             "pairs_per_s": rounds * P / dt, "frames_built_per_s": rounds * (P + 1) / dt, "failed_pairs": failed}
 
 
 def odometry_bench(ctx, n_frames=20):
-    """configs[3] shape: a 20-frame odometry stream (synthetic: no TUM / IL-RGBD data exists on the box), frames
-    enter as u16 depth + u8 RGB, persistent device pyramids, MsIcpParams::default() (README usage)."""
-    from align3d_amd import SyntheticDataset, run_odometry
+    """configs[3]: a 20-frame odometry stream, frames enter as u16 depth + u8 RGB, persistent device pyramids,
+    MsIcpParams::default() (README usage) — on the synthetic stream, and on the reference's own 20 sample1 frames
+    (tests/golden, real data with ground truth) when the fixture directory travels with the repository."""
+    from align3d_amd import SlamTbDataset, SyntheticDataset, run_odometry
 
-    ds = SyntheticDataset(7, n_frames)
-    run_odometry(ctx, ds, max_frames=3)
-    t0 = time.perf_counter()
-    run_odometry(ctx, ds, prefetch=False)
-    dt_seq = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    pred, metrics = run_odometry(ctx, ds)  # frame i+1 is built on a second stream while i-1 -> i is aligned
-    dt = time.perf_counter() - t0
-    return {"workload": f"{n_frames}-frame synthetic stream, device RangeImageBuilder + MsIcpParams::default()",
-            "frames_per_s": (n_frames - 1) / dt, "ms_per_frame": dt / (n_frames - 1) * 1e3,
-            "frames_per_s_without_prefetch": (n_frames - 1) / dt_seq,
-            "mean_trajectory_error": {"angle_deg": float(np.degrees(metrics.angle)), "translation_m": metrics.translation}}
+    def run(ds, label):
+        run_odometry(ctx, ds, max_frames=3)
+        t0 = time.perf_counter()
+        run_odometry(ctx, ds, prefetch=False)
+        dt_seq = time.perf_counter() - t0
+        per = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            pred, metrics = run_odometry(ctx, ds)  # frame i+1 is built on a second stream while i-1 -> i is aligned
+            per.append(time.perf_counter() - t0)
+        dt = float(np.median(per))
+        n = ds.len()
+        return {"workload": f"{n}-frame {label} stream, device RangeImageBuilder + MsIcpParams::default()",
+                "frames_per_s": (n - 1) / dt, "ms_per_frame": dt / (n - 1) * 1e3,
+                "ms_per_frame_stats": stats([t / (n - 1) * 1e3 for t in per]),
+                "frames_per_s_without_prefetch": (n - 1) / dt_seq,
+                "mean_trajectory_error": {"angle_deg": float(np.degrees(metrics.angle)), "translation_m": metrics.translation}}
+
+    out = run(SyntheticDataset(7, n_frames), "synthetic")
+    real = os.path.join(ROOT, "tests", "golden", "rgbd", "sample1")
+    if os.path.isdir(real):
+        out["sample1_real_data"] = run(SlamTbDataset.load(real), "sample1 (reference test data)")
+    return out
 
 
-def cpu_baseline(host_pyramids, params, n_pairs, gpu_poses):
-    """The CPU oracle ("port": a restatement, not the Rust reference) on the first n_pairs pairs."""
+# ---- CPU baselines (the oracle: a restatement, kind "port", never the Rust reference) ---------------------------
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # the GPU box gives a 1-GPU job a 16-core share of the host; do not oversubscribe it
+    return model, max(1, min(len(os.sched_getaffinity(0)), 16))
+
+
+def load_cpu_oracle():
+    """The oracle built for the host it is timed on (-O3 -march=native), falling back to the portable
+    test build.  Test infrastructure used as the measured CPU baseline only (never by the product)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    # the GPU box gives a 1-GPU job a 16-core share of the host; do not oversubscribe it
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    native = os.path.join(ROOT, "oracle", "_native", "liba3d_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=300)  # -B: -march=native must mean THIS host
+    except Exception as e:  # no compiler on the box: time the portable build
+        log(f"native oracle build failed ({e}); timing the portable -O2 build")
+    O.load(native if os.path.exists(native) else None)
+    return O, ("-O3 -march=native" if os.path.exists(native) else "-O2 (portable)")
 
+
+def cpu_baseline_main(O, host_pyramids, params, n_pairs, gpu_poses, cores, budget_s=20.0):
+    """ms3x15 on the first n_pairs pairs, threaded like the reference (4096-pixel chunks over the host's cores)."""
     def frame(dev_level):
         ri = dev_level.download(colors=False)  # the very arrays the GPU path reads
         k = ri.intrinsics
@@ -301,37 +393,104 @@ def cpu_baseline(host_pyramids, params, n_pairs, gpu_poses):
 
     parr = params.to_c_array()
     worst_ang = worst_tr = 0.0
-    t0 = time.time()
-    done = 0
+    host = {}
+    per = []
     for p in range(n_pairs):
-        tp = [frame(r) for r in host_pyramids[p]]
-        sp = [frame(r) for r in host_pyramids[p + 1]]
-        st, T = O.multiscale_align(parr, len(params), tp, sp, threads=cores)
-        done += 1
+        for q in (p, p + 1):
+            if q not in host:
+                host[q] = [frame(r) for r in host_pyramids[q]]
+        t0 = time.perf_counter()
+        st, T = O.multiscale_align(parr, len(params), host[p], host[p + 1], threads=cores)
+        per.append(time.perf_counter() - t0)
         if st == 0 and gpu_poses is not None:
             ang, tr = O.transform_metrics(gpu_poses[p].to_c(), T)
             worst_ang, worst_tr = max(worst_ang, abs(ang)), max(worst_tr, tr)
-        if time.time() - t0 > 30.0:
+        if sum(per) > budget_s:
             break
-    dt = time.time() - t0
+    t0 = time.perf_counter()
+    O.multiscale_align(parr, len(params), host[0], host[1], threads=1)
+    single_ms = (time.perf_counter() - t0) * 1e3
     return {
-        "value": done / dt,
-        "unit": "frame-pairs/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"{done} of the batch's frame pairs, same ms3x15 workload, oracle threaded over {cores} host threads "
-                  f"(4096-pixel chunks like the reference's rayon loop)",
-        "max_gpu_vs_cpu_angle_rad": worst_ang,
-        "max_gpu_vs_cpu_translation_m": worst_tr,
+        "value": len(per) / sum(per), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+        "sample": f"{len(per)} of the batch's frame pairs, same ms3x15 workload, oracle threaded over {cores} host "
+                  f"threads (4096-pixel chunks like the reference's rayon loop)",
+        "ms_per_pair_stats": stats([t * 1e3 for t in per]), "single_thread_ms_per_pair": single_ms,
+        "max_gpu_vs_cpu_angle_rad": worst_ang, "max_gpu_vs_cpu_translation_m": worst_tr,
     }
+
+
+def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clouds):
+    """The reference's other benches (benches/bench_{kdtree,icp,compute_normals,bilateral,image_icp}.rs,
+    README.md:130-134) on the oracle, threaded as the reference threads them, each bounded to a few seconds."""
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        per = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            per.append((time.perf_counter() - t0) * 1e3)
+        return per
+
+    # kd-tree: 500k queries on a 500k-point tree, single thread (bench_kdtree.rs:11-43; README: 101.75 ms)
+    n = 500_000
+    db = synth.uniform01_f32(10, 3 * n).reshape(n, 3)
+    q = synth.uniform01_f32(11, 3 * n).reshape(n, 3)
+    t0 = time.perf_counter()
+    tree = O.KdTree(db)
+    kd_build_ms = (time.perf_counter() - t0) * 1e3
+    per = timed(lambda: tree.nearest(q), 3)
+    out["kdtree_500k"] = {"value": n / (np.median(per) * 1e-3), "unit": "queries/s", "cores": 1, "kind": "port",
+                          "ms_stats": stats(per), "build_ms": kd_build_ms, "published_reference_ms": 101.75,
+                          "sample": "500k queries, 500k-point tree, single thread like R3dTree::nearest in a loop"}
+    del tree
+    # Icp 500k x 500k, single thread like the reference (bench_icp.rs:9-39): 2 iterations timed, scaled to 15
+    tgt, src = clouds
+    t0 = time.perf_counter()
+    ptree = O.KdTree(tgt.points)
+    icp_new_ms = (time.perf_counter() - t0) * 1e3
+    prm = O.params(max_iterations=2)
+    tv, sv = O.pcl_view(tgt.points, tgt.normals), O.pcl_view(src.points, src.normals)
+    pose = O.pose()
+
+    def icp2():
+        assert O.load().orc_pcl_icp_align(C.byref(prm), ptree.h, C.byref(tv), C.byref(sv), C.byref(pose), None) == 0
+
+    per = timed(icp2, 2)
+    it_ms = float(np.median(per)) / 2
+    out["pcl_icp_500k"] = {"value": 1e3 / (15 * it_ms), "unit": "aligns/s (15 iterations)", "cores": 1, "kind": "port",
+                           "ms_per_iteration": it_ms, "icp_new_ms": icp_new_ms,
+                           "sample": "2 of the 15 iterations timed, single thread like Icp::align; x 7.5 for an align"}
+    del ptree
+    # compute_normals on one 640x480 frame (bench_compute_normals.rs; README: 1.1778 ms, rayon over 1024-px chunks)
+    pts, msk = level0_host.points, level0_host.mask
+    per_mt = timed(lambda: O.compute_normals(pts, msk, threads=cores), 20)
+    per_st = timed(lambda: O.compute_normals(pts, msk), 10)
+    out["compute_normals_640x480"] = {"value": float(np.median(per_mt)), "unit": "ms", "cores": cores, "kind": "port",
+                                      "ms_stats": stats(per_mt), "single_thread_ms": float(np.median(per_st)),
+                                      "published_reference_ms": 1.1778, "sample": "20 repetitions of one frame"}
+    # bilateral filter on one 640x480 depth image, single thread like the reference (bench_bilateral.rs)
+    per = timed(lambda: O.bilateral(depth_u16), 3)
+    out["bilateral_640x480"] = {"value": float(np.median(per)), "unit": "ms", "cores": 1, "kind": "port",
+                                "ms_stats": stats(per), "sample": "3 repetitions of one frame, single thread"}
+    # bench10: one 640x480 level, IcpParams::default() with 10 iterations (bench_image_icp.rs; README: 38.576 ms)
+    ft, fs = bench10_pair
+    p10 = O.params(max_iterations=10)
+    per = timed(lambda: O.image_icp_align(p10, ft, fs, threads=cores), 5)
+    per1 = timed(lambda: O.image_icp_align(p10, ft, fs, threads=1), 1)
+    out["bench10"] = {"value": float(np.median(per)), "unit": "ms per alignment", "cores": cores, "kind": "port",
+                      "ms_stats": stats(per), "single_thread_ms": float(np.median(per1)),
+                      "published_reference_ms": 38.576, "sample": "5 repetitions of one pair of the batch"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs-per-gpu", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=600, help="timed steps (600 x 3.4 ms = a 2 s timed region)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pairs-per-gpu", type=int, default=PAIRS_PER_STREAM)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
@@ -364,35 +523,40 @@ def main():
     ctx = Context(device)
     P, W, H = args.pairs_per_gpu, args.width, args.height
     params = MsIcpParams.repeat(3, IcpParams.default())  # ms3x15
+    # ONE global list of world x P pairs, sharded in contiguous blocks.  Global pair j = frames
+    # (j % P, j % P + 1) of stream 1000 + j // P, so a rank's block is (a slice of) one stream and needs P + 1 frames.
+    lo, hi = shard_range(world * P, world, rank)
+    assert hi - lo == P and lo // P == (hi - 1) // P, "a rank's block lies inside one stream"
+    stream_id, first = lo // P, lo % P
     t0 = time.time()
-    host_pyramids, poses_gt, build_ms = build_stream_pyramids(ctx, seed=1000 + rank, n_frames=P + 1, width=W, height=H)
+    host_pyramids, poses_gt, build_ms = build_stream_pyramids(ctx, seed=1000 + stream_id, n_frames=P + 1, width=W,
+                                                              height=H, first=first, total=P + 1)
     if rank == 0:
         log(f"rendered and built {P + 1} synthetic frame pyramids in {time.time() - t0:.1f}s "
-            f"({build_ms:.2f} ms per frame on the device, PCIe upload of depth + RGB included)")
-    # pair p: target = frame p, source = frame p + 1; every pyramid level uploaded once, resident in HBM
+            f"({build_ms:.3f} ms per frame on the device, PCIe upload of depth + RGB included)")
+    # pair p: target = frame p, source = frame p + 1; every pyramid level resident in HBM
     targets = [host_pyramids[p] for p in range(P)]
     sources = [host_pyramids[p + 1] for p in range(P)]
     batch = MultiscaleAlignBatch(ctx, params, targets, sources)
 
-    d_mats = gathered = ext_stream = host_mats = None
+    d_mats = gathered = ext_stream = host_mats = mats = None
     if multi and use_nccl:
         mats = torch.zeros((P, 16), dtype=torch.float32, device="cuda")
-        gathered = torch.zeros((world * P, 16), dtype=torch.float32, device="cuda")
         d_mats = C.c_void_p(mats.data_ptr())
         ext_stream = torch.cuda.ExternalStream(ctx.lib.a3d_context_stream(ctx.handle))
     elif multi:  # gloo rehearsal: the poses go through host memory
         d_mats = ctx.malloc(P * 64)
         host_mats = np.zeros((P, 16), np.float32)
-        gathered = torch.zeros((world * P, 16), dtype=torch.float32)
 
     def step():
+        nonlocal gathered
         batch.enqueue(matrices_device=d_mats)
         if multi and use_nccl:
             with torch.cuda.stream(ext_stream):  # ordered after the kernels on the context stream
-                dist.all_gather_into_tensor(gathered, mats)
+                gathered = gather_poses(mats)
         elif multi:
             ctx.to_host(d_mats, host_mats)
-            dist.all_gather_into_tensor(gathered, torch.from_numpy(host_mats))
+            gathered = gather_poses(torch.from_numpy(host_mats))
 
     def sync_all():
         if multi:
@@ -418,6 +582,17 @@ def main():
 
     out = None
     if rank == 0:
+        # ---- repeated short timings of the same step (>= 20 repetitions, min / median / max) ----
+        rep_steps = max(1, min(30, args.steps))
+        reps = []
+        if not multi:
+            for _ in range(20):
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(rep_steps):
+                    batch.enqueue()
+                ctx.synchronize()
+                reps.append((time.perf_counter() - t1) / rep_steps * 1e3)
         # ---- roofline of the dominant kernel (image_icp_kernel), HIP events on the launch stream ----
         # The batch runs `conc` pair groups on separate streams, so `conc` launches are in flight at once.
         # per_launch: what one launch does (its own bytes / its own duration: what rocprofv3 --kernel-trace
@@ -426,12 +601,12 @@ def main():
         # the concurrent launches summed without double counting their overlap.
         conc = batch.concurrency()
         kernel_ms, region_ms, launches = [], [], 0
-        for _ in range(max(3, args.steps)):  # launch sequence as it runs in the timed steps (no per-launch events)
+        for _ in range(20):  # launch sequence as it runs in the timed steps (no per-launch events)
             batch.enqueue()
             ctx.synchronize()
             region_ms.append(batch.last_timing()[0])
         batch.set_profiling(True)
-        for _ in range(max(3, args.steps)):  # per-launch durations, events around every launch on its stream
+        for _ in range(20):  # per-launch durations, events around every launch on its stream
             batch.enqueue()
             ctx.synchronize()
             kernel_ms.append(batch.last_kernel_ms())
@@ -443,23 +618,27 @@ def main():
         bytes_per_launch = step_alg_bytes / max(1, launches)
         avg_launch_ms = kms / max(1, launches)
         achieved = step_alg_bytes / (rms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(P, W, H, conc)
-        roofline = {
+        traffic, traffic_src = (measured_traffic("bench", pairs_per_gpu=P, concurrent_launches=conc)
+                                if (W, H) == (640, 480) else (None, None))
+        roof = {
             "bound": "hbm", "kernel": "image_icp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
             "traffic_source": traffic_src,
             "launches_per_step": int(launches), "concurrent_launches": conc,
             "avg_launch_us": avg_launch_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
             "per_launch_GBs": bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9,
-            "launch_sequence_ms": rms,
+            "launch_sequence_ms": rms, "launch_sequence_ms_stats": stats(region_ms),
             "kernel_share_of_step": rms / ms_per_step,
         }
         poses, status = batch.align()
-        extra = {"failed_pairs": int(np.count_nonzero(status))}
-        if multi:  # the gathered buffer starts with this rank's own 4x4 poses
-            own = gathered[:P].cpu().numpy().reshape(P, 4, 4)
+        extra = {"failed_pairs": int(np.count_nonzero(status)),
+                 "timing": {"timed_region_s": elapsed, "ms_per_step_repeated": stats(reps) if reps else None,
+                            "steps_per_repeat": rep_steps}}
+        if multi:  # the gathered buffer holds every rank's block in global pair order; this rank's starts at lo
+            own = gathered[lo:hi].cpu().numpy().reshape(P, 4, 4)
             extra["gather_matches_local_poses"] = bool(
                 all(np.allclose(own[p], poses[p].matrix(), atol=1e-6) for p in range(P)))
+            extra["gathered_pairs"] = int(gathered.shape[0])
         # accuracy against the synthetic ground truth (reported, not a parity claim)
         errs = []
         for p in range(P):
@@ -468,29 +647,56 @@ def main():
             errs.append((np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)), np.linalg.norm(d[:3, 3])))
         extra["mean_error_vs_synthetic_gt"] = {"angle_rad": float(np.mean([e[0] for e in errs])),
                                                "translation_m": float(np.mean([e[1] for e in errs]))}
+        level0_host = depth0 = clouds = None
         if not args.no_extras and world == 1:
             # configs[1]: one pair alone on the GPU (latency-bound: 45 dependent iterations)
             ms1 = MultiscaleAlign.new(ctx, params, targets[0])
             for _ in range(2):
                 ms1.align(sources[0])
-            t1 = time.perf_counter()
-            for _ in range(5):
+            lat = []
+            for _ in range(15):
+                t1 = time.perf_counter()
                 ms1.align(sources[0])
-            extra["single_pair_ms3x15_latency_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+                lat.append((time.perf_counter() - t1) * 1e3)
+            extra["single_pair_ms3x15_latency_ms"] = float(np.median(lat))
+            extra["single_pair_ms3x15_latency_ms_stats"] = stats(lat)
             extra["named_shapes"] = named_shapes_bench(ctx, targets, sources)
             extra["kdtree"] = kdtree_bench(ctx)
             extra["kdtree"]["x_vs_published_cpu_101.75ms"] = 101.75 / extra["kdtree"]["ms_per_500k_queries"]
-            extra["pcl_icp"] = pcl_icp_bench(ctx)
+            extra["pcl_icp"], clouds = pcl_icp_bench(ctx)
             extra["odometry"] = odometry_bench(ctx)
-            extra["frame_prep"] = frame_prep_bench(ctx, host_pyramids[0][0].download(), synth.frame_stream(1000, 1, W, H)[0][0][0])
+            level0_host = host_pyramids[0][0].download()
+            depth0 = synth.frame_stream(1000, 1, W, H)[0][0][0]
+            extra["frame_prep"] = frame_prep_bench(ctx, level0_host, depth0)
             # what a caller with host buffers pays per new frame: u16 depth + u8 RGB over PCIe, then bilateral,
-            # back-projection, normals, pyramid, luma and intensity maps on the device
+            # back-projection, normals, pyramid, luma and intensity maps on the device (batched build of 65 frames)
             extra["frame_build_ms_incl_pcie"] = build_ms
             extra["pairs_per_s_including_one_frame_build_per_pair"] = 1e3 / (build_ms + ms_per_step / P)
             extra["streaming_from_host_frames"] = streaming_bench(ctx, params, P, W, H)
         cpu = None
         if world == 1 and args.cpu_pairs > 0:
-            cpu = cpu_baseline(host_pyramids, params, min(args.cpu_pairs, P), poses)
+            O, flags = load_cpu_oracle()
+            model, cores = cpu_info()
+            cpu = cpu_baseline_main(O, host_pyramids, params, min(args.cpu_pairs, P), poses, cores)
+            cpu["cpu_model"], cpu["compiler_flags"] = model, flags
+            if level0_host is not None:
+                def oframe(dev_level):
+                    ri = dev_level.download(colors=False)
+                    k = ri.intrinsics
+                    return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
+                sec = cpu_baselines_secondary(O, cores, level0_host, depth0,
+                                              (oframe(host_pyramids[0][0]), oframe(host_pyramids[1][0])), clouds)
+                for v in sec.values():
+                    v["cpu_model"], v["compiler_flags"] = model, flags
+                extra["cpu_baselines"] = sec
+                # GPU / CPU beside each other (a reported baseline, not the target: the roofline fraction is)
+                extra["gpu_vs_cpu"] = {
+                    "kdtree_500k": extra["kdtree"]["value"] / sec["kdtree_500k"]["value"],
+                    "pcl_icp_iteration": sec["pcl_icp_500k"]["ms_per_iteration"] * 1e3 / extra["pcl_icp"]["us_per_iteration"],
+                    "compute_normals": sec["compute_normals_640x480"]["value"] / extra["frame_prep"]["compute_normals_ms"],
+                    "bilateral": sec["bilateral_640x480"]["value"] / extra["frame_prep"]["bilateral_filter_ms_host_to_host"],
+                    "bench10_single_pair": sec["bench10"]["value"] / extra["named_shapes"]["bench10"]["single_pair_latency_ms"],
+                }
         out = {
             "metric": "ICP frame-pairs/sec (640x480, 3-lvl, 15 iters)",
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -499,10 +705,11 @@ def main():
             "config": {"workload": f"ms3x15: {P} independent {W}x{H} frame pairs per GPU resident in HBM, "
                                    "MsIcpParams::repeat(3, IcpParams::default()) = 3 levels x 15 iterations "
                                    "(configs[1] pair shape, batched as the per-GPU shard of configs[4])",
-                       "pairs_per_gpu": P, "levels": 3, "iterations_per_level": iters,
+                       "pairs_per_gpu": P, "global_pairs": world * P, "levels": 3, "iterations_per_level": iters,
+                       "sharding": f"contiguous blocks of one {world * P}-pair list (shard_range): this rank [{lo}, {hi})",
                        "collective": (f"one all-gather of 16 f32 per pair per step ({'RCCL' if use_nccl else 'gloo rehearsal'})"
                                       if multi else "none")},
-            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+            "roofline": roof, "cpu_baseline": cpu, "extra": extra,
         }
     sync_all()
     batch.free()

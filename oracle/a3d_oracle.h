@@ -81,6 +81,9 @@ a3d_status orc_pcl_icp_align(const a3d_icp_params* params, const orc_kdtree* tre
 /* RangeImage::compute_normals (src/range_image/structure.rs:184-262) */
 void orc_compute_normals(const float* points, const uint8_t* mask, uint64_t width, uint64_t height,
                          float* out_normals);
+/* the same pixel loop spread over `threads` threads in the reference's 1024-pixel chunks (structure.rs:193-201) */
+void orc_compute_normals_mt(const float* points, const uint8_t* mask, uint64_t width, uint64_t height,
+                            int32_t threads, float* out_normals);
 /* BilateralFilter::filter (src/bilateral/edge_aware_filter.rs:126-135) */
 a3d_status orc_bilateral_filter_u16(const uint16_t* image, uint64_t width, uint64_t height,
                                     double sigma_space, double sigma_color, uint16_t* out,

@@ -6,6 +6,7 @@
 // formula is replayed.  orc_rgb_pyr_down restates image-0.24.7's blur: PARITY UNPINNED.
 #include <algorithm>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "a3d_oracle.h"
@@ -190,10 +191,12 @@ bool neighborhood_mean_point(uint64_t src_v, uint64_t src_u, const uint8_t* mask
 extern "C" {
 
 // RangeImage::compute_normals (src/range_image/structure.rs:184-262)
-void orc_compute_normals(const float* points, const uint8_t* mask, uint64_t w, uint64_t h, float* out) {
+// One 1024-pixel-aligned range of the pixel loop: the reference runs it as rayon chunks of 1024 (structure.rs:193-201).
+static void compute_normals_range(const float* points, const uint8_t* mask, uint64_t w, uint64_t h, float* out,
+                                  uint64_t begin, uint64_t end) {
   const float thr_sq = 2.0f * 2.0f;
-  std::fill(out, out + 3 * w * h, 0.0f);
-  for (uint64_t idx = 0; idx < w * h; ++idx) {
+  std::fill(out + 3 * begin, out + 3 * end, 0.0f);
+  for (uint64_t idx = begin; idx < end; ++idx) {
     uint64_t row = idx / w, col = idx % w;
     V3 center = load3(points, idx);  // centre mask is NOT checked (:207)
     V3 left = point_or_zero(points, mask, w, h, row, i32_as_usize((int32_t)col - 1));
@@ -222,6 +225,24 @@ void orc_compute_normals(const float* points, const uint8_t* mask, uint64_t w, u
     float mag = std::sqrt(norm_squared(normal));
     if (mag > 1e-6f) store3(out, idx, normal / mag);
   }
+}
+
+void orc_compute_normals(const float* points, const uint8_t* mask, uint64_t w, uint64_t h, float* out) {
+  compute_normals_range(points, mask, w, h, out, 0, w * h);
+}
+
+// The same with the reference's chunking spread over `threads` threads (pixels are independent: same result).
+void orc_compute_normals_mt(const float* points, const uint8_t* mask, uint64_t w, uint64_t h, int32_t threads,
+                            float* out) {
+  const uint64_t n = w * h, chunks = (n + 1023) / 1024;
+  if (threads <= 1) return compute_normals_range(points, mask, w, h, out, 0, n);
+  std::vector<std::thread> pool;
+  const uint64_t per = (chunks + threads - 1) / threads;
+  for (int t = 0; t < threads; ++t) {
+    const uint64_t b = std::min(n, (uint64_t)t * per * 1024), e = std::min(n, b + per * 1024);
+    if (b < e) pool.emplace_back(compute_normals_range, points, mask, w, h, out, b, e);
+  }
+  for (auto& th : pool) th.join();
 }
 
 a3d_status orc_bilateral_filter_u16(const uint16_t* image, uint64_t w, uint64_t h, double sigma_space,

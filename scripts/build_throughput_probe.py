@@ -1,28 +1,57 @@
-"""Frame-build throughput (u16 depth + RGB -> resident 3-level pyramid) with N builder threads, each on its own
-context (stream + scratch) of the same GPU."""
+"""Frame-build throughput (u16 depth + RGB -> resident 3-level pyramid): single builds, batched builds of 16 / 65
+frames (pageable and page-locked host buffers), and N builder threads each with its own context."""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from align3d_amd import BilateralFilter, Context, RangeImageBuilder, SyntheticDataset
+import numpy as np
+from align3d_amd import BilateralFilter, Context, RangeImageBuilder, synth
 
-ds = SyntheticDataset(7, 4)
-frames = [ds.get(i) for i in range(4)]
-for n_threads in (1, 2, 3, 4, 6, 8):
+W, H = 640, 480
+frames, _ = synth.frame_stream(4242, 65, W, H)
+cam = synth.camera(W, H)
+ctx = Context(0)
+b = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+
+
+def free(pyrs):
+    for lv in (lv for p in pyrs for lv in p):
+        lv.free()
+
+
+def timed(label, fn, n_frames, reps=5):
+    free(fn())
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+        free(out)
+    t = float(np.median(ts))
+    print(f"{label}: {t / n_frames * 1e3:.3f} ms per frame ({n_frames / t:.0f} frames/s)", flush=True)
+
+
+timed("single builds, pageable", lambda: [b.build(cam, d, c, synth.DEPTH_SCALE) for d, c in frames[:16]], 16)
+timed("batch of 16, pageable", lambda: b.build_many(cam, frames[:16], synth.DEPTH_SCALE), 16)
+timed("batch of 65, pageable", lambda: b.build_many(cam, frames, synth.DEPTH_SCALE), 65)
+pinned = []
+for d, c in frames:
+    pd, pc = ctx.pinned_empty(d.shape, d.dtype), ctx.pinned_empty(c.shape, c.dtype)
+    pd[...], pc[...] = d, c
+    pinned.append((pd, pc))
+timed("single builds, page-locked", lambda: [b.build(cam, d, c, synth.DEPTH_SCALE) for d, c in pinned[:16]], 16)
+timed("batch of 16, page-locked", lambda: b.build_many(cam, pinned[:16], synth.DEPTH_SCALE), 16)
+timed("batch of 65, page-locked", lambda: b.build_many(cam, pinned, synth.DEPTH_SCALE), 65)
+nb = RangeImageBuilder(ctx)
+timed("batch of 65, page-locked, no bilateral filter", lambda: nb.build_many(cam, pinned, synth.DEPTH_SCALE), 65)
+for n_threads in (2, 4):
     ctxs = [Context(0) for _ in range(n_threads)]
     builders = [RangeImageBuilder(c).with_bilateral_filter(BilateralFilter.default()) for c in ctxs]
-    per_thread = 60
-    def work(k):
-        b = builders[k]
-        for i in range(per_thread):
-            pyr = b.build_device(*frames[i % 4])
-            for lv in pyr:
-                lv.free()
-    for k in range(n_threads):  # warm each context (scratch, arena pool)
-        for lv in builders[k].build_device(*frames[0]):
-            lv.free()
-    ts = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
-    t0 = time.perf_counter()
-    [t.start() for t in ts]; [t.join() for t in ts]
-    dt = time.perf_counter() - t0
-    print(f"{n_threads} builder thread(s): {n_threads * per_thread / dt:.0f} frames/s ({dt / (n_threads * per_thread) * 1e3:.3f} ms per frame)", flush=True)
+    def work(k, out):
+        out[k] = builders[k].build_many(cam, pinned[k::n_threads], synth.DEPTH_SCALE)
+    def run():
+        out = [None] * n_threads
+        ts = [threading.Thread(target=work, args=(k, out)) for k in range(n_threads)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        return [p for o in out for p in o]
+    timed(f"65 frames over {n_threads} builder threads / contexts, page-locked", run, 65)
     for c in ctxs:
         c.close()

@@ -1,10 +1,12 @@
-"""50 frame builds on one context (for rocprofv3 --kernel-trace --stats)."""
+"""10 batched frame builds of 16 frames on one context (for rocprofv3 --kernel-trace --stats)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from align3d_amd import BilateralFilter, Context, RangeImageBuilder, SyntheticDataset
-ds = SyntheticDataset(7, 2)
+from align3d_amd import BilateralFilter, Context, RangeImageBuilder, synth
+frames, _ = synth.frame_stream(4242, 16, 640, 480)
+cam = synth.camera(640, 480)
 ctx = Context(0)
 b = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
-for i in range(50):
-    for lv in b.build_device(*ds.get(i % 2)):
-        lv.free()
+for i in range(10):
+    for p in b.build_many(cam, frames, synth.DEPTH_SCALE):
+        for lv in p:
+            lv.free()

@@ -1,15 +1,23 @@
-# Round profile of the default bench: (1) rocprofv3 --kernel-trace --stats, (2) per-grid summary,
-# (3) FETCH_SIZE / WRITE_SIZE passes -> HBM bytes per launch.  Outputs under gpurun_out/profile_<round>/;
-# copy the summaries into profiles/ afterwards.
+# The round's committed evidence: for the headline bench and for each secondary workload (kd-tree queries, Icp,
+# frame build) (1) rocprofv3 --kernel-trace --stats, (2) a per-grid summary, (3) FETCH_SIZE / WRITE_SIZE passes ->
+# HBM bytes per launch of its dominant kernel.  Outputs under gpurun_out/profile_<round>/; copy them into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ROUND=${ROUND:-round1}
+ROUND=${ROUND:-round2}
 OUT=gpurun_out/profile_$ROUND
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-extras --cpu-pairs 0 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err &&
-K=$(ls $OUT/trace/*/*kernel_trace.csv | head -1) && S=$(ls $OUT/trace/*/*kernel_stats.csv | head -1) &&
-cp $S $OUT/${ROUND}_bench_kernel_stats.csv &&
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-extras --cpu-pairs 0   ($ROUND, MI355X)"; python3 scripts/summarize_trace.py $K | sed -n 1,40p; } > $OUT/${ROUND}_bench_per_grid.txt &&
-ROUND=$ROUND CONC=${CONC:-3} bash scripts/traffic_pmc.sh > /dev/null &&
-cp gpurun_out/${ROUND}_hbm_traffic.json $OUT/ &&
+trace() {  # NAME program args...
+  local NAME=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- "$@" > $OUT/${NAME}_under_rocprof.out 2> $OUT/trace_$NAME.err &&
+  cp $(ls $OUT/trace_$NAME/*/*kernel_stats.csv | head -1) $OUT/${ROUND}_${NAME}_kernel_stats.csv &&
+  { echo "# rocprofv3 --kernel-trace --stats -- $*   ($ROUND, MI355X)"; python3 scripts/summarize_trace.py $(ls $OUT/trace_$NAME/*/*kernel_trace.csv | head -1) | sed -n 1,40p; } > $OUT/${ROUND}_${NAME}_per_grid.txt
+}
+trace bench python3 bench.py --steps 5 --warmup 2 --no-extras --cpu-pairs 0 &&
+trace kdtree python3 scripts/kd_probe.py &&
+trace pcl_icp python3 scripts/pcl_probe.py &&
+trace frame_build python3 scripts/build_trace_probe.py &&
+ROUND=$ROUND bash scripts/traffic_pmc.sh bench image_icp_kernel "pairs_per_gpu=64 concurrent_launches=${CONC:-3}" python3 bench.py --steps 2 --warmup 1 --no-extras --cpu-pairs 0 > /dev/null &&
+ROUND=$ROUND bash scripts/traffic_pmc.sh kdtree kdtree_nearest_kernel "queries=500000 points=500000" python3 scripts/kd_probe.py > /dev/null &&
+ROUND=$ROUND bash scripts/traffic_pmc.sh pcl_icp pcl_icp_kernel "source_points=500000 target_points=500000" python3 scripts/pcl_probe.py > /dev/null &&
+cp gpurun_out/${ROUND}_*_traffic.json $OUT/ &&
 python3 bench.py > $OUT/${ROUND}_bench.json 2> $OUT/bench.err &&
-head -12 $OUT/${ROUND}_bench_per_grid.txt && cat $OUT/${ROUND}_hbm_traffic.json && tail -c 1500 $OUT/${ROUND}_bench.json
+head -12 $OUT/${ROUND}_bench_per_grid.txt && cat $OUT/${ROUND}_*_traffic.json && tail -c 2500 $OUT/${ROUND}_bench.json

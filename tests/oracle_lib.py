@@ -16,13 +16,15 @@ _P = C.c_void_p
 _lib = None
 
 
-def load():
+def load(path=None):
+    """Loads the oracle once per process.  `path`: another build of the same sources (bench.py's cpu_baseline leg
+    times oracle/_native/liba3d_oracle_native.so, built -O3 -march=native on the host it runs on)."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(ORACLE_SO):
+    if path is None and not os.path.exists(ORACLE_SO):
         subprocess.check_call(["make", "-C", ORACLE_DIR])
-    lib = C.CDLL(ORACLE_SO)
+    lib = C.CDLL(path or ORACLE_SO)
     f = lib.orc_gn_mean_squared_residual
     f.restype = C.c_float
     lib.orc_backproject_depth.restype = C.c_uint64
@@ -44,6 +46,7 @@ def load():
     lib.orc_pcl_icp_accumulate.argtypes = [_P, _P, _P, _P, _P, C.c_int32, _P]
     lib.orc_pcl_icp_align.argtypes = [_P, _P, _P, _P, _P, _P]
     lib.orc_compute_normals.argtypes = [_P, _P, C.c_uint64, C.c_uint64, _P]
+    lib.orc_compute_normals_mt.argtypes = [_P, _P, C.c_uint64, C.c_uint64, C.c_int32, _P]
     lib.orc_bilateral_filter_u16.argtypes = [_P, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _P, _P]
     lib.orc_bilateral_grid_slice_u16.argtypes = lib.orc_bilateral_filter_u16.argtypes
     lib.orc_backproject_depth.argtypes = [_P, C.c_uint64, C.c_uint64] + [C.c_double] * 5 + [_P, _P]
@@ -136,11 +139,14 @@ class Frame:
         return v
 
 
-def compute_normals(points, mask):
+def compute_normals(points, mask, threads=1):
     lib = load()
     h, w = mask.shape
     out = np.empty((h, w, 3), np.float32)
-    lib.orc_compute_normals(ptr(points), ptr(mask), w, h, ptr(out))
+    if threads > 1:
+        lib.orc_compute_normals_mt(ptr(points), ptr(mask), w, h, threads, ptr(out))
+    else:
+        lib.orc_compute_normals(ptr(points), ptr(mask), w, h, ptr(out))
     return out
 
 

@@ -95,8 +95,25 @@ def test_bench_reads_the_committed_traffic_profile():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     bench = importlib.import_module("bench")
-    traffic, src = bench.measured_traffic(64, 640, 480, 3)
+    traffic, src = bench.measured_traffic("bench", pairs_per_gpu=64, concurrent_launches=3)
     assert src and src.startswith("profiles/") and 5e7 < traffic < 2e8  # ~1e8 bytes per launch of 21-22 pairs
-    assert bench.measured_traffic(64, 640, 480, 1) == (None, None)      # no profile of a one-stream run is committed
-    assert bench.measured_traffic(48, 640, 480, 3) == (None, None)
+    assert bench.measured_traffic("bench", pairs_per_gpu=64, concurrent_launches=1) == (None, None)  # no such profile
+    assert bench.measured_traffic("bench", pairs_per_gpu=48, concurrent_launches=3) == (None, None)
+    assert bench.measured_traffic("no_such_workload") == (None, None)
     assert bench.level_bytes(640, 480) == 13218576 and bench.level_bytes(160, 120) == 827856
+
+
+def test_bench_global_pair_list_is_sharded_in_contiguous_blocks():
+    """bench.py's N > 1 layout: ONE list of 64 N pairs, rank r owns shard_range(64 N, N, r) = stream r of the
+    concatenated 65-frame streams, and a stream's frames do not depend on how many of them are rendered."""
+    from align3d_amd import synth
+    from align3d_amd.distributed import shard_range
+
+    for world in (1, 2, 4, 8):
+        blocks = [shard_range(world * 64, world, r) for r in range(world)]
+        assert blocks == [(64 * r, 64 * r + 64) for r in range(world)]
+    a, pa = synth.frame_stream(1003, 5, 64, 48)
+    b, pb = synth.frame_stream(1003, 9, 64, 48, first=2, count=3)
+    for k in range(3):
+        assert np.array_equal(a[2 + k][0], b[k][0]) and np.array_equal(a[2 + k][1], b[k][1])
+        assert np.array_equal(pa[2 + k][0], pb[k][0]) and np.array_equal(pa[2 + k][1], pb[k][1])

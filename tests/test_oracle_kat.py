@@ -251,3 +251,13 @@ def test_bilateral_grid_slice_known_answer_near_pin():
     # verify_slice: dest_image[(421, 123)] == 2266 with the reference's JPEG decoder; Pillow's decode of the same
     # file differs by at most one grey level per channel, which moves this value by at most one count (2265 here)
     assert abs(int(out[421, 123]) - 2266) <= 1
+
+
+def test_threaded_normals_equal_the_sequential_loop():
+    """orc_compute_normals_mt (bench.py's CPU baseline form: the reference's 1024-pixel rayon chunks over threads)
+    writes exactly what the sequential pixel loop writes."""
+    s = SlamTbSample("sample1")
+    fr = O.build_frame(*s.load(1), *s.intrinsics(1), s.depth_scale(1))
+    for threads in (2, 5, 16):
+        assert np.array_equal(O.compute_normals(fr.points, fr.mask, threads=threads).view(np.uint32),
+                              fr.normals.view(np.uint32))
