@@ -17,6 +17,7 @@ from .context import Context  # noqa: F401
 from .icp import Icp, ImageIcp, MultiscaleAlign, MultiscaleAlignBatch, PointCloud  # noqa: F401
 from .icp_params import IcpParams, MsIcpParams  # noqa: F401
 from .kdtree import R3dTree  # noqa: F401
+from .multi import MultiContext, MultiscaleAlignMultiBatch  # noqa: F401
 from .range_image import CameraIntrinsics, DeviceRangeImage, RangeImage, RangeImageBuilder  # noqa: F401
 from .transform import Transform  # noqa: F401
 from .dataset import (DatasetError, IndoorLidarDataset, SlamTbDataset, SubsetDataset, SyntheticDataset,  # noqa: F401

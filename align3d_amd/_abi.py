@@ -179,6 +179,17 @@ SIGNATURES = {
     "a3d_multiscale_batch_set_profiling": (_ST, [_P, C.c_int32]),
     "a3d_multiscale_batch_last_kernel_ms": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_multiscale_batch_concurrency": (_ST, [_P, C.POINTER(C.c_uint32)]),
+    "a3d_multi_shard_range": (_ST, [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "a3d_multi_context_create": (_ST, [C.POINTER(C.c_int32), C.c_uint64, _PP]),
+    "a3d_multi_context_destroy": (_ST, [_P]),
+    "a3d_multi_context_size": (C.c_uint64, [_P]),
+    "a3d_multi_context_device": (_P, [_P, C.c_uint64]),
+    "a3d_multiscale_batch_new_multi": (
+        _ST,
+        [_P, C.POINTER(IcpParamsC), C.c_uint64, C.c_uint64, C.c_uint64, _PP, _PP, _PP],
+    ),
+    "a3d_multiscale_multi_batch_align": (_ST, [_P, C.POINTER(PoseC), _P, C.POINTER(C.c_int32), _PP]),
+    "a3d_multiscale_multi_batch_free": (_ST, [_P]),
     "a3d_kdtree_stats": (_ST, [_P, C.POINTER(C.c_uint64)]),
     "a3d_kdtree_download": (_ST, [_P, _P, _P, C.POINTER(C.c_uint64)]),
     "a3d_kdtree_new": (_ST, [_P, _P, C.c_uint64, _PP]),

@@ -107,6 +107,8 @@ typedef struct a3d_context a3d_context;
 typedef struct a3d_device_image a3d_device_image;       /* one RangeImage resident in HBM */
 typedef struct a3d_multiscale a3d_multiscale;           /* MultiscaleAlign */
 typedef struct a3d_multiscale_batch a3d_multiscale_batch; /* P independent MultiscaleAlign jobs */
+typedef struct a3d_multi_context a3d_multi_context;     /* one a3d_context per device of a device list */
+typedef struct a3d_multiscale_multi_batch a3d_multiscale_multi_batch; /* P MultiscaleAlign jobs over several GPUs */
 typedef struct a3d_kdtree a3d_kdtree;                   /* R3dTree */
 typedef struct a3d_pcl_icp a3d_pcl_icp;                 /* Icp */
 
@@ -274,6 +276,37 @@ a3d_status a3d_multiscale_batch_concurrency(a3d_multiscale_batch* batch, uint32_
  * kernel's launches / number of launches). */
 a3d_status a3d_multiscale_batch_last_timing(a3d_multiscale_batch* batch, float* out_total_ms,
                                             uint64_t* out_pixel_kernel_launches);
+
+/* ---- P independent MultiscaleAlign jobs over a device list (one host process, several GPUs) ---------------
+ * The path shards over independent frame pairs only (no intra-pair sharding): pair j of P goes to device
+ * floor(j D / P) — contiguous blocks, 512 pairs over 8 GPUs = 64 each — every device runs its block as one
+ * a3d_multiscale_batch on its own context, enqueued by its own host thread, and ONE gather collects the 4x4 poses
+ * (16 f32 per pair) into a buffer on the first device (device-to-device copies over xGMI).  The images of a pair
+ * must be resident on the device that owns the pair: build or upload them through a3d_multi_context_device(mc, d). */
+
+/* Block [begin, end) of n_items owned by `device` of n_devices (remainders go to the first devices).  Host only. */
+a3d_status a3d_multi_shard_range(uint64_t n_items, uint64_t n_devices, uint64_t device, uint64_t* out_begin,
+                                 uint64_t* out_end);
+/* One context per entry of device_ids (an id may repeat: several contexts = streams on one GPU). */
+a3d_status a3d_multi_context_create(const int32_t* device_ids, uint64_t n_devices, a3d_multi_context** out);
+a3d_status a3d_multi_context_destroy(a3d_multi_context* mc);
+uint64_t a3d_multi_context_size(const a3d_multi_context* mc);
+/* The context of entry `index` (borrowed; NULL if out of range): frames of the pairs that entry owns are built on it. */
+a3d_context* a3d_multi_context_device(a3d_multi_context* mc, uint64_t index);
+/* MultiscaleAlign::new for every pair, as a3d_multiscale_batch_new: [n_pairs][n_levels] handle tables in global pair
+ * order.  A3D_INVALID_PARAMETER if an image lives on another device than the owner of its pair. */
+a3d_status a3d_multiscale_batch_new_multi(a3d_multi_context* mc, const a3d_icp_params* params, uint64_t n_params,
+                                          uint64_t n_pairs, uint64_t n_levels,
+                                          const a3d_device_image* const* target_pyramids,
+                                          const a3d_device_image* const* source_pyramids,
+                                          a3d_multiscale_multi_batch** out);
+/* Runs every pair on its device and gathers.  Each output is nullable: out_poses_host [n_pairs], out_matrices_host
+ * [n_pairs][16] f32 row-major 4x4, out_status_host [n_pairs], *out_matrices_device0 = the gathered [n_pairs][16]
+ * buffer on the first device (owned by the batch, overwritten by the next call).  Returns when all are complete. */
+a3d_status a3d_multiscale_multi_batch_align(a3d_multiscale_multi_batch* batch, a3d_pose* out_poses_host,
+                                            float* out_matrices_host, int32_t* out_status_host,
+                                            const float** out_matrices_device0);
+a3d_status a3d_multiscale_multi_batch_free(a3d_multiscale_multi_batch* batch);
 
 /* ---- R3dTree (src/kdtree.rs:19-106) ------------------------------------------------------- */
 

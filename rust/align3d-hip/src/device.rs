@@ -1,0 +1,113 @@
+//! Context, status handling and RAII handles over the raw bindings.
+use crate::sys;
+use align3d::{range_image::RangeImage, transform::Transform};
+use nalgebra::{Quaternion, Vector3};
+use std::cell::RefCell;
+use std::ffi::CStr;
+
+/// Text of the most recent failure on this thread.
+pub fn last_error() -> String {
+    unsafe { CStr::from_ptr(sys::a3d_last_error()).to_string_lossy().into_owned() }
+}
+
+/// Statuses that are panics in the reference panic here too, with the library's text (which quotes the reference's
+/// `expect` messages); everything else unexpected is a panic as well: the reference's signatures have no error path.
+pub fn check(status: sys::a3d_status, what: &str) {
+    if status != sys::A3D_OK {
+        panic!("{what}: {}", last_error());
+    }
+}
+
+/// One GPU, one HIP stream (a3d_context).  The reference's objects are plain data used from any thread; here every
+/// thread gets its own context on first use (`Context::current()`), which keeps `align(&self)` re-entrant.
+pub struct Context(pub *mut sys::a3d_context);
+
+impl Context {
+    pub fn new(device_index: i32) -> Self {
+        let mut ctx = std::ptr::null_mut();
+        check(unsafe { sys::a3d_context_create(device_index, &mut ctx) }, "a3d_context_create");
+        Context(ctx)
+    }
+
+    /// This thread's context on device `ALIGN3D_HIP_DEVICE` (default 0).
+    pub fn current() -> *mut sys::a3d_context {
+        thread_local! { static CTX: RefCell<Option<Context>> = RefCell::new(None); }
+        CTX.with(|c| {
+            let mut c = c.borrow_mut();
+            if c.is_none() {
+                let dev = std::env::var("ALIGN3D_HIP_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0);
+                *c = Some(Context::new(dev));
+            }
+            c.as_ref().unwrap().0
+        })
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { sys::a3d_context_destroy(self.0) };
+    }
+}
+
+/// `Transform` <-> `a3d_pose` (Isometry3<f32> storage: translation + quaternion i, j, k, w).
+pub fn pose_of(t: &Transform) -> sys::a3d_pose {
+    let tr = t.0.translation.vector;
+    let q = t.0.rotation.quaternion().coords; // (i, j, k, w)
+    sys::a3d_pose { t: [tr[0], tr[1], tr[2]], q: [q[0], q[1], q[2], q[3]] }
+}
+
+pub fn transform_of(p: &sys::a3d_pose) -> Transform {
+    // the library returns the quaternion exactly as nalgebra would hold it; `new` re-normalises a unit quaternion,
+    // which changes nothing beyond the last bit
+    Transform::new(&Vector3::new(p.t[0], p.t[1], p.t[2]), &Quaternion::new(p.q[3], p.q[0], p.q[1], p.q[2]))
+}
+
+/// The borrowed view of a `RangeImage`: standard-layout arrays go across as raw pointers, no host copies.
+pub fn view_of(image: &RangeImage) -> sys::a3d_range_image_view {
+    let k = &image.intrinsics;
+    sys::a3d_range_image_view {
+        points: image.points.as_ptr() as *const f32, // Array2<Vector3<f32>>: 12-byte stride
+        mask: image.mask.as_ptr(),
+        normals: image.normals.as_ref().map_or(std::ptr::null(), |n| n.as_ptr() as *const f32),
+        intensities: image.intensities.as_ref().map_or(std::ptr::null(), |i| i.as_ptr()),
+        intensity_map: image.intensity_map.as_ref().map_or(std::ptr::null(), |m| m.as_array().as_ptr()),
+        fx: k.fx,
+        fy: k.fy,
+        cx: k.cx,
+        cy: k.cy,
+        width: image.width() as u64,
+        height: image.height() as u64,
+    }
+}
+
+/// One `RangeImage` resident in HBM (a3d_device_image); freed on drop.
+pub struct DeviceImage(pub *mut sys::a3d_device_image);
+
+impl DeviceImage {
+    pub fn upload(ctx: *mut sys::a3d_context, image: &RangeImage) -> Self {
+        assert!(image.points.is_standard_layout() && image.mask.is_standard_layout());
+        let view = view_of(image);
+        let mut out = std::ptr::null_mut();
+        check(unsafe { sys::a3d_range_image_upload(ctx, &view, &mut out) }, "a3d_range_image_upload");
+        DeviceImage(out)
+    }
+}
+
+impl Drop for DeviceImage {
+    fn drop(&mut self) {
+        unsafe { sys::a3d_range_image_free(self.0) };
+    }
+}
+
+/// `IcpParams` -> `a3d_icp_params`, field for field (src/icp/icp_params.rs:8-23).
+pub fn params_of(p: &align3d::icp::IcpParams) -> sys::a3d_icp_params {
+    sys::a3d_icp_params {
+        max_iterations: p.max_iterations as u64,
+        weight: p.weight,
+        color_weight: p.color_weight,
+        max_point_to_plane_distance: p.max_point_to_plane_distance,
+        max_distance: p.max_distance,
+        max_normal_angle: p.max_normal_angle,
+        max_color_distance: p.max_color_distance,
+    }
+}

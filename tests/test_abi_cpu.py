@@ -105,3 +105,34 @@ def test_cpp_host_mirror_cpu_checks():
     out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "host_mirror_test")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout or "GPU is present" in out.stdout
+
+
+def test_multi_device_sharding_and_argument_validation_without_a_gpu():
+    """The multi-GPU entry points below Python (a3d_multi_*): the partition rule is the one of SURVEY §8e (and of
+    align3d_amd.distributed.shard_range), malformed arguments are statuses, and without a GPU the context list
+    reports A3D_HIP_ERROR like a3d_context_create."""
+    from align3d_amd.distributed import shard_range as py_shard
+    from align3d_amd.multi import shard_range
+
+    for n, d in [(512, 8), (64, 1), (10, 3), (7, 8), (0, 4), (513, 8)]:
+        blocks = [shard_range(n, d, k) for k in range(d)]
+        assert blocks == [py_shard(n, d, k) for k in range(d)]
+        assert [j for lo, hi in blocks for j in range(lo, hi)] == list(range(n))
+    assert shard_range(512, 8, 3) == (192, 256)
+    lib = _abi.load_library()
+    lo, hi = C.c_uint64(), C.c_uint64()
+    assert lib.a3d_multi_shard_range(10, 0, 0, C.byref(lo), C.byref(hi)) == 1      # no devices
+    assert lib.a3d_multi_shard_range(10, 2, 2, C.byref(lo), C.byref(hi)) == 1      # device index out of range
+    assert lib.a3d_multi_shard_range(10, 2, 1, None, C.byref(hi)) == 1
+    h = C.c_void_p()
+    assert lib.a3d_multi_context_create(None, 1, C.byref(h)) == 1
+    ids = (C.c_int32 * 2)(0, 0)
+    assert lib.a3d_multi_context_create(ids, 0, C.byref(h)) == 1
+    assert lib.a3d_multi_context_size(None) == 0 and not lib.a3d_multi_context_device(None, 0)
+    assert lib.a3d_multiscale_batch_new_multi(None, None, 3, 4, 3, None, None, C.byref(h)) == 1
+    assert lib.a3d_multiscale_multi_batch_align(None, None, None, None, None) == 1
+    assert lib.a3d_multiscale_multi_batch_free(None) == 0 and lib.a3d_multi_context_destroy(None) == 0
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.a3d_multi_context_create(ids, 2, C.byref(h)) == 4  # A3D_HIP_ERROR: no device
+        assert b"no HIP device" in lib.a3d_last_error()

@@ -484,3 +484,51 @@ def test_images_may_be_freed_right_after_an_enqueue_only_align():
     finally:
         side.close()
         main.close()
+
+
+def test_multi_device_batch_equals_the_single_device_batch():
+    """a3d_multiscale_batch_new_multi on the one-GPU box: the device list [0] gives bit for bit the poses of
+    a3d_multiscale_batch_new; the list [0, 0] (two contexts = two streams on the same GPU) exercises the block
+    partition, the per-device host threads and the peer-copy gather with more than one block; an image resident on
+    the wrong entry's device list slot is fine on one GPU (same device) but a wrong COUNT is rejected."""
+    from align3d_amd import BilateralFilter, Context, MultiContext, MultiscaleAlignMultiBatch, RangeImageBuilder, synth
+    from align3d_amd.multi import shard_range
+
+    P = 10
+    frames, _ = synth.frame_stream(77, P + 1, 320, 240)
+    cam = synth.camera(320, 240)
+    prm = MsIcpParams.repeat(3, IcpParams.default())
+    single = Context(0)
+    try:
+        b = RangeImageBuilder(single).with_bilateral_filter(BilateralFilter.default())
+        pyr = b.build_many(cam, frames, synth.DEPTH_SCALE)
+        batch = MultiscaleAlignBatch(single, prm, pyr[:P], pyr[1:])
+        want, want_status = batch.align()
+        batch.free()
+        want_bits = np.array([np.concatenate([t.t, t.q]) for t in want], np.float32).view(np.uint32)
+        for ids in ([0], [0, 0], [0, 0, 0]):
+            mc = MultiContext(ids)
+            assert len(mc) == len(ids)
+            tp, sp = [], []
+            for d in range(len(ids)):  # each entry builds the frames of the pairs it owns on its own context
+                lo, hi = shard_range(P, len(ids), d)
+                if lo == hi:
+                    continue
+                own = RangeImageBuilder(mc.device(d)).with_bilateral_filter(BilateralFilter.default()).build_many(
+                    cam, frames[lo:hi + 1], synth.DEPTH_SCALE)
+                tp += own[:-1]
+                sp += own[1:]
+            mb = MultiscaleAlignMultiBatch(mc, prm, tp, sp)
+            got, status, mats = mb.align()
+            got_bits = np.array([np.concatenate([t.t, t.q]) for t in got], np.float32).view(np.uint32)
+            assert np.array_equal(status, want_status) and np.array_equal(got_bits, want_bits), ids
+            for p in range(P):  # the gathered 4x4 matrices are these poses, in global pair order
+                assert np.allclose(mats[p].reshape(4, 4), got[p].matrix(), atol=1e-6), (ids, p)
+            again = mb.align()[2]
+            assert np.array_equal(mats.view(np.uint32), again.view(np.uint32))
+            with pytest.raises(InvalidParameter):
+                MultiscaleAlignMultiBatch(mc, MsIcpParams.repeat(2, IcpParams.default()), tp, sp)
+            mb.free()
+            mc.close()
+    finally:
+        single.close()
