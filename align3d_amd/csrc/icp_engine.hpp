@@ -362,6 +362,20 @@ __device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job
     if (cg < GN_PARTIAL / 2 && slice < 8) {  // the first 256 threads of the block (blocks may be larger)
       const unsigned long long* base = (const unsigned long long*)job_partials + cg;
       uint32_t t = slice;
+      // a single pair runs on ~256 fat blocks: 32 partials per slice, all of them in flight at once (one memory
+      // round trip instead of four; the accumulators are dead here, so the registers are free)
+      for (; t + 248 < tiles; t += 256) {
+        unsigned long long v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+          v[k] = __hip_atomic_load(base + (size_t)(t + 8 * k) * (GN_PARTIAL / 2), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          sum0 += (double)__uint_as_float((unsigned)v[k]);
+          sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
+        }
+      }
       for (; t + 56 < tiles; t += 64) {
         unsigned long long v[8];
 #pragma unroll

@@ -12,13 +12,17 @@
 //
 // Both give the order of `slice::sort_by(partial_cmp)` (src/kdtree.rs:41-45): keys are canonicalised (-0.0 -> +0.0)
 // before the monotone float -> u32 map, equal keys keep their previous order.
+#include <cstdlib>
+#include <cstring>
+
 #include "kdtree.hpp"
 
 using namespace a3d;
 
 namespace {
 
-constexpr uint32_t ITEMS = 4096;  // items per block in every kernel below (256 threads x 16)
+constexpr uint32_t ITEMS = 4096;        // items per block of the LDS bitonic sort (256 threads x 16)
+constexpr uint32_t RADIX_ITEMS = 2048;  // items per block of the radix passes: 245 blocks at 500k keys (the chip has 256 CUs)
 
 __device__ __forceinline__ uint32_t ordered_bits(float v) {
   const uint32_t u = __float_as_uint(v + 0.0f);  // -0.0 -> +0.0
@@ -27,20 +31,24 @@ __device__ __forceinline__ uint32_t ordered_bits(float v) {
 
 // ---- device-wide LSD radix sort, one 8-bit digit per pass ---------------------------------------------------
 
+// FUSED: the table is block-major (hist[block][digit]) and no scan kernel follows — every scatter block derives its
+// own offsets from the table (below).  Otherwise digit-major for the one-block scan.
+template <bool FUSED>
 __global__ void __launch_bounds__(256)
     radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t nblocks,
                       uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * ITEMS;
+  const uint32_t base = blockIdx.x * RADIX_ITEMS;
 #pragma unroll 4
-  for (uint32_t r = 0; r < ITEMS / 256; ++r) {
+  for (uint32_t r = 0; r < RADIX_ITEMS / 256; ++r) {
     const uint32_t i = base + r * 256 + threadIdx.x;
     if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+  if (FUSED) hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+  else hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // Exclusive scan of `m` counters in place, one block of 1024 threads, each owning one contiguous chunk.
@@ -81,6 +89,11 @@ __global__ void __launch_bounds__(1024) exclusive_scan_kernel(uint32_t* __restri
   }
 }
 
+// FUSED: `offsets` is the raw block-major histogram table.  Thread d of every block walks column d of the table
+// (coalesced: 256 consecutive words per row): the counts of the blocks before this one + the digit's total, then one
+// 256-wide exclusive scan of the totals in LDS gives the digit's start — the scan kernel of the unfused form (a single
+// block, 43 us per pass at 500k points: half of the whole tree build) disappears; the table (nblocks KiB) stays in L2.
+template <bool FUSED>
 __global__ void __launch_bounds__(256)
     radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
@@ -90,9 +103,42 @@ __global__ void __launch_bounds__(256)
   const uint32_t t = threadIdx.x, w = t >> 6;
   const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const unsigned long long lower = (1ull << lane) - 1ull;
-  base[t] = offsets[(size_t)t * nblocks + blockIdx.x];
-  const uint32_t first = blockIdx.x * ITEMS;
-  for (uint32_t r = 0; r < ITEMS / 256; ++r) {
+  if (FUSED) {
+    uint32_t below = 0, total = 0;
+    uint32_t b = 0;
+    for (; b + 8 <= nblocks; b += 8) {  // eight rows in flight
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = offsets[(size_t)(b + k) * 256 + t];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        total += v[k];
+        below += (b + k < blockIdx.x) ? v[k] : 0u;
+      }
+    }
+    for (; b < nblocks; ++b) {
+      const uint32_t v = offsets[(size_t)b * 256 + t];
+      total += v;
+      below += b < blockIdx.x ? v : 0u;
+    }
+    // exclusive scan of the 256 digit totals: inside each wave with shuffles, then across the four waves
+    uint32_t incl = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= (uint32_t)off) incl += up;
+    }
+    if (lane == 63) wcount[0][w] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t ww = 0; ww < w; ++ww) before += wcount[0][ww];
+    base[t] = before + incl - total + below;
+    __syncthreads();  // wcount[0][0..3] are rewritten below
+  } else {
+    base[t] = offsets[(size_t)t * nblocks + blockIdx.x];
+  }
+  const uint32_t first = blockIdx.x * RADIX_ITEMS;
+  for (uint32_t r = 0; r < RADIX_ITEMS / 256; ++r) {
     wcount[0][t] = 0, wcount[1][t] = 0, wcount[2][t] = 0, wcount[3][t] = 0;
     __syncthreads();  // also orders the previous round's base update
     const uint32_t i = first + r * 256 + t;
@@ -196,7 +242,7 @@ __global__ void __launch_bounds__(256)
 namespace a3d {
 
 size_t kdtree_sort_scratch_bytes(uint32_t n) {
-  const size_t nblocks = ((size_t)n + ITEMS - 1) / ITEMS;
+  const size_t nblocks = ((size_t)n + RADIX_ITEMS - 1) / RADIX_ITEMS;
   return 256 * nblocks * sizeof(uint32_t);
 }
 
@@ -204,12 +250,20 @@ size_t kdtree_sort_scratch_bytes(uint32_t n) {
 // *in_b tells where the result is.
 a3d_status kdtree_radix_sort_pairs(hipStream_t s, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a,
                                    uint32_t* vals_b, uint32_t n, int end_bit, uint32_t* hist, bool* in_b) {
-  const uint32_t nblocks = (n + ITEMS - 1) / ITEMS;
+  const uint32_t nblocks = (n + RADIX_ITEMS - 1) / RADIX_ITEMS;
   bool flip = false;
   for (int shift = 0; shift < end_bit; shift += 8) {
     const uint64_t* kin = flip ? keys_b : keys_a;
     const uint32_t* vin = flip ? vals_b : vals_a;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(256), 0, s, kin, n, shift, nblocks, hist);
+    const bool force_unfused = getenv("A3D_KDTREE_SCAN") && !strcmp(getenv("A3D_KDTREE_SCAN"), "unfused");
+    if (nblocks <= 1024 && !force_unfused) {  // up to 2M keys: every scatter block reads the whole table (at most 1 MiB, L2-resident)
+      hipLaunchKernelGGL(radix_hist_kernel<true>, dim3(nblocks), dim3(256), 0, s, kin, n, shift, nblocks, hist);
+      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(256), 0, s, kin, vin, flip ? keys_a : keys_b,
+                         flip ? vals_a : vals_b, n, shift, nblocks, hist);
+      flip = !flip;
+      continue;
+    }
+    hipLaunchKernelGGL(radix_hist_kernel<false>, dim3(nblocks), dim3(256), 0, s, kin, n, shift, nblocks, hist);
     const uint32_t m = 256u * nblocks;
     if (m <= SCAN_LDS_WORDS) {
       static bool big_lds_allowed = false;  // more than 64 KiB of dynamic LDS has to be requested once
@@ -221,7 +275,7 @@ a3d_status kdtree_radix_sort_pairs(hipStream_t s, uint64_t* keys_a, uint64_t* ke
       hipLaunchKernelGGL(exclusive_scan_kernel<true>, dim3(1), dim3(1024), m * sizeof(uint32_t), s, hist, m);
     } else
       hipLaunchKernelGGL(exclusive_scan_kernel<false>, dim3(1), dim3(1024), 0, s, hist, m);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, s, kin, vin, flip ? keys_a : keys_b,
+    hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(256), 0, s, kin, vin, flip ? keys_a : keys_b,
                        flip ? vals_a : vals_b, n, shift, nblocks, hist);
     flip = !flip;
   }

@@ -488,16 +488,17 @@ def test_images_may_be_freed_right_after_an_enqueue_only_align():
 
 def test_multi_device_batch_equals_the_single_device_batch():
     """a3d_multiscale_batch_new_multi on the one-GPU box: the device list [0] gives bit for bit the poses of
-    a3d_multiscale_batch_new; the list [0, 0] (two contexts = two streams on the same GPU) exercises the block
-    partition, the per-device host threads and the peer-copy gather with more than one block; an image resident on
-    the wrong entry's device list slot is fine on one GPU (same device) but a wrong COUNT is rejected."""
+    a3d_multiscale_batch_new; the lists [0, 0] and [0, 0, 0] (several contexts = streams on the same GPU) exercise
+    the block partition, the per-device host threads and the peer-copy gather with more than one block; a parameter
+    list of the wrong length is rejected like MultiscaleAlign::new."""
     from align3d_amd import BilateralFilter, Context, MultiContext, MultiscaleAlignMultiBatch, RangeImageBuilder, synth
     from align3d_amd.multi import shard_range
 
     P = 10
     frames, _ = synth.frame_stream(77, P + 1, 320, 240)
     cam = synth.camera(320, 240)
-    prm = MsIcpParams.repeat(3, IcpParams.default())
+    # contractive parameters (SURVEY §10): differences of f32 association between batch shapes are not amplified
+    prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 6))
     single = Context(0)
     try:
         b = RangeImageBuilder(single).with_bilateral_filter(BilateralFilter.default())
@@ -521,7 +522,22 @@ def test_multi_device_batch_equals_the_single_device_batch():
             mb = MultiscaleAlignMultiBatch(mc, prm, tp, sp)
             got, status, mats = mb.align()
             got_bits = np.array([np.concatenate([t.t, t.q]) for t in got], np.float32).view(np.uint32)
-            assert np.array_equal(status, want_status) and np.array_equal(got_bits, want_bits), ids
+            assert np.array_equal(status, want_status)
+            # bit for bit the single-device batch of the same shape: a block's tiling (and with it the association of
+            # the f32 block partials) depends on how many pairs the block holds, so every block is compared with the
+            # single-device batch of exactly its pairs; across shapes the poses agree far inside the 1e-4 tolerance
+            for d in range(len(ids)):
+                lo, hi = shard_range(P, len(ids), d)
+                if lo == hi:
+                    continue
+                blk = MultiscaleAlignBatch(single, prm, pyr[lo:hi], pyr[lo + 1:hi + 1])
+                ref, _ = blk.align()
+                blk.free()
+                ref_bits = np.array([np.concatenate([t.t, t.q]) for t in ref], np.float32).view(np.uint32)
+                assert np.array_equal(got_bits[lo:hi], ref_bits), (ids, d)
+            for p in range(P):
+                ang, tr = transform_diff(got[p], want[p])
+                assert ang <= 1e-5 and tr <= 1e-5, (ids, p, ang, tr)
             for p in range(P):  # the gathered 4x4 matrices are these poses, in global pair order
                 assert np.allclose(mats[p].reshape(4, 4), got[p].matrix(), atol=1e-6), (ids, p)
             again = mb.align()[2]

@@ -137,6 +137,20 @@ def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, monkeypatch, ca
     assert np.array_equal(dl, hl)
 
 
+@pytest.mark.parametrize("case", ["n1000", "dup", "n270213"])
+def test_kdtree_device_build_with_the_separate_scan_kernel(ctx, monkeypatch, case):
+    """Above 4M keys the radix passes keep their digit-major table and one-block scan kernel instead of deriving the
+    offsets inside the scatter blocks; A3D_KDTREE_SCAN=unfused forces that form at test sizes.  Same tree."""
+    db = _kd_cases()[case]
+    host = _build(ctx, db, "host", monkeypatch)
+    monkeypatch.setenv("A3D_KDTREE_SCAN", "unfused")
+    dev = _build(ctx, db, "device", monkeypatch, 64)
+    monkeypatch.delenv("A3D_KDTREE_SCAN")
+    hs, hl = host.download()
+    ds, dl = dev.download()
+    assert dev.stats() == host.stats() and np.array_equal(ds, hs) and np.array_equal(dl, hl)
+
+
 def test_kdtree_device_build_nan_rules(ctx, monkeypatch):
     """NaN in a coordinate that gets compared is the reference's panic; one that never is compared is not."""
     for mode in ("host", "device"):
