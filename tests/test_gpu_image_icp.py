@@ -548,3 +548,53 @@ def test_multi_device_batch_equals_the_single_device_batch():
             mc.close()
     finally:
         single.close()
+
+
+CONTENTION_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["A3D_ROOT"])
+import numpy as np
+from align3d_amd import Context, IcpParams, MsIcpParams, MultiscaleAlignBatch
+from bench import build_stream_pyramids
+ctx = Context(0)
+P = 24
+pyr, _, _ = build_stream_pyramids(ctx, 1000, P + 1, 640, 480)
+b = MultiscaleAlignBatch(ctx, MsIcpParams.repeat(3, IcpParams.default()), pyr[:P], pyr[1:])
+ref, bad = None, 0
+for it in range(40):
+    poses, status = b.align()
+    o = np.array([np.concatenate([t.t, t.q]) for t in poses], np.float32).view(np.uint32)
+    if ref is None:
+        ref = o
+    elif not np.array_equal(ref, o):
+        bad += 1
+np.save(os.environ["A3D_OUT"], ref)
+print(f"pid {os.getpid()} streams={b.concurrency()} differing_repeats={bad}", flush=True)
+sys.exit(1 if bad else 0)
+"""
+
+
+def test_batch_is_repeat_identical_with_a_second_process_competing_for_the_gpu(tmp_path):
+    """The cross-XCD hand-off of the last-block solve (write-through partials, drained stores, one relaxed ticket, no
+    release / acquire fence: DESIGN.md §4) is only as safe as its tests: two fresh processes (started, never re-exec'ed)
+    run the 3-stream-group batch 40 times each AT THE SAME TIME, so that blocks of one pair are descheduled and
+    spread over the XCDs differently from run to run.  Every repeat must reproduce the first bit for bit, and both
+    processes must agree (a race on the partials or the ticket shows up as a pose that differs in the last bits)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(CONTENTION_WORKER)
+    procs = []
+    for k in range(2):
+        env = dict(os.environ, A3D_ROOT=root, A3D_OUT=str(tmp_path / f"poses{k}.npy"))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out
+        assert "differing_repeats=0" in out and "streams=3" in out, out
+    a, b = np.load(tmp_path / "poses0.npy"), np.load(tmp_path / "poses1.npy")
+    assert np.array_equal(a, b)
