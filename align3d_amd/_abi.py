@@ -160,6 +160,10 @@ SIGNATURES = {
         _ST,
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC), C.POINTER(GnStateC)],
     ),
+    "a3d_image_icp_accumulate_weighted": (
+        _ST,
+        [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC)],
+    ),
     "a3d_image_icp_align_trace": (
         _ST,
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(PoseC), _P],

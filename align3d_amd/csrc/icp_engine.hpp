@@ -24,8 +24,17 @@ struct JobState {
 enum SolveMode : int {
   SOLVE_IMAGE_ICP = 0,  // geom.add_weighted(color, w, cw); residual = weighted mean (image_icp.rs:150-151)
   SOLVE_PCL_ICP = 1,    // residual = mean, then weight(w)  (pcl_icp.rs:94-95)
-  SOLVE_NONE = 2        // leave the block partials alone (test hook: read the accumulators back)
+  SOLVE_NONE = 2,       // leave the block partials alone (test hook: read the accumulators back)
+  // The partials already hold geom.add_weighted(color, w, cw): H and g were accumulated from the weighted
+  // Jacobians (GN_MERGED layout below); only the residual's two sums and counts are still separate.
+  SOLVE_IMAGE_ICP_MERGED = 3
 };
+
+// Merged accumulator of the image ICP kernel: the solve only ever sees H = Hg w^2 + Hc cw^2 and
+// g = gg w + gc cw (GaussNewton::add_weighted, gaussnewton.rs:115-121), so a thread accumulates those directly
+// from J' = w J instead of two separate 6x6 systems: 31 running sums instead of 58.
+//   [0, 21) H   [21, 27) g   27 sum rg^2   28 count_g   29 sum rc^2   30 count_c
+constexpr int GN_MERGED = 31;
 
 // What the last block of a job needs in order to finish the iteration on the device.
 struct SolveArgs {
@@ -175,6 +184,7 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
   const int r = tid / 6, c = tid % 6;
   const bool cell = tid < 36;  // lane (r, c) owns matrix element [r][c]
   const bool image_mode = a.mode == SOLVE_IMAGE_ICP;
+  const bool merged = a.mode == SOLVE_IMAGE_ICP_MERGED;
   // the job state (pose 0..6, best 7..13, best_residual 14): one float per lane, in flight during the solve
   const float state_word = tid < 15 ? ld_coherent((const float*)st + tid) : 0.0f;
   double v = 0.0;
@@ -182,8 +192,9 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
     const int t = tri6(r < c ? r : c, r < c ? c : r);
     const float hg = (float)sums[t], hc = (float)sums[GN_ACC + t];
     // add_weighted: H = Hg w1^2 + Hc w2^2 ; weight(): H *= w^2   (all f32)
-    const float h = image_mode ? hg * (a.weight * a.weight) + hc * (a.color_weight * a.color_weight)
-                               : hg * (a.weight * a.weight);
+    const float h = merged ? hg
+                           : image_mode ? hg * (a.weight * a.weight) + hc * (a.color_weight * a.color_weight)
+                                        : hg * (a.weight * a.weight);
     v = (double)h;
   }
   A3D_STAMP(3);
@@ -209,11 +220,11 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
   // From here on every lane computes the same values (all inputs are wave-uniform); only lane 0 stores.
   float residual;
   {
-    const float ssq_g = (float)sums[27], ssq_c = (float)sums[GN_ACC + 27];
-    const double cnt_g = sums[28], cnt_c = sums[GN_ACC + 28];
+    const float ssq_g = (float)sums[27], ssq_c = (float)sums[merged ? 29 : GN_ACC + 27];
+    const double cnt_g = sums[28], cnt_c = sums[merged ? 30 : GN_ACC + 28];
     // ImageIcp: weighted sum / combined count ; Icp: plain mean taken before weight()
-    const double count = image_mode ? cnt_g + cnt_c : cnt_g;
-    const float ssq = image_mode ? ssq_g * a.weight + ssq_c * a.color_weight : ssq_g;
+    const double count = (image_mode || merged) ? cnt_g + cnt_c : cnt_g;
+    const float ssq = (image_mode || merged) ? ssq_g * a.weight + ssq_c * a.color_weight : ssq_g;
     residual = ssq / (float)count;
     if (!(count != 0.0)) ok = 0;  // solve(): None if count == 0
   }
@@ -230,7 +241,7 @@ __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const float gg = (float)sums[21 + i], gc = (float)sums[GN_ACC + 21 + i];
-    bvec[i] = (double)(image_mode ? gg * a.weight + gc * a.color_weight : gg * a.weight);
+    bvec[i] = (double)(merged ? gg : image_mode ? gg * a.weight + gc * a.color_weight : gg * a.weight);
 #pragma unroll
     for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = Lm[i * 6 + j];  // lower triangle, row-major packed
   }
@@ -438,6 +449,26 @@ __device__ __forceinline__ void gn_step(float* __restrict__ acc, float r, const 
   for (int i = 0; i < 6; ++i) acc[21 + i] = __builtin_fmaf(J[i], r, acc[21 + i]);
   acc[27] = __builtin_fmaf(r, r, acc[27]);
   acc[28] += 1.0f;
+}
+
+// One pixel into the merged accumulator: Jg, Jc already multiplied by their weights (Jc and rc zero when the colour
+// term is rejected), rg / rc the plain residuals.  Same FMA count as two gn_step calls, 27 fewer live registers.
+__device__ __forceinline__ void gn_step_merged(float* __restrict__ acc, float rg, const float Jg[6], float rc,
+                                               const float Jc[6], float color_live) {
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      acc[t] = __builtin_fmaf(Jc[i], Jc[j], __builtin_fmaf(Jg[i], Jg[j], acc[t]));
+      ++t;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[21 + i] = __builtin_fmaf(Jc[i], rc, __builtin_fmaf(Jg[i], rg, acc[21 + i]));
+  acc[27] = __builtin_fmaf(rg, rg, acc[27]);
+  acc[28] += 1.0f;
+  acc[29] = __builtin_fmaf(rc, rc, acc[29]);
+  acc[30] += color_live;
 }
 
 }  // namespace a3d

@@ -230,14 +230,31 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
 // per step (tuning options).  Reading the loop's s_waitcnt's in the ISA is part of maintaining this kernel: a
 // short-circuit `&&` around a load, a u8 -> f32 conversion next to its load or a 64-bit multiply-add with a
 // don't-care high half each cost a full drain of the pipeline per pixel before they were found.
-template <int G>
-__global__ void __launch_bounds__(256)
+//
+// MERGED: the thread accumulates geom.add_weighted(color, w, cw) directly (31 sums from the weighted Jacobians,
+// icp_engine.hpp) instead of the two 29-entry systems: same FMAs, 27 fewer live registers, one more wave per SIMD.
+template <int G, bool MERGED>
+__global__ void __launch_bounds__(256, MERGED ? 5 : 1)
     image_icp_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
                      float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve, int PPT) {
   const int pair = blockIdx.y;
-  float acc[GN_PARTIAL];
+  constexpr int NACC = MERGED ? GN_MERGED : GN_PARTIAL;
+  float acc[NACC];
 #pragma unroll
-  for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+  const float wg = solve.weight, wc = solve.color_weight;
+  // one live pixel into the accumulators (the geometric term counts even when the colour term is rejected)
+  auto accumulate = [&](const Terms& t) {
+    if (MERGED) {
+      float Jg[6], Jc[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jg[k] = wg * t.Jg[k], Jc[k] = t.color ? wc * t.Jc[k] : 0.0f;
+      gn_step_merged(acc, t.rg, Jg, t.color ? t.rc : 0.0f, Jc, t.color ? 1.0f : 0.0f);
+    } else {
+      gn_step(acc, t.rg, t.Jg);
+      if (t.color) gn_step(acc + (MERGED ? 0 : GN_ACC), t.rc, t.Jc);
+    }
+  };
   JobState* st = &states[pair];
   if (st->status == A3D_OK) {
     const LevelDesc d = descs[pair];
@@ -271,11 +288,7 @@ __global__ void __launch_bounds__(256)
         const MapPx mp = stage_c(d, gt, cur, mw);                   // gathers(k) land; issue map cell(k)
         nxt = stage_b(d, T, s_next, twf, thf);                      // issue gathers(k+1)
         nxt_i = s_next.intensity;
-        if (cur.live) {
-          const Terms t = stage_d(d, gt, cur, mp, cur_i, mw);
-          gn_step(acc, t.rg, t.Jg);  // the geometric term is accumulated even when the colour term is rejected
-          if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
-        }
+        if (cur.live) accumulate(stage_d(d, gt, cur, mp, cur_i, mw));
       };
 #pragma unroll 1
       for (int k0 = 0; k0 < PPT; k0 += 2) {  // PPT is even (batch_commit_descs); surplus pixels are out of range
@@ -310,11 +323,7 @@ __global__ void __launch_bounds__(256)
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        if (cur[g].live) {
-          const Terms t = stage_d(d, gt, cur[g], mp[g], cur_int[g], mw);
-          gn_step(acc, t.rg, t.Jg);  // the geometric term is accumulated even when the colour term is rejected
-          if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
-        }
+        if (cur[g].live) accumulate(stage_d(d, gt, cur[g], mp[g], cur_int[g], mw));
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) cur[g] = nxt[g], cur_int[g] = nxt_int[g], s1[g] = s2[g];
@@ -324,8 +333,8 @@ __global__ void __launch_bounds__(256)
   // a failed job stays frozen: its blocks contribute nothing and nobody runs its solve
   SolveArgs sa = solve;
   if (st->status != A3D_OK) sa.mode = SOLVE_NONE;
-  block_finish<GN_PARTIAL>(acc, partials + (size_t)pair * gridDim.x * GN_PARTIAL, blockIdx.x, gridDim.x,
-                           counters + pair, st, sa, pair);
+  block_finish<NACC>(acc, partials + (size_t)pair * gridDim.x * GN_PARTIAL, blockIdx.x, gridDim.x,
+                     counters + pair, st, sa, pair);
 }
 
 // ---- one launch per pyramid level ------------------------------------------------------------------
@@ -632,6 +641,9 @@ struct a3d_multiscale_batch {
   bool profile_kernels = false;
   uint32_t resident_blocks = 1024;  // blocks of the per-pixel kernel the chip holds at once
   bool use_mfma = false;  // VALU accumulation measured faster on MI355X so far (kernel variants)
+  // A3D_ICP_ACCUM=merged: 31 merged running sums (H and g of add_weighted directly) instead of 2 x 29: 96 VGPRs,
+  // one more wave per SIMD — measured 18.5 k against 18.7 k pairs/s (occupancy is not what limits the kernel): opt-in
+  bool merged_accumulators = false;
   // Pair groups launched on separate streams: one group's launch ramp and last-block solve overlap the other
   // groups' streaming (pairs are independent, so the groups never synchronise until the final read-out).
   uint32_t n_streams = 1;
@@ -737,13 +749,18 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
                          partials, counters, solve, ppt);
   } else {
     if (b->group[level] == 4)
-      hipLaunchKernelGGL((image_icp_kernel<4>), grid, block, 0, s, descs, states, b->gates[level], partials,
+      hipLaunchKernelGGL((image_icp_kernel<4, false>), grid, block, 0, s, descs, states, b->gates[level], partials,
                          counters, solve, ppt);
     else if (b->group[level] == 2)
-      hipLaunchKernelGGL((image_icp_kernel<2>), grid, block, 0, s, descs, states, b->gates[level], partials,
+      hipLaunchKernelGGL((image_icp_kernel<2, false>), grid, block, 0, s, descs, states, b->gates[level], partials,
                          counters, solve, ppt);
-    else
-      hipLaunchKernelGGL((image_icp_kernel<1>), grid, block, 0, s, descs, states, b->gates[level], partials,
+    else if (b->merged_accumulators && solve.mode == SOLVE_IMAGE_ICP) {
+      SolveArgs merged = solve;  // the partials hold add_weighted(geom, color) already: tell the tail
+      merged.mode = SOLVE_IMAGE_ICP_MERGED;
+      hipLaunchKernelGGL((image_icp_kernel<1, true>), grid, block, 0, s, descs, states, b->gates[level], partials,
+                         counters, merged, ppt);
+    } else
+      hipLaunchKernelGGL((image_icp_kernel<1, false>), grid, block, 0, s, descs, states, b->gates[level], partials,
                          counters, solve, ppt);
   }
   A3D_HIP_TRY(hipGetLastError());
@@ -822,13 +839,18 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   b->ppt.assign(n_levels, 1);
   b->group.assign(n_levels, 1);
   b->h_descs.resize((size_t)n_levels * n_pairs);
+  if (const char* env = getenv("A3D_ICP_ACCUM")) {  // tuning knob
+    b->use_mfma = strcmp(env, "mfma") == 0;
+    b->merged_accumulators = strcmp(env, "merged") == 0;
+  }
   {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_kernel<1>, 256, 0) != hipSuccess || per_cu < 1)
-      per_cu = 4;
+    const hipError_t e = b->merged_accumulators
+                             ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_kernel<1, true>, 256, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_kernel<1, false>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 4;
     b->resident_blocks = (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)per_cu;
   }
-  if (const char* env = getenv("A3D_ICP_ACCUM")) b->use_mfma = strcmp(env, "mfma") == 0;        // tuning knob
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
   A3D_HIP_TRY(hipMalloc((void**)&b->d_states, n_pairs * sizeof(JobState)));
@@ -1126,6 +1148,51 @@ a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* para
   if (st == A3D_HIP_ERROR) set_error("a3d_image_icp_accumulate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   if (st != A3D_OK) return st;
   gn_states_from_sums(sums, out_geom, out_color);
+  return A3D_OK;
+}
+
+// Test hook for the merged-accumulator kernel (A3D_ICP_ACCUM=merged): one pass from `pose`, returning what it hands
+// to the solve: geom.add_weighted(color, weight, color_weight) (gaussnewton.rs:115-121) — H, g, the weighted residual
+// sum and the combined count.
+a3d_status a3d_image_icp_accumulate_weighted(a3d_context* ctx, const a3d_icp_params* params,
+                                             const a3d_device_image* target, const a3d_device_image* source,
+                                             const a3d_pose* pose, a3d_gn_state* out_state) {
+  A3D_REQUIRE(ctx && params && out_state, A3D_INVALID_PARAMETER, "null argument");
+  std::unique_ptr<a3d_multiscale_batch> b;
+  A3D_TRY(batch_create(ctx, params, 1, 1, &b));
+  A3D_TRY(fill_desc(target, source, &b->h_descs[0]));
+  A3D_TRY(batch_commit_descs(b.get()));
+  Pose h_pose = pose ? pose_from_c(pose) : pose_eye();
+  Pose* d_pose = nullptr;
+  A3D_HIP_TRY(hipMalloc((void**)&d_pose, sizeof(Pose)));
+  a3d_status st = A3D_OK;
+  double sums[GN_PARTIAL];
+  hipStream_t s = ctx->stream;
+  if (hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess) st = A3D_HIP_ERROR;
+  if (st == A3D_OK) st = launch_job_init(s, b->d_states, d_pose, 1);
+  if (st == A3D_OK) {  // the merged kernel, with its tail switched off: the partials stay as the blocks wrote them
+    SolveArgs sa{};
+    sa.weight = params->weight, sa.color_weight = params->color_weight, sa.mode = SOLVE_NONE;
+    hipLaunchKernelGGL((image_icp_kernel<1, true>), dim3(b->tiles[0], 1), dim3(256), 0, s, b->d_descs, b->d_states, b->gates[0],
+                       b->d_partials, b->d_counters, sa, (int)b->ppt[0]);
+    if (hipGetLastError() != hipSuccess) st = A3D_HIP_ERROR;
+  }
+  if (st == A3D_OK) st = launch_gn_readback(s, b->d_partials, (int)b->tiles[0], b->d_readback);
+  if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
+    st = A3D_HIP_ERROR;
+  if (hipStreamSynchronize(s) != hipSuccess) st = A3D_HIP_ERROR;
+  hipFree(d_pose);
+  if (st == A3D_HIP_ERROR) set_error("a3d_image_icp_accumulate_weighted: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  if (st != A3D_OK) return st;
+  int t = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) {
+      const float v = (float)sums[t++];
+      out_state->hessian[i * 6 + j] = out_state->hessian[j * 6 + i] = v;
+    }
+  for (int i = 0; i < 6; ++i) out_state->gradient[i] = (float)sums[21 + i];
+  out_state->squared_residual_sum = (float)sums[27] * params->weight + (float)sums[29] * params->color_weight;
+  out_state->count = (uint64_t)sums[28] + (uint64_t)sums[30];
   return A3D_OK;
 }
 

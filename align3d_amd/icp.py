@@ -70,6 +70,18 @@ class ImageIcp:
         )
         return g.as_dict(), c.as_dict()
 
+    def accumulate_weighted(self, source, transform):
+        """One pass of the opt-in merged accumulation (A3D_ICP_ACCUM=merged: a thread sums geom.add_weighted(color, w,
+        cw) directly): the merged accumulator H, g, weighted residual sum, combined count (test hook)."""
+        src = _dev(self.ctx, source)
+        p, t, g = self.params.to_c(), transform.to_c(), _abi.GnStateC()
+        _abi.check(
+            self.ctx.lib.a3d_image_icp_accumulate_weighted(self.ctx.handle, C.byref(p), self.target.handle, src.handle,
+                                                           C.byref(t), C.byref(g)),
+            "ImageIcp accumulate_weighted",
+        )
+        return g.as_dict()
+
 
 class MultiscaleAlign:
     """MultiscaleAlign (src/icp/multiscale.rs:7-68)."""

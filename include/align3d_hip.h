@@ -219,6 +219,13 @@ a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* para
                                     const a3d_pose* pose, a3d_gn_state* out_geom,
                                     a3d_gn_state* out_color);
 
+/* The same pass through the opt-in merged-accumulator kernel (A3D_ICP_ACCUM=merged: a thread sums
+ * geom.add_weighted(color, weight, color_weight) (src/optim/gaussnewton.rs:115-121) directly, from the weighted
+ * Jacobians), returning that merged accumulator: H, g, the weighted residual sum and the combined count.  Test hook. */
+a3d_status a3d_image_icp_accumulate_weighted(a3d_context* ctx, const a3d_icp_params* params,
+                                             const a3d_device_image* target, const a3d_device_image* source,
+                                             const a3d_pose* pose, a3d_gn_state* out_state);
+
 /* Instrumentation (no reference counterpart): a3d_image_icp_align that also writes, per iteration,
  * [residual, t(3), q_ijkw(4)] of the transform after that iteration's update; out_trace holds
  * 8 * params->max_iterations floats. */

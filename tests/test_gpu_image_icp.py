@@ -38,6 +38,20 @@ def _check_accumulators(ctx, prm, ft, fs, T):
     assert eh < 1e-4 and eg < 1e-3 and es < 1e-4
 
 
+def _check_merged_accumulator(ctx, prm, ft, fs, T):
+    """The opt-in merged accumulation (A3D_ICP_ACCUM=merged: 31 sums from the weighted Jacobians) against
+    geom.add_weighted(color, w, cw) of the oracle's f64-summed accumulators (gaussnewton.rs:115-121)."""
+    icp = ImageIcp.new(ctx, prm, to_range_image(ft))
+    got = icp.accumulate_weighted(to_range_image(fs), T)
+    st, g_ref, c_ref = O.image_icp_accumulate(prm.to_c(), ft, fs, T.to_c(), accum_f64=True)
+    assert st == 0
+    O.load().orc_gn_add_weighted(C.byref(g_ref), C.byref(c_ref), prm.weight, prm.color_weight)
+    ref = g_ref.as_dict()
+    assert got["count"] == ref["count"]
+    eh, eg, es = gn_rel_err(got, ref)
+    assert eh < ACC_TOL and eg < ACC_TOL and es < ACC_TOL, (eh, eg, es)
+
+
 def _oracle_step(prm, ft, fs, T, accum_f64):
     """One reference iteration (image_icp.rs:145-153) from T with the oracle: (residual, new transform)."""
     st, g, c = O.image_icp_accumulate(prm.to_c(), ft, fs, T.to_c(), accum_f64=accum_f64)
@@ -58,6 +72,8 @@ def test_per_iteration_accumulators(ctx, sample, tgt, src, bilateral, which):
     prm = IcpParams.default() if which == "default" else MsIcpParams.default()[0]
     _check_accumulators(ctx, prm, ft, fs, Transform.eye())
     _check_accumulators(ctx, prm, ft, fs, small_pose(1))
+    _check_merged_accumulator(ctx, prm, ft, fs, Transform.eye())
+    _check_merged_accumulator(ctx, prm, ft, fs, small_pose(1))
 
 
 def test_teacher_forced_along_oracle_trajectory(ctx):
@@ -69,6 +85,7 @@ def test_teacher_forced_along_oracle_trajectory(ctx):
     for it in (0, 3, 8):
         T = Transform(trace[it, 1:4], trace[it, 4:8])
         _check_accumulators(ctx, prm, ft, fs, T)
+        _check_merged_accumulator(ctx, prm, ft, fs, T)
     # end-to-end on this non-contractive configuration: reported only
     T_gpu, tr_gpu = ImageIcp.new(ctx, prm, to_range_image(ft)).align(to_range_image(fs), trace=True)
     ang, tr = transform_diff(T_gpu, T_ref)
@@ -352,6 +369,7 @@ def test_ragged_small_images_per_iteration(ctx, w, h):
 
 @pytest.mark.parametrize("knobs", [
     {"A3D_ICP_ACCUM": "mfma"},
+    {"A3D_ICP_ACCUM": "merged"},
     {"A3D_ICP_GROUP": "2"},
     {"A3D_ICP_GROUP_LEVELS": "1,2,4"},
     {"A3D_ICP_WAVES": "3"},
