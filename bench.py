@@ -82,6 +82,8 @@ def build_stream_pyramids(ctx, seed, n_frames, width, height, first=0, total=Non
     back-projection, normals, pyramid, luma, intensity maps: a3d_range_image_build_pyramids).  Returns the device
     pyramids, the ground-truth camera poses and the per-frame build time (depth + RGB upload included)."""
     frames, poses = synth.frame_stream(seed, total or n_frames, width, height, first=first, count=n_frames)
+    all_d, all_c = np.stack([d for d, _ in frames]), np.stack([c for _, c in frames])  # one buffer per array
+    frames = [(all_d[i], all_c[i]) for i in range(n_frames)]
     builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
     cam = synth.camera(width, height)
     for lv in builder.build(cam, *frames[0], synth.DEPTH_SCALE):  # first use of the context: scratch, tap tables
@@ -267,13 +269,13 @@ def streaming_bench(ctx, params, P, W, H, rounds=6, builders=1, pinned=True):
     import threading
 
     frames, _ = synth.frame_stream(4242, P + 1, W, H)  # the same host frames every round: they are rebuilt each time
-    if pinned:  # page-locked host buffers: the upload is a DMA at the PCIe rate, not the pageable staging path
-        held = []
-        for d, rgb in frames:
-            pd, pr = ctx.pinned_empty(d.shape, d.dtype), ctx.pinned_empty(rgb.shape, rgb.dtype)
-            pd[...], pr[...] = d, rgb
-            held.append((pd, pr))
-        frames = held
+    # the stream's frames lie back to back in ONE buffer per array (as a capture ring would hold them): the builder
+    # then uploads a 16-frame chunk with one copy per array; page-locked: a DMA at the PCIe rate
+    alloc = ctx.pinned_empty if pinned else (lambda shape, dtype: np.empty(shape, dtype))
+    all_d, all_c = alloc((P + 1, H, W), np.uint16), alloc((P + 1, H, W, 3), np.uint8)
+    for i, (d, rgb) in enumerate(frames):
+        all_d[i], all_c[i] = d, rgb
+    frames = [(all_d[i], all_c[i]) for i in range(P + 1)]
     cam = synth.camera(W, H)
     ctxs = [Context(ctx.device_index) for _ in range(builders)]
     bld = [RangeImageBuilder(c).with_bilateral_filter(BilateralFilter.default()) for c in ctxs]

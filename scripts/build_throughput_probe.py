@@ -40,6 +40,11 @@ for d, c in frames:
 timed("single builds, page-locked", lambda: [b.build(cam, d, c, synth.DEPTH_SCALE) for d, c in pinned[:16]], 16)
 timed("batch of 16, page-locked", lambda: b.build_many(cam, pinned[:16], synth.DEPTH_SCALE), 16)
 timed("batch of 65, page-locked", lambda: b.build_many(cam, pinned, synth.DEPTH_SCALE), 65)
+cd, cc = ctx.pinned_empty((65, H, W), np.uint16), ctx.pinned_empty((65, H, W, 3), np.uint8)
+for i, (d, c) in enumerate(frames):
+    cd[i], cc[i] = d, c
+contig = [(cd[i], cc[i]) for i in range(65)]
+timed("batch of 65, page-locked, frames back to back in one buffer", lambda: b.build_many(cam, contig, synth.DEPTH_SCALE), 65)
 nb = RangeImageBuilder(ctx)
 timed("batch of 65, page-locked, no bilateral filter", lambda: nb.build_many(cam, pinned, synth.DEPTH_SCALE), 65)
 for n_threads in (2, 4):
