@@ -75,9 +75,9 @@ struct a3d_context {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   int num_cus = 0;
   // Grow-only scratch regions for per-call temporaries (all work on a context is ordered on its one stream,
-  // so successive calls may reuse them): [0] frame builder temporaries, [1] bilateral grids.
-  void* scratch[2] = {nullptr, nullptr};
-  size_t scratch_size[2] = {0, 0};
+  // so successive calls may reuse them): [0] frame builder temporaries, [1] bilateral grids, [2] kd-tree build.
+  void* scratch[3] = {nullptr, nullptr, nullptr};
+  size_t scratch_size[3] = {0, 0, 0};
   // Pyramid arenas handed back by a3d_range_image_free, kept for the next frame of the same size: a frame
   // stream then costs no hipMalloc / hipFree (each of which synchronises the whole device) per frame.
   // Guarded by a mutex because an image may be freed from another thread than the one building frames.

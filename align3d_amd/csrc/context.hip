@@ -246,6 +246,7 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   if (ctx->pinned_words) hipHostFree(ctx->pinned_words);
   hipFree(ctx->scratch[0]);
   hipFree(ctx->scratch[1]);
+  hipFree(ctx->scratch[2]);
   hipEventDestroy(ctx->ev_start);
   hipEventDestroy(ctx->ev_stop);
   hipStreamDestroy(ctx->stream);

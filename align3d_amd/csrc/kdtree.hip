@@ -264,8 +264,11 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
     A3D_REQUIRE(t->max_depth <= 23, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout (leaf byte offsets are 32-bit)");
     t->n_split = (uint32_t)((1ull << t->max_depth) - 1);
     t->n_leaf_slots = (1ull << t->max_depth) * 16;
-    float* d_points = nullptr;
-    A3D_HIP_TRY(hipMalloc((void**)&d_points, (size_t)n * 12));
+    // the points are staged at the head of the context's kd-tree scratch region (grow-only, reused by every build on
+    // this context: no hipMalloc / hipFree — each a device-wide synchronisation — for temporaries)
+    void* region = nullptr;
+    A3D_TRY(ctx_scratch(ctx, 2, kdtree_build_scratch_bytes(t->n, t->max_depth, ctx->stream), &region));
+    float* d_points = (float*)region;
     a3d_status st = A3D_OK;
     if (hipMemcpyAsync(d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
       set_error("a3d_kdtree_new: upload failed: %s", hipGetErrorString(hipGetLastError()));
@@ -273,7 +276,6 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
     }
     if (st == A3D_OK) st = kdtree_build_device(t.get(), d_points);
     hipStreamSynchronize(ctx->stream);
-    hipFree(d_points);
     if (st != A3D_OK) {
       a3d_kdtree_free(t.release());
       return st;
@@ -368,10 +370,14 @@ a3d_status a3d_kdtree_download(a3d_kdtree* t, float* out_split, float* out_leave
 a3d_status a3d_kdtree_free(a3d_kdtree* t) {
   if (!t) return A3D_OK;
   hipStreamSynchronize(t->ctx->stream);
-  hipFree(t->d_split);
-  hipFree(t->d_leaves);
+  if (t->d_block) {  // device build: one allocation
+    hipFree(t->d_block);
+  } else {
+    hipFree(t->d_split);
+    hipFree(t->d_leaves);
+    hipFree(t->d_slot_of_point);
+  }
   hipFree(t->d_leaf_normals);
-  hipFree(t->d_slot_of_point);
   delete t;
   return A3D_OK;
 }
@@ -386,13 +392,13 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
   a3d_kdtree* t = icp->tree;
   a3d_status st = A3D_OK;
   if (target->normals && t->d_slot_of_point) {  // device build: scatter on the device
-    float* d_n = nullptr;
-    if (hipMalloc((void**)&d_n, (size_t)t->n * 12) != hipSuccess ||
+    // staged where the build staged the points (dead by now): the head of the context's kd-tree scratch region
+    float* d_n = (float*)ctx->scratch[2];
+    if (!d_n || ctx->scratch_size[2] < (size_t)t->n * 12 ||
         hipMemcpyAsync(d_n, target->normals, (size_t)t->n * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
       st = A3D_HIP_ERROR;
     if (st == A3D_OK) st = kdtree_scatter_normals_device(t, d_n);
     hipStreamSynchronize(ctx->stream);
-    hipFree(d_n);
     icp->target_has_normals = true;
   } else if (target->normals) {  // scatter the target normals into the leaf slots of their points
     std::vector<float4> ln(t->n_leaf_slots, make_float4(0.f, 0.f, 0.f, 0.f));

@@ -14,6 +14,7 @@ struct a3d_kdtree {
   uint32_t max_depth = 0;      // depth of the deepest leaf
   uint32_t n_split = 0;        // heap entries: 2^max_depth - 1
   uint64_t n_leaf_slots = 0;   // 2^max_depth leaves * 16
+  void* d_block = nullptr;     // device build: ONE allocation behind d_leaves, d_split, d_slot_of_point
   float* d_split = nullptr;    // [n_split] split values, heap order (root = 0, children 2i+1, 2i+2)
   float4* d_leaves = nullptr;  // [n_leaf_slots]
   float4* d_leaf_normals = nullptr;  // same slots: {nx, ny, nz, 0} (only for Icp targets)
@@ -38,6 +39,8 @@ void kdtree_shape(uint32_t n, uint32_t* max_depth, uint64_t* n_leaves, uint64_t*
 // Device build (kdtree_build.hip): one segmented stable radix sort per level; bit-identical to the host build.
 // Expects t->n, max_depth, n_split, n_leaf_slots set; fills d_split, d_leaves, d_slot_of_point.
 a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points);
+// Size of the context scratch region [2] a device build of n points needs: the staged points + the temporaries.
+size_t kdtree_build_scratch_bytes(uint32_t n, uint32_t max_depth, hipStream_t s);
 // leaf_normals[slot_of_point[i]] = normals[i] (device build)
 a3d_status kdtree_scatter_normals_device(a3d_kdtree* t, const float* d_normals);
 

@@ -160,14 +160,38 @@ inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256)); }
 namespace a3d {
 
 // d_points: [n][3] on the device.  Fills t->d_split, t->d_leaves, t->d_slot_of_point (all device).
+// Bytes of temporaries kdtree_build_device needs for n points (behind the staged points, see a3d_kdtree_new).
+size_t kdtree_build_scratch_bytes(uint32_t n, uint32_t max_depth, hipStream_t s) {
+  auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
+  const size_t max_nodes = max_depth ? (1ull << (max_depth - 1)) : 1;
+  size_t sort_bytes = 0, wide_bytes = 0;
+  if (max_depth > 0) {
+    (void)rocprim::segmented_radix_sort_pairs(nullptr, sort_bytes, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr,
+                                              (uint32_t*)nullptr, n, (unsigned)max_nodes, (uint32_t*)nullptr,
+                                              (uint32_t*)nullptr, 0, 32, s);
+    (void)rocprim::radix_sort_pairs(nullptr, wide_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, n, 0, 64, s);
+    sort_bytes = std::max(sort_bytes, wide_bytes);
+  }
+  return 2 * pad((size_t)n * 4) + 2 * pad((size_t)n * 8) + 2 * pad(max_nodes * 4) + 256 + pad(sort_bytes) +
+         pad(kdtree_sort_scratch_bytes(n)) + pad((size_t)n * 12);
+}
+
 a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
   a3d_context* ctx = t->ctx;
   hipStream_t s = ctx->stream;
   const uint32_t n = t->n, D = t->max_depth;
   const uint64_t n_slots = (1ull << D) * 16;
-  A3D_HIP_TRY(hipMalloc((void**)&t->d_split, std::max<size_t>(1, (size_t)t->n_split) * sizeof(float)));
-  A3D_HIP_TRY(hipMalloc((void**)&t->d_leaves, n_slots * sizeof(float4)));
-  A3D_HIP_TRY(hipMalloc((void**)&t->d_slot_of_point, (size_t)n * sizeof(uint32_t)));
+  {  // the tree's three arrays in ONE allocation (hipMalloc synchronises the device): leaves first (16-byte records)
+    auto pad256 = [](size_t b) { return ((b + 255) / 256) * 256; };
+    const size_t leaves_b = pad256(n_slots * sizeof(float4)), split_b = pad256(std::max<size_t>(1, (size_t)t->n_split) * 4);
+    char* block = nullptr;
+    A3D_HIP_TRY(hipMalloc((void**)&block, leaves_b + split_b + (size_t)n * sizeof(uint32_t)));
+    t->d_block = block;
+    t->d_leaves = (float4*)block;
+    t->d_split = (float*)(block + leaves_b);
+    t->d_slot_of_point = (uint32_t*)(block + leaves_b + split_b);
+  }
   A3D_HIP_TRY(hipMemsetAsync(t->d_split, 0, std::max<size_t>(1, (size_t)t->n_split) * sizeof(float), s));
   hipLaunchKernelGGL(fill_leaves_kernel, grid_for(n_slots), dim3(256), 0, s, t->d_leaves, n_slots);
 
@@ -195,12 +219,10 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
   const size_t hist_bytes = pad(kdtree_sort_scratch_bytes(n));
   const size_t total = 2 * pad((size_t)n * 4) + 2 * pad((size_t)n * 8) + 2 * pad(max_nodes * 4) + 256 +
                        pad(sort_bytes) + hist_bytes;
-  char* base = nullptr;
-  A3D_HIP_TRY(hipMalloc((void**)&base, total));
-  struct Free {
-    void* p;
-    ~Free() { hipFree(p); }
-  } guard{base};
+  // temporaries live in the context's grow-only kd-tree scratch region, BEHIND the points the caller staged there
+  char* base = (char*)ctx->scratch[2] + pad((size_t)n * 12);
+  A3D_REQUIRE(ctx->scratch[2] && ctx->scratch_size[2] >= pad((size_t)n * 12) + total, A3D_INVALID_PARAMETER,
+              "internal: kd-tree scratch region too small");
   uint32_t* idx_a = (uint32_t*)base;
   uint32_t* idx_b = (uint32_t*)(base + pad((size_t)n * 4));
   char* keys_a = base + 2 * pad((size_t)n * 4);
