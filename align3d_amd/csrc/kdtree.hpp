@@ -219,47 +219,64 @@ __device__ __forceinline__ void kd_row_argmin(unsigned d, unsigned row_shift, un
 
 // Cooperative leaf scan: the 64 queries of a wave are served 4 at a time, 16 lanes per query, one leaf slot per
 // lane, so a wave-wide load touches 4 leaves = 8 cache lines instead of 64 lanes x 1 line each.
-// In: base/q of THIS lane's query (leaf byte offsets fit 32 bits: max_depth <= 23 is checked on the host).
-// Out: this lane's winner (slot index, distance); the caller re-reads the winning record where it needs it.
-// Every lane of the wave must be active.
+// Split in two so that a kernel can put other work (the descent of its NEXT query) between the loads and their use:
+//   KdScan sc(leaves, base);  sc.issue_first();  ...other work...  sc.finish(q, &slot, &dist);
+// base / q belong to THIS lane's query (leaf byte offsets fit 32 bits: max_depth <= 23 is checked on the host); the
+// caller re-reads the winning record by slot where it needs it.  Every lane of the wave must be active.
+struct KdScan {
+  const char* lbase;
+  unsigned sub, row_shift, base, base_off, sub_off;
+  float4 p[8];
+
+  __device__ __forceinline__ KdScan(const float4* __restrict__ leaves, uint32_t base_) {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    lbase = (const char*)leaves;
+    sub = lane & 15u, row_shift = lane & 48u;
+    base = base_, base_off = base_ * 16u, sub_off = sub * 16u;  // bytes
+  }
+  template <int J>
+  __device__ __forceinline__ float4 load() const {
+    return *(const float4*)(lbase + (size_t)(row_bcast_u<J>(base_off) + sub_off));
+  }
+  // rounds 0..7: all eight loads in flight
+  __device__ __forceinline__ void issue_first() {
+    p[0] = load<0>(), p[1] = load<1>(), p[2] = load<2>(), p[3] = load<3>();
+    p[4] = load<4>(), p[5] = load<5>(), p[6] = load<6>(), p[7] = load<7>();
+  }
+  template <int J>
+  __device__ __forceinline__ void round(const float4& P, V3 q, unsigned& my_d, unsigned& my_slot) const {
+    const V3 c{P.x, P.y, P.z};
+    const float df = norm_squared(V3{row_bcast_f<J>(q.x), row_bcast_f<J>(q.y), row_bcast_f<J>(q.z)} - c);
+    // `dist < min_dist` from f32::MAX: NaN, +inf and f32::MAX itself can never win; rank them last
+    const unsigned d = (df < KD_F32_MAX) ? __float_as_uint(df) : 0x7F800000u;
+    unsigned m, s;
+    kd_row_argmin(d, row_shift, &m, &s);
+    const bool mine = sub == (unsigned)J;
+    // all 16 candidates lost: the reference returns slot 0 and f32::MAX (ctz gave 0 already)
+    my_d = mine ? min(m, __float_as_uint(KD_F32_MAX)) : my_d;
+    my_slot = mine ? s : my_slot;
+  }
+  __device__ __forceinline__ void finish(V3 q, uint32_t* out_slot, float* out_dist) {
+    unsigned my_d = __float_as_uint(KD_F32_MAX), my_slot = 0;
+    round<0>(p[0], q, my_d, my_slot), round<1>(p[1], q, my_d, my_slot), round<2>(p[2], q, my_d, my_slot);
+    round<3>(p[3], q, my_d, my_slot), round<4>(p[4], q, my_d, my_slot), round<5>(p[5], q, my_d, my_slot);
+    round<6>(p[6], q, my_d, my_slot), round<7>(p[7], q, my_d, my_slot);
+    p[0] = load<8>(), p[1] = load<9>(), p[2] = load<10>(), p[3] = load<11>();
+    p[4] = load<12>(), p[5] = load<13>(), p[6] = load<14>(), p[7] = load<15>();
+    round<8>(p[0], q, my_d, my_slot), round<9>(p[1], q, my_d, my_slot), round<10>(p[2], q, my_d, my_slot);
+    round<11>(p[3], q, my_d, my_slot), round<12>(p[4], q, my_d, my_slot), round<13>(p[5], q, my_d, my_slot);
+    round<14>(p[6], q, my_d, my_slot), round<15>(p[7], q, my_d, my_slot);
+    *out_slot = base + my_slot;
+    *out_dist = __uint_as_float(my_d);
+  }
+};
+
+// The scan in one piece.
 __device__ __forceinline__ void kdtree_scan_leaves_coop(const float4* __restrict__ leaves, uint32_t base, V3 q,
                                                         uint32_t* out_slot, float* out_dist) {
-  const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const unsigned sub = lane & 15u, row_shift = lane & 48u;
-  const unsigned base_off = base * 16u, sub_off = sub * 16u;  // bytes
-  const unsigned f32_max = __float_as_uint(KD_F32_MAX), f32_inf = 0x7F800000u;
-  unsigned my_d = f32_max, my_slot = 0;
-  const char* lbase = (const char*)leaves;
-#define A3D_KD_ROUND(J, P)                                                                          \
-  {                                                                                                 \
-    const V3 c{P.x, P.y, P.z};                                                                      \
-    const float df = norm_squared(V3{row_bcast_f<J>(q.x), row_bcast_f<J>(q.y), row_bcast_f<J>(q.z)} - c); \
-    /* `dist < min_dist` from f32::MAX: NaN, +inf and f32::MAX itself can never win; rank them last */ \
-    const unsigned d = (df < KD_F32_MAX) ? __float_as_uint(df) : f32_inf;                           \
-    unsigned m, s;                                                                                  \
-    kd_row_argmin(d, row_shift, &m, &s);                                                            \
-    const bool mine = sub == (unsigned)(J);                                                         \
-    /* all 16 candidates lost: the reference returns slot 0 and f32::MAX (ctz gave 0 already) */    \
-    my_d = mine ? min(m, f32_max) : my_d;                                                           \
-    my_slot = mine ? s : my_slot;                                                                   \
-  }
-#define A3D_KD_LOAD(J) (*(const float4*)(lbase + (size_t)(row_bcast_u<J>(base_off) + sub_off)))
-  {  // eight rounds at a time: all eight loads are in flight before the first reduction
-    const float4 p0 = A3D_KD_LOAD(0), p1 = A3D_KD_LOAD(1), p2 = A3D_KD_LOAD(2), p3 = A3D_KD_LOAD(3);
-    const float4 p4 = A3D_KD_LOAD(4), p5 = A3D_KD_LOAD(5), p6 = A3D_KD_LOAD(6), p7 = A3D_KD_LOAD(7);
-    A3D_KD_ROUND(0, p0) A3D_KD_ROUND(1, p1) A3D_KD_ROUND(2, p2) A3D_KD_ROUND(3, p3)
-    A3D_KD_ROUND(4, p4) A3D_KD_ROUND(5, p5) A3D_KD_ROUND(6, p6) A3D_KD_ROUND(7, p7)
-  }
-  {
-    const float4 p0 = A3D_KD_LOAD(8), p1 = A3D_KD_LOAD(9), p2 = A3D_KD_LOAD(10), p3 = A3D_KD_LOAD(11);
-    const float4 p4 = A3D_KD_LOAD(12), p5 = A3D_KD_LOAD(13), p6 = A3D_KD_LOAD(14), p7 = A3D_KD_LOAD(15);
-    A3D_KD_ROUND(8, p0) A3D_KD_ROUND(9, p1) A3D_KD_ROUND(10, p2) A3D_KD_ROUND(11, p3)
-    A3D_KD_ROUND(12, p4) A3D_KD_ROUND(13, p5) A3D_KD_ROUND(14, p6) A3D_KD_ROUND(15, p7)
-  }
-#undef A3D_KD_LOAD
-#undef A3D_KD_ROUND
-  *out_slot = base + my_slot;
-  *out_dist = __uint_as_float(my_d);
+  KdScan sc(leaves, base);
+  sc.issue_first();
+  sc.finish(q, out_slot, out_dist);
 }
 
 }  // namespace a3d
