@@ -261,3 +261,51 @@ def test_threaded_normals_equal_the_sequential_loop():
     for threads in (2, 5, 16):
         assert np.array_equal(O.compute_normals(fr.points, fr.mask, threads=threads).view(np.uint32),
                               fr.normals.view(np.uint32))
+
+
+# ---- the oracle against a second, independently written restatement (tests/numpy_restatement.py) ----------------
+
+def test_two_restatements_agree_on_the_bilateral_filter_bit_for_bit():
+    import numpy_restatement as NP
+
+    s = SlamTbSample("sample1")
+    depth, _ = s.load(4)
+    crop = np.ascontiguousarray(depth[100:292, 200:456])  # 192 x 256 of real depth with holes and edges
+    st, ref, dims = O.bilateral(crop)
+    got, gdims = NP.bilateral_filter_u16(crop)
+    assert st == 0 and gdims == dims and np.array_equal(got, ref)
+    img = bloei_luma16()[150:330, 100:300]                # the reference's KAT image, other sigmas
+    st, ref, dims = O.bilateral(img, 4.5, 30.0)
+    got, gdims = NP.bilateral_filter_u16(img, 4.5, 30.0)
+    assert st == 0 and gdims == dims and np.array_equal(got, ref)
+
+
+def test_two_restatements_agree_on_the_normals_bit_for_bit():
+    import numpy_restatement as NP
+
+    for sample, frame in (("sample1", 0), ("sample2", 1)):
+        s = SlamTbSample(sample)
+        fr = O.build_frame(*s.load(frame), *s.intrinsics(frame), s.depth_scale(frame))
+        got = NP.compute_normals(fr.points, fr.mask)
+        assert np.array_equal(got.view(np.uint32), fr.normals.view(np.uint32)), sample
+
+
+@pytest.mark.parametrize("which", ["default", "msdefault"])
+def test_two_restatements_agree_on_the_image_icp_pixel_loop(which):
+    """Inlier counts exact; H, g, sum r^2 of both terms equal to f64 round-off (the per-sample f32 values are the
+    same numbers in both restatements, only the order of the f64 additions differs)."""
+    import numpy_restatement as NP
+
+    s = SlamTbSample("sample1")
+    ft = O.build_frame(*s.load(0), *s.intrinsics(0), s.depth_scale(0))
+    fs = O.build_frame(*s.load(5), *s.intrinsics(5), s.depth_scale(5))
+    prm = O.params() if which == "default" else O.ms_default_params()[0]
+    for T in (O.pose(), O.exp_se3(np.array([0.004, -0.003, 0.002, 0.003, 0.002, -0.004], np.float32))):
+        st, g_ref, c_ref = O.image_icp_accumulate(prm, ft, fs, T, accum_f64=True)
+        assert st == 0
+        rg, Jg, rc, Jc = NP.image_icp_terms(prm, ft, fs, np.array(T.t[:], np.float32), np.array(T.q[:], np.float32))
+        for (r, J), ref in (((rg, Jg), g_ref.as_dict()), ((rc, Jc), c_ref.as_dict())):
+            H, g, ssq, count = NP.gn_sums(r, J)
+            assert count == ref["count"] and count > 100000
+            assert np.allclose(H, ref["H"], rtol=2e-7, atol=0) and np.allclose(g, ref["g"], rtol=2e-6, atol=1e-9)
+            assert abs(ssq - float(ref["ssq"])) <= 2e-7 * ssq
