@@ -49,14 +49,24 @@ inline void check(a3d_status s) {
 class Context {
  public:
   explicit Context(int device_index = 0) { check(a3d_context_create(device_index, &ctx_)); }
-  ~Context() { a3d_context_destroy(ctx_); }
+  /// A context owned by someone else (MultiContext::device): used like any other, not destroyed here.
+  static Context borrowed(a3d_context* raw) {
+    Context c(raw, false);
+    return c;
+  }
+  Context(Context&& o) noexcept : ctx_(o.ctx_), owned_(o.owned_) { o.ctx_ = nullptr; }
+  ~Context() {
+    if (owned_ && ctx_) a3d_context_destroy(ctx_);
+  }
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   a3d_context* raw() const { return ctx_; }
   void synchronize() const { check(a3d_context_synchronize(ctx_)); }
 
  private:
+  Context(a3d_context* raw, bool owned) : ctx_(raw), owned_(owned) {}
   a3d_context* ctx_ = nullptr;
+  bool owned_ = true;
 };
 
 /// Transform = Isometry3<f32>: translation + unit quaternion (i, j, k, w).
@@ -216,6 +226,22 @@ class RangeImageBuilder {
     for (a3d_device_image* im : raw) out.emplace_back(im);
     return out;
   }
+  /// The same for n frames of one stream (same size and camera) in one launch sequence
+  /// (a3d_range_image_build_pyramids): returns pyramids[frame][level].
+  std::vector<std::vector<RangeImage>> build_many(const CameraIntrinsics& k, const std::vector<const uint16_t*>& depth,
+                                                   const std::vector<const uint8_t*>& rgb, double depth_scale) const {
+    if (depth.size() != rgb.size()) throw InvalidParameter("A3D_INVALID_PARAMETER: one depth and one rgb image per frame");
+    std::vector<std::vector<RangeImage>> out;
+    if (depth.empty()) return out;
+    std::vector<a3d_device_image*> raw(depth.size() * p_.pyramid_levels, nullptr);
+    check(a3d_range_image_build_pyramids(ctx_.raw(), &p_, depth.size(), depth.data(), rgb.data(), k.width, k.height, k.fx,
+                                         k.fy, k.cx, k.cy, depth_scale, raw.data()));
+    for (size_t f = 0; f < depth.size(); ++f) {
+      out.emplace_back();
+      for (uint64_t l = 0; l < p_.pyramid_levels; ++l) out.back().emplace_back(raw[f * p_.pyramid_levels + l]);
+    }
+    return out;
+  }
 
  private:
   const Context& ctx_;
@@ -355,6 +381,70 @@ class MultiscaleAlignBatch {
  private:
   size_t n_pairs_;
   a3d_multiscale_batch* b_ = nullptr;
+  std::vector<int32_t> status_;
+};
+
+/// One context per entry of a device list (a3d_multi_context): device(i) is the context the frames of the pairs
+/// entry i owns are built on (shard(n_pairs, i) tells which pairs those are: contiguous blocks).
+class MultiContext {
+ public:
+  explicit MultiContext(const std::vector<int32_t>& device_ids) {
+    check(a3d_multi_context_create(device_ids.data(), device_ids.size(), &mc_));
+  }
+  ~MultiContext() { a3d_multi_context_destroy(mc_); }
+  MultiContext(const MultiContext&) = delete;
+  MultiContext& operator=(const MultiContext&) = delete;
+  size_t size() const { return a3d_multi_context_size(mc_); }
+  Context device(size_t i) const { return Context::borrowed(a3d_multi_context_device(mc_, i)); }
+  std::pair<uint64_t, uint64_t> shard(uint64_t n_pairs, size_t i) const {
+    uint64_t lo = 0, hi = 0;
+    check(a3d_multi_shard_range(n_pairs, size(), i, &lo, &hi));
+    return {lo, hi};
+  }
+  a3d_multi_context* raw() const { return mc_; }
+
+ private:
+  a3d_multi_context* mc_ = nullptr;
+};
+
+/// P independent MultiscaleAlign jobs over the devices of a MultiContext (a3d_multiscale_batch_new_multi): pyramids in
+/// global pair order, each pair's images resident on the device that owns it; align() gathers every device's poses.
+class MultiscaleAlignMultiBatch {
+ public:
+  MultiscaleAlignMultiBatch(const MultiContext& mc, const MsIcpParams& params,
+                            const std::vector<const std::vector<RangeImage>*>& target_pyramids,
+                            const std::vector<const std::vector<RangeImage>*>& source_pyramids)
+      : n_pairs_(target_pyramids.size()) {
+    if (target_pyramids.size() != source_pyramids.size() || target_pyramids.empty())
+      throw InvalidParameter("A3D_INVALID_PARAMETER: one target and one source pyramid per pair are required");
+    const size_t levels = target_pyramids[0]->size();
+    std::vector<const a3d_device_image*> t, s;
+    for (size_t p = 0; p < n_pairs_; ++p)
+      for (size_t l = 0; l < levels; ++l) {
+        t.push_back(target_pyramids[p]->at(l).raw());
+        s.push_back(source_pyramids[p]->at(l).raw());
+      }
+    auto prm = params.to_c();
+    check(a3d_multiscale_batch_new_multi(mc.raw(), prm.data(), prm.size(), n_pairs_, levels, t.data(), s.data(), &b_));
+  }
+  ~MultiscaleAlignMultiBatch() { a3d_multiscale_multi_batch_free(b_); }
+  MultiscaleAlignMultiBatch(const MultiscaleAlignMultiBatch&) = delete;
+  MultiscaleAlignMultiBatch& operator=(const MultiscaleAlignMultiBatch&) = delete;
+  /// One Transform per pair; matrices (nullable) receives the gathered [n_pairs][16] row-major 4x4 poses.
+  std::vector<Transform> align(std::vector<float>* matrices = nullptr) {
+    std::vector<a3d_pose> poses(n_pairs_);
+    status_.assign(n_pairs_, 0);
+    if (matrices) matrices->assign(n_pairs_ * 16, 0.0f);
+    check(a3d_multiscale_multi_batch_align(b_, poses.data(), matrices ? matrices->data() : nullptr, status_.data(), nullptr));
+    std::vector<Transform> out;
+    for (const a3d_pose& p : poses) out.push_back(Transform::from_c(p));
+    return out;
+  }
+  const std::vector<int32_t>& status() const { return status_; }
+
+ private:
+  size_t n_pairs_;
+  a3d_multiscale_multi_batch* b_ = nullptr;
   std::vector<int32_t> status_;
 };
 

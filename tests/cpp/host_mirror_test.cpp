@@ -106,6 +106,27 @@ int main(int argc, char** argv) {
       EXPECT(false);
     } catch (const InvalidParameter&) {
     }
+    // the batched builder and the device-list batch: three frames (frame 1 shifted), two pairs over the list {0, 0}
+    std::vector<uint16_t> depth1(depth);
+    for (auto& d : depth1) d = (uint16_t)(d + 7);
+    MultiContext mc({0, 0});
+    EXPECT(mc.size() == 2 && mc.shard(2, 0).first == 0 && mc.shard(2, 0).second == 1 && mc.shard(2, 1).first == 1);
+    Context c0 = mc.device(0), c1 = mc.device(1);
+    RangeImageBuilder b0(c0), b1(c1);
+    b0.with_bilateral_filter(&bf2).pyramid_levels(2);
+    b1.with_bilateral_filter(&bf2).pyramid_levels(2);
+    // pair 0 = frames (0, 1) on entry 0, pair 1 = frames (1, 2) on entry 1
+    auto f01 = b0.build_many(k, {depth.data(), depth1.data()}, {rgb.data(), rgb.data()}, 0.001);
+    auto f12 = b1.build_many(k, {depth1.data(), depth.data()}, {rgb.data(), rgb.data()}, 0.001);
+    EXPECT(f01.size() == 2 && f01[0].size() == 2 && f12[1][1].width() == 32);
+    MultiscaleAlignMultiBatch mb(mc, prm, {&f01[0], &f12[0]}, {&f01[1], &f12[1]});
+    std::vector<float> mats;
+    std::vector<Transform> Tm = mb.align(&mats);
+    EXPECT(Tm.size() == 2 && mb.status()[0] == 0 && mb.status()[1] == 0 && mats.size() == 32);
+    auto many = builder.build_many(k, {depth.data(), depth1.data()}, {rgb.data(), rgb.data()}, 0.001);
+    Transform ref01 = MultiscaleAlign(ctx, prm, many[0]).align(many[1]);
+    for (int i = 0; i < 3; ++i) EXPECT(std::fabs(Tm[0].translation[i] - ref01.translation[i]) < 2e-6f);
+    EXPECT(std::fabs(mats[3] - Tm[0].translation[0]) < 1e-6f && std::fabs(mats[16 + 7] - Tm[1].translation[1]) < 1e-6f);
   }
   std::printf("host mirror GPU checks OK\n");
   return 0;
