@@ -83,6 +83,9 @@ struct a3d_context {
   // Guarded by a mutex because an image may be freed from another thread than the one building frames.
   std::mutex pool_mutex;
   std::vector<std::pair<void*, size_t>> arena_pool;
+  // every arena that is its own hipMalloc (pooled or held by live images): all released with the context, so that
+  // images still alive at a3d_context_destroy do not leak device memory (they must not be used afterwards)
+  std::vector<void*> single_arenas;
   // Arenas are carved out of slabs of SLAB_ARENAS at a time (one hipMalloc, i.e. one device-wide synchronisation,
   // per 16 frames instead of per frame); slices return to the pool and the slabs live as long as the context.
   std::vector<void*> arena_slabs;

@@ -99,9 +99,18 @@ static bool in_slab(const a3d_context* ctx, const void* p, size_t slab_stride_un
 
 // Frees every pooled arena that is a single allocation (slab slices stay): called when a hipMalloc fails, so that
 // memory parked in the pool is not the reason for an out-of-memory status.
+static void forget_single_locked(a3d_context* ctx, void* p) {
+  for (size_t i = 0; i < ctx->single_arenas.size(); ++i)
+    if (ctx->single_arenas[i] == p) {
+      ctx->single_arenas.erase(ctx->single_arenas.begin() + (long)i);
+      return;
+    }
+}
+
 static void trim_pool_locked(a3d_context* ctx) {
   for (size_t i = 0; i < ctx->arena_pool.size();) {
     if (!in_slab(ctx, ctx->arena_pool[i].first)) {
+      forget_single_locked(ctx, ctx->arena_pool[i].first);
       hipFree(ctx->arena_pool[i].first);
       ctx->arena_pool.erase(ctx->arena_pool.begin() + (long)i);
     } else {
@@ -155,6 +164,7 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
     trim_pool_locked(ctx);  // give back what the pool holds, then try once more
     A3D_HIP_TRY(hipMalloc(&out->base, bytes));
   }
+  ctx->single_arenas.push_back(out->base);
   out->bytes = bytes;
   out->slab_slice = false;
   return A3D_OK;
@@ -176,7 +186,13 @@ void ctx_arena_release(a3d_context* ctx, DeviceArena* arena) {
       arena->base = nullptr;
     }
   }
-  if (arena->base) hipFree(arena->base);
+  if (arena->base) {
+    {
+      std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+      forget_single_locked(ctx, arena->base);
+    }
+    hipFree(arena->base);
+  }
   arena->base = nullptr;
 }
 
@@ -239,8 +255,7 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   for (hipEvent_t e : ctx->copy_events) hipEventDestroy(e);
   hipStreamDestroy(ctx->copy_stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
-  for (auto& a : ctx->arena_pool)
-    if (!in_slab(ctx, a.first)) hipFree(a.first);
+  for (void* a : ctx->single_arenas) hipFree(a);  // pooled ones and those of images that are still alive
   for (void* slab : ctx->arena_slabs) hipFree(slab);
   for (auto& t : ctx->tables) hipFree(t.d);
   if (ctx->pinned_words) hipHostFree(ctx->pinned_words);

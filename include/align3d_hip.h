@@ -132,6 +132,8 @@ const char* a3d_status_string(a3d_status s);
 
 /* Binds HIP device `device_index`, creates the context's stream. A3D_HIP_ERROR if there is no GPU. */
 a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx);
+/* Releases the context's stream, scratch regions and every pyramid arena, including those of images that are still
+ * alive: images (and the objects that borrow them) must not be used after their context has been destroyed. */
 a3d_status a3d_context_destroy(a3d_context* ctx);
 a3d_status a3d_context_synchronize(a3d_context* ctx);
 /* The context's hipStream_t, for callers that want to order their own work after ours. */

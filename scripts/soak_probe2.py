@@ -1,23 +1,82 @@
+"""Device memory in use before / after hundreds of cycles of every object that allocates: batches, trees, Icp,
+batched frame builds (arena pool and slabs), the multi-device batch, odometry.  Growth after the first cycles = a leak."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from align3d_amd import Context, IcpParams, MsIcpParams, MultiscaleAlignBatch, R3dTree
+from align3d_amd import (BilateralFilter, Context, Icp, IcpParams, MsIcpParams, MultiContext, MultiscaleAlignBatch,
+                         MultiscaleAlignMultiBatch, PointCloud, R3dTree, RangeImageBuilder, SyntheticDataset, run_odometry, synth)
 from bench import build_stream_pyramids
+
+
 def used():
-    torch.cuda.synchronize(); free, total = torch.cuda.mem_get_info(); return (total - free) / 2**20
+    torch.cuda.synchronize()
+    free, total = torch.cuda.mem_get_info()
+    return (total - free) / 2**20
+
+
+def cycle(label, fn, groups=4, reps=25):
+    fn()
+    fn()
+    m = used()
+    for k in range(groups):
+        for _ in range(reps):
+            fn()
+        print(f"{label} x{reps * (k + 1)}: {used() - m:+.1f} MiB", flush=True)
+
+
 ctx = Context(0)
 pyr, _, _ = build_stream_pyramids(ctx, 5, 17, 640, 480)
 prm = MsIcpParams.repeat(3, IcpParams.default())
-b = MultiscaleAlignBatch(ctx, prm, pyr[:16], pyr[1:]); b.align(); b.free()
-m0 = used()
-for k in range(5):
-    for rep in range(40):
-        b = MultiscaleAlignBatch(ctx, prm, pyr[:16], pyr[1:]); b.align(); b.free()
-    print(f"batch cycles {40 * (k + 1)}: {used() - m0:+.1f} MiB", flush=True)
+
+
+def batch_cycle():
+    b = MultiscaleAlignBatch(ctx, prm, pyr[:16], pyr[1:])
+    b.align()
+    b.free()
+
+
+cycle("batch new/align/free", batch_cycle)
 pts = np.random.default_rng(0).random((200000, 3), dtype=np.float32)
-R3dTree.new(ctx, pts).free()
-m1 = used()
-for k in range(4):
-    for rep in range(40):
-        R3dTree.new(ctx, pts).free()
-    print(f"tree builds {40 * (k + 1)}: {used() - m1:+.1f} MiB", flush=True)
+cycle("R3dTree new/free", lambda: R3dTree.new(ctx, pts).free())
+nrm = np.random.default_rng(1).normal(size=(200000, 3)).astype(np.float32)
+nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+pc = PointCloud(pts, nrm)
+
+
+def icp_cycle():
+    icp = Icp.new(ctx, IcpParams(max_iterations=2), pc)
+    icp.align(pc)
+    icp.free()
+
+
+cycle("Icp new/align/free", icp_cycle)
+frames, _ = synth.frame_stream(9, 20, 640, 480)
+cam = synth.camera(640, 480)
+bld = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+
+
+def build_cycle():
+    for p in bld.build_many(cam, frames, synth.DEPTH_SCALE):
+        for lv in p:
+            lv.free()
+
+
+cycle("build_many(20 frames)/free", build_cycle, reps=10)
+
+
+def multi_cycle():
+    mc = MultiContext([0, 0])
+    tp, sp = [], []
+    for d in range(2):
+        own = RangeImageBuilder(mc.device(d)).build_many(cam, frames[4 * d:4 * d + 5], synth.DEPTH_SCALE)
+        tp += own[:-1]
+        sp += own[1:]
+    mb = MultiscaleAlignMultiBatch(mc, prm, tp, sp)
+    mb.align()
+    mb.free()
+    mc.close()
+
+
+cycle("MultiContext + multi batch", multi_cycle, reps=5)
+ds = SyntheticDataset(7, 6)
+cycle("run_odometry(6 frames)", lambda: run_odometry(ctx, ds), reps=5)
