@@ -438,9 +438,13 @@ static a3d_status pcl_upload_source(a3d_pcl_icp* icp, const a3d_point_cloud_view
   A3D_REQUIRE(source->normals, A3D_MISSING_FIELD, "Please, the source point cloud should have normals.");
   A3D_REQUIRE(source->points && source->len > 0 && source->len < (1ull << 31), A3D_INVALID_PARAMETER,
               "bad source cloud");
-  const size_t bytes = source->len * 12;
-  A3D_HIP_TRY(hipMalloc((void**)d_pts, bytes));
-  A3D_HIP_TRY(hipMalloc((void**)d_nrm, bytes));
+  // staged in the context's grow-only kd-tree scratch region (idle between tree builds; calls on one context are
+  // serialised and this one is host-synchronous): no hipMalloc / hipFree pair — two device-wide synchronisations — per align
+  const size_t bytes = source->len * 12, stride = ((bytes + 255) / 256) * 256;
+  void* region = nullptr;
+  A3D_TRY(ctx_scratch(icp->ctx, 2, 2 * stride, &region));
+  *d_pts = (float*)region;
+  *d_nrm = (float*)((char*)region + stride);
   A3D_HIP_TRY(hipMemcpyAsync(*d_pts, source->points, bytes, hipMemcpyHostToDevice, icp->ctx->stream));
   A3D_HIP_TRY(hipMemcpyAsync(*d_nrm, source->normals, bytes, hipMemcpyHostToDevice, icp->ctx->stream));
   return A3D_OK;
@@ -492,8 +496,6 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
     st = A3D_HIP_ERROR;
   if (hipStreamSynchronize(s) != hipSuccess && st == A3D_OK) st = A3D_HIP_ERROR;
   if (st == A3D_OK) hipEventElapsedTime(&icp->last_device_ms, icp->ev0, icp->ev1);
-  hipFree(d_pts);
-  hipFree(d_nrm);
   if (st == A3D_HIP_ERROR) set_error("a3d_pcl_icp_align: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   if (st != A3D_OK) return st;
   pose_to_c(h.pose, out_pose);
@@ -521,8 +523,6 @@ a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* 
   if (st == A3D_OK && hipMemcpyAsync(sums, icp->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
     st = A3D_HIP_ERROR;
   if (hipStreamSynchronize(s) != hipSuccess && st == A3D_OK) st = A3D_HIP_ERROR;
-  hipFree(d_pts);
-  hipFree(d_nrm);
   hipFree(d_pose);
   if (st == A3D_HIP_ERROR) set_error("a3d_pcl_icp_accumulate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   if (st != A3D_OK) return st;
