@@ -494,20 +494,57 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const uint32_t w = (uint32_t)width, h = (uint32_t)height, n = w * h;
-  uint16_t *d_img = nullptr, *d_out = nullptr;
+  // image and result staged in the context's grow-only scratch region (no hipMalloc / hipFree per call)
+  const size_t stride = (((size_t)n * 2 + 255) / 256) * 256;
+  void* region = nullptr;
+  A3D_TRY(ctx_scratch(ctx, 0, 2 * stride, &region));
+  uint16_t *d_img = (uint16_t*)region, *d_out = (uint16_t*)((char*)region + stride);
   a3d_status st = A3D_OK;
-  if (hipMalloc((void**)&d_img, n * 2) != hipSuccess || hipMalloc((void**)&d_out, n * 2) != hipSuccess ||
-      hipMemcpyAsync(d_img, image, n * 2, hipMemcpyHostToDevice, s) != hipSuccess) {
+  if (hipMemcpyAsync(d_img, image, (size_t)n * 2, hipMemcpyHostToDevice, s) != hipSuccess) {
     set_error("a3d_bilateral_filter_u16: upload: %s", hipGetErrorString(hipGetLastError()));
     st = A3D_HIP_ERROR;
   }
-  if (st == A3D_OK) st = bilateral_filter_device(ctx, d_img, d_out, w, h, sigma_space, sigma_color, out_grid_dims);
-  if (st == A3D_OK && (hipMemcpyAsync(out_image, d_out, n * 2, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                       hipStreamSynchronize(s) != hipSuccess)) {
-    set_error("a3d_bilateral_filter_u16: download: %s", hipGetErrorString(hipGetLastError()));
-    st = A3D_HIP_ERROR;
+  const char* mode = getenv("A3D_BILATERAL");
+  const bool one_pass = n < (1u << PACK_SHIFT) && !(mode && (!strcmp(mode, "unfused") || !strcmp(mode, "sync")));
+  if (st == A3D_OK && !one_pass) {  // the pass-per-launch path (huge images, cross-check): min / max via the host
+    st = bilateral_filter_device(ctx, d_img, d_out, w, h, sigma_space, sigma_color, out_grid_dims);
+    if (st == A3D_OK && (hipMemcpyAsync(out_image, d_out, n * 2, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                         hipStreamSynchronize(s) != hipSuccess)) {
+      set_error("a3d_bilateral_filter_u16: download: %s", hipGetErrorString(hipGetLastError()));
+      st = A3D_HIP_ERROR;
+    }
+    return st;
   }
-  hipFree(d_img);
-  hipFree(d_out);
+  // One enqueue, no host round trip for min / max: the frame builder's grid path with one frame, then the slice; a
+  // grid that outgrew the scratch region is run again with more room.
+  for (int attempt = 0; st == A3D_OK && attempt < 3; ++attempt) {
+    if (ctx->grid_capacity == 0) ctx->grid_capacity = bilateral_grid_cells(w, h, sigma_space, sigma_color, 4096);
+    GridBatch gb;
+    st = bilateral_grids_enqueue(ctx, d_img, 1, w, h, sigma_space, sigma_color, ctx->grid_capacity, &gb);
+    if (st != A3D_OK) break;
+    const GridDims none{0, 0, 0};
+    hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, 1.0 / sigma_space, 1.0 / sigma_color,
+                       0u, none, (const double2*)gb.blurred, d_out, gb.scal + SC_OVERFLOW, (const uint32_t*)gb.scal);
+    uint32_t* r = ctx->pinned_words;
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(r, gb.scal, SC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(out_image, d_out, (size_t)n * 2, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      set_error("a3d_bilateral_filter_u16: %s", hipGetErrorString(hipGetLastError()));
+      return A3D_HIP_ERROR;
+    }
+    if (r[SC_TOO_BIG]) {
+      const unsigned long long need = (unsigned long long)r[SC_GH] * r[SC_GW] * r[SC_GD];
+      ctx->grid_capacity = need + need / 4;
+      A3D_REQUIRE(attempt < 2, A3D_HIP_ERROR, "a3d_bilateral_filter_u16: the grid kept outgrowing its scratch region");
+      continue;
+    }
+    if (out_grid_dims) out_grid_dims[0] = r[SC_GH], out_grid_dims[1] = r[SC_GW], out_grid_dims[2] = r[SC_GD];
+    if (r[SC_OVERFLOW]) {
+      set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
+      return A3D_CAST_OVERFLOW;
+    }
+    break;
+  }
   return st;
 }

@@ -177,12 +177,12 @@ def test_bilateral_fused_and_unfused_paths_agree(ctx, monkeypatch):
     for img, ss, sc in cases:
         st, ref, dims = O.bilateral(img, ss, sc)
         outs = {}
-        for mode in ("fused", "unfused"):
+        for mode in ("fused", "sync", "unfused"):  # one enqueue / min-max via the host / pass per launch
             monkeypatch.setenv("A3D_BILATERAL", mode)
             f = BilateralFilter.new(ss, sc)
             outs[mode] = f.filter(ctx, img)
             assert f.last_grid_dims == dims
-        assert st == 0 and np.array_equal(outs["fused"], ref) and np.array_equal(outs["unfused"], ref)
+        assert st == 0 and all(np.array_equal(o, ref) for o in outs.values())
 
 
 def test_frames_in_page_locked_host_memory_build_the_same_pyramid(ctx):
