@@ -123,6 +123,7 @@ SIGNATURES = {
     "a3d_last_error": (C.c_char_p, []),
     "a3d_status_string": (C.c_char_p, [C.c_int]),
     "a3d_context_create": (_ST, [C.c_int32, _PP]),
+    "a3d_context_create_with_priority": (_ST, [C.c_int32, C.c_int32, _PP]),
     "a3d_context_destroy": (_ST, [_P]),
     "a3d_context_synchronize": (_ST, [_P]),
     "a3d_context_stream": (_P, [_P]),
@@ -179,6 +180,7 @@ SIGNATURES = {
     "a3d_multiscale_batch_align": (_ST, [_P, C.POINTER(PoseC), _P, C.POINTER(C.c_int32)]),
     "a3d_multiscale_batch_free": (_ST, [_P]),
     "a3d_multiscale_batch_rebind": (_ST, [_P, _P, _P]),
+    "a3d_multiscale_batch_results": (_ST, [_P, C.POINTER(PoseC), C.POINTER(C.c_int32)]),
     "a3d_multiscale_batch_last_timing": (_ST, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "a3d_multiscale_batch_set_profiling": (_ST, [_P, C.c_int32]),
     "a3d_multiscale_batch_last_kernel_ms": (_ST, [_P, C.POINTER(C.c_float)]),

@@ -5,10 +5,13 @@ from . import _abi
 
 
 class Context:
-    def __init__(self, device_index=0):
+    def __init__(self, device_index=0, priority=0):
+        """priority < 0: the device's highest stream priority (a frame-builder context next to an aligning one),
+        0: default, > 0: lowest."""
         self.lib = _abi.load_library()
         self.handle = C.c_void_p()
-        _abi.check(self.lib.a3d_context_create(int(device_index), C.byref(self.handle)), "a3d_context_create")
+        _abi.check(self.lib.a3d_context_create_with_priority(int(device_index), int(priority), C.byref(self.handle)),
+                   "a3d_context_create")
         self.device_index = int(device_index)
         self._sibling = None
 

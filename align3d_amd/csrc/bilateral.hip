@@ -205,45 +205,42 @@ __global__ void __launch_bounds__(256)
 constexpr int BZP = BR + 1;          // z pitch padded to 17 cells: a thread walking a z line does not hit one bank
 constexpr int BCELLS = BR * BR * BZP;  // x 16 B = 68 KiB of LDS
 
-// Two passes of the [1 2 1]/4 blur along one 16-cell line held in registers.  `ok(i)`: cell i is one the reference
-// writes (otherwise it is zero after every pass); `first_has_no_prev`: the line starts at channel 0 of the grid,
-// where the reference's "previous" read aliases an always-zero cell.
-template <typename OK>
-__device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok, bool first_has_no_prev) {
+// Two passes of the [1 2 1] blur along one 16-cell line held in registers, WITHOUT the reference's division by four:
+// the grid starts as integers below 2^40 (u16 sums of fewer than 2^24 pixels), so every value the reference's six
+// passes produce is an integer multiple of 4^-k below 2^40 — exact in f64 — and (prev + next + 2 cur) * 0.25 never
+// rounds.  The kernel therefore carries 4^k times the reference's values (integers below 2^52, equally exact) and
+// scales by 2^-12 once, when it writes the cell: bit-identical, at half the f64 instructions.
+// `ok(i)`: cell i is one the reference writes (otherwise it is zero after every pass).  MASKED = false: the tile
+// lies inside the written box on this axis and the other two, ok is true everywhere (no selects).
+template <bool MASKED, typename OK>
+__device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok) {
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
-    double2 prev = make_double2(0.0, 0.0);  // left of the tile: stale layers, never part of the final 12^3
-    (void)first_has_no_prev;                // (prev starts at zero either way)
+    // left of the tile: stale layers, never part of the final 12^3 (at grid channel 0 the reference's "previous" read
+    // aliases an always-zero cell: also zero)
+    double2 prev = make_double2(0.0, 0.0);
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       const double2 cur = v[i];
       const double2 next = i + 1 < BR ? v[i + 1] : make_double2(0.0, 0.0);
-      double2 o = make_double2(0.0, 0.0);
-      if (ok(i)) {
-        o.x = (prev.x + next.x + 2.0 * cur.x) * 0.25;
-        o.y = (prev.y + next.y + 2.0 * cur.y) * 0.25;
-      }
+      double2 o;
+      o.x = __builtin_fma(2.0, cur.x, prev.x + next.x);  // exact (integers below 2^53): same as (p + n) + 2 c
+      o.y = __builtin_fma(2.0, cur.y, prev.y + next.y);
+      if (MASKED && !ok(i)) o = make_double2(0.0, 0.0);
       v[i] = o;
       prev = cur;
     }
   }
 }
 
-__global__ void __launch_bounds__(256)
-    blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double2* __restrict__ out,
-                      const uint32_t* __restrict__ dyn, unsigned long long capacity,
-                      const uint8_t* __restrict__ tile_flags, uint32_t flags_stride) {
-  __shared__ double2 tile[BCELLS];
-  if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
-  packed += blockIdx.y * capacity;
-  out += blockIdx.y * capacity;
-  if (tile_flags) tile_flags += (size_t)blockIdx.y * flags_stride;
-  if (!dyn_dims(dyn, &g, nullptr)) return;
-  // 1-D launch (the host may not know the dimensions): block -> tile (row, column, channel), channel fastest
-  const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
-  if (blockIdx.x >= tx * ty * tz) return;
-  const int r0 = (int)(blockIdx.x / (ty * tz)) * BT - 2, c0 = (int)((blockIdx.x / tz) % ty) * BT - 2,
-            z0 = (int)(blockIdx.x % tz) * BT - 2;
+// One tile.  `known_occupied`: the tile comes from the splat's list of marked windows; otherwise emptiness is decided
+// from the loaded window.  `zeros_only`: an unmarked first-channel tile, written as zeros (see below).
+__device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const unsigned long long* __restrict__ packed,
+                                          const GridDims g, double2* __restrict__ out, bool known_occupied,
+                                          bool zeros_only) {
+  const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT;
+  const int r0 = (int)(tile_id / (ty * tz)) * BT - 2, c0 = (int)((tile_id / tz) % ty) * BT - 2,
+            z0 = (int)(tile_id % tz) * BT - 2;
   const int gh = (int)g.gh, gw = (int)g.gw, gd = (int)g.gd;
   const int t = (int)threadIdx.x, hi = t >> 4, lo = t & 15;
   // the first channel tile of an empty window is written as zeros (see below), other empty tiles are left alone
@@ -253,14 +250,16 @@ __global__ void __launch_bounds__(256)
       if (gr < gh && gc2 < gw && gz2 < gd) out[((size_t)gr * gw + gc2) * gd + gz2] = make_double2(0.0, 0.0);
     }
   };
-  if (tile_flags && !tile_flags[blockIdx.x]) {  // the splat marked every window it touched: nothing to load
-    if (z0 == -2) write_zeros();
+  if (zeros_only) {
+    write_zeros();
     return;
   }
   auto at = [](int lr, int lc, int lz) { return (lr * BR + lc) * BZP + lz; };
   auto row_ok = [&](int gr) { return gr >= 1 && gr <= gh - 2; };
   auto col_ok = [&](int gc) { return gc >= 1 && gc <= gw - 2; };
   auto chan_ok = [&](int gz) { return gz >= 0 && gz <= gd - 2; };
+  // a tile whose 16^3 window lies inside the box of cells the reference writes needs no masks (block-uniform)
+  const bool inside = r0 >= 1 && r0 + BR - 1 <= gh - 2 && c0 >= 1 && c0 + BR - 1 <= gw - 2 && z0 >= 0 && z0 + BR - 1 <= gd - 2;
   double2 v[BR];
   // ---- axis 0: thread = (column hi, channel lo) owns the 16 rows; read straight from the packed grid -------
   {
@@ -282,12 +281,13 @@ __global__ void __launch_bounds__(256)
     bool mine = false;
 #pragma unroll
     for (int i = 0; i < BR; ++i) mine |= (v[i].x != 0.0) | (v[i].y != 0.0);
-    if (!tile_flags && !__syncthreads_or(mine ? 1 : 0)) {  // (no flags from the splat: decided from the loaded window)
+    if (!known_occupied && !__syncthreads_or(mine ? 1 : 0)) {  // (no list from the splat: decided from the loaded window)
       if (z0 == -2) write_zeros();
       return;
     }
     const bool line_ok = col_ok(gc) && chan_ok(gz) && gz < gd;
-    blur_line_twice(v, [&](int i) { return line_ok && row_ok(r0 + i); }, false);
+    if (inside) blur_line_twice<false>(v, [](int) { return true; });
+    else blur_line_twice<true>(v, [&](int i) { return line_ok && row_ok(r0 + i); });
 #pragma unroll
     for (int i = 0; i < BR; ++i) tile[at(i, hi, lo)] = v[i];
   }
@@ -298,7 +298,8 @@ __global__ void __launch_bounds__(256)
     for (int i = 0; i < BR; ++i) v[i] = tile[at(hi, i, lo)];
     const int gr = r0 + hi, gz = z0 + lo;
     const bool line_ok = row_ok(gr) && chan_ok(gz);
-    blur_line_twice(v, [&](int i) { return line_ok && col_ok(c0 + i); }, false);
+    if (inside) blur_line_twice<false>(v, [](int) { return true; });
+    else blur_line_twice<true>(v, [&](int i) { return line_ok && col_ok(c0 + i); });
 #pragma unroll
     for (int i = 0; i < BR; ++i) tile[at(hi, i, lo)] = v[i];  // same thread rewrites its own line: no barrier before
   }
@@ -311,7 +312,8 @@ __global__ void __launch_bounds__(256)
     const bool line_ok = row_ok(gr) && col_ok(gc);
     // at grid channel 0 the "previous" cell is the aliased zero; inside a tile that is local channel 2 of the
     // first tile (z0 = -2), whose local channels 0 and 1 lie outside the grid and are zero anyway
-    blur_line_twice(v, [&](int i) { return line_ok && chan_ok(z0 + i); }, false);
+    if (inside) blur_line_twice<false>(v, [](int) { return true; });
+    else blur_line_twice<true>(v, [&](int i) { return line_ok && chan_ok(z0 + i); });
 #pragma unroll
     for (int i = 0; i < BR; ++i) tile[at(hi, lo, i)] = v[i];
   }
@@ -321,7 +323,65 @@ __global__ void __launch_bounds__(256)
     const int lz = l % BR, lc = (l / BR) % BR, lr = l / (BR * BR);
     if (lr < 2 || lr >= BR - 2 || lc < 2 || lc >= BR - 2 || lz < 2 || lz >= BR - 2) continue;
     const int gr = r0 + lr, gc = c0 + lc, gz = z0 + lz;
-    if (gr < gh && gc < gw && gz < gd) out[((size_t)gr * gw + gc) * gd + gz] = tile[at(lr, lc, lz)];
+    if (gr < gh && gc < gw && gz < gd) {
+      const double2 c = tile[at(lr, lc, lz)];
+      out[((size_t)gr * gw + gc) * gd + gz] = make_double2(c.x * 0x1p-12, c.y * 0x1p-12);  // six passes x 1/4, exact
+    }
+  }
+}
+
+// Turns the tile flags the splat wrote into two lists per frame: the marked windows (the blur's work) and the
+// unmarked first-channel tiles (written as zeros).  A depth image marks 20-30 % of its tiles; launching one block
+// per TILE made the blur a block-dispatch benchmark (each block holds 68 KiB of LDS, two fit a CU, and an empty one
+// still waits for its slot): 180 us per 16 frames, of which the arithmetic was a third.
+__global__ void __launch_bounds__(256)
+    tile_list_kernel(const uint8_t* __restrict__ tile_flags, uint32_t flags_stride, uint32_t* __restrict__ scal,
+                     uint32_t* __restrict__ lists) {
+  uint32_t* sc = scal + blockIdx.y * SC_STRIDE;
+  GridDims g;
+  if (!dyn_dims(sc, &g, nullptr)) return;
+  const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
+  const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+  const bool in = id < tx * ty * tz;
+  const bool marked = in && tile_flags[(size_t)blockIdx.y * flags_stride + id] != 0;
+  const bool zero = in && !marked && id % tz == 0;
+  uint32_t* work = lists + (size_t)blockIdx.y * 2 * flags_stride;
+  auto append = [&](bool mine, uint32_t* counter, uint32_t* list) {  // one atomic per wave
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+    if (!m) return;
+    const uint32_t lane = __lane_id(), leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, leader);
+    if (mine) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = id;
+  };
+  append(marked, &sc[SC_NLIST], work);
+  append(zero, &sc[SC_NZERO], work + flags_stride);
+}
+
+// grid = (blocks, frames).  With `lists`: every block walks its frame's lists with stride gridDim.x (the launch is
+// sized to the blocks the chip holds at once).  Without: one block per tile, blockIdx.x = tile.
+__global__ void __launch_bounds__(256)
+    blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double2* __restrict__ out,
+                      const uint32_t* __restrict__ dyn, unsigned long long capacity,
+                      const uint32_t* __restrict__ lists, uint32_t flags_stride) {
+  __shared__ double2 tile[BCELLS];
+  if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
+  packed += blockIdx.y * capacity;
+  out += blockIdx.y * capacity;
+  if (!dyn_dims(dyn, &g, nullptr)) return;
+  if (!lists) {
+    // 1-D launch (the host may not know the dimensions): block -> tile (row, column, channel), channel fastest
+    const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
+    if (blockIdx.x < tx * ty * tz) blur_tile(tile, blockIdx.x, packed, g, out, false, false);
+    return;
+  }
+  lists += (size_t)blockIdx.y * 2 * flags_stride;
+  const uint32_t n_work = dyn[SC_NLIST], n_zero = dyn[SC_NZERO];
+  for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {
+    const bool work = j < n_work;
+    blur_tile(tile, work ? lists[j] : lists[flags_stride + (j - n_work)], packed, g, out, true, !work);
+    __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
   }
 }
 
@@ -403,7 +463,7 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
                            g, (unsigned long long*)d_b, (const uint32_t*)nullptr, 0ull, (uint8_t*)nullptr, 0u);
         hipLaunchKernelGGL(blur_fused_kernel,
                            dim3(((g.gd + BT - 1) / BT) * ((g.gw + BT - 1) / BT) * ((g.gh + BT - 1) / BT)), dim3(256), 0, s,
-                           (const unsigned long long*)d_b, g, d_a, (const uint32_t*)nullptr, 0ull, (const uint8_t*)nullptr, 0u);
+                           (const unsigned long long*)d_b, g, d_a, (const uint32_t*)nullptr, 0ull, (const uint32_t*)nullptr, 0u);
       } else {
         hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
                            (double*)d_a);
@@ -455,7 +515,8 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   const uint32_t flags_stride = ((tiles + 255) / 256) * 256;
   // [scalars of every frame][tile flags of every frame]: cleared together
   const size_t scal_only = (((size_t)n_frames * SC_STRIDE * 4 + 255) / 256) * 256;
-  const size_t scal_bytes = scal_only + (size_t)n_frames * flags_stride;
+  const size_t flag_bytes = (size_t)n_frames * flags_stride;
+  const size_t scal_bytes = scal_only + flag_bytes + (size_t)n_frames * 2 * flags_stride * 4;  // + the two tile lists
   capacity += capacity & 1;  // even: every frame's packed grid starts 16-byte aligned
   const size_t packed_bytes = (((size_t)n_frames * capacity * 8 + 255) / 256) * 256;
   void* region = nullptr;
@@ -465,7 +526,8 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   out->packed = (unsigned long long*)((char*)region + scal_bytes);
   out->blurred = (double2*)((char*)out->packed + packed_bytes);
   out->capacity = capacity;
-  A3D_HIP_TRY(hipMemsetAsync(region, 0, scal_bytes, s));
+  uint32_t* lists = (uint32_t*)(flags + flag_bytes);
+  A3D_HIP_TRY(hipMemsetAsync(region, 0, scal_only + flag_bytes, s));
   hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64), n_frames), dim3(256), 0, s, d_depth, n,
                      out->scal, true);
   hipLaunchKernelGGL(dims_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s, out->scal, n_frames, w, h, sigma_space,
@@ -476,9 +538,14 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   const GridDims none{0, 0, 0};
   hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 2047) / 2048, n_frames), dim3(256), 0, s, d_depth, w, h, inv_ss, inv_sc, 0u,
                      none, out->packed, (const uint32_t*)out->scal, capacity, flags, flags_stride);
-  hipLaunchKernelGGL(blur_fused_kernel, dim3(std::max(1u, tiles), n_frames), dim3(256), 0, s,
+  hipLaunchKernelGGL(tile_list_kernel, dim3((std::max(1u, tiles) + 255) / 256, n_frames), dim3(256), 0, s,
+                     (const uint8_t*)flags, flags_stride, out->scal, lists);
+  // two blocks of the blur fit a CU (68 KiB of LDS each): one resident round, shared out over the frames
+  const uint32_t resident = 2u * (uint32_t)std::max(1, ctx->num_cus);
+  const uint32_t per_frame = std::max(8u, std::min(std::max(1u, tiles), (resident + n_frames - 1) / n_frames));
+  hipLaunchKernelGGL(blur_fused_kernel, dim3(per_frame, n_frames), dim3(256), 0, s,
                      (const unsigned long long*)out->packed, none, out->blurred, (const uint32_t*)out->scal, capacity,
-                     (const uint8_t*)flags, flags_stride);
+                     (const uint32_t*)lists, flags_stride);
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }

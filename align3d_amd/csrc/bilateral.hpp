@@ -15,7 +15,8 @@ __device__ __forceinline__ uint32_t f64_as_usize(double x) { return x > 0.0 ? (u
 // Device-side scalars of one filter call.  When a kernel gets a non-null `dyn` pointer, the grid dimensions and the
 // colour minimum come from there instead of from its arguments: the host then enqueues the whole filter without
 // the min/max round trip.  A batch of frames has one block of SC_STRIDE words per frame.
-enum { SC_MIN = 0, SC_MAX = 1, SC_OVERFLOW = 2, SC_GH = 4, SC_GW = 5, SC_GD = 6, SC_TOO_BIG = 7, SC_WORDS = 8 };
+enum { SC_MIN = 0, SC_MAX = 1, SC_OVERFLOW = 2, SC_GH = 4, SC_GW = 5, SC_GD = 6, SC_TOO_BIG = 7, SC_WORDS = 8,
+       SC_NLIST = 8, SC_NZERO = 9 };  // (device only) lengths of the frame's blur tile lists
 constexpr uint32_t SC_STRIDE = 16;  // words between the scalar blocks of consecutive frames (64 B: one per line)
 
 __device__ __forceinline__ bool dyn_dims(const uint32_t* __restrict__ dyn, GridDims* g, uint32_t* color_min) {

@@ -69,6 +69,9 @@ a3d_status compute_normals_device(a3d_context* ctx, const float* d_points, const
                                   uint32_t w, uint32_t h);
 }  // namespace a3d
 
+namespace a3d {
+struct UseFence;
+}
 struct a3d_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -110,6 +113,10 @@ struct a3d_context {
     void* d;
   };
   std::vector<CachedTable> tables;
+  // Everything this context has enqueued on its own stream without waiting for it (a3d_range_image_compute_normals on
+  // a built image): registered with the image's arena like a consumer's fence, so that a3d_range_image_free need not
+  // wait for the whole stream (another thread may be building the next frames on it).
+  std::shared_ptr<a3d::UseFence> self_fence;
 };
 
 namespace a3d {
@@ -145,6 +152,10 @@ struct UseFence {
     std::lock_guard<std::mutex> lock(m);
     if (ev && recorded) hipEventSynchronize(ev);
   }
+  bool wait_on(hipStream_t s) {  // device-side wait: `s` continues after everything recorded so far
+    std::lock_guard<std::mutex> lock(m);
+    return !(ev && recorded) || hipStreamWaitEvent(s, ev, 0) == hipSuccess;
+  }
   void retire() {  // the consumer is gone (it synchronised its streams first)
     std::lock_guard<std::mutex> lock(m);
     if (ev) hipEventDestroy(ev);
@@ -161,6 +172,14 @@ a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void*
 // (up to 128 arenas / 4 GiB per context are kept) or frees it.
 a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out);
 void ctx_arena_release(a3d_context* ctx, DeviceArena* arena);
+}  // namespace a3d
+
+struct a3d_device_image;
+namespace a3d {
+// Registers a consumer's (or an enqueue-only producer's) fence with the arena an image lives in: the arena is not
+// recycled before the fence has passed.  Individually allocated images are released with hipFree, which waits for
+// the device by itself.
+void attach_fence(const a3d_device_image* im, const std::shared_ptr<UseFence>& fence);
 }  // namespace a3d
 
 // One RangeImage in HBM, in the reference's own standard layout (DESIGN.md "Data layout in HBM").

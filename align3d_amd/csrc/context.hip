@@ -170,6 +170,15 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
   return A3D_OK;
 }
 
+void attach_fence(const a3d_device_image* im, const std::shared_ptr<UseFence>& fence) {
+  DeviceArena* a = im ? im->arena : nullptr;
+  if (!a) return;  // individually allocated arrays are released with hipFree, which synchronises the device
+  std::lock_guard<std::mutex> lock(a->fence_mutex);
+  for (const auto& f : a->fences)
+    if (f == fence) return;
+  a->fences.push_back(fence);
+}
+
 void ctx_arena_release(a3d_context* ctx, DeviceArena* arena) {
   {  // consumers on other streams that were enqueued without a host synchronisation must be done with the arena
     std::lock_guard<std::mutex> lock(arena->fence_mutex);
@@ -218,6 +227,10 @@ const char* a3d_status_string(a3d_status s) {
 }
 
 a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx) {
+  return a3d_context_create_with_priority(device_index, 0, out_ctx);
+}
+
+a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priority, a3d_context** out_ctx) {
   A3D_REQUIRE(out_ctx, A3D_INVALID_PARAMETER, "out_ctx is null");
   // A batch runs its pair groups on three streams, odometry adds a builder stream, and a host framework in
   // the same process (PyTorch + RCCL) brings its own.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES
@@ -238,8 +251,14 @@ a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx) {
   hipDeviceProp_t prop;
   A3D_HIP_TRY(hipGetDeviceProperties(&prop, device_index));
   ctx->num_cus = prop.multiProcessorCount;
-  A3D_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  A3D_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  {  // priority < 0: the device's highest stream priority, > 0: its lowest, 0: the default
+    int least = 0, greatest = 0;
+    A3D_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int prio = priority < 0 ? greatest : priority > 0 ? least : 0;
+    A3D_HIP_TRY(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio));
+    A3D_HIP_TRY(hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio));
+  }
+  ctx->self_fence = std::make_shared<UseFence>();
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_start));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_stop));
   A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, a3d_context::PINNED_WORDS * sizeof(uint32_t), hipHostMallocDefault));

@@ -116,7 +116,10 @@ a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* 
 
 a3d_status a3d_range_image_free(a3d_device_image* im) {
   if (!im) return A3D_OK;
-  hipStreamSynchronize(im->ctx->stream);
+  // No wait for the context's stream here: whoever enqueued work on this image without waiting for it registered a
+  // fence with the image's arena (enqueue-only batch alignments, compute_normals below), every other entry point
+  // returns with its work complete, and hipFree (images without an arena) waits for the device by itself.  A thread
+  // building the next frames on this context therefore does not stall the thread that frees the previous ones.
   if (im->arena) {  // arrays live in a shared arena: release it with its last user
     if (--im->arena->refs == 0) {
       ctx_arena_release(im->ctx, im->arena);
@@ -142,6 +145,10 @@ a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
               "this image was built without normals (a3d_builder_params.with_normals = 0)");
   if (!im->normals) A3D_HIP_TRY(hipMalloc((void**)&im->normals, n * 3 * sizeof(float)));
   A3D_TRY(launch_compute_normals(im->ctx, im->points, im->mask, im->normals, im->width, im->height));
+  if (im->arena) {  // enqueue-only: the arena must outlive the launch (a3d_range_image_free)
+    im->ctx->self_fence->record(im->ctx->stream);
+    attach_fence(im, im->ctx->self_fence);
+  }
   im->has_normals = true;
   return A3D_OK;
 }

@@ -654,6 +654,7 @@ struct a3d_multiscale_batch {
   // "every launch this batch has enqueued so far": registered with the arenas of the images the batch reads, so
   // that an image freed after an enqueue-only align (no host synchronisation) is not recycled under the kernels
   std::shared_ptr<UseFence> fence = std::make_shared<UseFence>();
+  std::shared_ptr<UseFence> descs_uploaded = std::make_shared<UseFence>();  // h_descs -> d_descs copy of the last rebind
 
   ~a3d_multiscale_batch() {
     fence->retire();
@@ -698,15 +699,6 @@ a3d_status fill_desc(const a3d_device_image* target, const a3d_device_image* sou
 }
 
 // The image's arena (if it has one) will wait for this batch's launches before it is recycled.
-void attach_fence(const a3d_device_image* im, const std::shared_ptr<UseFence>& fence) {
-  DeviceArena* a = im ? im->arena : nullptr;
-  if (!a) return;  // individually allocated arrays are released with hipFree, which synchronises the device
-  std::lock_guard<std::mutex> lock(a->fence_mutex);
-  for (const auto& f : a->fences)
-    if (f == fence) return;
-  a->fences.push_back(fence);
-}
-
 Gates make_gates(const a3d_icp_params& p) {
   Gates g;
   g.max_distance_sqr = p.max_distance * p.max_distance;
@@ -1016,11 +1008,18 @@ a3d_status batch_collect_timing(a3d_multiscale_batch* b) {
   return A3D_OK;
 }
 
-a3d_status read_results(a3d_multiscale_batch* b, a3d_pose* out_poses, int32_t* out_status, a3d_status* worst) {
+// `behind_fence`: read on the context's copy stream, ordered after the batch's own last enqueue only, so that work
+// enqueued on the context stream since then (the next round of a pipelined stream of batches) is not waited for.
+a3d_status read_results(a3d_multiscale_batch* b, a3d_pose* out_poses, int32_t* out_status, a3d_status* worst,
+                        bool behind_fence = false) {
   const uint32_t P = b->n_pairs;
   std::vector<Pose> poses(P);
   std::vector<int32_t> status(P);
   hipStream_t s = b->ctx->stream;
+  if (behind_fence) {
+    s = b->ctx->copy_stream;
+    A3D_REQUIRE(b->fence->wait_on(s), A3D_HIP_ERROR, "hipStreamWaitEvent failed");
+  }
   A3D_HIP_TRY(hipMemcpyAsync(poses.data(), b->d_poses, P * sizeof(Pose), hipMemcpyDeviceToHost, s));
   A3D_HIP_TRY(hipMemcpyAsync(status.data(), b->d_status, P * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   A3D_HIP_TRY(hipStreamSynchronize(s));
@@ -1256,8 +1255,11 @@ a3d_status a3d_multiscale_batch_rebind(a3d_multiscale_batch* b, const a3d_device
                                        const a3d_device_image* const* source_pyramids) {
   A3D_REQUIRE(b && target_pyramids && source_pyramids, A3D_INVALID_PARAMETER, "null argument");
   A3D_HIP_TRY(hipSetDevice(b->ctx->device));
-  // the descriptors of the previous batch may still be in use by launches that have not run yet
-  A3D_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  // the descriptors may still be in use by THIS batch's launches that have not run yet (or by their upload): wait for
+  // those only — another batch running on the same context keeps running (two batches alternating over a stream of
+  // rounds, the next one rebound and enqueued while the previous one computes)
+  b->fence->wait();
+  b->descs_uploaded->wait();
   const uint32_t P = b->n_pairs, L = b->n_levels;
   for (uint32_t p = 0; p < P; ++p)
     for (uint32_t l = 0; l < L; ++l)
@@ -1265,8 +1267,17 @@ a3d_status a3d_multiscale_batch_rebind(a3d_multiscale_batch* b, const a3d_device
                         &b->h_descs[(size_t)l * P + p]));
   for (size_t k = 0; k < (size_t)P * L; ++k) attach_fence(target_pyramids[k], b->fence), attach_fence(source_pyramids[k], b->fence);
   A3D_TRY(batch_commit_descs(b));
-  A3D_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  b->descs_uploaded->record(b->ctx->stream);
   return A3D_OK;
+}
+
+// Host-synchronous read of the most recent pass's results (after an enqueue-only batch_align): waits for that pass
+// only as far as stream order requires (everything enqueued on the context before this call).
+a3d_status a3d_multiscale_batch_results(a3d_multiscale_batch* b, a3d_pose* out_poses_host, int32_t* out_status_host) {
+  A3D_REQUIRE(b && (out_poses_host || out_status_host), A3D_INVALID_PARAMETER, "null argument");
+  A3D_HIP_TRY(hipSetDevice(b->ctx->device));
+  a3d_status worst;
+  return read_results(b, out_poses_host, out_status_host, &worst, true);
 }
 
 a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* b, a3d_pose* out_poses_host, float* out_matrices_device,

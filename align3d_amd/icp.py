@@ -173,6 +173,16 @@ class MultiscaleAlignBatch:
         """Enqueues one pass without synchronising the host."""
         _abi.check(self.ctx.lib.a3d_multiscale_batch_align(self.handle, None, matrices_device, None))
 
+    def results(self):
+        """(list of Transform, int32 status array) of the most recent pass: waits for that pass only, not for what
+        was enqueued on the context since (another batch's pass)."""
+        poses = (_abi.PoseC * self.n_pairs)()
+        status = np.zeros(self.n_pairs, np.int32)
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_results(self.handle, poses,
+                                                             status.ctypes.data_as(C.POINTER(C.c_int32))),
+                   "a3d_multiscale_batch_results")
+        return [Transform.from_c(p) for p in poses], status
+
     def set_profiling(self, on):
         _abi.check(self.ctx.lib.a3d_multiscale_batch_set_profiling(self.handle, 1 if on else 0))
 

@@ -295,12 +295,12 @@ def named_shapes_bench(ctx, targets, sources):
     return out
 
 
-def streaming_bench(ctx, params, P, W, H, rounds=6, builders=1, pinned=True):
+def streaming_bench(ctx, params, P, W, H, rounds=32, builders=1, pinned=True, builder_priority=-1):
     """End to end from host frames: every round, P + 1 NEW frames (u16 depth + u8 RGB in host memory) are uploaded
-    and built into resident pyramids by `builders` threads, each on its own context (HIP stream + scratch) with ONE
-    batched build call for its share of the frames, while the previous round's P frame pairs are being aligned on the
-    main context.  Reports pairs/s with every frame crossing PCIe and being filtered / back-projected / pyramided
-    exactly once."""
+    and built into resident pyramids by `builders` threads (whole rounds in turn, each thread on its own context = HIP
+    stream + scratch, ONE batched build call per round) running ahead of the alignment, which alternates two batch
+    objects on the main context so that round r is enqueued behind round r-1 without waiting for it.  Reports pairs/s
+    with every frame crossing PCIe and being filtered / back-projected / pyramided exactly once."""
     import threading
 
     frames, _ = synth.frame_stream(4242, P + 1, W, H)  # the same host frames every round: they are rebuilt each time
@@ -312,50 +312,66 @@ def streaming_bench(ctx, params, P, W, H, rounds=6, builders=1, pinned=True):
         all_d[i], all_c[i] = d, rgb
     frames = [(all_d[i], all_c[i]) for i in range(P + 1)]
     cam = synth.camera(W, H)
-    ctxs = [Context(ctx.device_index) for _ in range(builders)]
+    # the builders' streams get the device's highest priority: the build is the dependent chain of the two workloads
+    ctxs = [Context(ctx.device_index, priority=builder_priority) for _ in range(builders)]
     bld = [RangeImageBuilder(c).with_bilateral_filter(BilateralFilter.default()) for c in ctxs]
 
-    def build_round():
-        out = [None] * (P + 1)
-
-        def work(k):  # a contiguous share of the round's frames, ~12 launches per 16 frames
-            lo, hi = (P + 1) * k // builders, (P + 1) * (k + 1) // builders
-            out[lo:hi] = bld[k].build_many(cam, frames[lo:hi], synth.DEPTH_SCALE)
-
-        ts = [threading.Thread(target=work, args=(k,)) for k in range(builders)]
-        for t in ts:
-            t.start()
-        return out, ts
+    def build_round(k=0):  # one batched build call: ~12 launches per 16 frames
+        return bld[k].build_many(cam, frames, synth.DEPTH_SCALE)
 
     def free_round(pyr):
         for lv in (lv for p in pyr for lv in p):
             lv.free()
 
-    cur, ts = build_round()  # warm-up round (scratch, arena pools, code objects)
-    for t in ts:
-        t.join()
-    batch = MultiscaleAlignBatch(ctx, params, cur[:P], cur[1:])
-    batch.align()
-    t0 = time.perf_counter()
-    failed = 0
-    for _ in range(rounds):
-        nxt, ts = build_round()                      # builders work on the next round ...
-        batch.rebind(cur[:P], cur[1:])               # (one batch object for the whole stream: nothing allocated)
-        _, status = batch.align()                    # ... while this round is aligned
-        failed += int(np.count_nonzero(status))
-        for t in ts:
-            t.join()
-        free_round(cur)
-        cur = nxt
-    dt = time.perf_counter() - t0
-    batch.free()
+    for k in range(builders):  # warm-up rounds (scratch, arena pools, code objects)
+        cur = build_round(k)
+        if k + 1 < builders:
+            free_round(cur)
+    # two batch objects alternate: round r is rebound and enqueued behind round r-1 while that one still computes, so
+    # the alignment stream never waits for the host; the builders run one round ahead through a bounded queue
+    batches = [MultiscaleAlignBatch(ctx, params, cur[:P], cur[1:]) for _ in range(2)]
+    for b in batches:
+        b.align()
     free_round(cur)
+    import queue
+
+    # builder k builds rounds k, k + builders, ... (whole rounds, so that the exposed upload of one builder's first
+    # chunk lies under the other builder's kernels), each one round ahead of the alignment
+    built = [queue.Queue(maxsize=1) for _ in range(builders)]
+
+    def producer(k):
+        for _ in range(k, rounds, builders):
+            built[k].put(build_round(k))
+
+    t0 = time.perf_counter()
+    prods = [threading.Thread(target=producer, args=(k,)) for k in range(builders)]
+    for t in prods:
+        t.start()
+    failed, prev = 0, None
+    for r in range(rounds):
+        pyr = built[r % builders].get()
+        b = batches[r % 2]
+        b.rebind(pyr[:P], pyr[1:])                   # (nothing allocated; waits for this batch's own round r-2 only)
+        b.enqueue()
+        if prev is not None:                         # read round r-1 while round r computes
+            _, status = prev[0].results()
+            failed += int(np.count_nonzero(status))
+            free_round(prev[1])
+        prev = (b, pyr)
+    _, status = prev[0].results()
+    failed += int(np.count_nonzero(status))
+    dt = time.perf_counter() - t0
+    for t in prods:
+        t.join()
+    free_round(prev[1])
+    for b in batches:
+        b.free()
     for c in ctxs:
         c.close()
     return {"workload": f"{rounds} rounds of {P} pairs, {P + 1} new frames per round from "
                         f"{'page-locked' if pinned else 'pageable'} host memory, "
-                        f"{builders} builder threads (one batched build call each) overlapping the alignment of the "
-                        f"previous round",
+                        f"{builders} builder threads (whole rounds in turn, one batched build call per round) running "
+                        f"ahead of the alignment, two batch objects alternating (round r enqueued behind round r-1)",
             "pairs_per_s": rounds * P / dt, "frames_built_per_s": rounds * (P + 1) / dt, "failed_pairs": failed}
 
 

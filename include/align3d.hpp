@@ -48,7 +48,10 @@ inline void check(a3d_status s) {
 /// One GPU + one HIP stream; every object below is created on a Context and must not outlive it.
 class Context {
  public:
-  explicit Context(int device_index = 0) { check(a3d_context_create(device_index, &ctx_)); }
+  /// priority < 0: the device's highest stream priority (a frame-builder context beside an aligning one), > 0: lowest.
+  explicit Context(int device_index = 0, int priority = 0) {
+    check(a3d_context_create_with_priority(device_index, priority, &ctx_));
+  }
   /// A context owned by someone else (MultiContext::device): used like any other, not destroyed here.
   static Context borrowed(a3d_context* raw) {
     Context c(raw, false);
@@ -372,6 +375,17 @@ class MultiscaleAlignBatch {
     std::vector<a3d_pose> poses(n_pairs_);
     status_.assign(n_pairs_, 0);
     check(a3d_multiscale_batch_align(b_, poses.data(), nullptr, status_.data()));
+    std::vector<Transform> out;
+    for (const a3d_pose& p : poses) out.push_back(Transform::from_c(p));
+    return out;
+  }
+  /// One pass without synchronising the host; results() reads it (and waits for it alone).  Two batches alternating
+  /// over a stream of rounds — rebind + enqueue the next while the previous computes — keep the GPU busy.
+  void enqueue() { check(a3d_multiscale_batch_align(b_, nullptr, nullptr, nullptr)); }
+  std::vector<Transform> results() {
+    std::vector<a3d_pose> poses(n_pairs_);
+    status_.assign(n_pairs_, 0);
+    check(a3d_multiscale_batch_results(b_, poses.data(), status_.data()));
     std::vector<Transform> out;
     for (const a3d_pose& p : poses) out.push_back(Transform::from_c(p));
     return out;

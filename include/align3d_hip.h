@@ -132,6 +132,10 @@ const char* a3d_status_string(a3d_status s);
 
 /* Binds HIP device `device_index`, creates the context's stream. A3D_HIP_ERROR if there is no GPU. */
 a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx);
+/* The same with a stream priority: < 0 the device's highest, 0 the default, > 0 its lowest.  A frame-builder context
+ * that shares the GPU with a batch alignment wants the highest: its many short kernels are then dispatched ahead of
+ * the alignment's long ones instead of queueing behind them (the build is the dependent chain of the two). */
+a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priority, a3d_context** out_ctx);
 /* Releases the context's stream, scratch regions and every pyramid arena, including those of images that are still
  * alive: images (and the objects that borrow them) must not be used after their context has been destroyed. */
 a3d_status a3d_context_destroy(a3d_context* ctx);
@@ -267,8 +271,13 @@ a3d_status a3d_multiscale_batch_new(a3d_context* ctx, const a3d_icp_params* para
  * out_poses_host == NULL and out_status_host == NULL the call only enqueues (no host sync). */
 a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* batch, a3d_pose* out_poses_host,
                                       float* out_matrices_device, int32_t* out_status_host);
+/* Results of the most recent pass of `batch` (the way to read an enqueue-only batch_align): host-synchronous, but
+ * waits for that pass only, not for work enqueued on the context since (another batch's pass: two batches
+ * alternating over a stream of rounds keep the GPU busy while the host reads the previous round). */
+a3d_status a3d_multiscale_batch_results(a3d_multiscale_batch* batch, a3d_pose* out_poses_host, int32_t* out_status_host);
 /* Points an existing batch at other pyramids (same pair and level counts, same layout as _new): the next
- * batch_align runs on them.  A stream of batches reuses one object and allocates nothing per batch. */
+ * batch_align runs on them.  A stream of batches reuses one object and allocates nothing per batch.  Waits for this
+ * batch's own earlier passes only. */
 a3d_status a3d_multiscale_batch_rebind(a3d_multiscale_batch* batch, const a3d_device_image* const* target_pyramids,
                                        const a3d_device_image* const* source_pyramids);
 a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* batch);

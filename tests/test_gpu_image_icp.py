@@ -616,3 +616,56 @@ def test_batch_is_repeat_identical_with_a_second_process_competing_for_the_gpu(t
         assert "differing_repeats=0" in out and "streams=3" in out, out
     a, b = np.load(tmp_path / "poses0.npy"), np.load(tmp_path / "poses1.npy")
     assert np.array_equal(a, b)
+
+
+def test_two_batches_alternating_over_a_stream_of_rounds():
+    """a3d_multiscale_batch_results: round r is rebound and enqueued on one batch while round r-1 is still computing
+    on the other (same context), then round r-1 is read and its frames freed.  Every round must give exactly what a
+    host-synchronous align of the same frames gives; results() must not be disturbed by the pass enqueued after it."""
+    from align3d_amd import BilateralFilter, Context, RangeImageBuilder, synth
+
+    main, side = Context(0), Context(0)
+    try:
+        P, R = 10, 5
+        cam = synth.camera(640, 480)
+        bld = RangeImageBuilder(side).with_bilateral_filter(BilateralFilter.default())
+        prm = MsIcpParams.repeat(3, IcpParams.default())
+        streams = [synth.frame_stream(700 + r, P + 1, 640, 480)[0] for r in range(R)]
+        want = []
+        for fr in streams:  # the reference results, one synchronous batch per round
+            pyr = bld.build_many(cam, fr, synth.DEPTH_SCALE)
+            b = MultiscaleAlignBatch(main, prm, pyr[:P], pyr[1:])
+            poses, status = b.align()
+            assert not np.any(status)
+            want.append(np.array([list(p.t) + list(p.q) for p in poses], np.float32))
+            b.free()
+            for lv in (lv for p in pyr for lv in p):
+                lv.free()
+        first = bld.build_many(cam, streams[0], synth.DEPTH_SCALE)
+        batches = [MultiscaleAlignBatch(main, prm, first[:P], first[1:]) for _ in range(2)]
+        for lv in (lv for p in first for lv in p):
+            lv.free()
+        prev, got = None, []
+        for r in range(R):
+            pyr = bld.build_many(cam, streams[r], synth.DEPTH_SCALE)
+            b = batches[r % 2]
+            b.rebind(pyr[:P], pyr[1:])
+            b.enqueue()
+            if prev is not None:
+                poses, status = prev[0].results()
+                assert not np.any(status)
+                got.append(np.array([list(p.t) + list(p.q) for p in poses], np.float32))
+                for lv in (lv for p in prev[1] for lv in p):
+                    lv.free()
+            prev = (b, pyr)
+        poses, status = prev[0].results()
+        got.append(np.array([list(p.t) + list(p.q) for p in poses], np.float32))
+        for lv in (lv for p in prev[1] for lv in p):
+            lv.free()
+        for r in range(R):
+            assert np.array_equal(got[r].view(np.uint32), want[r].view(np.uint32)), r
+        for b in batches:
+            b.free()
+    finally:
+        side.close()
+        main.close()
