@@ -195,6 +195,13 @@ __global__ void __launch_bounds__(256)
   if (run) atomicAdd(&grid[run_cell], run);
 }
 
+// BilateralGrid::normalize (grid.rs:90-104) after the pass-per-launch blur: (value, weight) cells -> normalised values.
+__global__ void __launch_bounds__(256)
+    normalize_kernel(const double2* __restrict__ in, double* __restrict__ out, unsigned long long cells) {
+  const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+  if (i < cells) out[i] = normalized_cell(in[i].x, in[i].y);
+}
+
 // The six blur passes (axis 0 twice, axis 1 twice, axis 2 twice; edge_aware_filter.rs:68-114) on one
 // (T+4)^3 tile held in LDS: each pass needs its neighbours along one axis only, so after the two passes of an axis
 // the two outermost layers of the tile along that axis are stale and the central T^3 cells are exactly what six
@@ -202,8 +209,8 @@ __global__ void __launch_bounds__(256)
 // other cell is zero in both of the reference's buffers forever, which is what `interior ? blur : 0` reproduces
 // (cells outside the grid count as such zeros).  One read of the packed grid, one write of the blurred grid:
 // 24 B of HBM traffic per cell instead of 6 x 32 B.
-constexpr int BZP = BR + 1;          // z pitch padded to 17 cells: a thread walking a z line does not hit one bank
-constexpr int BCELLS = BR * BR * BZP;  // x 16 B = 68 KiB of LDS
+constexpr int BZP = BR;               // z pitch: every LDS access of the tile has the channel axis across lanes
+constexpr int BCELLS = BR * BR * BZP;  // x 16 B = 64 KiB of LDS
 
 // Two passes of the [1 2 1] blur along one 16-cell line held in registers, WITHOUT the reference's division by four:
 // the grid starts as integers below 2^40 (u16 sums of fewer than 2^24 pixels), so every value the reference's six
@@ -236,7 +243,7 @@ __device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok) {
 // One tile.  `known_occupied`: the tile comes from the splat's list of marked windows; otherwise emptiness is decided
 // from the loaded window.  `zeros_only`: an unmarked first-channel tile, written as zeros (see below).
 __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const unsigned long long* __restrict__ packed,
-                                          const GridDims g, double2* __restrict__ out, bool known_occupied,
+                                          const GridDims g, double* __restrict__ out, bool known_occupied,
                                           bool zeros_only) {
   const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT;
   const int r0 = (int)(tile_id / (ty * tz)) * BT - 2, c0 = (int)((tile_id / tz) % ty) * BT - 2,
@@ -247,7 +254,7 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
   auto write_zeros = [&]() {
     for (int l = t; l < BT * BT * BT; l += 256) {
       const int gr = r0 + 2 + l / (BT * BT), gc2 = c0 + 2 + (l / BT) % BT, gz2 = l % BT;
-      if (gr < gh && gc2 < gw && gz2 < gd) out[((size_t)gr * gw + gc2) * gd + gz2] = make_double2(0.0, 0.0);
+      if (gr < gh && gc2 < gw && gz2 < gd) out[((size_t)gr * gw + gc2) * gd + gz2] = 0.0;
     }
   };
   if (zeros_only) {
@@ -288,11 +295,42 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
     const bool line_ok = col_ok(gc) && chan_ok(gz) && gz < gd;
     if (inside) blur_line_twice<false>(v, [](int) { return true; });
     else blur_line_twice<true>(v, [&](int i) { return line_ok && row_ok(r0 + i); });
+    // ---- axis 2 (channels) in the same layout: the 16 channels of a (row, column) line sit in the 16 lanes of one
+    // DPP row, so "previous" and "next" are row shifts by one lane (zero shifted in at the ends of the window: stale
+    // layers there, and the reference's aliased always-zero "previous" at grid channel 0).  The axes commute exactly:
+    // every intermediate grid is zero outside the box of written cells, and the arithmetic is exact.
+    {
+      auto shifted = [](double x, bool from_lower_lane) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        int lo32 = (int)(uint32_t)b, hi32 = (int)(uint32_t)(b >> 32);
+        if (from_lower_lane) {  // row_shr:1 = 0x111, bound_ctrl: lanes without a source get 0
+          lo32 = __builtin_amdgcn_update_dpp(0, lo32, 0x111, 0xF, 0xF, true);
+          hi32 = __builtin_amdgcn_update_dpp(0, hi32, 0x111, 0xF, 0xF, true);
+        } else {                // row_shl:1 = 0x101
+          lo32 = __builtin_amdgcn_update_dpp(0, lo32, 0x101, 0xF, 0xF, true);
+          hi32 = __builtin_amdgcn_update_dpp(0, hi32, 0x101, 0xF, 0xF, true);
+        }
+        return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi32 << 32) | (uint32_t)lo32));
+      };
+      const bool lane_ok = col_ok(gc) && chan_ok(gz);
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const bool ok = inside || (lane_ok && row_ok(r0 + i));
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+          const double2 cur = v[i];
+          double2 o;
+          o.x = __builtin_fma(2.0, cur.x, shifted(cur.x, true) + shifted(cur.x, false));
+          o.y = __builtin_fma(2.0, cur.y, shifted(cur.y, true) + shifted(cur.y, false));
+          v[i] = ok ? o : make_double2(0.0, 0.0);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < BR; ++i) tile[at(i, hi, lo)] = v[i];
   }
   __syncthreads();
-  // ---- axis 1: thread = (row hi, channel lo) owns the 16 columns -------------------------------------------
+  // ---- axis 1: thread = (row hi, channel lo) owns the 16 columns; the central 12^3 cells go straight to the grid ----
   {
 #pragma unroll
     for (int i = 0; i < BR; ++i) v[i] = tile[at(hi, i, lo)];
@@ -300,32 +338,15 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
     const bool line_ok = row_ok(gr) && chan_ok(gz);
     if (inside) blur_line_twice<false>(v, [](int) { return true; });
     else blur_line_twice<true>(v, [&](int i) { return line_ok && col_ok(c0 + i); });
+    // (a wave stores 4 rows x 12 channels = four 192-byte runs per column)
+    if (hi >= 2 && hi < BR - 2 && lo >= 2 && lo < BR - 2 && gr < gh && gz < gd) {
 #pragma unroll
-    for (int i = 0; i < BR; ++i) tile[at(hi, i, lo)] = v[i];  // same thread rewrites its own line: no barrier before
-  }
-  __syncthreads();
-  // ---- axis 2: thread = (row hi, column lo) owns the 16 channels -------------------------------------------
-  {
-#pragma unroll
-    for (int i = 0; i < BR; ++i) v[i] = tile[at(hi, lo, i)];
-    const int gr = r0 + hi, gc = c0 + lo;
-    const bool line_ok = row_ok(gr) && col_ok(gc);
-    // at grid channel 0 the "previous" cell is the aliased zero; inside a tile that is local channel 2 of the
-    // first tile (z0 = -2), whose local channels 0 and 1 lie outside the grid and are zero anyway
-    if (inside) blur_line_twice<false>(v, [](int) { return true; });
-    else blur_line_twice<true>(v, [&](int i) { return line_ok && chan_ok(z0 + i); });
-#pragma unroll
-    for (int i = 0; i < BR; ++i) tile[at(hi, lo, i)] = v[i];
-  }
-  __syncthreads();
-  // ---- the central 12^3 cells, written with the channel axis across lanes ------------------------------------
-  for (int l = t; l < BR * BR * BR; l += 256) {
-    const int lz = l % BR, lc = (l / BR) % BR, lr = l / (BR * BR);
-    if (lr < 2 || lr >= BR - 2 || lc < 2 || lc >= BR - 2 || lz < 2 || lz >= BR - 2) continue;
-    const int gr = r0 + lr, gc = c0 + lc, gz = z0 + lz;
-    if (gr < gh && gc < gw && gz < gd) {
-      const double2 c = tile[at(lr, lc, lz)];
-      out[((size_t)gr * gw + gc) * gd + gz] = make_double2(c.x * 0x1p-12, c.y * 0x1p-12);  // six passes x 1/4, exact
+      for (int i = 2; i < BR - 2; ++i) {
+        const int gc = c0 + i;
+        // normalised (grid.rs:90-104): value / weight — the common factor 4^6 cancels exactly — or, where the weight
+        // is zero, the value itself (x 4^-6: the six divisions by four)
+        if (gc < gw) out[((size_t)gr * gw + gc) * gd + gz] = v[i].y > 0.0 ? v[i].x / v[i].y : v[i].x * 0x1p-12;
+      }
     }
   }
 }
@@ -362,7 +383,7 @@ __global__ void __launch_bounds__(256)
 // grid = (blocks, frames).  With `lists`: every block walks its frame's lists with stride gridDim.x (the launch is
 // sized to the blocks the chip holds at once).  Without: one block per tile, blockIdx.x = tile.
 __global__ void __launch_bounds__(256)
-    blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double2* __restrict__ out,
+    blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double* __restrict__ out,
                       const uint32_t* __restrict__ dyn, unsigned long long capacity,
                       const uint32_t* __restrict__ lists, uint32_t flags_stride) {
   __shared__ double2 tile[BCELLS];
@@ -388,7 +409,7 @@ __global__ void __launch_bounds__(256)
 // BilateralGrid::slice (grid.rs:106-130): every pixel, zeros included; num::cast::<f64,u16>
 __global__ void __launch_bounds__(256)
     slice_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
-                 uint32_t color_min, GridDims g, const double2* __restrict__ grid, uint16_t* __restrict__ out,
+                 uint32_t color_min, GridDims g, const double* __restrict__ grid, uint16_t* __restrict__ out,
                  uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ dyn) {
   if (!dyn_dims(dyn, &g, &color_min)) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -463,7 +484,8 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
                            g, (unsigned long long*)d_b, (const uint32_t*)nullptr, 0ull, (uint8_t*)nullptr, 0u);
         hipLaunchKernelGGL(blur_fused_kernel,
                            dim3(((g.gd + BT - 1) / BT) * ((g.gw + BT - 1) / BT) * ((g.gh + BT - 1) / BT)), dim3(256), 0, s,
-                           (const unsigned long long*)d_b, g, d_a, (const uint32_t*)nullptr, 0ull, (const uint32_t*)nullptr, 0u);
+                           (const unsigned long long*)d_b, g, (double*)d_a, (const uint32_t*)nullptr, 0ull,
+                           (const uint32_t*)nullptr, 0u);
       } else {
         hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
                            (double*)d_a);
@@ -475,10 +497,13 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
             hipLaunchKernelGGL(blur_axis_kernel, dim3(blocks), dim3(256), 0, s, src, dst, g, axis);
             std::swap(src, dst);
           }
-        // six passes: the result is back in d_a (== src after the final swap)
+        // six passes: the result is back in d_a (== src after the final swap); normalised into the other buffer
+        hipLaunchKernelGGL(normalize_kernel, dim3((uint32_t)((cells + 255) / 256)), dim3(256), 0, s, (const double2*)src,
+                           (double*)dst, (unsigned long long)cells);
+        src = dst;
       }
       hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
-                         src, d_out, d_scal + 2, (const uint32_t*)nullptr);
+                         (const double*)src, d_out, d_scal + 2, (const uint32_t*)nullptr);
       if (hipGetLastError() != hipSuccess) fail("kernel launch");
     }
     if (st == A3D_OK && (hipMemcpyAsync(h_scal + 2, d_scal + 2, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -520,11 +545,11 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   capacity += capacity & 1;  // even: every frame's packed grid starts 16-byte aligned
   const size_t packed_bytes = (((size_t)n_frames * capacity * 8 + 255) / 256) * 256;
   void* region = nullptr;
-  A3D_TRY(ctx_scratch(ctx, 1, scal_bytes + packed_bytes + (size_t)n_frames * capacity * 16 + 256, &region));
+  A3D_TRY(ctx_scratch(ctx, 1, scal_bytes + packed_bytes + (size_t)n_frames * capacity * 8 + 256, &region));
   out->scal = (uint32_t*)region;
   uint8_t* flags = (uint8_t*)region + scal_only;
   out->packed = (unsigned long long*)((char*)region + scal_bytes);
-  out->blurred = (double2*)((char*)out->packed + packed_bytes);
+  out->blurred = (double*)((char*)out->packed + packed_bytes);
   out->capacity = capacity;
   uint32_t* lists = (uint32_t*)(flags + flag_bytes);
   A3D_HIP_TRY(hipMemsetAsync(region, 0, scal_only + flag_bytes, s));
@@ -591,7 +616,7 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
     if (st != A3D_OK) break;
     const GridDims none{0, 0, 0};
     hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, 1.0 / sigma_space, 1.0 / sigma_color,
-                       0u, none, (const double2*)gb.blurred, d_out, gb.scal + SC_OVERFLOW, (const uint32_t*)gb.scal);
+                       0u, none, (const double*)gb.blurred, d_out, gb.scal + SC_OVERFLOW, (const uint32_t*)gb.scal);
     uint32_t* r = ctx->pinned_words;
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(r, gb.scal, SC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||

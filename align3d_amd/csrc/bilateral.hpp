@@ -29,17 +29,19 @@ __device__ __forceinline__ bool dyn_dims(const uint32_t* __restrict__ dyn, GridD
 
 __device__ __forceinline__ uint32_t clampu(uint32_t v, uint32_t hi) { return v > hi ? hi : v; }
 
-// BilateralGrid::normalize (grid.rs:90-104) folded into the read, then trilinear (grid.rs:132-162)
-__device__ __forceinline__ double cell_value(const double2* __restrict__ grid, GridDims g, uint32_t r, uint32_t c,
-                                             uint32_t z) {
-  const double2 v = grid[((size_t)r * g.gw + c) * g.gd + z];
-  return v.y > 0.0 ? v.x / v.y : v.x;
+// BilateralGrid::normalize (grid.rs:90-104): where weight > 0, value /= weight.  Applied once per cell by whoever
+// writes the blurred grid, which therefore holds ONE f64 per cell (the weight channel is never read again): the slice
+// gathers 8 B per cell and divides nothing, instead of 16 B and eight f64 divisions per pixel.
+__device__ __forceinline__ double normalized_cell(double value, double weight) { return weight > 0.0 ? value / weight : value; }
+// trilinear (grid.rs:132-162) reads the value channel
+__device__ __forceinline__ double cell_value(const double* __restrict__ grid, GridDims g, uint32_t r, uint32_t c, uint32_t z) {
+  return grid[((size_t)r * g.gw + c) * g.gd + z];
 }
 
 // BilateralGrid::slice for one pixel (grid.rs:106-130, trilinear :132-162): every pixel, zeros included.
 // Returns false when the value is not representable as u16 (num::cast::<f64,u16>().unwrap() would panic).
 __device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t c, double inv_ss, double inv_sc,
-                                            uint32_t color_min, GridDims g, const double2* __restrict__ grid,
+                                            uint32_t color_min, GridDims g, const double* __restrict__ grid,
                                             uint16_t* out) {
   const double row = (double)r * inv_ss + 2.0;
   const double col = (double)c * inv_ss + 2.0;
@@ -67,11 +69,11 @@ __device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t
 }
 
 // Where the blurred grids of a batch of frames live (the context's grid scratch region):
-// [n_frames x SC_STRIDE words of scalars][n_frames x capacity packed u64 cells][n_frames x capacity double2 cells]
+// [n_frames x SC_STRIDE words of scalars][n_frames x capacity packed u64 cells][n_frames x capacity f64 cells (normalised values)]
 struct GridBatch {
   uint32_t* scal = nullptr;
   unsigned long long* packed = nullptr;
-  double2* blurred = nullptr;
+  double* blurred = nullptr;
   unsigned long long capacity = 0;  // cells per frame
 };
 

@@ -39,7 +39,7 @@ constexpr int ST_W = 32, ST_H = 16, OWN_W = ST_W - 2, OWN_H = ST_H - 2;
 template <bool FILTER>
 __global__ void __launch_bounds__(ST_W* ST_H)
     level0_kernel(const uint16_t* __restrict__ depth, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
-                  const double2* __restrict__ grids, unsigned long long capacity, uint32_t* __restrict__ scal, float fx,
+                  const double* __restrict__ grids, unsigned long long capacity, uint32_t* __restrict__ scal, float fx,
                   float fy, float cx, float cy, float scale, FrameBases bases, size_t off_points, size_t off_mask,
                   size_t off_normals, bool with_normals) {
   __shared__ float sp[3][ST_H][ST_W + 1];
@@ -201,44 +201,70 @@ struct TapRow {
 };
 
 // imageops::blur + 2x subsample fused: the pyramid keeps only the even rows and columns of the blurred image,
-// so the vertical pass is evaluated at even rows only and never leaves the chip.  One block = one output row x
-// BLUR_TILE output columns: the vertical sums (u8 -> f32, the crate's f32 intermediate) of the source columns
-// this tile's horizontal taps touch go to LDS, then the horizontal pass, clamp and round-half-away (u8) read
-// them back.  Per output the additions run in tap order from 0.0f in both passes, as in the crate.
-constexpr uint32_t BLUR_TILE = 64;
-constexpr uint32_t BLUR_SPAN = 3 * (2 * BLUR_TILE + MAX_TAPS + 2);  // floats of vertical results a tile can need
+// so the vertical pass is evaluated at even rows only and never leaves the chip.  One block = BLUR_ROWS output rows x
+// BLUR_TILE output columns: the source bytes its taps touch are fetched once, as aligned 32-bit words, into LDS
+// (consecutive output rows share all but two of their source rows); the vertical sums (u8 -> f32, the crate's f32
+// intermediate) go to a second LDS array, then the horizontal pass, clamp and round-half-away (u8) read them back.
+// Per output the additions run in tap order from 0.0f in both passes, as in the crate.
+constexpr uint32_t BLUR_TILE = 64, BLUR_ROWS = 4;
+constexpr uint32_t BLUR_SPAN = 3 * (2 * BLUR_TILE + MAX_TAPS + 2);   // bytes / vertical results a tile's row can need
+constexpr uint32_t RAW_ROWS = 2 * (BLUR_ROWS - 1) + MAX_TAPS;        // source rows under BLUR_ROWS output rows
+constexpr uint32_t RAW_PITCH = ((BLUR_SPAN + 3 + 3) / 4) * 4;        // bytes per staged source row (+ alignment slack)
 __global__ void __launch_bounds__(256)
-    blur_halve_kernel(size_t off_src, uint32_t w, uint32_t dw, const TapRow* __restrict__ taps_v,
+    blur_halve_kernel(size_t off_src, uint32_t w, uint32_t dw, uint32_t dh, const TapRow* __restrict__ taps_v,
                       const TapRow* __restrict__ taps_h, size_t off_dst, FrameBases bases) {
-  __shared__ float s_v[BLUR_SPAN];
+  __shared__ uint32_t s_raw[RAW_ROWS * RAW_PITCH / 4];
+  __shared__ float s_v[BLUR_ROWS * BLUR_SPAN];
+  __shared__ uint32_t s_shift[RAW_ROWS];
   const uint8_t* __restrict__ rgb = (const uint8_t*)(bases.arena[blockIdx.z] + off_src);  // blockIdx.z = frame
   uint8_t* __restrict__ out = (uint8_t*)(bases.arena[blockIdx.z] + off_dst);
-  const uint32_t dy = blockIdx.y, dx0 = blockIdx.x * BLUR_TILE, dx1 = min(dx0 + BLUR_TILE, dw) - 1;
-  const TapRow* tv = taps_v + dy;  // row 2*dy of the source (table built with stride 2): block-uniform
-  const int32_t vleft = tv->left, vcount = tv->count;
-  const int32_t cmin = taps_h[dx0].left, cmax = taps_h[dx1].left + taps_h[dx1].count;  // source columns [cmin, cmax)
-  const uint32_t span = (uint32_t)(cmax - cmin) * 3u;
-  for (uint32_t e = threadIdx.x; e < span; e += 256) {
-    const uint8_t* col = rgb + (size_t)vleft * w * 3 + (size_t)cmin * 3 + e;
+  const uint32_t dy0 = blockIdx.y * BLUR_ROWS, rows = min(BLUR_ROWS, dh - dy0);
+  const uint32_t dx0 = blockIdx.x * BLUR_TILE, dx1 = min(dx0 + BLUR_TILE, dw) - 1;
+  // rows [vtop, vbot) and columns [cmin, cmax) of the source under this tile (tap tables: block-uniform reads)
+  const int32_t vtop = taps_v[dy0].left, vbot = taps_v[dy0 + rows - 1].left + taps_v[dy0 + rows - 1].count;
+  const int32_t cmin = taps_h[dx0].left, cmax = taps_h[dx1].left + taps_h[dx1].count;
+  const uint32_t span = (uint32_t)(cmax - cmin) * 3u, nraw = (uint32_t)(vbot - vtop);
+  // ---- the source bytes, whole aligned words per row (the arena's arrays are 256-byte aligned and padded, and the
+  // colour array is never the arena's last, so the word holding a row's last byte may be read) --------------------
+  const uint32_t words = (span + 3 + 3) / 4;  // a row starts 0..3 bytes into its first word
+  for (uint32_t e = threadIdx.x; e < nraw * words; e += 256) {
+    const uint32_t j = e / words, k = e % words;
+    const size_t first = ((size_t)(vtop + (int32_t)j) * w + (size_t)cmin) * 3;
+    s_raw[j * (RAW_PITCH / 4) + k] = *(const uint32_t*)(rgb + (first & ~(size_t)3) + 4 * (size_t)k);
+  }
+  if (threadIdx.x < nraw)  // where in its first word each staged row starts
+    s_shift[threadIdx.x] = (uint32_t)((((size_t)(vtop + (int32_t)threadIdx.x) * w + (size_t)cmin) * 3) & 3);
+  __syncthreads();
+  // ---- vertical pass: rows x span sums (row and taps block-uniform, the bytes of a row across lanes) ----------
+  const uint8_t* raw = (const uint8_t*)s_raw;
+  for (uint32_t r = 0; r < rows; ++r) {
+    const TapRow* tv = taps_v + dy0 + r;  // row 2 * (dy0 + r) of the source (table built with stride 2)
+    const int32_t j0 = tv->left - vtop, vcount = tv->count;
+    for (uint32_t x = threadIdx.x; x < span; x += 256) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int k = 0; k < MAX_TAPS; ++k)
+        if (k < vcount) {
+          const uint32_t j = (uint32_t)(j0 + k);
+          acc += (float)raw[j * RAW_PITCH + s_shift[j] + x] * tv->w[k];
+        }
+      s_v[r * BLUR_SPAN + x] = acc;
+    }
+  }
+  __syncthreads();
+  // ---- horizontal pass: a thread owns one (column, channel) of the tile for all its rows: taps read once ------
+  const uint32_t o = threadIdx.x, dx = dx0 + o / 3, ch = o % 3;
+  if (o >= BLUR_TILE * 3 || dx >= dw) return;
+  const TapRow th = taps_h[dx];
+  const uint32_t h0 = (uint32_t)(th.left - cmin) * 3u + ch;
+  for (uint32_t r = 0; r < rows; ++r) {
     float acc = 0.0f;
 #pragma unroll
     for (int k = 0; k < MAX_TAPS; ++k)
-      if (k < vcount) acc += (float)col[(size_t)k * w * 3] * tv->w[k];
-    s_v[e] = acc;
+      if (k < th.count) acc += s_v[r * BLUR_SPAN + h0 + 3u * (uint32_t)k] * th.w[k];
+    acc = fminf(fmaxf(acc, 0.0f), 255.0f);
+    out[((size_t)(dy0 + r) * dw + dx) * 3 + ch] = (uint8_t)roundf(acc);
   }
-  __syncthreads();
-  const uint32_t o = threadIdx.x;  // over BLUR_TILE * 3 outputs
-  if (o >= BLUR_TILE * 3) return;
-  const uint32_t dx = dx0 + o / 3, ch = o % 3;
-  if (dx >= dw) return;
-  const TapRow* th = taps_h + dx;
-  const int32_t hleft = th->left - cmin, hcount = th->count;
-  float acc = 0.0f;
-#pragma unroll
-  for (int k = 0; k < MAX_TAPS; ++k)
-    if (k < hcount) acc += s_v[(uint32_t)(hleft + k) * 3u + ch] * th->w[k];
-  acc = fminf(fmaxf(acc, 0.0f), 255.0f);
-  out[((size_t)dy * dw + dx) * 3 + ch] = (uint8_t)roundf(acc);
 }
 
 // Tap tables of image::imageops::blur's sampling filter (support 2 sigma, weights renormalised over the
@@ -323,12 +349,12 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
     GridBatch gb;
     A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb));
     hipLaunchKernelGGL(level0_kernel<true>, grid0, dim3(ST_W * ST_H), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
-                       1.0 / prm->sigma_color, (const double2*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
+                       1.0 / prm->sigma_color, (const double*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
                        bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0);
     A3D_HIP_TRY(hipMemcpyAsync(result, gb.scal, (size_t)F * SC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   } else {
     hipLaunchKernelGGL(level0_kernel<false>, grid0, dim3(ST_W * ST_H), 0, s, d_depth, w, h, 0.0, 0.0,
-                       (const double2*)nullptr, 0ull, (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points,
+                       (const double*)nullptr, 0ull, (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points,
                        L0.mask, L0.normals, prm->with_normals != 0);
   }
   // RangeImage::pyramid (structure.rs:342-351): normals exist at level 0 only (builder.rs:79-82), coarser levels
@@ -342,8 +368,8 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
     TapRow *d_tv = nullptr, *d_th = nullptr;
     A3D_TRY(taps_for(ctx, S.h, D.h, sigma, &d_tv));
     A3D_TRY(taps_for(ctx, S.w, D.w, sigma, &d_th));
-    hipLaunchKernelGGL(blur_halve_kernel, dim3((D.w + BLUR_TILE - 1) / BLUR_TILE, D.h, F), dim3(256), 0, s, S.colors, S.w,
-                       D.w, d_tv, d_th, D.colors, bases);
+    hipLaunchKernelGGL(blur_halve_kernel, dim3((D.w + BLUR_TILE - 1) / BLUR_TILE, (D.h + BLUR_ROWS - 1) / BLUR_ROWS, F),
+                       dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
   }
   if (prm->with_intensity)
     hipLaunchKernelGGL(luma_imap_kernel, dim3(((w + 2) * (h + 2) + 255) / 256, (uint32_t)prm->pyramid_levels, F), dim3(256),
