@@ -125,74 +125,150 @@ __global__ void dims_kernel(uint32_t* __restrict__ sc, uint32_t n_frames, uint32
 
 // Clears the cells of each frame's packed grid that its dimensions actually use (a batch's grids are `capacity`
 // cells apart; clearing whole capacities would move several times the bytes).
+// Also fills the frame's colour -> channel table (grid.rs:74: floor((v - min) / sigma_color + 0.5) + 2 for each of the
+// 65 536 values of v, in the splat's own f64 arithmetic): the splat then looks a channel up instead of converting
+// u16 -> f64 -> usize per pixel (conversions run at a quarter of the f64 rate).  The launch has 65 536 threads per frame.
 __global__ void __launch_bounds__(256)
-    clear_packed_kernel(unsigned long long* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity) {
+    clear_packed_kernel(unsigned long long* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
+                        uint32_t* __restrict__ channel_of, double inv_sc) {
   dyn += blockIdx.y * SC_STRIDE;
   grid += blockIdx.y * capacity;
   GridDims g;
-  if (!dyn_dims(dyn, &g, nullptr)) return;
+  uint32_t color_min = 0;
+  if (!dyn_dims(dyn, &g, &color_min)) return;
+  for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < 65536u; v += gridDim.x * 256u)
+    channel_of[blockIdx.y * 65536u + v] = v >= color_min ? f64_as_usize((double)(v - color_min) * inv_sc + 0.5) + 2 : 0u;
   const unsigned long long cells = (unsigned long long)g.gh * g.gw * g.gd;
   ulonglong2* g2 = (ulonglong2*)grid;  // capacity offsets keep 16-byte alignment when capacity is even (it is)
   for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < (cells + 1) / 2; i += gridDim.x * 256ull)
     g2[i] = make_ulonglong2(0ull, 0ull);
 }
 
-// A thread splats EIGHT consecutive pixels (one 16-byte load) and merges runs that fall into the same cell before it
-// issues an atomic: a cell is 4.5 pixels wide and neighbouring depths usually share a channel, so eight pixels cost 2-3
-// atomics instead of 8, and the same-address chains at the L2 get 3x shorter.  Integer adds: any grouping is exact.
+// The splat as a GATHER: a thread owns one (row, column) of the grid — all its channels — and visits the pixels that
+// splat into it: the 4-5 image rows r with floor(r / sigma + 0.5) + 2 == its grid row (grid.rs:60-78) times the 4-5
+// columns likewise, found with the splat's own f64 expression.  Nobody else touches its cells, so the sums are plain
+// read-modify-writes on the cleared grid (no atomics, no same-address chains at the L2), consecutive pixels of one
+// channel are merged in registers first, and neighbouring threads read neighbouring pixels (coalesced).  Integer adds:
+// any grouping is exact.  Also marks the blur tiles whose window holds a cell it wrote.
 __global__ void __launch_bounds__(256)
-    splat_packed_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
-                        uint32_t color_min, GridDims g, unsigned long long* __restrict__ grid,
-                        const uint32_t* __restrict__ dyn, unsigned long long capacity, uint8_t* __restrict__ tile_flags,
-                        uint32_t flags_stride) {
+    splat_packed_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, const uint32_t* __restrict__ row_starts,
+                        const uint32_t* __restrict__ col_starts, double inv_sc, uint32_t color_min, GridDims g,
+                        unsigned long long* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
+                        uint8_t* __restrict__ tile_flags, uint32_t flags_stride, const uint32_t* __restrict__ channel_of) {
   if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
   img += (size_t)blockIdx.y * w * h;
   grid += blockIdx.y * capacity;
   if (tile_flags) tile_flags += (size_t)blockIdx.y * flags_stride;
+  if (channel_of) channel_of += blockIdx.y * 65536u;
   if (!dyn_dims(dyn, &g, &color_min)) return;
   const uint32_t ty = (g.gw + BT - 1) / BT, tz = (g.gd + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
-  // marks the blur tiles whose 16^3 window (12^3 tile + 2 cells of halo) contains the cell: 1 to 8 of them
-  auto mark = [&](uint32_t gr, uint32_t gc, uint32_t gz) {
-    const uint32_t a = gr / BT, b = gc / BT, c = gz / BT, la = gr % BT, lb = gc % BT, lc = gz % BT;
-    const uint32_t a0 = (la < 2 && a > 0) ? a - 1 : a, a1 = (la >= BT - 2 && a + 1 < tx) ? a + 1 : a;
-    const uint32_t b0 = (lb < 2 && b > 0) ? b - 1 : b, b1 = (lb >= BT - 2 && b + 1 < ty) ? b + 1 : b;
-    const uint32_t c0 = (lc < 2 && c > 0) ? c - 1 : c, c1 = (lc >= BT - 2 && c + 1 < tz) ? c + 1 : c;
-    for (uint32_t i = a0; i <= a1; ++i)
-      for (uint32_t j = b0; j <= b1; ++j)
-        for (uint32_t k = c0; k <= c1; ++k) tile_flags[(i * ty + j) * tz + k] = 1;
-  };
-  const uint32_t n = w * h, base = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
-  if (base >= n) return;
-  uint32_t px[8];
-  if (base + 8 <= n && (((uintptr_t)(img + base)) & 15u) == 0) {
-    const uint4 q = *(const uint4*)(img + base);
-    px[0] = q.x & 0xFFFFu, px[1] = q.x >> 16, px[2] = q.y & 0xFFFFu, px[3] = q.y >> 16;
-    px[4] = q.z & 0xFFFFu, px[5] = q.z >> 16, px[6] = q.w & 0xFFFFu, px[7] = q.w >> 16;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) px[k] = base + k < n ? img[base + k] : 0u;
+  // pixels splat into grid rows 2 .. gh - 2 and columns 2 .. gw - 2 (floor(x / sigma + 0.5) <= floor(x / sigma) + 1):
+  // one thread per such (row, column)
+  const uint32_t cols = g.gw - 3, total = (g.gh - 3) * cols, first_id = blockIdx.x * 256u, id = first_id + threadIdx.x;
+  if (first_id >= total) return;
+  // Tile marks go through LDS first: the threads of a frame write ~500 000 marks to the ~1 700 flag bytes of its
+  // tiles, and that many stores to a dozen cache lines queue up at the L2 (they, not the sums, bounded this kernel).
+  // The block's marks fall into a window of tile rows [ia, ib] x all tile columns x all channel tiles = a contiguous
+  // range of the flag array; each set entry is stored once per block.  (Windows beyond MARKS entries: direct stores.)
+  constexpr uint32_t MARKS = 8192;
+  __shared__ uint8_t s_marks[MARKS];
+  const uint32_t last_id = min(first_id + 255u, total - 1u);
+  const uint32_t ra = (first_id / cols + 2) / BT, rb = (last_id / cols + 2) / BT;
+  const uint32_t ia = ra > 0 ? ra - 1 : 0u, ib = min(rb + 1, tx - 1), entries = (ib - ia + 1) * ty * tz;
+  const bool marks_in_lds = tile_flags && entries <= MARKS;
+  if (marks_in_lds) {
+    for (uint32_t e = threadIdx.x; e < entries; e += 256) s_marks[e] = 0;
+    __syncthreads();
   }
-  uint32_t row = base / w, col = base % w;
-  size_t run_cell = ~(size_t)0;
-  unsigned long long run = 0;
+  const bool active = id < total;
+  const uint32_t t_row = active ? id / cols : 0u, t_col = active ? id % cols : 0u, gr = t_row + 2, gc = t_col + 2;
+  // the image rows / columns that splat into this grid row / column: [starts[t], starts[t + 1]) (splat_starts, host);
+  // threads past the end get an empty footprint
+  const uint32_t r_lo = row_starts[t_row], r_hi = active ? row_starts[t_row + 1] : r_lo;
+  const uint32_t c_lo = col_starts[t_col], c_hi = col_starts[t_col + 1];
+  const size_t column = ((size_t)gr * g.gw + gc) * g.gd;
+  // Sums per channel are collected in four register slots (a footprint rarely spans more channels), branch-free per
+  // pixel, and added to the grid at the end with all loads in flight together: anything done per channel CHANGE runs
+  // for the whole wave at almost every pixel position, since some lane changes channel there.
+  constexpr int SLOTS = 4;
+  constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+  uint32_t slot_ch[SLOTS], used = 0;
+  unsigned long long slot_sum[SLOTS];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint32_t color = px[k];
-    if (color != 0) {  // `color <= I::min_value()` (:67); pixels past the image were read as 0
-      const uint32_t grow = f64_as_usize((double)row * inv_ss + 0.5) + 2;
-      const uint32_t gcol = f64_as_usize((double)col * inv_ss + 0.5) + 2;
-      const uint32_t ch = f64_as_usize((double)(color - color_min) * inv_sc + 0.5) + 2;
-      const size_t cell = ((size_t)grow * g.gw + gcol) * g.gd + ch;
-      if (cell != run_cell) {
-        if (run) atomicAdd(&grid[run_cell], run);
-        run_cell = cell, run = 0;
-        if (tile_flags) mark(grow, gcol, ch);
+  for (int q = 0; q < SLOTS; ++q) slot_ch[q] = EMPTY, slot_sum[q] = 0;
+  // the blur tiles whose 16^3 window (12^3 tile + 2 cells of halo) contains a cell of this column: rows and columns
+  // of tiles are the thread's own, the channel tiles depend on the cell
+  const uint32_t ta = gr / BT, tb = gc / BT, la = gr % BT, lb = gc % BT;
+  const uint32_t a0 = (la < 2 && ta > 0) ? ta - 1 : ta, a1 = (la >= BT - 2 && ta + 1 < tx) ? ta + 1 : ta;
+  const uint32_t b0 = (lb < 2 && tb > 0) ? tb - 1 : tb, b1 = (lb >= BT - 2 && tb + 1 < ty) ? tb + 1 : tb;
+  auto flush = [&]() {  // this thread's cells: nobody else reads or writes them
+    unsigned long long old[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) old[q] = slot_ch[q] != EMPTY ? grid[column + slot_ch[q]] : 0ull;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+      if (slot_ch[q] != EMPTY) {
+        grid[column + slot_ch[q]] = old[q] + slot_sum[q];
+        if (tile_flags) {
+          const uint32_t tc = slot_ch[q] / BT, lc = slot_ch[q] % BT;
+          const uint32_t z0 = (lc < 2 && tc > 0) ? tc - 1 : tc, z1 = (lc >= BT - 2 && tc + 1 < tz) ? tc + 1 : tc;
+          for (uint32_t i = a0; i <= a1; ++i)
+            for (uint32_t j = b0; j <= b1; ++j) {
+              if (marks_in_lds) {
+                s_marks[((i - ia) * ty + j) * tz + z0] = 1;
+                s_marks[((i - ia) * ty + j) * tz + z1] = 1;
+              } else {
+                tile_flags[(i * ty + j) * tz + z0] = 1;
+                tile_flags[(i * ty + j) * tz + z1] = 1;
+              }
+            }
+        }
       }
-      run += ((unsigned long long)color << PACK_SHIFT) + 1ull;
+      slot_ch[q] = EMPTY, slot_sum[q] = 0;
     }
-    if (++col == w) col = 0, ++row;
+    used = 0;
+  };
+  // the footprint in patches of UR x UC pixels whose loads are all issued before the first is used (the default
+  // sigma's footprint, 4-5 x 4-5 pixels, is one patch)
+  constexpr uint32_t UR = 5, UC = 6;
+  __shared__ uint16_t s_px[UR * UC][256];  // a thread's patch, parked so that the loop over it stays rolled (the
+                                           // unrolled form is 14 000 instructions: it does not fit the instruction cache)
+  for (uint32_t r0 = r_lo; r0 < r_hi; r0 += UR)
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += UC) {
+#pragma unroll
+      for (uint32_t i = 0; i < UR; ++i)
+#pragma unroll
+        for (uint32_t k = 0; k < UC; ++k) {
+          const bool in = r0 + i < r_hi && c0 + k < c_hi;
+          const uint16_t v = img[in ? (size_t)(r0 + i) * w + (c0 + k) : (size_t)r_lo * w + c_lo];  // (unconditional load)
+          s_px[i * UC + k][threadIdx.x] = in ? v : (uint16_t)0;
+        }
+#pragma unroll 1
+      for (uint32_t j = 0; j < UR * UC; ++j) {
+        const uint32_t color = s_px[j][threadIdx.x];
+        const bool valid = color != 0;  // `color <= I::min_value()` (:67); pixels outside the footprint were parked as 0
+        const uint32_t ch = channel_of ? channel_of[color] : f64_as_usize((double)(color - color_min) * inv_sc + 0.5) + 2;
+        const unsigned long long add = valid ? ((unsigned long long)color << PACK_SHIFT) + 1ull : 0ull;
+        bool hit = false;
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) hit |= slot_ch[q] == ch;
+        if (__builtin_expect(valid && !hit && used == SLOTS, 0)) flush();  // a fifth channel under this footprint: rare
+        const bool fresh = valid && !hit;  // takes the next free slot
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) {
+          const bool take = fresh && used == (uint32_t)q;
+          if (take) slot_ch[q] = ch;
+          slot_sum[q] += (valid && slot_ch[q] == ch) ? add : 0ull;
+        }
+        used += fresh ? 1u : 0u;
+      }
+    }
+  flush();
+  if (marks_in_lds) {
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < entries; e += 256)
+      if (s_marks[e]) tile_flags[ia * ty * tz + e] = 1;
   }
-  if (run) atomicAdd(&grid[run_cell], run);
 }
 
 // BilateralGrid::normalize (grid.rs:90-104) after the pass-per-launch blur: (value, weight) cells -> normalised values.
@@ -425,6 +501,27 @@ __global__ void __launch_bounds__(256)
 namespace a3d {
 
 // The whole filter on device-resident images.  One small host round trip (min / max) sizes the grid.
+// starts[t] = the first image coordinate x <= size with floor(x / sigma + 0.5) >= t (grid.rs:60-78, in the splat's own
+// f64 arithmetic: this file is compiled without contraction for host and device alike), t = 0 .. cells: the pixels
+// that splat into grid row / column t + 2 are [starts[t], starts[t + 1]).  Cached per (size, sigma) on the context.
+a3d_status splat_starts(a3d_context* ctx, uint32_t size, double sigma_space, uint32_t cells, const uint32_t** out) {
+  uint32_t key[4] = {0x53504C54u /* 'SPLT' */, size, 0, 0};
+  memcpy(&key[2], &sigma_space, 8);
+  for (const auto& t : ctx->tables)
+    if (!memcmp(t.key, key, sizeof(key))) {
+      *out = (const uint32_t*)t.d;
+      return A3D_OK;
+    }
+  const double inv_ss = 1.0 / sigma_space;
+  std::vector<uint32_t> starts(cells + 1);
+  uint32_t x = 0;
+  for (uint32_t t = 0; t <= cells; ++t) {
+    while (x < size && f64_as_usize((double)x * inv_ss + 0.5) < t) ++x;
+    starts[t] = x;
+  }
+  return ctx_cached_table(ctx, key, starts.data(), starts.size() * 4, (void**)out);
+}
+
 a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w, uint32_t h,
                                    double sigma_space, double sigma_color, uint64_t out_grid_dims[3]) {
   hipStream_t s = ctx->stream;
@@ -480,8 +577,13 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
       const double inv_ss = 1.0 / sigma_space, inv_sc = 1.0 / sigma_color;
       double2* src = d_a;
       if (fused) {
-        hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 2047) / 2048), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin,
-                           g, (unsigned long long*)d_b, (const uint32_t*)nullptr, 0ull, (uint8_t*)nullptr, 0u);
+        const uint32_t *row_starts = nullptr, *col_starts = nullptr;
+        if (splat_starts(ctx, h, sigma_space, g.gh - 3, &row_starts) != A3D_OK ||
+            splat_starts(ctx, w, sigma_space, g.gw - 3, &col_starts) != A3D_OK)
+          return A3D_HIP_ERROR;
+        hipLaunchKernelGGL(splat_packed_kernel, dim3(((g.gh - 3) * (g.gw - 3) + 255) / 256), dim3(256), 0, s, d_img, w, h,
+                           row_starts, col_starts, inv_sc, cmin, g, (unsigned long long*)d_b, (const uint32_t*)nullptr, 0ull,
+                           (uint8_t*)nullptr, 0u, (const uint32_t*)nullptr);
         hipLaunchKernelGGL(blur_fused_kernel,
                            dim3(((g.gd + BT - 1) / BT) * ((g.gw + BT - 1) / BT) * ((g.gh + BT - 1) / BT)), dim3(256), 0, s,
                            (const unsigned long long*)d_b, g, (double*)d_a, (const uint32_t*)nullptr, 0ull,
@@ -541,7 +643,8 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   // [scalars of every frame][tile flags of every frame]: cleared together
   const size_t scal_only = (((size_t)n_frames * SC_STRIDE * 4 + 255) / 256) * 256;
   const size_t flag_bytes = (size_t)n_frames * flags_stride;
-  const size_t scal_bytes = scal_only + flag_bytes + (size_t)n_frames * 2 * flags_stride * 4;  // + the two tile lists
+  const size_t list_bytes = (size_t)n_frames * 2 * flags_stride * 4;  // the two tile lists
+  const size_t scal_bytes = scal_only + flag_bytes + list_bytes + (size_t)n_frames * 65536 * 4;  // + colour -> channel
   capacity += capacity & 1;  // even: every frame's packed grid starts 16-byte aligned
   const size_t packed_bytes = (((size_t)n_frames * capacity * 8 + 255) / 256) * 256;
   void* region = nullptr;
@@ -552,17 +655,23 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   out->blurred = (double*)((char*)out->packed + packed_bytes);
   out->capacity = capacity;
   uint32_t* lists = (uint32_t*)(flags + flag_bytes);
+  uint32_t* channel_of = (uint32_t*)((char*)lists + list_bytes);
+  const uint32_t *row_starts = nullptr, *col_starts = nullptr;
+  A3D_TRY(splat_starts(ctx, h, sigma_space, gh - 3, &row_starts));  // (before anything is enqueued: a first use synchronises)
+  A3D_TRY(splat_starts(ctx, w, sigma_space, gw - 3, &col_starts));
   A3D_HIP_TRY(hipMemsetAsync(region, 0, scal_only + flag_bytes, s));
   hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64), n_frames), dim3(256), 0, s, d_depth, n,
                      out->scal, true);
   hipLaunchKernelGGL(dims_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s, out->scal, n_frames, w, h, sigma_space,
                      sigma_color, capacity);
+  const double inv_sc = 1.0 / sigma_color;
   hipLaunchKernelGGL(clear_packed_kernel, dim3(256, n_frames), dim3(256), 0, s, out->packed, (const uint32_t*)out->scal,
-                     capacity);
-  const double inv_ss = 1.0 / sigma_space, inv_sc = 1.0 / sigma_color;
+                     capacity, channel_of, inv_sc);
   const GridDims none{0, 0, 0};
-  hipLaunchKernelGGL(splat_packed_kernel, dim3((n + 2047) / 2048, n_frames), dim3(256), 0, s, d_depth, w, h, inv_ss, inv_sc, 0u,
-                     none, out->packed, (const uint32_t*)out->scal, capacity, flags, flags_stride);
+  // (gh and gw depend on the image size only: the launch covers every (row, column) pixels can splat into)
+  hipLaunchKernelGGL(splat_packed_kernel, dim3(((gh - 3) * (gw - 3) + 255) / 256, n_frames), dim3(256), 0, s, d_depth, w, h,
+                     row_starts, col_starts, inv_sc, 0u, none, out->packed, (const uint32_t*)out->scal, capacity, flags,
+                     flags_stride, (const uint32_t*)channel_of);
   hipLaunchKernelGGL(tile_list_kernel, dim3((std::max(1u, tiles) + 255) / 256, n_frames), dim3(256), 0, s,
                      (const uint8_t*)flags, flags_stride, out->scal, lists);
   // two blocks of the blur fit a CU (68 KiB of LDS each): one resident round, shared out over the frames

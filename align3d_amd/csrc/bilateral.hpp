@@ -10,7 +10,7 @@ struct GridDims {
 };
 
 // `x as usize` for a non-negative finite f64
-__device__ __forceinline__ uint32_t f64_as_usize(double x) { return x > 0.0 ? (uint32_t)x : 0u; }
+__host__ __device__ __forceinline__ uint32_t f64_as_usize(double x) { return x > 0.0 ? (uint32_t)x : 0u; }
 
 // Device-side scalars of one filter call.  When a kernel gets a non-null `dyn` pointer, the grid dimensions and the
 // colour minimum come from there instead of from its arguments: the host then enqueues the whole filter without
