@@ -173,7 +173,10 @@ def test_bilateral_fused_and_unfused_paths_agree(ctx, monkeypatch):
     cases = [(rng.integers(0, 65536, size=(97, 131)).astype(np.uint16), 3.0, 700.0),
              (rng.integers(300, 9000, size=(480, 640)).astype(np.uint16), 4.5, 30.0),
              (rng.integers(0, 3, size=(50, 60)).astype(np.uint16), 1.5, 0.7),
-             (np.full((13, 17), 40000, np.uint16), 20.0, 5.0)]
+             (np.full((13, 17), 40000, np.uint16), 20.0, 5.0),
+             # 32 772 channels: 2 731 channel tiles, more tile marks than the splat's LDS window holds (direct stores),
+             # far more than four channels under a footprint (slot overflow), a grid that outgrows the first capacity
+             (rng.integers(0, 65536, size=(50, 60)).astype(np.uint16), 3.0, 2.0)]
     for img, ss, sc in cases:
         st, ref, dims = O.bilateral(img, ss, sc)
         outs = {}
