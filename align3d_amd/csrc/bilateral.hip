@@ -106,6 +106,19 @@ __global__ void __launch_bounds__(256)
 // ONE u64 (value sum << 24 | count) and a pixel is ONE integer atomic instead of two f64 atomics; integer adds are
 // exact, so the cell holds exactly the reference's f64 sums.
 constexpr int PACK_SHIFT = 24;
+// When at most 255 pixels can splat into one (row, column) of the grid — sigma_space below ~14 — the count of a cell
+// is < 2^8 and its value sum < 255 x 65535 < 2^24: the cell is ONE u32 (value sum << 8 | count), half the bytes to
+// clear, to add into and to load in the blur.
+template <typename CELL>
+struct Pack;
+template <>
+struct Pack<unsigned long long> {
+  static constexpr int SHIFT = PACK_SHIFT;
+};
+template <>
+struct Pack<uint32_t> {
+  static constexpr int SHIFT = 8;
+};
 constexpr int BT = 12, BR = BT + 4;  // blur tiles: 16^3 cells per tile, 12^3 of them final
 
 // grid.rs:37-56 on the device (same f64 arithmetic as the host path), plus the capacity check
@@ -129,18 +142,18 @@ __global__ void dims_kernel(uint32_t* __restrict__ sc, uint32_t n_frames, uint32
 // 65 536 values of v, in the splat's own f64 arithmetic): the splat then looks a channel up instead of converting
 // u16 -> f64 -> usize per pixel (conversions run at a quarter of the f64 rate).  The launch has 65 536 threads per frame.
 __global__ void __launch_bounds__(256)
-    clear_packed_kernel(unsigned long long* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
-                        uint32_t* __restrict__ channel_of, double inv_sc) {
+    clear_packed_kernel(char* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
+                        uint32_t cell_bytes, uint32_t* __restrict__ channel_of, double inv_sc) {
   dyn += blockIdx.y * SC_STRIDE;
-  grid += blockIdx.y * capacity;
+  grid += blockIdx.y * capacity * cell_bytes;  // (capacity is a multiple of four cells: 16-byte aligned either way)
   GridDims g;
   uint32_t color_min = 0;
   if (!dyn_dims(dyn, &g, &color_min)) return;
   for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < 65536u; v += gridDim.x * 256u)
     channel_of[blockIdx.y * 65536u + v] = v >= color_min ? f64_as_usize((double)(v - color_min) * inv_sc + 0.5) + 2 : 0u;
-  const unsigned long long cells = (unsigned long long)g.gh * g.gw * g.gd;
-  ulonglong2* g2 = (ulonglong2*)grid;  // capacity offsets keep 16-byte alignment when capacity is even (it is)
-  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < (cells + 1) / 2; i += gridDim.x * 256ull)
+  const unsigned long long bytes = (unsigned long long)g.gh * g.gw * g.gd * cell_bytes;
+  ulonglong2* g2 = (ulonglong2*)grid;
+  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < (bytes + 15) / 16; i += gridDim.x * 256ull)
     g2[i] = make_ulonglong2(0ull, 0ull);
 }
 
@@ -150,10 +163,11 @@ __global__ void __launch_bounds__(256)
 // read-modify-writes on the cleared grid (no atomics, no same-address chains at the L2), consecutive pixels of one
 // channel are merged in registers first, and neighbouring threads read neighbouring pixels (coalesced).  Integer adds:
 // any grouping is exact.  Also marks the blur tiles whose window holds a cell it wrote.
+template <typename CELL>
 __global__ void __launch_bounds__(256)
     splat_packed_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, const uint32_t* __restrict__ row_starts,
                         const uint32_t* __restrict__ col_starts, double inv_sc, uint32_t color_min, GridDims g,
-                        unsigned long long* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
+                        CELL* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
                         uint8_t* __restrict__ tile_flags, uint32_t flags_stride, const uint32_t* __restrict__ channel_of) {
   if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
   img += (size_t)blockIdx.y * w * h;
@@ -193,7 +207,7 @@ __global__ void __launch_bounds__(256)
   constexpr int SLOTS = 4;
   constexpr uint32_t EMPTY = 0xFFFFFFFFu;
   uint32_t slot_ch[SLOTS], used = 0;
-  unsigned long long slot_sum[SLOTS];
+  CELL slot_sum[SLOTS];
 #pragma unroll
   for (int q = 0; q < SLOTS; ++q) slot_ch[q] = EMPTY, slot_sum[q] = 0;
   // the blur tiles whose 16^3 window (12^3 tile + 2 cells of halo) contains a cell of this column: rows and columns
@@ -202,9 +216,9 @@ __global__ void __launch_bounds__(256)
   const uint32_t a0 = (la < 2 && ta > 0) ? ta - 1 : ta, a1 = (la >= BT - 2 && ta + 1 < tx) ? ta + 1 : ta;
   const uint32_t b0 = (lb < 2 && tb > 0) ? tb - 1 : tb, b1 = (lb >= BT - 2 && tb + 1 < ty) ? tb + 1 : tb;
   auto flush = [&]() {  // this thread's cells: nobody else reads or writes them
-    unsigned long long old[SLOTS];
+    CELL old[SLOTS];
 #pragma unroll
-    for (int q = 0; q < SLOTS; ++q) old[q] = slot_ch[q] != EMPTY ? grid[column + slot_ch[q]] : 0ull;
+    for (int q = 0; q < SLOTS; ++q) old[q] = slot_ch[q] != EMPTY ? grid[column + slot_ch[q]] : (CELL)0;
 #pragma unroll
     for (int q = 0; q < SLOTS; ++q) {
       if (slot_ch[q] != EMPTY) {
@@ -248,7 +262,7 @@ __global__ void __launch_bounds__(256)
         const uint32_t color = s_px[j][threadIdx.x];
         const bool valid = color != 0;  // `color <= I::min_value()` (:67); pixels outside the footprint were parked as 0
         const uint32_t ch = channel_of ? channel_of[color] : f64_as_usize((double)(color - color_min) * inv_sc + 0.5) + 2;
-        const unsigned long long add = valid ? ((unsigned long long)color << PACK_SHIFT) + 1ull : 0ull;
+        const CELL add = valid ? ((CELL)color << Pack<CELL>::SHIFT) + (CELL)1 : (CELL)0;
         bool hit = false;
 #pragma unroll
         for (int q = 0; q < SLOTS; ++q) hit |= slot_ch[q] == ch;
@@ -258,7 +272,7 @@ __global__ void __launch_bounds__(256)
         for (int q = 0; q < SLOTS; ++q) {
           const bool take = fresh && used == (uint32_t)q;
           if (take) slot_ch[q] = ch;
-          slot_sum[q] += (valid && slot_ch[q] == ch) ? add : 0ull;
+          slot_sum[q] += (valid && slot_ch[q] == ch) ? add : (CELL)0;
         }
         used += fresh ? 1u : 0u;
       }
@@ -318,7 +332,8 @@ __device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok) {
 
 // One tile.  `known_occupied`: the tile comes from the splat's list of marked windows; otherwise emptiness is decided
 // from the loaded window.  `zeros_only`: an unmarked first-channel tile, written as zeros (see below).
-__device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const unsigned long long* __restrict__ packed,
+template <typename CELL>
+__device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const CELL* __restrict__ packed,
                                           const GridDims g, double* __restrict__ out, bool known_occupied,
                                           bool zeros_only) {
   const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT;
@@ -351,9 +366,9 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       const int gr = r0 + i;
-      unsigned long long u = 0;
+      CELL u = 0;
       if (line_in && gr >= 0 && gr < gh) u = packed[((size_t)gr * gw + gc) * gd + gz];
-      v[i] = make_double2((double)(u >> PACK_SHIFT), (double)(u & ((1ull << PACK_SHIFT) - 1)));
+      v[i] = make_double2((double)(u >> Pack<CELL>::SHIFT), (double)(u & (((CELL)1 << Pack<CELL>::SHIFT) - 1)));
     }
     // Empty windows: a depth image occupies ~1 % of its grid's cells and 20-30 % of its tiles.  A tile whose whole
     // 16^3 window holds no splat blurs to zero, and the slice never reads it: a pixel's eight cells lie within one cell
@@ -458,8 +473,9 @@ __global__ void __launch_bounds__(256)
 
 // grid = (blocks, frames).  With `lists`: every block walks its frame's lists with stride gridDim.x (the launch is
 // sized to the blocks the chip holds at once).  Without: one block per tile, blockIdx.x = tile.
+template <typename CELL>
 __global__ void __launch_bounds__(256)
-    blur_fused_kernel(const unsigned long long* __restrict__ packed, GridDims g, double* __restrict__ out,
+    blur_fused_kernel(const CELL* __restrict__ packed, GridDims g, double* __restrict__ out,
                       const uint32_t* __restrict__ dyn, unsigned long long capacity,
                       const uint32_t* __restrict__ lists, uint32_t flags_stride) {
   __shared__ double2 tile[BCELLS];
@@ -581,10 +597,10 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
         if (splat_starts(ctx, h, sigma_space, g.gh - 3, &row_starts) != A3D_OK ||
             splat_starts(ctx, w, sigma_space, g.gw - 3, &col_starts) != A3D_OK)
           return A3D_HIP_ERROR;
-        hipLaunchKernelGGL(splat_packed_kernel, dim3(((g.gh - 3) * (g.gw - 3) + 255) / 256), dim3(256), 0, s, d_img, w, h,
+        hipLaunchKernelGGL(splat_packed_kernel<unsigned long long>, dim3(((g.gh - 3) * (g.gw - 3) + 255) / 256), dim3(256), 0, s, d_img, w, h,
                            row_starts, col_starts, inv_sc, cmin, g, (unsigned long long*)d_b, (const uint32_t*)nullptr, 0ull,
                            (uint8_t*)nullptr, 0u, (const uint32_t*)nullptr);
-        hipLaunchKernelGGL(blur_fused_kernel,
+        hipLaunchKernelGGL(blur_fused_kernel<unsigned long long>,
                            dim3(((g.gd + BT - 1) / BT) * ((g.gw + BT - 1) / BT) * ((g.gh + BT - 1) / BT)), dim3(256), 0, s,
                            (const unsigned long long*)d_b, g, (double*)d_a, (const uint32_t*)nullptr, 0ull,
                            (const uint32_t*)nullptr, 0u);
@@ -645,13 +661,19 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   const size_t flag_bytes = (size_t)n_frames * flags_stride;
   const size_t list_bytes = (size_t)n_frames * 2 * flags_stride * 4;  // the two tile lists
   const size_t scal_bytes = scal_only + flag_bytes + list_bytes + (size_t)n_frames * 65536 * 4;  // + colour -> channel
-  capacity += capacity & 1;  // even: every frame's packed grid starts 16-byte aligned
-  const size_t packed_bytes = (((size_t)n_frames * capacity * 8 + 255) / 256) * 256;
+  capacity = (capacity + 3) & ~3ull;  // a multiple of four cells: every frame's packed grid starts 16-byte aligned
+  // at most floor(sigma) + 1 image rows (columns) round to one grid row (column): 4-byte cells while a (row, column)
+  // can not receive more than 255 pixels (A3D_BILATERAL_CELLS=wide: always 8-byte cells, a cross-check)
+  const uint32_t reach = (uint32_t)std::min(sigma_space, 1e6) + 2;
+  const char* cells_mode = getenv("A3D_BILATERAL_CELLS");
+  const bool narrow = reach * reach <= 255 && !(cells_mode && !strcmp(cells_mode, "wide"));
+  const uint32_t cell_bytes = narrow ? 4 : 8;
+  const size_t packed_bytes = (((size_t)n_frames * capacity * cell_bytes + 255) / 256) * 256;
   void* region = nullptr;
   A3D_TRY(ctx_scratch(ctx, 1, scal_bytes + packed_bytes + (size_t)n_frames * capacity * 8 + 256, &region));
   out->scal = (uint32_t*)region;
   uint8_t* flags = (uint8_t*)region + scal_only;
-  out->packed = (unsigned long long*)((char*)region + scal_bytes);
+  out->packed = (char*)region + scal_bytes;
   out->blurred = (double*)((char*)out->packed + packed_bytes);
   out->capacity = capacity;
   uint32_t* lists = (uint32_t*)(flags + flag_bytes);
@@ -665,21 +687,31 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   hipLaunchKernelGGL(dims_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s, out->scal, n_frames, w, h, sigma_space,
                      sigma_color, capacity);
   const double inv_sc = 1.0 / sigma_color;
-  hipLaunchKernelGGL(clear_packed_kernel, dim3(256, n_frames), dim3(256), 0, s, out->packed, (const uint32_t*)out->scal,
-                     capacity, channel_of, inv_sc);
+  hipLaunchKernelGGL(clear_packed_kernel, dim3(256, n_frames), dim3(256), 0, s, (char*)out->packed, (const uint32_t*)out->scal,
+                     capacity, cell_bytes, channel_of, inv_sc);
   const GridDims none{0, 0, 0};
   // (gh and gw depend on the image size only: the launch covers every (row, column) pixels can splat into)
-  hipLaunchKernelGGL(splat_packed_kernel, dim3(((gh - 3) * (gw - 3) + 255) / 256, n_frames), dim3(256), 0, s, d_depth, w, h,
-                     row_starts, col_starts, inv_sc, 0u, none, out->packed, (const uint32_t*)out->scal, capacity, flags,
-                     flags_stride, (const uint32_t*)channel_of);
-  hipLaunchKernelGGL(tile_list_kernel, dim3((std::max(1u, tiles) + 255) / 256, n_frames), dim3(256), 0, s,
-                     (const uint8_t*)flags, flags_stride, out->scal, lists);
-  // two blocks of the blur fit a CU (68 KiB of LDS each): one resident round, shared out over the frames
+  const dim3 splat_grid(((gh - 3) * (gw - 3) + 255) / 256, n_frames);
+  // two blocks of the blur fit a CU (64 KiB of LDS each): one resident round, shared out over the frames
   const uint32_t resident = 2u * (uint32_t)std::max(1, ctx->num_cus);
   const uint32_t per_frame = std::max(8u, std::min(std::max(1u, tiles), (resident + n_frames - 1) / n_frames));
-  hipLaunchKernelGGL(blur_fused_kernel, dim3(per_frame, n_frames), dim3(256), 0, s,
-                     (const unsigned long long*)out->packed, none, out->blurred, (const uint32_t*)out->scal, capacity,
-                     (const uint32_t*)lists, flags_stride);
+  const dim3 list_grid((std::max(1u, tiles) + 255) / 256, n_frames);
+  if (narrow) {
+    hipLaunchKernelGGL(splat_packed_kernel<uint32_t>, splat_grid, dim3(256), 0, s, d_depth, w, h, row_starts, col_starts, inv_sc,
+                       0u, none, (uint32_t*)out->packed, (const uint32_t*)out->scal, capacity, flags, flags_stride,
+                       (const uint32_t*)channel_of);
+    hipLaunchKernelGGL(tile_list_kernel, list_grid, dim3(256), 0, s, (const uint8_t*)flags, flags_stride, out->scal, lists);
+    hipLaunchKernelGGL(blur_fused_kernel<uint32_t>, dim3(per_frame, n_frames), dim3(256), 0, s, (const uint32_t*)out->packed,
+                       none, out->blurred, (const uint32_t*)out->scal, capacity, (const uint32_t*)lists, flags_stride);
+  } else {
+    hipLaunchKernelGGL(splat_packed_kernel<unsigned long long>, splat_grid, dim3(256), 0, s, d_depth, w, h, row_starts,
+                       col_starts, inv_sc, 0u, none, (unsigned long long*)out->packed, (const uint32_t*)out->scal, capacity,
+                       flags, flags_stride, (const uint32_t*)channel_of);
+    hipLaunchKernelGGL(tile_list_kernel, list_grid, dim3(256), 0, s, (const uint8_t*)flags, flags_stride, out->scal, lists);
+    hipLaunchKernelGGL(blur_fused_kernel<unsigned long long>, dim3(per_frame, n_frames), dim3(256), 0, s,
+                       (const unsigned long long*)out->packed, none, out->blurred, (const uint32_t*)out->scal, capacity,
+                       (const uint32_t*)lists, flags_stride);
+  }
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }

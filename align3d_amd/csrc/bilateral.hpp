@@ -69,10 +69,10 @@ __device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t
 }
 
 // Where the blurred grids of a batch of frames live (the context's grid scratch region):
-// [n_frames x SC_STRIDE words of scalars][n_frames x capacity packed u64 cells][n_frames x capacity f64 cells (normalised values)]
+// [n_frames x SC_STRIDE words of scalars][n_frames x capacity packed u32 / u64 cells][n_frames x capacity f64 cells (normalised values)]
 struct GridBatch {
   uint32_t* scal = nullptr;
-  unsigned long long* packed = nullptr;
+  void* packed = nullptr;  // u32 or u64 cells (bilateral.hip: Pack)
   double* blurred = nullptr;
   unsigned long long capacity = 0;  // cells per frame
 };
