@@ -22,5 +22,5 @@ from .range_image import CameraIntrinsics, DeviceRangeImage, RangeImage, RangeIm
 from .transform import Transform  # noqa: F401
 from .dataset import (DatasetError, IndoorLidarDataset, SlamTbDataset, SubsetDataset, SyntheticDataset,  # noqa: F401
                       TumRgbdDataset, load_dataset)
-from .odometry import run_odometry  # noqa: F401
+from .odometry import run_odometry, run_odometry_batched  # noqa: F401
 from .trajectory import Trajectory, TrajectoryBuilder, TransformMetrics  # noqa: F401

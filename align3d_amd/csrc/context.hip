@@ -170,6 +170,24 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
   return A3D_OK;
 }
 
+a3d_status ctx_stream_acquire(a3d_context* ctx, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> lock(ctx->stream_mutex);
+    if (!ctx->idle_streams.empty()) {
+      *out = ctx->idle_streams.back();
+      ctx->idle_streams.pop_back();
+      return A3D_OK;
+    }
+  }
+  A3D_HIP_TRY(hipStreamCreateWithPriority(out, hipStreamNonBlocking, ctx->stream_priority));
+  return A3D_OK;
+}
+
+void ctx_stream_release(a3d_context* ctx, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(ctx->stream_mutex);
+  ctx->idle_streams.push_back(s);
+}
+
 void attach_fence(const a3d_device_image* im, const std::shared_ptr<UseFence>& fence) {
   DeviceArena* a = im ? im->arena : nullptr;
   if (!a) return;  // individually allocated arrays are released with hipFree, which synchronises the device
@@ -255,6 +273,7 @@ a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priori
     int least = 0, greatest = 0;
     A3D_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     const int prio = priority < 0 ? greatest : priority > 0 ? least : 0;
+    ctx->stream_priority = prio;
     A3D_HIP_TRY(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio));
     A3D_HIP_TRY(hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio));
   }
@@ -274,6 +293,7 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   for (hipEvent_t e : ctx->copy_events) hipEventDestroy(e);
   hipStreamDestroy(ctx->copy_stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
+  for (hipStream_t st : ctx->idle_streams) hipStreamDestroy(st);  // (after the engine: it hands its streams back)
   for (void* a : ctx->single_arenas) hipFree(a);  // pooled ones and those of images that are still alive
   for (void* slab : ctx->arena_slabs) hipFree(slab);
   for (auto& t : ctx->tables) hipFree(t.d);

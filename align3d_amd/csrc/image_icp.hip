@@ -622,6 +622,7 @@ struct a3d_multiscale_batch {
   std::vector<Gates> gates;
   std::vector<uint32_t> tiles, ppt, group;  // per level: tiles per pair, pixels per thread, pixels in flight
   std::vector<LevelDesc> h_descs;      // [level][pair]
+  void* d_block = nullptr;  // one allocation behind every small device array below
   LevelDesc* d_descs = nullptr;
   JobState* d_states = nullptr;
   float* d_partials = nullptr;
@@ -658,20 +659,13 @@ struct a3d_multiscale_batch {
 
   ~a3d_multiscale_batch() {
     fence->retire();
-    hipFree(d_descs);
-    hipFree(d_states);
+    hipFree(d_block);  // descs, states, counters, epochs, poses, init, status, readback
     hipFree(d_partials);
-    hipFree(d_counters);
-    hipFree(d_epochs);
-    hipFree(d_poses);
-    hipFree(d_init);
-    hipFree(d_status);
-    hipFree(d_readback);
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
     for (auto e : kev) hipEventDestroy(e);
     for (int i = 0; i < 3; ++i) {
-      if (aux_streams[i]) hipStreamDestroy(aux_streams[i]);
+      if (aux_streams[i]) ctx_stream_release(ctx, aux_streams[i]);  // (the owner synchronised them before deleting us)
       if (ev_join[i]) hipEventDestroy(ev_join[i]);
     }
     if (ev_fork) hipEventDestroy(ev_fork);
@@ -844,13 +838,26 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     b->resident_blocks = (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)per_cu;
   }
   A3D_HIP_TRY(hipSetDevice(ctx->device));
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_descs, b->h_descs.size() * sizeof(LevelDesc)));
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_states, n_pairs * sizeof(JobState)));
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_counters, n_pairs * sizeof(unsigned)));
+  {  // every small device array of the batch in ONE allocation (each hipMalloc / hipFree synchronises the device:
+     // nine of them made creating and destroying a batch cost ~12 ms, six alignments' worth)
+    size_t total = 0;
+    auto take = [&](size_t bytes) {
+      const size_t at = total;
+      total += ((bytes + 255) / 256) * 256;
+      return at;
+    };
+    const size_t o_descs = take(b->h_descs.size() * sizeof(LevelDesc)), o_states = take(n_pairs * sizeof(JobState)),
+                 o_counters = take(n_pairs * sizeof(unsigned)), o_epochs = take(n_pairs * sizeof(unsigned)),
+                 o_poses = take(n_pairs * sizeof(Pose)), o_init = take(n_pairs * sizeof(Pose)),
+                 o_status = take(n_pairs * sizeof(int32_t)), o_readback = take(GN_PARTIAL * sizeof(double));
+    A3D_HIP_TRY(hipMalloc((void**)&b->d_block, total));
+    char* base = (char*)b->d_block;
+    b->d_descs = (LevelDesc*)(base + o_descs), b->d_states = (JobState*)(base + o_states);
+    b->d_counters = (unsigned*)(base + o_counters), b->d_epochs = (unsigned*)(base + o_epochs);
+    b->d_poses = (Pose*)(base + o_poses), b->d_init = (Pose*)(base + o_init);
+    b->d_status = (int32_t*)(base + o_status), b->d_readback = (double*)(base + o_readback);
+  }
   A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_epochs, n_pairs * sizeof(unsigned)));
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_poses, n_pairs * sizeof(Pose)));
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_init, n_pairs * sizeof(Pose)));
   if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
   if (const char* env = getenv("A3D_ICP_PERSISTENT_LEVELS")) b->level_mask = (uint32_t)strtoul(env, nullptr, 0);
   // measured (scripts/streams_sweep*.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
@@ -861,7 +868,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   if (b->n_streams > 1) {
     A3D_HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     for (uint32_t g = 1; g < b->n_streams; ++g) {
-      A3D_HIP_TRY(hipStreamCreateWithFlags(&b->aux_streams[g - 1], hipStreamNonBlocking));
+      A3D_TRY(ctx_stream_acquire(ctx, &b->aux_streams[g - 1]));  // from the context's pool of idle streams
       A3D_HIP_TRY(hipEventCreateWithFlags(&b->ev_join[g - 1], hipEventDisableTiming));
     }
   }
@@ -872,8 +879,6 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     b->level_resident_blocks = (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)std::max(0, per_cu);
     if (b->use_level_kernel && b->level_resident_blocks) b->resident_blocks = b->level_resident_blocks;
   }
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_status, n_pairs * sizeof(int32_t)));
-  A3D_HIP_TRY(hipMalloc((void**)&b->d_readback, GN_PARTIAL * sizeof(double)));
   A3D_HIP_TRY(hipEventCreate(&b->ev0));
   A3D_HIP_TRY(hipEventCreate(&b->ev1));
   *out = std::move(b);

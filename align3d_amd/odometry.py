@@ -9,8 +9,9 @@ same as the sequential loop's: both stages are deterministic and share nothing b
 import queue
 import threading
 
+from . import _abi
 from .bilateral import BilateralFilter
-from .icp import MultiscaleAlign
+from .icp import MultiscaleAlign, MultiscaleAlignBatch
 from .icp_params import MsIcpParams
 from .range_image import RangeImageBuilder
 from .trajectory import TrajectoryBuilder, TransformMetrics
@@ -85,6 +86,70 @@ def run_odometry(ctx, dataset, params=None, builder=None, max_frames=None, prefe
         if last is not None:
             for lv in last:
                 lv.free()
+    pred = tb.build()
+    gt = dataset.trajectory()
+    metrics = None
+    if gt is not None:
+        metrics = TransformMetrics.mean_trajectory_error(pred, gt.slice(0, n).first_frame_at_origin())
+    return pred, metrics
+
+
+def _same_camera(a, b):
+    return (a.fx, a.fy, a.cx, a.cy, a.width, a.height) == (b.fx, b.fy, b.cx, b.cy, b.width, b.height)
+
+
+def run_odometry_batched(ctx, dataset, params=None, builder=None, max_frames=None, window=64):
+    """run_odometry for a RECORDED sequence (the example's use: a dataset on disk, examples/src/bin/odometry.rs:28-69).
+    Frame-to-frame odometry is a chain only in its last step: the alignment of frames i-1 and i depends on nothing
+    but those two frames, the trajectory is the running product of the results (TrajectoryBuilder::accumulate,
+    trajectory.rs:164-168).  So a window of up to `window` + 1 consecutive frames is built in ONE batched builder call
+    and its `window` alignments run as ONE MultiscaleAlignBatch (frame i-1 the target, frame i the source), windows
+    overlapping by one frame; the transforms are accumulated on the host in frame order.  Same arithmetic per pair as
+    run_odometry (results agree to the batch kernels' summation order, ~1e-7); many times its frame rate, because the
+    single-pair path is a chain of 70 dependent ~14 us launches per alignment and the batch is not.
+    Returns (predicted Trajectory, mean TransformMetrics against the dataset's ground truth or None)."""
+    params = params or MsIcpParams.default()
+    builder = builder or RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+    n = dataset.len() if max_frames is None else min(max_frames, dataset.len())
+    tb = TrajectoryBuilder.with_start(Transform.eye(), 0.0)
+    free = lambda pyr: [lv.free() for lv in pyr]
+    batches = {}  # pairs in the batch -> MultiscaleAlignBatch (rebound from window to window)
+    carry = None  # the last frame of the previous window: (index, pyramid)
+    i = 0
+    try:
+        while i < n:
+            # a run of frames that one builder call can take: same camera, depth scale and size
+            cam, depth, rgb, scale = dataset.get(i)
+            run = [(depth, rgb)]
+            while i + len(run) < n and len(run) < window + (0 if carry else 1):
+                cam2, d2, c2, s2 = dataset.get(i + len(run))
+                if not (_same_camera(cam, cam2) and s2 == scale and d2.shape == depth.shape):
+                    break
+                run.append((d2, c2))
+            pyrs = builder.build_many(cam, run, scale)
+            seq = ([carry[1]] if carry else []) + pyrs  # consecutive frames i - 1 (if carried), i, i + 1, ...
+            first = i - (1 if carry else 0)
+            if len(seq) >= 2:
+                P = len(seq) - 1
+                if P in batches:
+                    batches[P].rebind(seq[:-1], seq[1:])
+                else:
+                    batches[P] = MultiscaleAlignBatch(ctx, params, seq[:-1], seq[1:])
+                poses, status = batches[P].align()
+                for k, (T, st) in enumerate(zip(poses, status)):
+                    if st != 0:
+                        raise _abi.A3dError(int(st), f"alignment of frames {first + k} and {first + k + 1}: GaussNewton::solve() "
+                                                     f"returned None (count == 0 or Cholesky failed)")
+                    tb.accumulate(T, float(first + k + 1))
+            for pyr in seq[:-1]:
+                free(pyr)
+            carry = (first + len(seq) - 1, seq[-1])
+            i += len(run)
+    finally:
+        if carry is not None:
+            free(carry[1])
+        for b in batches.values():
+            b.free()
     pred = tb.build()
     gt = dataset.trajectory()
     metrics = None

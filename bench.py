@@ -379,7 +379,7 @@ def odometry_bench(ctx, n_frames=20):
     """configs[3]: a 20-frame odometry stream, frames enter as u16 depth + u8 RGB, persistent device pyramids,
     MsIcpParams::default() (README usage) — on the synthetic stream, and on the reference's own 20 sample1 frames
     (tests/golden, real data with ground truth) when the fixture directory travels with the repository."""
-    from align3d_amd import SlamTbDataset, SyntheticDataset, run_odometry
+    from align3d_amd import SlamTbDataset, SyntheticDataset, run_odometry, run_odometry_batched
 
     def run(ds, label):
         run_odometry(ctx, ds, max_frames=3)
@@ -393,10 +393,23 @@ def odometry_bench(ctx, n_frames=20):
             per.append(time.perf_counter() - t0)
         dt = float(np.median(per))
         n = ds.len()
+        # the same sequence as a recorded one: one batched build + ONE batch of n - 1 alignments (run_odometry_batched)
+        run_odometry_batched(ctx, ds)
+        per_b = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            pred_b, metrics_b = run_odometry_batched(ctx, ds)
+            per_b.append(time.perf_counter() - t0)
+        dt_b = float(np.median(per_b))
         return {"workload": f"{n}-frame {label} stream, device RangeImageBuilder + MsIcpParams::default()",
                 "frames_per_s": (n - 1) / dt, "ms_per_frame": dt / (n - 1) * 1e3,
                 "ms_per_frame_stats": stats([t / (n - 1) * 1e3 for t in per]),
                 "frames_per_s_without_prefetch": (n - 1) / dt_seq,
+                "recorded_sequence_batched": {
+                    "frames_per_s": (n - 1) / dt_b, "ms_per_frame": dt_b / (n - 1) * 1e3,
+                    "ms_per_frame_stats": stats([t / (n - 1) * 1e3 for t in per_b]),
+                    "mean_trajectory_error": {"angle_deg": float(np.degrees(metrics_b.angle)),
+                                              "translation_m": metrics_b.translation}},
                 "mean_trajectory_error": {"angle_deg": float(np.degrees(metrics.angle)), "translation_m": metrics.translation}}
 
     class InMemory:

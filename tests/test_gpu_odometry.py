@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib as O
 from align3d_amd import (BilateralFilter, MsIcpParams, MultiscaleAlign, RangeImageBuilder, SlamTbDataset,
-                         SyntheticDataset, TransformMetrics, run_odometry)
+                         SyntheticDataset, TransformMetrics, run_odometry, run_odometry_batched)
 from data_util import GOLDEN
 from gpu_util import oracle_pyramid, transform_diff
 
@@ -138,3 +138,25 @@ def test_tum_formatted_stream_odometry(ctx, tmp_path):
         tb.accumulate(MultiscaleAlign.new(ctx, MsIcpParams.default(), pyr[i - 1]).align(pyr[i]), float(i))
     for a, b in zip(pred.camera_to_world, tb.build().camera_to_world):
         assert np.array_equal(a.t, b.t) and np.array_equal(a.q, b.q)
+
+
+def test_batched_odometry_of_a_recorded_sequence_equals_the_frame_by_frame_loop(ctx):
+    """run_odometry_batched: the 19 alignments of the 20 sample1 frames as ONE batch (and as windows of 7 pairs that
+    overlap by a frame) give the frame-by-frame trajectory — same arithmetic per pair; the batch kernels sum in another
+    order (<= 1e-5) — and the same mean trajectory error against the ground truth."""
+    ds = SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1"))
+    seq, m_seq = run_odometry(ctx, ds, prefetch=False)
+    for window in (64, 7):
+        pred, m = run_odometry_batched(ctx, ds, window=window)
+        assert pred.len() == seq.len() == 20
+        for i, (a, b) in enumerate(zip(pred.camera_to_world, seq.camera_to_world)):
+            ang, tr = transform_diff(a, b)
+            assert ang <= 1e-5 and tr <= 1e-5, (window, i, ang, tr)
+        assert abs(m.angle - m_seq.angle) <= 1e-5 and abs(m.translation - m_seq.translation) <= 1e-5
+    # a stream whose camera changes half-way is cut into runs at the change
+    syn = SyntheticDataset(5, 6)
+    a, _ = run_odometry(ctx, syn, prefetch=False)
+    b, _ = run_odometry_batched(ctx, syn, window=2)
+    for x, y in zip(a.camera_to_world, b.camera_to_world):
+        ang, tr = transform_diff(x, y)
+        assert ang <= 1e-5 and tr <= 1e-5
