@@ -19,7 +19,8 @@ class Context:
         """A second context on the same GPU (its own stream and scratch), created once and closed with this one:
         the stream frame builds run on while this context aligns (align3d_amd.odometry)."""
         if self._sibling is None:
-            self._sibling = Context(self.device_index)
+            # highest stream priority: the builder's short kernels go ahead of the alignment's long ones
+            self._sibling = Context(self.device_index, priority=-1)
         return self._sibling
 
     def synchronize(self):

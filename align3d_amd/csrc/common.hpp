@@ -117,18 +117,18 @@ struct a3d_context {
   // a built image): registered with the image's arena like a consumer's fence, so that a3d_range_image_free need not
   // wait for the whole stream (another thread may be building the next frames on it).
   std::shared_ptr<a3d::UseFence> self_fence;
-  // Idle side streams (the pair groups of a batch alignment run on them): created on demand with the context's
-  // priority, handed back when a batch dies, destroyed with the context.
+  // Side streams (the pair groups of a batch alignment run on them), created on demand with the context's priority
+  // and SHARED by every batch of the context: batches of one context are ordered on its main stream anyway (fork /
+  // join events), and the runtime maps streams onto a handful of hardware queues — a process that gave every batch
+  // its own side streams ended up with two batches' groups serialised on one queue.  Destroyed with the context.
   int stream_priority = 0;
   std::mutex stream_mutex;
-  std::vector<hipStream_t> idle_streams;
+  std::vector<hipStream_t> side_streams;
 };
 
 namespace a3d {
-// A side stream of the context (from its pool of idle ones, or new); release hands it back (the caller has
-// synchronised it or ordered it behind the context stream).
-a3d_status ctx_stream_acquire(a3d_context* ctx, hipStream_t* out);
-void ctx_stream_release(a3d_context* ctx, hipStream_t s);
+// Side stream `index` of the context (created on first use; shared, never released).
+a3d_status ctx_side_stream(a3d_context* ctx, uint32_t index, hipStream_t* out);
 // Returns a scratch region of at least `bytes` (256-byte aligned); growing one synchronises the stream first.
 a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out);
 

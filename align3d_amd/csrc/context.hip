@@ -170,22 +170,15 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
   return A3D_OK;
 }
 
-a3d_status ctx_stream_acquire(a3d_context* ctx, hipStream_t* out) {
-  {
-    std::lock_guard<std::mutex> lock(ctx->stream_mutex);
-    if (!ctx->idle_streams.empty()) {
-      *out = ctx->idle_streams.back();
-      ctx->idle_streams.pop_back();
-      return A3D_OK;
-    }
-  }
-  A3D_HIP_TRY(hipStreamCreateWithPriority(out, hipStreamNonBlocking, ctx->stream_priority));
-  return A3D_OK;
-}
-
-void ctx_stream_release(a3d_context* ctx, hipStream_t s) {
+a3d_status ctx_side_stream(a3d_context* ctx, uint32_t index, hipStream_t* out) {
   std::lock_guard<std::mutex> lock(ctx->stream_mutex);
-  ctx->idle_streams.push_back(s);
+  while (ctx->side_streams.size() <= index) {
+    hipStream_t s = nullptr;
+    A3D_HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, ctx->stream_priority));
+    ctx->side_streams.push_back(s);
+  }
+  *out = ctx->side_streams[index];
+  return A3D_OK;
 }
 
 void attach_fence(const a3d_device_image* im, const std::shared_ptr<UseFence>& fence) {
@@ -293,7 +286,10 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   for (hipEvent_t e : ctx->copy_events) hipEventDestroy(e);
   hipStreamDestroy(ctx->copy_stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
-  for (hipStream_t st : ctx->idle_streams) hipStreamDestroy(st);  // (after the engine: it hands its streams back)
+  for (hipStream_t st : ctx->side_streams) {
+    hipStreamSynchronize(st);
+    hipStreamDestroy(st);
+  }
   for (void* a : ctx->single_arenas) hipFree(a);  // pooled ones and those of images that are still alive
   for (void* slab : ctx->arena_slabs) hipFree(slab);
   for (auto& t : ctx->tables) hipFree(t.d);

@@ -665,7 +665,6 @@ struct a3d_multiscale_batch {
     if (ev1) hipEventDestroy(ev1);
     for (auto e : kev) hipEventDestroy(e);
     for (int i = 0; i < 3; ++i) {
-      if (aux_streams[i]) ctx_stream_release(ctx, aux_streams[i]);  // (the owner synchronised them before deleting us)
       if (ev_join[i]) hipEventDestroy(ev_join[i]);
     }
     if (ev_fork) hipEventDestroy(ev_fork);
@@ -868,7 +867,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   if (b->n_streams > 1) {
     A3D_HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     for (uint32_t g = 1; g < b->n_streams; ++g) {
-      A3D_TRY(ctx_stream_acquire(ctx, &b->aux_streams[g - 1]));  // from the context's pool of idle streams
+      A3D_TRY(ctx_side_stream(ctx, g - 1, &b->aux_streams[g - 1]));  // shared by the context's batches
       A3D_HIP_TRY(hipEventCreateWithFlags(&b->ev_join[g - 1], hipEventDisableTiming));
     }
   }

@@ -313,7 +313,10 @@ def streaming_bench(ctx, params, P, W, H, rounds=32, builders=1, pinned=True, bu
     frames = [(all_d[i], all_c[i]) for i in range(P + 1)]
     cam = synth.camera(W, H)
     # the builders' streams get the device's highest priority: the build is the dependent chain of the two workloads
-    ctxs = [Context(ctx.device_index, priority=builder_priority) for _ in range(builders)]
+    # (the first builder is the main context's sibling — the odometry loop's builder context — so that the process does not
+    # hold more streams than the runtime has hardware queues: streams that share a queue serialise)
+    ctxs = [ctx.sibling() if (k == 0 and builder_priority < 0) else Context(ctx.device_index, priority=builder_priority)
+            for k in range(builders)]
     bld = [RangeImageBuilder(c).with_bilateral_filter(BilateralFilter.default()) for c in ctxs]
 
     def build_round(k=0):  # one batched build call: ~12 launches per 16 frames
@@ -367,7 +370,8 @@ def streaming_bench(ctx, params, P, W, H, rounds=32, builders=1, pinned=True, bu
     for b in batches:
         b.free()
     for c in ctxs:
-        c.close()
+        if c is not ctx._sibling:
+            c.close()
     return {"workload": f"{rounds} rounds of {P} pairs, {P + 1} new frames per round from "
                         f"{'page-locked' if pinned else 'pageable'} host memory, "
                         f"{builders} builder threads (whole rounds in turn, one batched build call per round) running "
