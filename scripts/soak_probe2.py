@@ -80,3 +80,8 @@ def multi_cycle():
 cycle("MultiContext + multi batch", multi_cycle, reps=5)
 ds = SyntheticDataset(7, 6)
 cycle("run_odometry(6 frames)", lambda: run_odometry(ctx, ds), reps=5)
+from align3d_amd import run_odometry_batched
+cycle("run_odometry_batched(6 frames, windows of 2)", lambda: run_odometry_batched(ctx, ds, window=2), reps=5)
+import bench
+cycle("streaming_bench (3 rounds of 16 pairs, two alternating batches, images freed behind fences)",
+      lambda: bench.streaming_bench(ctx, prm, 16, 640, 480, rounds=3), groups=3, reps=4)
