@@ -29,6 +29,14 @@ impl Context {
         Context(ctx)
     }
 
+    /// A context whose streams have the device's highest (`priority < 0`) or lowest (`> 0`) priority: the context a
+    /// frame-builder thread uses next to an aligning one (a3d_context_create_with_priority).
+    pub fn with_priority(device_index: i32, priority: i32) -> Self {
+        let mut ctx = std::ptr::null_mut();
+        check(unsafe { sys::a3d_context_create_with_priority(device_index, priority, &mut ctx) }, "a3d_context_create");
+        Context(ctx)
+    }
+
     /// This thread's context on device `ALIGN3D_HIP_DEVICE` (default 0).
     pub fn current() -> *mut sys::a3d_context {
         thread_local! { static CTX: RefCell<Option<Context>> = RefCell::new(None); }
