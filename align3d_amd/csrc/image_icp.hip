@@ -163,9 +163,10 @@ __device__ __forceinline__ MapPx stage_c(const LevelDesc& d, const Gates& gt, Pr
   const V3 diff = px.tp - px.p;
   // angle_between_normals(&p, &n) >= max_normal_angle on the POINT p; NaN (|p.n| > 1) passes (image_icp.rs:118-123)
   const float pn = dot(px.p, px.tn);
-  px.live = px.live && (px.tmask == 1)                              // RangeImage::get_point: mask == 1 (structure.rs:176)
-            && !(norm_squared(diff) > gt.max_distance_sqr)       // image_icp.rs:114
-            && !(pn >= -1.0f && pn <= gt.dot_reject_max);
+  // (bitwise on purpose: the short-circuit form compiles to three nested exec-mask branches per pixel)
+  px.live = px.live & (px.tmask == 1)                               // RangeImage::get_point: mask == 1 (structure.rs:176)
+            & !(norm_squared(diff) > gt.max_distance_sqr)        // image_icp.rs:114
+            & !((pn >= -1.0f) & (pn <= gt.dot_reject_max));
   MapPx m;
   m.ui = px.live ? f32_as_usize(px.u) : 0u;
   m.vi = px.live ? f32_as_usize(px.v) : 0u;
@@ -182,20 +183,29 @@ struct Terms {  // stage D: the two residuals and Jacobians of a live pixel
 };
 __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, const ProjPx& px, const MapPx& m,
                                          uint8_t intensity, uint32_t mw) {
+  // What decides whether a pixel counts — the transform, the projection, the gates above, and here the colour
+  // residual with its gate — is the reference's arithmetic operation for operation (no fused multiply-adds, IEEE
+  // division).  What follows a passed gate only feeds the sums: the two Jacobians and the geometric residual may use
+  // a*b+c in one rounding and a refined reciprocal instead of a division (each term within 1-3 ulp of the
+  // reference's; the sums are compared with an f64 oracle at 1e-6, where the order of summation already costs more).
+  auto fms = [](float a, float b, float c, float e) { return __builtin_fmaf(a, b, -(c * e)); };  // a b - c e
   Terms t;
   const V3 P = px.p, n = px.tn;
   {  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
-    t.rg = dot(px.tp - P, n);
-    const V3 tw = cross(P, n);
-    t.Jg[0] = n.x, t.Jg[1] = n.y, t.Jg[2] = n.z, t.Jg[3] = tw.x, t.Jg[4] = tw.y, t.Jg[5] = tw.z;
+    const V3 df = px.tp - P;
+    t.rg = __builtin_fmaf(df.z, n.z, __builtin_fmaf(df.y, n.y, df.x * n.x));
+    t.Jg[0] = n.x, t.Jg[1] = n.y, t.Jg[2] = n.z;
+    t.Jg[3] = fms(P.y, n.z, P.z, n.y), t.Jg[4] = fms(P.z, n.x, P.x, n.z), t.Jg[5] = fms(P.x, n.y, P.y, n.x);
   }
   // IntensityMap::bilinear_grad (src/intensity_map.rs:184-210), H = 0.005
   const float uf = px.u - (float)m.ui, vf = px.v - (float)m.vi;
-  const float value = bilerp(m.t00, m.t10, m.t01, m.t11, uf, vf);
+  const float value = bilerp(m.t00, m.t10, m.t01, m.t11, uf, vf);  // exact: the colour gate reads it
   const float Hh = 0.005f, H_INV = 1.0f / 0.005f;
   const float u2 = px.u + Hh, v2 = px.v + Hh;
   // the shifted samples share the cell except within 0.005 of a texel boundary: those (rare) lanes resample
   // from memory, behind ONE wave-uniform branch so that the common path has no per-lane branches
+  // (uh, vh like `value`, operation for operation: du = (uh - value) / H amplifies a last-bit difference between the
+  // two by value / (H * slope), three to four decimal orders)
   float uh = bilerp(m.t00, m.t10, m.t01, m.t11, u2 - (float)m.ui, vf);
   float vh = bilerp(m.t00, m.t10, m.t01, m.t11, uf, v2 - (float)m.vi);
   const bool u_leaves = f32_as_usize(u2) != m.ui, v_leaves = f32_as_usize(v2) != m.vi;
@@ -206,20 +216,17 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
   const float du = (uh - value) * H_INV;
   const float dv = (vh - value) * H_INV;
   const float sc = (float)intensity * 0.003921569f;  // image_icp.rs:131 (u8 -> f32 is exact)
-  // CameraIntrinsics::project_grad (src/camera.rs:82-89): fx / z, -x fx / zz, fy / z, -y fy / zz
-  const float z = P.z, zz = z * z;
-  const float nxf = -P.x * d.fx, nyf = -P.y * d.fy;
-  const DivBy dz = div_prepare(z), dzz = div_prepare(zz);
-  float dfx = div_by(d.fx, dz), dfy = div_by(d.fy, dz), dcx = div_by(nxf, dzz), dcy = div_by(nyf, dzz);
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(div_den_ok(z) & div_den_ok(zz) & div_num_ok(nxf) &
-                                                     div_num_ok(nyf) & div_num_ok(d.fx) & div_num_ok(d.fy))) != 0ull,
-                       0))
-    dfx = d.fx / z, dfy = d.fy / z, dcx = nxf / zz, dcy = nyf / zz;  // rare: plain IEEE divide (wave-uniform)
-  const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
+  // CameraIntrinsics::project_grad (src/camera.rs:82-89): fx / z, -x fx / zz, fy / z, -y fy / zz through the
+  // refined reciprocal of z (rcp + one Newton step)
+  const float z = P.z;
+  const float r0 = __builtin_amdgcn_rcpf(z);
+  const float rz = __builtin_fmaf(__builtin_fmaf(-z, r0, 1.0f), r0, r0), rzz = rz * rz;
+  const float dfx = d.fx * rz, dfy = d.fy * rz, dcx = (-P.x * d.fx) * rzz, dcy = (-P.y * d.fy) * rzz;
+  const V3 gr{du * dfx, dv * dfy, __builtin_fmaf(du, dcx, dv * dcy)};
   t.rc = sc - value;
   t.color = t.rc * t.rc <= gt.max_color_distance_sqr;  // image_icp.rs:136
-  const V3 twc = cross(P, gr);
-  t.Jc[0] = gr.x, t.Jc[1] = gr.y, t.Jc[2] = gr.z, t.Jc[3] = twc.x, t.Jc[4] = twc.y, t.Jc[5] = twc.z;
+  t.Jc[0] = gr.x, t.Jc[1] = gr.y, t.Jc[2] = gr.z;
+  t.Jc[3] = fms(P.y, gr.z, P.z, gr.y), t.Jc[4] = fms(P.z, gr.x, P.x, gr.z), t.Jc[5] = fms(P.x, gr.y, P.y, gr.x);
   return t;
 }
 
