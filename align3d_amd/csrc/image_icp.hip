@@ -33,8 +33,20 @@ struct Gates {
   float dot_reject_max;  // reject iff -1 <= p.n <= dot_reject_max  (== acos(p.n).abs() >= max_normal_angle)
 };
 
-// `u as usize` (Rust): NaN and negatives -> 0; the callers only see u < width.
-__device__ __forceinline__ uint32_t f32_as_usize(float x) { return x > 0.0f ? (uint32_t)x : 0u; }
+// `u as usize` (Rust): NaN and negatives -> 0; the callers only see u < width.  That is what v_cvt_u32_f32 does by
+// itself (it saturates: NaN -> 0, negative -> 0), but a C++ cast of such a value is undefined, so the portable form
+// costs two v_max before the conversion; the instruction is named instead.
+__device__ __forceinline__ uint32_t f32_as_usize(float x) {
+  uint32_t r;
+  asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+// `x as i32` (Rust): saturating, NaN -> 0 = v_cvt_i32_f32.
+__device__ __forceinline__ int32_t f32_as_i32(float x) {
+  int32_t r;
+  asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 
 // ---- loads ------------------------------------------------------------------------------------------
 // Array bases come out of a descriptor (uniform, SGPRs); every access is base + 32-bit byte offset in
@@ -53,7 +65,10 @@ typedef f32x3 __attribute__((aligned(4))) f32x3_u;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x2 __attribute__((aligned(4))) f32x2_u;
 __device__ __forceinline__ V3 ld_v3(const float* base, uint32_t idx) {
-  const f32x3 v = ld<f32x3_u>(base, idx * 12u);
+  // idx * 12 as two shifts and an add: v_mul_lo_u32 is a quarter-rate instruction (pixel indices are < 2^28)
+  uint32_t off;
+  asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(off) : "v"(idx));  // 3 idx
+  const f32x3 v = ld<f32x3_u>(base, off << 2);
   return {v.x, v.y, v.z};
 }
 
@@ -146,8 +161,7 @@ __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, con
   // (u + 0.5) as i32 -> as usize -> get_point bounds test: in range iff -1 < x < dim (NaN casts to 0)
   const float ur = o.u + 0.5f, vr = o.v + 0.5f;
   o.live = s.live & !((ur <= -1.0f) | (ur >= twf) | (vr <= -1.0f) | (vr >= thf));
-  const uint32_t col = (ur != ur) ? 0u : (uint32_t)(int)ur;
-  const uint32_t row = (vr != vr) ? 0u : (uint32_t)(int)vr;
+  const uint32_t col = (uint32_t)f32_as_i32(ur), row = (uint32_t)f32_as_i32(vr);  // (NaN casts to 0)
   const uint32_t tidx = o.live ? __umul24(row, d.tw) + col : 0u;
   o.tp = ld_v3(d.tgt_points, tidx);
   o.tn = ld_v3(d.tgt_normals, tidx);
@@ -168,9 +182,8 @@ __device__ __forceinline__ MapPx stage_c(const LevelDesc& d, const Gates& gt, Pr
             & !(norm_squared(diff) > gt.max_distance_sqr)        // image_icp.rs:114
             & !((pn >= -1.0f) & (pn <= gt.dot_reject_max));
   MapPx m;
-  m.ui = px.live ? f32_as_usize(px.u) : 0u;
-  m.vi = px.live ? f32_as_usize(px.v) : 0u;
-  const uint32_t o = texel_offset(m.vi, mw, m.ui);
+  m.ui = f32_as_usize(px.u), m.vi = f32_as_usize(px.v);
+  const uint32_t o = px.live ? texel_offset(m.vi, mw, m.ui) : 0u;  // (rejected pixels read texel 0)
   const f32x2 a = ld<f32x2_u>(d.imap, o), b = ld<f32x2_u>(d.imap, o + mw * 4u);
   m.t00 = a.x, m.t10 = a.y, m.t01 = b.x, m.t11 = b.y;
   return m;
