@@ -73,10 +73,11 @@ __device__ __forceinline__ V3 ld_v3(const float* base, uint32_t idx) {
 }
 
 // ---- IEEE division with a shared reciprocal -------------------------------------------------------------
-// The reference divides six times per pixel, four times by z and twice by z*z.  a / z below is the
-// arithmetic of the compiler's own correctly rounded f32 division (reciprocal estimate, one Newton step,
-// quotient, two fma corrections) minus its range scaling, with the refined reciprocal computed once per
-// denominator.  It returns the correctly rounded quotient for operands in `div_fast_ok` range (checked on
+// The reference divides six times per pixel, four times by z and twice by z*z; the two quotients of the projection
+// decide which target pixel a source pixel meets and are IEEE here (the four of the projection gradient only feed the
+// Jacobian: stage D multiplies by a refined reciprocal).  a / z below is the arithmetic of the compiler's own
+// correctly rounded f32 division (reciprocal estimate, one Newton step, quotient, two fma corrections) minus its
+// range scaling, with the refined reciprocal computed once per denominator.  It returns the correctly rounded quotient for operands in `div_fast_ok` range (checked on
 // 2e8 random pairs against IEEE division, and on the device by a3d_selftest_division); anything else takes
 // the plain `/`.
 struct DivBy {
