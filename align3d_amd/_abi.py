@@ -124,6 +124,7 @@ SIGNATURES = {
     "a3d_status_string": (C.c_char_p, [C.c_int]),
     "a3d_context_create": (_ST, [C.c_int32, _PP]),
     "a3d_context_create_with_priority": (_ST, [C.c_int32, C.c_int32, _PP]),
+    "a3d_context_create_pair": (_ST, [C.c_int32, _PP, _PP]),
     "a3d_context_destroy": (_ST, [_P]),
     "a3d_context_synchronize": (_ST, [_P]),
     "a3d_context_stream": (_P, [_P]),

@@ -5,21 +5,30 @@ from . import _abi
 
 
 class Context:
-    def __init__(self, device_index=0, priority=0):
+    def __init__(self, device_index=0, priority=0, _handle=None):
         """priority < 0: the device's highest stream priority (a frame-builder context next to an aligning one),
-        0: default, > 0: lowest."""
+        0: default, > 0: lowest.  A default-priority context is created together with its sibling (the builder context
+        `sibling()` returns): a3d_context_create_pair puts the two contexts' streams on the GPU's compute pipes in a
+        fixed relation, which contexts created at unrelated moments do not have."""
         self.lib = _abi.load_library()
         self.handle = C.c_void_p()
-        _abi.check(self.lib.a3d_context_create_with_priority(int(device_index), int(priority), C.byref(self.handle)),
-                   "a3d_context_create")
         self.device_index = int(device_index)
         self._sibling = None
+        if _handle is not None:
+            self.handle = _handle
+        elif int(priority) == 0:
+            builder = C.c_void_p()
+            _abi.check(self.lib.a3d_context_create_pair(int(device_index), C.byref(self.handle), C.byref(builder)),
+                       "a3d_context_create")
+            self._sibling = Context(device_index, priority=-1, _handle=builder)
+        else:
+            _abi.check(self.lib.a3d_context_create_with_priority(int(device_index), int(priority), C.byref(self.handle)),
+                       "a3d_context_create")
 
     def sibling(self):
-        """A second context on the same GPU (its own stream and scratch), created once and closed with this one:
-        the stream frame builds run on while this context aligns (align3d_amd.odometry)."""
+        """The builder context on the same GPU (its own streams and scratch, highest stream priority), created with this
+        one and closed with it: frame builds run on it while this context aligns (align3d_amd.odometry, bench.py)."""
         if self._sibling is None:
-            # highest stream priority: the builder's short kernels go ahead of the alignment's long ones
             self._sibling = Context(self.device_index, priority=-1)
         return self._sibling
 

@@ -52,6 +52,13 @@ class Context {
   explicit Context(int device_index = 0, int priority = 0) {
     check(a3d_context_create_with_priority(device_index, priority, &ctx_));
   }
+  /// An aligning context and the builder context that feeds it, created back to back (a3d_context_create_pair: the
+  /// builder's kernel stream then sits beside, not behind, the aligner's pair-group streams on the GPU's compute pipes).
+  static std::pair<Context, Context> pair(int device_index = 0) {
+    a3d_context *a = nullptr, *b = nullptr;
+    check(a3d_context_create_pair(device_index, &a, &b));
+    return {Context(a, true), Context(b, true)};
+  }
   /// A context owned by someone else (MultiContext::device): used like any other, not destroyed here.
   static Context borrowed(a3d_context* raw) {
     Context c(raw, false);

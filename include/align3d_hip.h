@@ -136,6 +136,13 @@ a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx);
  * that shares the GPU with a batch alignment wants the highest: its many short kernels are then dispatched ahead of
  * the alignment's long ones instead of queueing behind them (the build is the dependent chain of the two). */
 a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priority, a3d_context** out_ctx);
+/* An aligning context and the builder context (highest priority) that feeds it, created back to back.  Which compute
+ * pipe of the GPU a HIP stream lands on follows the order in which the process creates its streams, and a pipe
+ * dispatches one big grid at a time: created as a pair, the builder's kernel stream sits on the pipe of the aligner's
+ * idle copy stream, beside (not behind) the three streams a batch alignment's pair groups run on.  Created at
+ * unrelated moments, it lands wherever the process's stream count happens to point (measured: 11 k instead of 14 k
+ * frame pairs/s in the streaming loop).  Destroy both with a3d_context_destroy. */
+a3d_status a3d_context_create_pair(int32_t device_index, a3d_context** out_aligner, a3d_context** out_builder);
 /* Releases the context's stream, scratch regions and every pyramid arena, including those of images that are still
  * alive: images (and the objects that borrow them) must not be used after their context has been destroyed. */
 a3d_status a3d_context_destroy(a3d_context* ctx);

@@ -37,6 +37,13 @@ impl Context {
         Context(ctx)
     }
 
+    /// An aligning context and the builder context that feeds it, created back to back (a3d_context_create_pair).
+    pub fn pair(device_index: i32) -> (Self, Self) {
+        let (mut a, mut b) = (std::ptr::null_mut(), std::ptr::null_mut());
+        check(unsafe { sys::a3d_context_create_pair(device_index, &mut a, &mut b) }, "a3d_context_create_pair");
+        (Context(a), Context(b))
+    }
+
     /// This thread's context on device `ALIGN3D_HIP_DEVICE` (default 0).
     pub fn current() -> *mut sys::a3d_context {
         thread_local! { static CTX: RefCell<Option<Context>> = RefCell::new(None); }
