@@ -172,6 +172,10 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
 
 a3d_status ctx_side_stream(a3d_context* ctx, uint32_t index, hipStream_t* out) {
   std::lock_guard<std::mutex> lock(ctx->stream_mutex);
+  if (index == 2) {  // a fourth pair group takes the context's fourth stream (the copy stream: the fourth pipe)
+    *out = ctx->copy_stream;
+    return A3D_OK;
+  }
   while (ctx->side_streams.size() <= index) {
     hipStream_t s = nullptr;
     A3D_HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, ctx->stream_priority));
