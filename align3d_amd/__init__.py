@@ -7,9 +7,9 @@ hand-written HIP kernels for gfx950; there is no CPU fallback."""
 import os as _os
 
 # Streams beyond GPU_MAX_HW_QUEUES (HIP default: 4) share hardware queues and run one after the other; a batch
-# uses three, odometry one more, PyTorch / RCCL in the same process their own.  Must be set before the HIP
-# runtime initialises, which importing this package does not do yet.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# uses three, a context has four, an aligner + builder pair eight, PyTorch / RCCL in the same process their own.
+# Must be set before the HIP runtime initialises, which importing this package does not do yet.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from ._abi import A3dError, InvalidParameter, load_library  # noqa: F401
 from .bilateral import BilateralFilter  # noqa: F401

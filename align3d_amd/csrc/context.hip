@@ -247,12 +247,12 @@ a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx) {
 
 a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priority, a3d_context** out_ctx) {
   A3D_REQUIRE(out_ctx, A3D_INVALID_PARAMETER, "out_ctx is null");
-  // A batch runs its pair groups on three streams, odometry adds a builder stream, and a host framework in
-  // the same process (PyTorch + RCCL) brings its own.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES
+  // A batch runs its pair groups on three streams, a context has four, an aligner + builder pair eight, and a host
+  // framework in the same process (PyTorch + RCCL) brings its own.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES
   // hardware queues (default 4) and serialises streams that share one: with RCCL in the process the three
   // groups ran one after the other (5.35 instead of 3.85 ms per step).  Only effective if this is the
   // process's first HIP call; hosts that initialise HIP earlier should export it themselves.
-  setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+  setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0) {
