@@ -101,6 +101,19 @@ int main(int argc, char** argv) {
     batch.rebind({&b2, &a}, {&a, &b2});  // swapped roles: pair 0 now is what pair 1 was
     std::vector<Transform> Tr = batch.align();
     for (int i = 0; i < 3; ++i) EXPECT(Tr[0].translation[i] == Ts[1].translation[i] && Tr[1].translation[i] == Ts[0].translation[i]);
+    {  // an aligner + builder context pair, two batches alternating: enqueue the second before the first is read
+      auto pair = Context::pair(0);
+      Context& aligner = pair.first;
+      RangeImageBuilder pb(pair.second);  // frames are built on the builder context, aligned on the aligner
+      pb.with_bilateral_filter(&bf2).pyramid_levels(2);
+      std::vector<RangeImage> pa = pb.build(k, depth.data(), rgb.data(), 0.001), pc = pb.build(k, depth.data(), rgb.data(), 0.001);
+      MultiscaleAlignBatch first(aligner, prm, {&pa, &pc}, {&pc, &pa}), second(aligner, prm, {&pc, &pa}, {&pa, &pc});
+      first.enqueue();
+      second.enqueue();
+      std::vector<Transform> r1 = first.results(), r2 = second.results();
+      EXPECT(first.status()[0] == 0 && second.status()[1] == 0);
+      for (int i = 0; i < 3; ++i) EXPECT(r1[0].translation[i] == Ts[0].translation[i] && r2[0].translation[i] == Ts[1].translation[i]);
+    }
     try {
       RangeImageBuilder(ctx).pyramid_levels(9).build(k, depth.data(), rgb.data(), 0.001);  // 64x48 has no 9 levels
       EXPECT(false);
