@@ -181,6 +181,7 @@ SIGNATURES = {
     "a3d_multiscale_batch_align": (_ST, [_P, C.POINTER(PoseC), _P, C.POINTER(C.c_int32)]),
     "a3d_multiscale_batch_free": (_ST, [_P]),
     "a3d_multiscale_batch_rebind": (_ST, [_P, _P, _P]),
+    "a3d_multiscale_batch_last_level_ms": (_ST, [_P, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "a3d_multiscale_batch_results": (_ST, [_P, C.POINTER(PoseC), C.POINTER(C.c_int32)]),
     "a3d_multiscale_batch_last_timing": (_ST, [_P, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "a3d_multiscale_batch_set_profiling": (_ST, [_P, C.c_int32]),

@@ -660,6 +660,9 @@ struct a3d_multiscale_batch {
   double* d_readback = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;  // per pixel-kernel launch: start/stop pairs, when profiling
+  std::vector<uint8_t> kev_level;  // the pyramid level of each launch
+  float last_level_ms[16] = {0};
+  uint32_t last_level_launches[16] = {0};
   bool profile_kernels = false;
   uint32_t resident_blocks = 1024;  // blocks of the per-pixel kernel the chip holds at once
   bool use_mfma = false;  // VALU accumulation measured faster on MI355X so far (kernel variants)
@@ -926,8 +929,11 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
     A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx], ps));
     return A3D_OK;
   };
+  uint32_t profile_level = 0;  // the level of the launch being bracketed
   auto profile_end = [&](hipStream_t ps) -> a3d_status {
     if (b->profile_kernels) A3D_HIP_TRY(hipEventRecord(b->kev[2 * kidx + 1], ps));
+    if (b->kev_level.size() <= kidx) b->kev_level.resize(kidx + 1);
+    b->kev_level[kidx] = (uint8_t)profile_level;
     ++kidx;
     return A3D_OK;
   };
@@ -951,6 +957,7 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   uint32_t epoch_base = 0;
   for (uint32_t l = levels_to_run; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
     const a3d_icp_params& prm = b->params[l];
+    profile_level = l;
     SolveArgs sa;
     sa.weight = prm.weight, sa.color_weight = prm.color_weight;
     sa.mode = getenv("A3D_ICP_NOSOLVE") ? SOLVE_NONE : SOLVE_IMAGE_ICP;  // diagnostics: time the body alone
@@ -1023,11 +1030,14 @@ a3d_status batch_collect_timing(a3d_multiscale_batch* b) {
   A3D_HIP_TRY(hipEventSynchronize(b->ev1));
   A3D_HIP_TRY(hipEventElapsedTime(&b->last_total_ms, b->ev0, b->ev1));
   b->last_kernel_ms = 0.f;
+  for (int l = 0; l < 16; ++l) b->last_level_ms[l] = 0.f, b->last_level_launches[l] = 0;
   if (b->profile_kernels) {
     for (size_t k = 0; k < b->last_kernel_launches; ++k) {
       float ms = 0.f;
       A3D_HIP_TRY(hipEventElapsedTime(&ms, b->kev[2 * k], b->kev[2 * k + 1]));
       b->last_kernel_ms += ms;
+      const uint32_t l = k < b->kev_level.size() ? b->kev_level[k] : 0u;
+      b->last_level_ms[l & 15u] += ms, ++b->last_level_launches[l & 15u];
     }
   }
   return A3D_OK;
@@ -1338,6 +1348,15 @@ a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* b, float* o
   A3D_REQUIRE(b && out_kernel_ms, A3D_INVALID_PARAMETER, "null argument");
   A3D_TRY(batch_collect_timing(b));
   *out_kernel_ms = b->last_kernel_ms;
+  return A3D_OK;
+}
+
+// The same per pyramid level (profiling on): sum of the launch durations at `level` and how many launches that was.
+a3d_status a3d_multiscale_batch_last_level_ms(a3d_multiscale_batch* b, uint32_t level, float* out_ms, uint32_t* out_launches) {
+  A3D_REQUIRE(b && out_ms && level < 16, A3D_INVALID_PARAMETER, "bad argument");
+  A3D_TRY(batch_collect_timing(b));
+  *out_ms = b->last_level_ms[level];
+  if (out_launches) *out_launches = b->last_level_launches[level];
   return A3D_OK;
 }
 

@@ -202,6 +202,12 @@ class MultiscaleAlignBatch:
         _abi.check(self.ctx.lib.a3d_multiscale_batch_last_kernel_ms(self.handle, C.byref(ms)))
         return ms.value
 
+    def last_level_ms(self, level):
+        """(sum of the per-pixel kernel's launch durations at `level` in the last pass, number of launches); profiling on."""
+        ms, n = C.c_float(), C.c_uint32()
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_last_level_ms(self.handle, int(level), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def free(self):
         if self.handle and self.ctx.handle:  # a handle must not outlive its context
             self.ctx.lib.a3d_multiscale_batch_free(self.handle)

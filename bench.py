@@ -686,6 +686,8 @@ def main():
         # the concurrent launches summed without double counting their overlap.
         conc = batch.concurrency()
         kernel_ms, region_ms, launches = [], [], 0
+        level_ms = [[] for _ in range(len(params))]
+        level_launches = [0] * len(params)
         for _ in range(20):  # launch sequence as it runs in the timed steps (no per-launch events)
             batch.enqueue()
             ctx.synchronize()
@@ -696,6 +698,9 @@ def main():
             ctx.synchronize()
             kernel_ms.append(batch.last_kernel_ms())
             launches = batch.last_timing()[1]
+            for l in range(len(params)):
+                ms_l, level_launches[l] = batch.last_level_ms(l)
+                level_ms[l].append(ms_l)
         batch.set_profiling(False)
         kms, rms = float(np.median(kernel_ms)), float(np.median(region_ms))
         iters = [int(p.max_iterations) for p in params]
@@ -715,6 +720,18 @@ def main():
             "launch_sequence_ms": rms, "launch_sequence_ms_stats": stats(region_ms),
             "kernel_share_of_step": rms / ms_per_step,
         }
+        # per pyramid level: `conc` launches of a level run at once (the pair groups move in step), so the level's share
+        # of the sequence is its summed launch time / conc, and its bandwidth the level's bytes over that
+        per_level = []
+        for l in range(len(params)):
+            ms_l = float(np.median(level_ms[l])) / max(1, conc)
+            b_l = P * iters[l] * level_bytes(W >> l, H >> l)
+            per_level.append({"level": l, "size": f"{W >> l}x{H >> l}", "launches": int(level_launches[l]),
+                              "avg_launch_us": float(np.median(level_ms[l])) / max(1, level_launches[l]) * 1e3,
+                              "ms_of_sequence": ms_l, "algorithmic_bytes": b_l,
+                              "achieved_GBs": (b_l / (ms_l * 1e-3) / 1e9) if ms_l > 0 else None,
+                              "frac": (b_l / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_l > 0 else None})
+        roof["per_level"] = per_level
         poses, status = batch.align()
         extra = {"failed_pairs": int(np.count_nonzero(status)),
                  "timing": {"timed_region_s": elapsed, "ms_per_step_repeated": stats(reps) if reps else None,

@@ -295,6 +295,8 @@ a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* batch);
  * time, so that sum can exceed the wall time reported by a3d_multiscale_batch_last_timing. */
 a3d_status a3d_multiscale_batch_set_profiling(a3d_multiscale_batch* batch, int32_t on);
 a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* batch, float* out_kernel_ms);
+a3d_status a3d_multiscale_batch_last_level_ms(a3d_multiscale_batch* batch, uint32_t level, float* out_ms,
+                                              uint32_t* out_launches);  /* the same sum for one pyramid level */
 a3d_status a3d_multiscale_batch_concurrency(a3d_multiscale_batch* batch, uint32_t* out_streams);
 /* Time of the most recent batch_align on the device, between hipEvents recorded on the context
  * stream around its launches, and the share of it spent in the per-pixel kernel (sum of that
