@@ -277,6 +277,9 @@ __global__ void __launch_bounds__(256, MERGED ? 5 : 1)
     }
   };
   JobState* st = &states[pair];
+#ifdef A3D_TAIL_STAMPS
+  if (threadIdx.x == 0 && pair == 0 && blockIdx.x == 0) g_tail_stamps[8] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (st->status == A3D_OK) {
     const LevelDesc d = descs[pair];
     const Pose T = st->pose;
@@ -351,6 +354,9 @@ __global__ void __launch_bounds__(256, MERGED ? 5 : 1)
     }
     }  // G != 1
   }
+#ifdef A3D_TAIL_STAMPS
+  if (threadIdx.x == 0 && pair == 0 && blockIdx.x == 0) g_tail_stamps[9] = __builtin_amdgcn_s_memrealtime();
+#endif
   // a failed job stays frozen: its blocks contribute nothing and nobody runs its solve
   SolveArgs sa = solve;
   if (st->status != A3D_OK) sa.mode = SOLVE_NONE;
