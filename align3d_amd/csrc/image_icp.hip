@@ -1316,6 +1316,7 @@ a3d_status a3d_multiscale_batch_rebind(a3d_multiscale_batch* b, const a3d_device
 // only as far as stream order requires (everything enqueued on the context before this call).
 a3d_status a3d_multiscale_batch_results(a3d_multiscale_batch* b, a3d_pose* out_poses_host, int32_t* out_status_host) {
   A3D_REQUIRE(b && (out_poses_host || out_status_host), A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(b->fence->recorded, A3D_INVALID_PARAMETER, "a3d_multiscale_batch_results: no pass has been enqueued on this batch");
   A3D_HIP_TRY(hipSetDevice(b->ctx->device));
   a3d_status worst;
   return read_results(b, out_poses_host, out_status_host, &worst, true);

@@ -643,6 +643,8 @@ def test_two_batches_alternating_over_a_stream_of_rounds():
                 lv.free()
         first = bld.build_many(cam, streams[0], synth.DEPTH_SCALE)
         batches = [MultiscaleAlignBatch(main, prm, first[:P], first[1:]) for _ in range(2)]
+        with pytest.raises(A3dError):  # nothing enqueued yet: there are no results to read
+            batches[0].results()
         for lv in (lv for p in first for lv in p):
             lv.free()
         prev, got = None, []
