@@ -258,7 +258,11 @@ template <int G, bool MERGED>
 __global__ void __launch_bounds__(256, MERGED ? 5 : 1)
     image_icp_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
                      float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve, int PPT) {
-  const int pair = blockIdx.y;
+  // Odd iterations walk the pairs (and a pair's tiles) backwards: the arrays touched last by iteration k are touched
+  // first by iteration k + 1, while they are still in the Infinity Cache (a forward sweep over a working set larger
+  // than the cache re-reads everything from HBM every iteration).
+  const int pair = solve.reverse ? (int)(gridDim.y - 1u - blockIdx.y) : (int)blockIdx.y;
+  const uint32_t tile = solve.reverse ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
   constexpr int NACC = MERGED ? GN_MERGED : GN_PARTIAL;
   float acc[NACC];
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ void __launch_bounds__(256, MERGED ? 5 : 1)
     const Pose T = st->pose;
     const uint32_t mw = d.tw + 2;
     const float twf = (float)d.tw, thf = (float)d.th;
-    const uint32_t base = blockIdx.x * (256u * (uint32_t)PPT) + threadIdx.x;
+    const uint32_t base = tile * (256u * (uint32_t)PPT) + threadIdx.x;
     // Software pipeline, three batches deep: while batch k is being accumulated (stage D) the target
     // gathers of batch k+1 and the source records of batch k+2 are in flight, so the L1 miss queue of the
     // CU stays occupied during the arithmetic.
@@ -360,7 +364,7 @@ __global__ void __launch_bounds__(256, MERGED ? 5 : 1)
   // a failed job stays frozen: its blocks contribute nothing and nobody runs its solve
   SolveArgs sa = solve;
   if (st->status != A3D_OK) sa.mode = SOLVE_NONE;
-  block_finish<NACC>(acc, partials + (size_t)pair * gridDim.x * GN_PARTIAL, blockIdx.x, gridDim.x,
+  block_finish<NACC>(acc, partials + (size_t)pair * gridDim.x * GN_PARTIAL, tile, gridDim.x,
                      counters + pair, st, sa, pair);
 }
 
@@ -675,6 +679,9 @@ struct a3d_multiscale_batch {
   // A3D_ICP_ACCUM=merged: 31 merged running sums (H and g of add_weighted directly) instead of 2 x 29: 96 VGPRs,
   // one more wave per SIMD — measured 18.5 k against 18.7 k pairs/s (occupancy is not what limits the kernel): opt-in
   bool merged_accumulators = false;
+  // bit l: the odd iterations of level l sweep the pairs and tiles backwards (Infinity-Cache reuse between iterations;
+  // A3D_ICP_REVERSE=mask, default: every level)
+  uint32_t reverse_mask = 0xFFFFu;
   // Pair groups launched on separate streams: one group's launch ramp and last-block solve overlap the other
   // groups' streaming (pairs are independent, so the groups never synchronise until the final read-out).
   uint32_t n_streams = 1;
@@ -887,6 +894,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     b->d_status = (int32_t*)(base + o_status), b->d_readback = (double*)(base + o_readback);
   }
   A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
+  if (const char* env = getenv("A3D_ICP_REVERSE")) b->reverse_mask = (uint32_t)strtoul(env, nullptr, 0);  // tuning knob
   if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
   if (const char* env = getenv("A3D_ICP_PERSISTENT_LEVELS")) b->level_mask = (uint32_t)strtoul(env, nullptr, 0);
   // measured (scripts/streams_sweep*.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
@@ -964,7 +972,7 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   for (uint32_t l = levels_to_run; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
     const a3d_icp_params& prm = b->params[l];
     profile_level = l;
-    SolveArgs sa;
+    SolveArgs sa{};
     sa.weight = prm.weight, sa.color_weight = prm.color_weight;
     sa.mode = getenv("A3D_ICP_NOSOLVE") ? SOLVE_NONE : SOLVE_IMAGE_ICP;  // diagnostics: time the body alone
     sa.trace = d_trace, sa.trace_stride = trace_stride;
@@ -1012,6 +1020,7 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
     for (uint64_t it = 0; it < prm.max_iterations; ++it) {
       sa.first_in_level = it == 0, sa.last_in_level = it + 1 == prm.max_iterations;
       sa.trace_index = trace_index;
+      sa.reverse = (int)((it & 1u) && ((b->reverse_mask >> l) & 1u) && !d_trace);
       for (uint32_t g = 0; g < S; ++g) {
         const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
         hipStream_t gs = g == 0 ? s : b->aux_streams[g - 1];

@@ -9,7 +9,8 @@ sharded in contiguous blocks (align3d_amd.distributed.shard_range), every rank a
 RCCL all-gather collects the 4x4 poses in global pair order (gather_poses) — weak scaling.
 
     python bench.py --gpus 1 --steps 600 --warmup 20
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...            (no WORLD_SIZE in the env: starts N fresh rank processes itself)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (WORLD_SIZE must equal N)
 
 Prints ONE JSON line on rank 0 (contract in the round instructions) with `roofline` for the dominant
 kernel (the per-pixel kernel) and `cpu_baseline` (the CPU oracle timed on a bounded sample); `extra` holds the
@@ -72,7 +73,7 @@ def measured_traffic(name, **match):
             rec = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if all(rec.get(k) == v for k, v in match.items()):
+        if all(rec.get(k, 0 if k == "distinct_frames" else None) == v for k, v in match.items()):
             return float(rec["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
     return None, None
 
@@ -245,6 +246,19 @@ def frame_build_bench(ctx, n_frames, W, H):
         out[label] = {"ms_per_frame": float(np.median(per)), "ms_per_frame_stats": stats(per),
                       "frames_per_s": 1e3 / float(np.median(per))}
     out["workload"] = f"{n_frames} frames {W}x{H} per a3d_range_image_build_pyramids call, 3 levels, normals + intensity maps"
+    return out
+
+
+def live_pixel_fractions(ctx, params, target_pyramid, source_pyramid, pose):
+    """Per level: the share of source pixels whose geometric term is accumulated at `pose` (count_g / N from one
+    a3d_image_icp_accumulate pass): what fraction of the pixels the kernel streams also reaches its Jacobian stage."""
+    from align3d_amd import ImageIcp
+
+    out = []
+    for l in range(len(params)):
+        g, _ = ImageIcp.new(ctx, params[l], target_pyramid[l]).accumulate(source_pyramid[l], pose)
+        h, w = source_pyramid[l].shape
+        out.append(g["count"] / float(h * w))
     return out
 
 
@@ -469,7 +483,7 @@ def load_cpu_oracle():
     return O, ("-O3 -march=native" if os.path.exists(native) else "-O2 (portable)")
 
 
-def cpu_baseline_main(O, host_pyramids, params, n_pairs, gpu_poses, cores, budget_s=20.0):
+def cpu_baseline_main(O, host_pyramids, pair_frames, params, n_pairs, gpu_poses, cores, budget_s=20.0):
     """ms3x15 on the first n_pairs pairs, threaded like the reference (4096-pixel chunks over the host's cores)."""
     def frame(dev_level):
         ri = dev_level.download(colors=False)  # the very arrays the GPU path reads
@@ -481,11 +495,12 @@ def cpu_baseline_main(O, host_pyramids, params, n_pairs, gpu_poses, cores, budge
     host = {}
     per = []
     for p in range(n_pairs):
-        for q in (p, p + 1):
+        fa, fb = pair_frames[p]
+        for q in (fa, fb):
             if q not in host:
                 host[q] = [frame(r) for r in host_pyramids[q]]
         t0 = time.perf_counter()
-        st, T = O.multiscale_align(parr, len(params), host[p], host[p + 1], threads=cores)
+        st, T = O.multiscale_align(parr, len(params), host[fa], host[fb], threads=cores)
         per.append(time.perf_counter() - t0)
         if st == 0 and gpu_poses is not None:
             ang, tr = O.transform_metrics(gpu_poses[p].to_c(), T)
@@ -493,7 +508,7 @@ def cpu_baseline_main(O, host_pyramids, params, n_pairs, gpu_poses, cores, budge
         if sum(per) > budget_s:
             break
     t0 = time.perf_counter()
-    O.multiscale_align(parr, len(params), host[0], host[1], threads=1)
+    O.multiscale_align(parr, len(params), host[pair_frames[0][0]], host[pair_frames[0][1]], threads=1)
     single_ms = (time.perf_counter() - t0) * 1e3
     return {
         "value": len(per) / sum(per), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
@@ -570,6 +585,40 @@ def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clou
     return out
 
 
+def launch_ranks(n, argv):
+    """`--gpus N` without a launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one
+    per GPU) before this process has made any HIP call, let rank 0's JSON line through on the shared stdout and exit
+    non-zero if any rank fails.  Children are started, never exec'ed into (a process that has touched the GPU must
+    not be replaced)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                log(f"rank {r} exited with {code}: stopping the other ranks")
+                for q in pending.values():  # exactly the processes started above
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -583,11 +632,24 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (gloo + --device 0 rehearses the multi-rank path on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for this rank (default: LOCAL_RANK)")
+    ap.add_argument("--shared-frames", action="store_true",
+                    help="round-2 workload: pair p = frames (p, p + 1) of ONE 65-frame stream, so neighbouring pairs "
+                         "share a frame.  Default: 2 P distinct frames, pair p = frames (2p, 2p + 1): independent pairs")
+    ap.add_argument("--dump-gathered", default=None,
+                    help="rank 0 writes the gathered [world * P, 16] pose matrices of the last step to this .npy file")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="run the N > 1 code path (process group, all-gather on the context stream) even with one "
                          "rank: checks the RCCL path on a one-GPU box (launch under torchrun --nproc-per-node 1)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:  # nobody launched ranks for us: do it here, before anything touches the GPU
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        log(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to report a wrong n_gpus")
+        sys.exit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -611,17 +673,23 @@ def main():
     # ONE global list of world x P pairs, sharded in contiguous blocks.  Global pair j = frames
     # (j % P, j % P + 1) of stream 1000 + j // P, so a rank's block is (a slice of) one stream and needs P + 1 frames.
     lo, hi = shard_range(world * P, world, rank)
-    assert hi - lo == P and lo // P == (hi - 1) // P, "a rank's block lies inside one stream"
-    stream_id, first = lo // P, lo % P
+    assert hi - lo == P and lo % P == 0, "a rank's block is exactly one stream"
+    stream_id = lo // P
+    # Headline workload (configs[4]: INDEPENDENT pairs): 2 P distinct frames, pair p = (frame 2p -> frame 2p + 1), so no
+    # array is read by two pairs.  --shared-frames: the round-2 workload, pair p = (frame p, frame p + 1) of a
+    # (P + 1)-frame stream, where frame p + 1 is pair p's source and pair p + 1's target.
+    distinct = not args.shared_frames
+    pair_frames = [(2 * p, 2 * p + 1) for p in range(P)] if distinct else [(p, p + 1) for p in range(P)]
+    n_frames = 2 * P if distinct else P + 1
     t0 = time.time()
-    host_pyramids, poses_gt, build_ms = build_stream_pyramids(ctx, seed=1000 + stream_id, n_frames=P + 1, width=W,
-                                                              height=H, first=first, total=P + 1)
+    host_pyramids, poses_gt, build_ms = build_stream_pyramids(ctx, seed=1000 + stream_id, n_frames=n_frames, width=W,
+                                                              height=H)
     if rank == 0:
-        log(f"rendered and built {P + 1} synthetic frame pyramids in {time.time() - t0:.1f}s "
+        log(f"rendered and built {n_frames} synthetic frame pyramids in {time.time() - t0:.1f}s "
             f"({build_ms:.3f} ms per frame on the device, PCIe upload of depth + RGB included)")
-    # pair p: target = frame p, source = frame p + 1; every pyramid level resident in HBM
-    targets = [host_pyramids[p] for p in range(P)]
-    sources = [host_pyramids[p + 1] for p in range(P)]
+    # pair p: target = its first frame, source = its second; every pyramid level resident in HBM
+    targets = [host_pyramids[a] for a, _ in pair_frames]
+    sources = [host_pyramids[b] for _, b in pair_frames]
     batch = MultiscaleAlignBatch(ctx, params, targets, sources)
 
     d_mats = gathered = ext_stream = host_mats = mats = None
@@ -708,7 +776,7 @@ def main():
         bytes_per_launch = step_alg_bytes / max(1, launches)
         avg_launch_ms = kms / max(1, launches)
         achieved = step_alg_bytes / (rms * 1e-3) / 1e9
-        traffic, traffic_src = (measured_traffic("bench", pairs_per_gpu=P, concurrent_launches=conc)
+        traffic, traffic_src = (measured_traffic("bench", pairs_per_gpu=P, concurrent_launches=conc, distinct_frames=int(distinct))
                                 if (W, H) == (640, 480) else (None, None))
         roof = {
             "bound": "hbm", "kernel": "image_icp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -732,8 +800,18 @@ def main():
                               "achieved_GBs": (b_l / (ms_l * 1e-3) / 1e9) if ms_l > 0 else None,
                               "frac": (b_l / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_l > 0 else None})
         roof["per_level"] = per_level
+        for lv in per_level:  # flat copies: the driver's record keeps scalars only
+            roof[f"level{lv['level']}_frac"] = lv["frac"]
+            roof[f"level{lv['level']}_avg_launch_us"] = lv["avg_launch_us"]
+            roof[f"level{lv['level']}_share_of_sequence"] = lv["ms_of_sequence"] / rms if rms > 0 else None
         poses, status = batch.align()
-        extra = {"failed_pairs": int(np.count_nonzero(status)),
+        failed_pairs = int(np.count_nonzero(status))
+        roof["failed_pairs"] = failed_pairs  # a failed pair freezes and its blocks stop working: must be 0
+        # proof of work: the share of source pixels that pass every gate and reach the Jacobian stage, per level (one
+        # accumulate pass per level at the pair's final pose; dead pixels skip that stage)
+        for l, fr in enumerate(live_pixel_fractions(ctx, params, targets[0], sources[0], poses[0])):
+            roof[f"level{l}_live_pixel_frac_pair0"] = fr
+        extra = {"failed_pairs": failed_pairs,
                  "timing": {"timed_region_s": elapsed, "ms_per_step_repeated": stats(reps) if reps else None,
                             "steps_per_repeat": rep_steps}}
         if multi:  # the gathered buffer holds every rank's block in global pair order; this rank's starts at lo
@@ -741,10 +819,12 @@ def main():
             extra["gather_matches_local_poses"] = bool(
                 all(np.allclose(own[p], poses[p].matrix(), atol=1e-6) for p in range(P)))
             extra["gathered_pairs"] = int(gathered.shape[0])
+            if args.dump_gathered:
+                np.save(args.dump_gathered, gathered.cpu().numpy())
         # accuracy against the synthetic ground truth (reported, not a parity claim)
         errs = []
-        for p in range(P):
-            gt = synth.relative_pose(poses_gt[p], poses_gt[p + 1])
+        for p, (fa, fb) in enumerate(pair_frames):
+            gt = synth.relative_pose(poses_gt[fa], poses_gt[fb])
             d = np.linalg.inv(gt) @ poses[p].matrix().astype(np.float64)
             errs.append((np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)), np.linalg.norm(d[:3, 3])))
         extra["mean_error_vs_synthetic_gt"] = {"angle_rad": float(np.mean([e[0] for e in errs])),
@@ -767,7 +847,7 @@ def main():
             extra["kdtree"]["x_vs_published_cpu_101.75ms"] = 101.75 / extra["kdtree"]["ms_per_500k_queries"]
             extra["pcl_icp"], clouds = pcl_icp_bench(ctx)
             extra["odometry"] = odometry_bench(ctx)
-            level0_host = host_pyramids[0][0].download()
+            level0_host = targets[0][0].download()
             depth0 = synth.frame_stream(1000, 1, W, H)[0][0][0]
             extra["frame_prep"] = frame_prep_bench(ctx, level0_host, depth0)
             # what a caller with host buffers pays per new frame: u16 depth + u8 RGB over PCIe, then bilateral,
@@ -780,7 +860,7 @@ def main():
         if world == 1 and args.cpu_pairs > 0:
             O, flags = load_cpu_oracle()
             model, cores = cpu_info()
-            cpu = cpu_baseline_main(O, host_pyramids, params, min(args.cpu_pairs, P), poses, cores)
+            cpu = cpu_baseline_main(O, host_pyramids, pair_frames, params, min(args.cpu_pairs, P), poses, cores)
             cpu["cpu_model"], cpu["compiler_flags"] = model, flags
             if level0_host is not None:
                 def oframe(dev_level):
@@ -788,7 +868,7 @@ def main():
                     k = ri.intrinsics
                     return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
                 sec = cpu_baselines_secondary(O, cores, level0_host, depth0,
-                                              (oframe(host_pyramids[0][0]), oframe(host_pyramids[1][0])), clouds)
+                                              (oframe(targets[0][0]), oframe(sources[0][0])), clouds)
                 for v in sec.values():
                     v["cpu_model"], v["compiler_flags"] = model, flags
                 extra["cpu_baselines"] = sec
@@ -805,10 +885,19 @@ def main():
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ms3x15: {P} independent {W}x{H} frame pairs per GPU resident in HBM, "
-                                   "MsIcpParams::repeat(3, IcpParams::default()) = 3 levels x 15 iterations "
-                                   "(configs[1] pair shape, batched as the per-GPU shard of configs[4])",
+            "config": {"workload": (f"ms3x15 x {P} pairs/GPU, {'distinct' if distinct else 'shared'} frames, {W}x{H}, "
+                                    "3 lvl x 15 it, HBM-resident (configs[4] shard)"),
+                       "workload_detail": f"{P} independent {W}x{H} frame pairs per GPU resident in HBM ("
+                                          + ("2 P distinct frames: pair p = frames (2p, 2p+1), no array shared between pairs"
+                                             if distinct else "P + 1 frames: pair p = frames (p, p+1), neighbours share a frame")
+                                          + "), MsIcpParams::repeat(3, IcpParams::default()) = 3 levels x 15 iterations "
+                                            "(configs[1] pair shape, batched as the per-GPU shard of configs[4])",
+                       "distinct_frames": bool(distinct), "frames_resident_per_gpu": n_frames,
                        "pairs_per_gpu": P, "global_pairs": world * P, "levels": 3, "iterations_per_level": iters,
+                       "ranks_in_collective": (dist.get_world_size() if multi else 1),
+                       "gathered_pairs": (int(gathered.shape[0]) if multi else None),
+                       "gather_matches_local_poses": extra.get("gather_matches_local_poses"),
+                       "failed_pairs": failed_pairs,
                        "sharding": f"contiguous blocks of one {world * P}-pair list (shard_range): this rank [{lo}, {hi})",
                        "collective": (f"one all-gather of 16 f32 per pair per step ({'RCCL' if use_nccl else 'gloo rehearsal'})"
                                       if multi else "none")},

@@ -14,5 +14,5 @@ for cfg in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d['roofline']
-print('value %.0f pairs/s  ms/step %.3f  avg_launch_us %.1f  frac %.3f  failed %s' % (d['value'], d['ms_per_step'], r.get('avg_launch_us', 0), r['frac'], d['extra'].get('failed_pairs')))"
+print('value %.0f pairs/s  ms/step %.3f  avg_launch_us %.1f  frac %.3f  failed %s  level us %s  level frac %s' % (d['value'], d['ms_per_step'], r.get('avg_launch_us', 0), r['frac'], d['extra'].get('failed_pairs'), ['%.1f' % r.get('level%d_avg_launch_us' % l, 0) for l in range(3)], ['%.3f' % (r.get('level%d_frac' % l) or 0) for l in range(3)]))"
 done

@@ -1,0 +1,87 @@
+"""The N > 1 path of bench.py through REAL batches: `bench.py --gpus 2` starts two fresh rank processes itself, each
+rank builds and aligns its own block of the global pair list on the GPU, one all-gather (gloo here: the box has one
+GPU, both ranks use device 0) assembles the poses in global pair order.  Rank 1's block must equal, bit for bit, a
+single-process batch of the same pairs (stream 1001)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_world_size_mismatch_is_refused():
+    """WORLD_SIZE set by a launcher and different from --gpus: exit non-zero before anything touches a GPU."""
+    r = run_bench(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0"}, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared", [False, True])
+def test_two_fresh_ranks_align_their_own_blocks_and_gather(ctx, tmp_path, shared):
+    P = 8
+    dump = str(tmp_path / "gathered.npy")
+    args = ["--gpus", "2", "--backend", "gloo", "--device", "0", "--pairs-per-gpu", str(P), "--steps", "3", "--warmup", "1",
+            "--no-extras", "--cpu-pairs", "0", "--dump-gathered", dump] + (["--shared-frames"] if shared else [])
+    r = run_bench(args)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_pairs"] == 2 * P
+    assert out["config"]["ranks_in_collective"] == 2 and out["config"]["gathered_pairs"] == 2 * P
+    assert out["config"]["gather_matches_local_poses"] is True
+    assert out["config"]["distinct_frames"] is (not shared)
+    assert out["roofline"]["failed_pairs"] == 0
+    gathered = np.load(dump)
+    assert gathered.shape == (2 * P, 16) and gathered.dtype == np.float32
+
+    # rank 1's block = stream 1001, as one single-process batch on this process's context
+    sys.path.insert(0, ROOT)
+    import bench
+    from align3d_amd import IcpParams, MsIcpParams, MultiscaleAlignBatch
+
+    n_frames = P + 1 if shared else 2 * P
+    pyr, _, _ = bench.build_stream_pyramids(ctx, seed=1001, n_frames=n_frames, width=640, height=480)
+    pairs = [(p, p + 1) for p in range(P)] if shared else [(2 * p, 2 * p + 1) for p in range(P)]
+    batch = MultiscaleAlignBatch(ctx, MsIcpParams.repeat(3, IcpParams.default()), [pyr[a] for a, _ in pairs],
+                                 [pyr[b] for _, b in pairs])
+    d = ctx.malloc(P * 64)
+    _, status = batch.align(matrices_device=d)
+    mats = ctx.to_host(d, np.zeros((P, 16), np.float32))
+    ctx.free(d)
+    batch.free()
+    for lv in (lv for p in pyr for lv in p):
+        lv.free()
+    assert not status.any()
+    assert np.array_equal(gathered[P:].view(np.uint32), mats.view(np.uint32)), "rank 1's block is not the single-process batch"
+    # rank 0's block is another stream: not the same poses
+    assert not np.array_equal(gathered[:P], gathered[P:])
+    # every gathered matrix is a rigid transform
+    m = gathered.reshape(-1, 4, 4)
+    assert np.allclose(m[:, 3], [0, 0, 0, 1]) and np.allclose(np.linalg.det(m[:, :3, :3]), 1, atol=1e-5)
+
+
+def test_launcher_fails_loudly_when_a_rank_fails(tmp_path):
+    """On a machine without a GPU every rank fails at a3d_context_create: the launcher must return non-zero (and not
+    hang waiting for the other ranks).  On a GPU box the ranks succeed, which the gpu test above covers."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    r = run_bench(["--gpus", "2", "--backend", "gloo", "--device", "0", "--pairs-per-gpu", "2", "--steps", "1", "--warmup", "0",
+                   "--no-extras", "--cpu-pairs", "0"], timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
