@@ -43,7 +43,38 @@ __global__ void job_finish_kernel(const JobState* __restrict__ states, Pose* __r
   }
 }
 
+// Head-solve form: one block per job applies the job's last iteration (the partials of its last launch) and writes
+// the outputs from the resulting state.
+__global__ void __launch_bounds__(256)
+    job_finish_head_kernel(const JobState* __restrict__ states_in, const float* __restrict__ partials_in,
+                           uint32_t job_stride, HeadArgs head, Pose* __restrict__ poses_out,
+                           int32_t* __restrict__ status_out, float* __restrict__ matrices_out) {
+  __shared__ uint32_t s_state[JOB_WORDS];
+  const int j = blockIdx.x;
+  head_advance(states_in + j, nullptr, partials_in + (size_t)j * job_stride, head, j, s_state, true);
+  if (threadIdx.x == 0) {
+    const float* f = (const float*)s_state;
+    const Pose p{{f[0], f[1], f[2]}, {f[3], f[4], f[5], f[6]}};
+    if (poses_out) poses_out[j] = p;
+    if (status_out) status_out[j] = (int32_t)s_state[15];
+    if (matrices_out) {
+      float m[16];
+      pose_to_matrix(p, m);
+      for (int k = 0; k < 16; ++k) matrices_out[(size_t)j * 16 + k] = m[k];
+    }
+  }
+}
+
 }  // namespace
+
+a3d_status launch_job_finish_head(hipStream_t stream, const JobState* states_in, const float* partials_in,
+                                  uint32_t partials_job_stride, const HeadArgs& head, Pose* poses_out,
+                                  int32_t* status_out, float* matrices_out, int n_jobs) {
+  hipLaunchKernelGGL(job_finish_head_kernel, dim3(n_jobs), dim3(256), 0, stream, states_in, partials_in,
+                     partials_job_stride, head, poses_out, status_out, matrices_out);
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
 
 a3d_status launch_gn_readback(hipStream_t stream, const float* partials, int tiles, double* out58) {
   hipLaunchKernelGGL(gn_readback_kernel, dim3(1), dim3(64), 0, stream, partials, tiles, out58);

@@ -54,6 +54,11 @@ a3d_status launch_job_init(hipStream_t stream, JobState* states, const Pose* ini
 // poses_out[j] = states[j].pose ; status_out[j] ; matrices_out[j] = 4x4 row-major (each nullable)
 a3d_status launch_job_finish(hipStream_t stream, const JobState* states, Pose* poses_out, int32_t* status_out,
                              float* matrices_out, int n_jobs);
+// Head-solve form (HeadArgs below): applies the last iteration (partials of the last launch) and writes the outputs.
+struct HeadArgs;
+a3d_status launch_job_finish_head(hipStream_t stream, const JobState* states_in, const float* partials_in,
+                                  uint32_t partials_job_stride, const HeadArgs& head, Pose* poses_out,
+                                  int32_t* status_out, float* matrices_out, int n_jobs);
 // Converts the 58 f64 sums of launch_gn_readback into the ABI's two a3d_gn_state.
 void gn_states_from_sums(const double sums[GN_PARTIAL], a3d_gn_state* geom, a3d_gn_state* color);
 
@@ -169,159 +174,207 @@ __device__ __forceinline__ void store_status(JobState* st, int v) {
 }
 
 // ---- finishing an iteration on the device ---------------------------------------------------------
-// Called by every thread of the job's last block.  sums = GN_PARTIAL f64 totals in LDS.
 //   GaussNewton::add_weighted / weight / mean_squared_residual   src/optim/gaussnewton.rs:115-133
 //   GaussNewton::solve (f64 Cholesky, nalgebra's update order)    src/optim/gaussnewton.rs:84-93
 //   optim_transform = exp(update) * optim_transform, best tracking   src/icp/image_icp.rs:150-161,
 //                                                                   src/icp/pcl_icp.rs:94-103
-// The 6x6 factorisation runs one matrix element per thread out of LDS (column k: sqrt, scale the
-// column, rank-1 update of the trailing columns — the same operations on the same operands, in the
-// same order per element, as nalgebra's left-looking loop), which keeps the solve out of the
-// accumulate kernel's register budget; the substitutions and the pose update are one lane.
-__device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums, const SolveArgs& a, int job) {
+// The 6x6 factorisation runs one matrix element per lane with the operands exchanged by wave shuffles (column k:
+// sqrt, scale the column, rank-1 update of the trailing columns — the same operations on the same operands, in the
+// same order per element, as nalgebra's left-looking loop); the substitutions and the pose update are computed by
+// every lane alike (all inputs are wave-uniform).
+// ---- ticketless hand-off: the NEXT launch finishes the iteration ("head solve") ---------------------------------
+// The per-iteration chain above is  partial stores (write-through) -> drain -> agent-scope ticket -> last block:
+// partial loads -> solve -> agent-scope state stores -> kernel boundary -> state loads.  In the head form a launch
+// only stores its block partials (plain stores; the kernel boundary publishes them) and exits; every block of the
+// NEXT launch of the job loads the job's partials (tiles x 58 floats, L2 hits), sums them in the same fixed order and
+// runs the same solve redundantly before its pixel pass: no atomic, no drain, no last-block serialisation, and the
+// solve of every job runs at once instead of one after the other as jobs finish.  One block per job stores the new
+// state, into the OTHER of two state buffers (the blocks of this launch are still reading the current one); the
+// partials alternate between two buffers for the same reason.  job_finish_head_kernel applies the last iteration.
+struct HeadArgs {
+  float weight, color_weight;  // of the iteration being finished (the previous launch's level)
+  int mode;                    // SOLVE_IMAGE_ICP, or SOLVE_NONE: no previous iteration, the state is used as it is
+  uint32_t tiles;              // partials per job that the previous launch wrote
+  int first_in_level, last_in_level;
+  int trace_stride, trace_index;
+  float* trace;  // nullable: [job][trace_stride][8]
+};
+__host__ __device__ inline HeadArgs head_args_of(const SolveArgs& a) {
+  HeadArgs h;
+  h.weight = a.weight, h.color_weight = a.color_weight, h.mode = a.mode, h.tiles = 0;
+  h.first_in_level = a.first_in_level, h.last_in_level = a.last_in_level;
+  h.trace_stride = a.trace_stride, h.trace_index = a.trace_index, h.trace = a.trace;
+  return h;
+}
+constexpr int JOB_WORDS = 18;
+static_assert(sizeof(JobState) == JOB_WORDS * 4, "JobState is 18 words");
+
+// sqrt(x) and 1 / sqrt(x) of a positive f64: hardware estimate, two Goldschmidt steps, one correction of the root
+// (1-2 ulp; the compiler's sqrt + divide sequences cost ~3x the dependent operations).
+__device__ __forceinline__ double rsqrt_f64(double x, double* root) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g), h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g), h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  *root = __builtin_fma(d, h, g);
+  return h + h;
+}
+
+// One wave (threads 0..63 of the block).  Lane k < 18 holds word k of the job's state in `state_bits`; `sums` = the
+// 58 f64 totals of the iteration being finished (LDS).  Leaves the job's new state in s_state[0..18) (LDS) and, when
+// st_out is given, in global memory.  Same operations as gn_finish_block, except that the Cholesky's column scaling
+// and the substitutions multiply by the refined 1 / sqrt(pivot) instead of dividing (f64 results within 1-2 ulp,
+// the f32 update they round to is the same but for a last-bit tie).
+// COHERENT: st_out is read by other blocks of a running launch (the last-block forms): only the words that change are
+// stored, with agent-scope write-through stores.  write_trace: this caller owns the job's trace row.
+template <bool COHERENT = false>
+__device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const double* sums, const HeadArgs& a, int job,
+                                                uint32_t* s_state, JobState* st_out, bool write_trace) {
   __shared__ double Lm[36];
   const int tid = threadIdx.x;
-  if (tid >= 64) return;  // ONE wave finishes the iteration: everything below is wave-synchronous, no block barrier
-  const int r = tid / 6, c = tid % 6;
-  const bool cell = tid < 36;  // lane (r, c) owns matrix element [r][c]
-  const bool image_mode = a.mode == SOLVE_IMAGE_ICP;
-  const bool merged = a.mode == SOLVE_IMAGE_ICP_MERGED;
-  // the job state (pose 0..6, best 7..13, best_residual 14): one float per lane, in flight during the solve
-  const float state_word = tid < 15 ? ld_coherent((const float*)st + tid) : 0.0f;
-  double v = 0.0;
-  if (cell) {
-    const int t = tri6(r < c ? r : c, r < c ? c : r);
-    const float hg = (float)sums[t], hc = (float)sums[GN_ACC + t];
-    // add_weighted: H = Hg w1^2 + Hc w2^2 ; weight(): H *= w^2   (all f32)
-    const float h = merged ? hg
-                           : image_mode ? hg * (a.weight * a.weight) + hc * (a.color_weight * a.color_weight)
-                                        : hg * (a.weight * a.weight);
-    v = (double)h;
-  }
-  A3D_STAMP(3);
-  // Cholesky, column by column, operands exchanged with wave shuffles: sqrt of the pivot, scale the column,
-  // rank-1 update of the trailing columns.
-  int ok = 1;
-  const int src_c = cell ? c * 6 : 0, src_r = cell ? r * 6 : 0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const double diag = __shfl(v, k * 7, 64);
-    if (diag == 0.0 || !(diag >= 0.0)) ok = 0;  // zero, negative or NaN pivot: Cholesky::new() == None (wave-uniform)
-    const double sq = sqrt(diag);
-    if (tid == k * 7) v = sq;
-    if (cell && c == k && r > k) v = v / sq;
-    const double lck = __shfl(v, src_c + k, 64), lrk = __shfl(v, src_r + k, 64);
-    if (cell && c > k && r >= c) v = (-lck) * lrk + v;
-  }
-  A3D_STAMP(4);
-  if (cell) Lm[tid] = v;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the LDS writes above are visible to lane 0 below
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  // From here on every lane computes the same values (all inputs are wave-uniform); only lane 0 stores.
-  float residual;
-  {
-    const float ssq_g = (float)sums[27], ssq_c = (float)sums[merged ? 29 : GN_ACC + 27];
-    const double cnt_g = sums[28], cnt_c = sums[merged ? 30 : GN_ACC + 28];
-    // ImageIcp: weighted sum / combined count ; Icp: plain mean taken before weight()
-    const double count = (image_mode || merged) ? cnt_g + cnt_c : cnt_g;
-    const float ssq = (image_mode || merged) ? ssq_g * a.weight + ssq_c * a.color_weight : ssq_g;
-    residual = ssq / (float)count;
-    if (!(count != 0.0)) ok = 0;  // solve(): None if count == 0
-  }
-  if (!ok) {  // the reference's unwrap() panics here
-    if (tid == 0) {
-      st_coherent(&st->last_residual, residual);
-      store_status(st, A3D_SOLVE_FAILED);
+  auto wordf = [&](int lane) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)state_bits, lane)); };
+  const int status_in = __builtin_amdgcn_readlane((int)state_bits, 15);
+  uint32_t mine = state_bits;  // a frozen job, or nothing to apply: the state goes on unchanged
+  if (a.mode != SOLVE_NONE && status_in == A3D_OK) {
+    const int r = tid / 6, c = tid % 6;
+    const bool cell = tid < 36;  // lane (r, c) owns matrix element [r][c]
+    const bool image_mode = a.mode == SOLVE_IMAGE_ICP;
+    const bool merged = a.mode == SOLVE_IMAGE_ICP_MERGED;
+    double v = 0.0;
+    if (cell) {
+      const int t = tri6(r < c ? r : c, r < c ? c : r);
+      const float hg = (float)sums[t], hc = (float)sums[GN_ACC + t];
+      // add_weighted: H = Hg w1^2 + Hc w2^2 ; weight(): H *= w^2   (all f32)
+      const float h = merged ? hg
+                             : image_mode ? hg * (a.weight * a.weight) + hc * (a.color_weight * a.color_weight)
+                                          : hg * (a.weight * a.weight);
+      v = (double)h;
     }
-    return;
-  }
-  // The two substitutions in registers on one lane (the accumulators are dead here, so this fits the kernel's
-  // register budget): 12 divisions and 45 multiply / add pairs in one dependent chain.
-  double Lr[21], bvec[6];
+    int ok = 1;
+    const int src_c = cell ? c * 6 : 0, src_r = cell ? r * 6 : 0;
+    double rinv[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const float gg = (float)sums[21 + i], gc = (float)sums[GN_ACC + 21 + i];
-    bvec[i] = (double)(merged ? gg : image_mode ? gg * a.weight + gc * a.color_weight : gg * a.weight);
-#pragma unroll
-    for (int j = 0; j <= i; ++j) Lr[i * (i + 1) / 2 + j] = Lm[i * 6 + j];  // lower triangle, row-major packed
-  }
-#define A3D_L(row, col) Lr[(row) * ((row) + 1) / 2 + (col)]
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {  // solve_lower_triangular (column oriented)
-    const double coeff = bvec[i] / A3D_L(i, i);
-    bvec[i] = coeff;
-#pragma unroll
-    for (int rr = i + 1; rr < 6; ++rr) bvec[rr] = -coeff * A3D_L(rr, i) + bvec[rr];
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {  // ad_solve_lower_triangular: L^T x = b
-    double d = 0.0;
-#pragma unroll
-    for (int rr = i + 1; rr < 6; ++rr) d += A3D_L(rr, i) * bvec[rr];
-    bvec[i] = (bvec[i] - d) / A3D_L(i, i);
-  }
-#undef A3D_L
-  float update[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) update[i] = (float)bvec[i];
-  A3D_STAMP(5);
-  auto word = [&](int lane) {
-    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(state_word), lane));
-  };
-  Pose pose{{word(0), word(1), word(2)}, {word(3), word(4), word(5), word(6)}};
-  Pose best{{word(7), word(8), word(9)}, {word(10), word(11), word(12), word(13)}};
-  float best_residual = word(14);
-  if (a.first_in_level) {  // ImageIcp::align starts every level with best = initial, +inf
-    best_residual = __builtin_inff();
-    best = pose;
-  }
-  // sin and cos of theta / 2 (even lanes) and of theta (odd lanes) in one pass
-  Se3Trig tg;
-  tg.theta = se3_theta(update);
-  {
-    const float x = (tid & 1) ? tg.theta : 0.5f * tg.theta;
-    float sx, cx;
-    if (tg.theta <= 0.78539816f) {
-      // |x| <= pi/4 (every ICP update in practice): no range reduction needed, the single-precision minimax
-      // kernels of the Cephes library (sinf / cosf, < 1 ulp on this interval) — the device libm spends ~1 us of
-      // this single-lane tail in its general-argument path
-      const float z = x * x;
-      sx = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
-      cx = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    for (int k = 0; k < 6; ++k) {
+      const double diag = __shfl(v, k * 7, 64);
+      if (diag == 0.0 || !(diag >= 0.0)) ok = 0;  // zero, negative or NaN pivot: Cholesky::new() == None (wave-uniform)
+      double sq;
+      rinv[k] = rsqrt_f64(diag, &sq);
+      if (tid == k * 7) v = sq;
+      if (cell && c == k && r > k) v = v * rinv[k];
+      const double lck = __shfl(v, src_c + k, 64), lrk = __shfl(v, src_r + k, 64);
+      if (cell && c > k && r >= c) v = __builtin_fma(-lck, lrk, v);
+    }
+    if (cell) Lm[tid] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float residual;
+    {
+      const float ssq_g = (float)sums[27], ssq_c = (float)sums[merged ? 29 : GN_ACC + 27];
+      const double cnt_g = sums[28], cnt_c = sums[merged ? 30 : GN_ACC + 28];
+      // ImageIcp: weighted sum / combined count ; Icp: plain mean taken before weight()
+      const double count = (image_mode || merged) ? cnt_g + cnt_c : cnt_g;
+      const float ssq = (image_mode || merged) ? ssq_g * a.weight + ssq_c * a.color_weight : ssq_g;
+      residual = ssq / (float)count;
+      if (!(count != 0.0)) ok = 0;  // solve(): None if count == 0
+    }
+    if (!ok) {  // the reference's unwrap() panics here: the job freezes with A3D_SOLVE_FAILED
+      mine = tid == 15 ? (uint32_t)A3D_SOLVE_FAILED : tid == 16 ? __float_as_uint(residual) : mine;
     } else {
-      sx = sin_f32(x), cx = cos_f32(x);
-    }
-    auto lane_of = [](float v, int lane) {
-      return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
-    };
-    tg.sin_half = lane_of(sx, 0), tg.cos_half = lane_of(cx, 0);
-    tg.sin_theta = lane_of(sx, 1), tg.cos_theta = lane_of(cx, 1);
-  }
-  pose = compose(exp_se3_trig(update, tg), pose);  // Transform::exp(Se3(update)) * optim_transform
-  if (residual < best_residual) {         // stores the transform AFTER the update (image_icp.rs:158-161)
-    best_residual = residual;
-    best = pose;
-  }
-  if (a.trace && tid == 0) {
-    float* tr = a.trace + ((size_t)job * a.trace_stride + a.trace_index) * 8;
-    tr[0] = residual;
-    tr[1] = pose.t.x, tr[2] = pose.t.y, tr[3] = pose.t.z;
-    tr[4] = pose.q.i, tr[5] = pose.q.j, tr[6] = pose.q.k, tr[7] = pose.q.w;
-  }
-  if (a.last_in_level) pose = best;  // align() returns best_transform; the next level starts from it
-  // one store instruction for the whole state: lane k writes float k of JobState (status, word 15, stays)
-  {
-    const float w[17] = {pose.t.x, pose.t.y, pose.t.z, pose.q.i, pose.q.j, pose.q.k, pose.q.w,
-                         best.t.x, best.t.y, best.t.z, best.q.i, best.q.j, best.q.k, best.q.w,
-                         best_residual, 0.0f, residual};
-    float mine = w[0];
+      double bvec[6];
 #pragma unroll
-    for (int k = 1; k < 17; ++k) mine = tid == k ? w[k] : mine;
-    if (tid < 17 && tid != 15) st_coherent((float*)st + tid, mine);
+      for (int i = 0; i < 6; ++i) {
+        const float gg = (float)sums[21 + i], gc = (float)sums[GN_ACC + 21 + i];
+        bvec[i] = (double)(merged ? gg : image_mode ? gg * a.weight + gc * a.color_weight : gg * a.weight);
+      }
+#define A3D_L(row, col) Lm[(row) * 6 + (col)]
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {  // solve_lower_triangular (column oriented)
+        const double coeff = bvec[i] * rinv[i];
+        bvec[i] = coeff;
+#pragma unroll
+        for (int rr = i + 1; rr < 6; ++rr) bvec[rr] = __builtin_fma(-coeff, A3D_L(rr, i), bvec[rr]);
+      }
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {  // ad_solve_lower_triangular: L^T x = b
+        double d = 0.0;
+#pragma unroll
+        for (int rr = i + 1; rr < 6; ++rr) d = __builtin_fma(A3D_L(rr, i), bvec[rr], d);
+        bvec[i] = (bvec[i] - d) * rinv[i];
+      }
+#undef A3D_L
+      float update[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) update[i] = (float)bvec[i];
+      Pose pose{{wordf(0), wordf(1), wordf(2)}, {wordf(3), wordf(4), wordf(5), wordf(6)}};
+      Pose best{{wordf(7), wordf(8), wordf(9)}, {wordf(10), wordf(11), wordf(12), wordf(13)}};
+      float best_residual = wordf(14);
+      if (a.first_in_level) {  // ImageIcp::align starts every level with best = initial, +inf
+        best_residual = __builtin_inff();
+        best = pose;
+      }
+      Se3Trig tg;
+      tg.theta = se3_theta(update);
+      {  // sin and cos of theta / 2 (even lanes) and of theta (odd lanes) in one pass, as in gn_finish_block
+        const float x = (tid & 1) ? tg.theta : 0.5f * tg.theta;
+        float sx, cx;
+        if (tg.theta <= 0.78539816f) {
+          const float z = x * x;
+          sx = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+          cx = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+        } else {
+          sx = sin_f32(x), cx = cos_f32(x);
+        }
+        auto lane_of = [](float v, int lane) {
+          return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+        };
+        tg.sin_half = lane_of(sx, 0), tg.cos_half = lane_of(cx, 0);
+        tg.sin_theta = lane_of(sx, 1), tg.cos_theta = lane_of(cx, 1);
+      }
+      pose = compose(exp_se3_trig(update, tg), pose);  // Transform::exp(Se3(update)) * optim_transform
+      if (residual < best_residual) {                  // stores the transform AFTER the update (image_icp.rs:158-161)
+        best_residual = residual;
+        best = pose;
+      }
+      if (a.trace && write_trace && tid == 0) {
+        float* tr = a.trace + ((size_t)job * a.trace_stride + a.trace_index) * 8;
+        tr[0] = residual;
+        tr[1] = pose.t.x, tr[2] = pose.t.y, tr[3] = pose.t.z;
+        tr[4] = pose.q.i, tr[5] = pose.q.j, tr[6] = pose.q.k, tr[7] = pose.q.w;
+      }
+      if (a.last_in_level) pose = best;  // align() returns best_transform; the next level starts from it
+      const float w[17] = {pose.t.x, pose.t.y, pose.t.z, pose.q.i, pose.q.j, pose.q.k, pose.q.w,
+                           best.t.x, best.t.y, best.t.z, best.q.i, best.q.j, best.q.k, best.q.w,
+                           best_residual, 0.0f, residual};
+#pragma unroll
+      for (int k = 0; k < 17; ++k)
+        if (k != 15) mine = tid == k ? __float_as_uint(w[k]) : mine;
+    }
   }
-  A3D_STAMP(6);
+  if (tid < JOB_WORDS) {
+    if (s_state) s_state[tid] = mine;
+    if (st_out) {
+      if (!COHERENT)
+        ((uint32_t*)st_out)[tid] = mine;
+      else if (mine != state_bits)
+        __hip_atomic_store((uint32_t*)st_out + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
+
+// The last-block forms (block_publish_and_finish, the level kernel): called by every thread of the job's last block
+// with the 58 f64 totals in LDS; the state is read and written in place with agent-scope accesses.
+__device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums, const SolveArgs& a, int job) {
+  const int tid = threadIdx.x;
+  if (tid >= 64) return;  // ONE wave finishes the iteration: wave-synchronous, no block barrier
+  const uint32_t state_bits =
+      tid < JOB_WORDS ? __hip_atomic_load((const uint32_t*)st + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  gn_advance_wave<true>(state_bits, sums, head_args_of(a), job, nullptr, st, true);
+}
+
 
 // Tail of an accumulate kernel (all 256 threads call it): reduce the block's accumulators to one
 // partial, publish it, take a ticket on the job's counter; the block that arrives last sums all the
@@ -432,6 +485,70 @@ __device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   gn_finish_block(st, s_sums[0], args, job);
   return true;
+}
+
+// ---- head-solve hand-off (the HeadArgs comment above): every block of the NEXT launch finishes the iteration ----
+// Every thread of the block calls it (blocks of >= 256 threads).  Sums the job's `h.tiles` partials of the previous
+// launch — thread (component pair cg, slice s) adds tiles s, s + 8, ... in tile order, then the eight slices in a
+// fixed order: the same order as the last-block form above, so both forms give the same bits — runs the solve on
+// wave 0 and leaves the job's state in s_state (LDS, JOB_WORDS words) behind a block barrier.
+__device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st_out, const float* prev_partials,
+                                             const HeadArgs& h, int job, uint32_t* s_state, bool write_trace) {
+  __shared__ double s_sums[8][64];
+  const int tid = threadIdx.x;
+  uint32_t state_bits = 0;
+  if (tid < JOB_WORDS) state_bits = ((const uint32_t*)st_in)[tid];
+  if (h.mode != SOLVE_NONE) {
+    const int cg = tid & 31, slice = tid >> 5;
+    const uint32_t tiles = h.tiles;
+    if (cg < GN_PARTIAL / 2 && slice < 8) {
+      double sum0 = 0.0, sum1 = 0.0;
+      const unsigned long long* base = (const unsigned long long*)prev_partials + cg;
+      uint32_t t = slice;
+      for (; t + 248 < tiles; t += 256) {
+        unsigned long long v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = base[(size_t)(t + 8 * k) * (GN_PARTIAL / 2)];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          sum0 += (double)__uint_as_float((unsigned)v[k]);
+          sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
+        }
+      }
+      for (; t + 56 < tiles; t += 64) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(t + 8 * k) * (GN_PARTIAL / 2)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          sum0 += (double)__uint_as_float((unsigned)v[k]);
+          sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
+        }
+      }
+      unsigned long long v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t tt = t + 8 * k;
+        v[k] = tt < tiles ? base[(size_t)tt * (GN_PARTIAL / 2)] : 0ull;  // +0.0f, +0.0f: adds nothing
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        sum0 += (double)__uint_as_float((unsigned)v[k]);
+        sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
+      }
+      s_sums[slice][2 * cg] = sum0;
+      s_sums[slice][2 * cg + 1] = sum1;
+    }
+    __syncthreads();
+    if (tid < GN_PARTIAL) {
+      const int c = tid;
+      s_sums[0][c] = ((s_sums[0][c] + s_sums[1][c]) + (s_sums[2][c] + s_sums[3][c])) +
+                     ((s_sums[4][c] + s_sums[5][c]) + (s_sums[6][c] + s_sums[7][c]));
+    }
+    __syncthreads();
+  }
+  if (tid < 64) gn_advance_wave<false>(state_bits, s_sums[0], h, job, s_state, st_out, write_trace);
+  __syncthreads();
 }
 
 // acc[0..21) += J J^T (upper triangle), acc[21..27) += J r, acc[27] += r^2, acc[28] += 1

@@ -368,6 +368,58 @@ __global__ void __launch_bounds__(256, MERGED ? 5 : 1)
                      counters + pair, st, sa, pair);
 }
 
+// ---- head-solve form of the same kernel (icp_engine.hpp, "ticketless hand-off") --------------------------------
+// The launch of iteration k first finishes iteration k - 1: every block sums its pair's partials of the previous
+// launch and runs the solve (head_advance), then takes the pixel pass with the resulting pose and stores its own
+// partial with plain stores.  The source records of the first two pipeline steps do not depend on the pose and are in
+// flight during the head.  State and partials alternate between two buffers (in / out).
+__global__ void __launch_bounds__(256, 1)
+    image_icp_head_kernel(const LevelDesc* __restrict__ descs, const JobState* __restrict__ states_in,
+                          JobState* __restrict__ states_out, Gates gt, const float* __restrict__ partials_in,
+                          float* __restrict__ partials_out, uint32_t job_stride, HeadArgs head, int PPT) {
+  __shared__ uint32_t s_state[JOB_WORDS];
+  const int pair = blockIdx.y;
+  const uint32_t tile = blockIdx.x;
+  float acc[GN_PARTIAL];
+#pragma unroll
+  for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
+  const LevelDesc d = descs[pair];
+  const uint32_t mw = d.tw + 2;
+  const float twf = (float)d.tw, thf = (float)d.th;
+  const uint32_t base = tile * (256u * (uint32_t)PPT) + threadIdx.x;
+  auto src_at = [&](int k0) {
+    const uint32_t i = base + (uint32_t)k0 * 256u;
+    return stage_a(d, i, (k0 < PPT) && (i < d.src_n));
+  };
+  const SrcPx s0 = src_at(0);
+  SrcPx sa = src_at(1), sb;
+  head_advance(states_in + pair, tile == 0 ? states_out + pair : nullptr, partials_in + (size_t)pair * job_stride, head,
+               pair, s_state, tile == 0);
+  if ((int)s_state[15] == A3D_OK) {  // a failed job stays frozen: its blocks contribute nothing
+    auto uni = [&](int k) { return __uint_as_float(__builtin_amdgcn_readfirstlane(s_state[k])); };
+    const Pose T{{uni(0), uni(1), uni(2)}, {uni(3), uni(4), uni(5), uni(6)}};
+    ProjPx pa = stage_b(d, T, s0, twf, thf), pb;
+    uint8_t ia = s0.intensity, ib;
+    auto step = [&](ProjPx& cur, uint8_t cur_i, ProjPx& nxt, uint8_t& nxt_i, const SrcPx& s_next, SrcPx& s_new, int k0) {
+      s_new = src_at(k0 + 2);                                     // issue source record k+2
+      const MapPx mp = stage_c(d, gt, cur, mw);                   // gathers(k) land; issue map cell(k)
+      nxt = stage_b(d, T, s_next, twf, thf);                      // issue gathers(k+1)
+      nxt_i = s_next.intensity;
+      if (cur.live) {
+        const Terms t = stage_d(d, gt, cur, mp, cur_i, mw);
+        gn_step(acc, t.rg, t.Jg);
+        if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
+      }
+    };
+#pragma unroll 1
+    for (int k0 = 0; k0 < PPT; k0 += 2) {  // PPT is even (batch_commit_descs)
+      step(pa, ia, pb, ib, sa, sb, k0);
+      step(pb, ib, pa, ia, sb, sa, k0 + 1);
+    }
+  }
+  block_reduce_store<GN_PARTIAL, false>(acc, partials_out + (size_t)pair * job_stride + (size_t)tile * GN_PARTIAL);
+}
+
 // ---- one launch per pyramid level ------------------------------------------------------------------
 // When the grid of a level is exactly the set of blocks the chip holds at once (choose_tiling, waves = 1),
 // every block of every pair is resident for the whole launch, so the iterations of the level can run inside
@@ -658,6 +710,7 @@ struct a3d_multiscale_batch {
   JobState* d_states = nullptr;
   float* d_partials = nullptr;
   size_t partials_capacity = 0;  // floats
+  size_t partials_half = 0;      // floats per buffer of the two the head-solve form alternates between
   uint32_t max_tiles = 1;        // largest tiles[level]: the per-pair stride of a stream group's slice of d_partials
   unsigned* d_counters = nullptr;  // per pair: blocks that have published their partial in this launch
   unsigned* d_epochs = nullptr;    // per pair: iterations completed (level kernel hand-off word)
@@ -681,7 +734,11 @@ struct a3d_multiscale_batch {
   bool merged_accumulators = false;
   // bit l: the odd iterations of level l sweep the pairs and tiles backwards (Infinity-Cache reuse between iterations;
   // A3D_ICP_REVERSE=mask, default: every level)
-  uint32_t reverse_mask = 0xFFFFu;
+  uint32_t reverse_mask = 0;  // (measured on MI355X: no effect on the 64-pair batch, off by default)
+  // Head-solve hand-off (icp_engine.hpp): a launch finishes the PREVIOUS iteration at its head instead of the last
+  // block of a pair finishing the current one at its tail.  Two state buffers ([2][P]) and two partial buffers
+  // ([2][P][max_tiles][58]) alternate.  A3D_ICP_HANDOFF=ticket selects the last-block form.
+  bool head_solve = true;
   // Pair groups launched on separate streams: one group's launch ramp and last-block solve overlap the other
   // groups' streaming (pairs are independent, so the groups never synchronise until the final read-out).
   uint32_t n_streams = 1;
@@ -837,12 +894,13 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
   }
   b->max_tiles = (uint32_t)(max_partials / ((size_t)P * GN_PARTIAL));
-  if (b->partials_capacity < max_partials) {  // grow-only: a reused engine keeps its buffer
+  b->partials_half = max_partials;  // floats per buffer: the head-solve form alternates between two
+  if (b->partials_capacity < 2 * max_partials) {  // grow-only: a reused engine keeps its buffer
     if (b->d_partials) A3D_HIP_TRY(hipFree(b->d_partials));
     b->d_partials = nullptr;
     b->partials_capacity = 0;
-    A3D_HIP_TRY(hipMalloc((void**)&b->d_partials, max_partials * sizeof(float)));
-    b->partials_capacity = max_partials;
+    A3D_HIP_TRY(hipMalloc((void**)&b->d_partials, 2 * max_partials * sizeof(float)));
+    b->partials_capacity = 2 * max_partials;
   }
   A3D_HIP_TRY(hipMemcpyAsync(b->d_descs, b->h_descs.data(), b->h_descs.size() * sizeof(LevelDesc),
                              hipMemcpyHostToDevice, b->ctx->stream));
@@ -882,7 +940,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
       total += ((bytes + 255) / 256) * 256;
       return at;
     };
-    const size_t o_descs = take(b->h_descs.size() * sizeof(LevelDesc)), o_states = take(n_pairs * sizeof(JobState)),
+    const size_t o_descs = take(b->h_descs.size() * sizeof(LevelDesc)), o_states = take(2 * n_pairs * sizeof(JobState)),
                  o_counters = take(n_pairs * sizeof(unsigned)), o_epochs = take(n_pairs * sizeof(unsigned)),
                  o_poses = take(n_pairs * sizeof(Pose)), o_init = take(n_pairs * sizeof(Pose)),
                  o_status = take(n_pairs * sizeof(int32_t)), o_readback = take(GN_PARTIAL * sizeof(double));
@@ -894,6 +952,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     b->d_status = (int32_t*)(base + o_status), b->d_readback = (double*)(base + o_readback);
   }
   A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
+  if (const char* env = getenv("A3D_ICP_HANDOFF")) b->head_solve = strcmp(env, "ticket") != 0;  // cross-check knob
   if (const char* env = getenv("A3D_ICP_REVERSE")) b->reverse_mask = (uint32_t)strtoul(env, nullptr, 0);  // tuning knob
   if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
   if (const char* env = getenv("A3D_ICP_PERSISTENT_LEVELS")) b->level_mask = (uint32_t)strtoul(env, nullptr, 0);
@@ -969,9 +1028,43 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
     for (uint32_t g = 1; g < S; ++g) A3D_HIP_TRY(hipStreamWaitEvent(b->aux_streams[g - 1], b->ev_fork, 0));
   }
   uint32_t epoch_base = 0;
+  // head-solve form: launch k finishes iteration k - 1 at its head (HeadArgs describes iteration k - 1)
+  bool head = b->head_solve && !level_kernel && !mask && !b->use_mfma && !b->merged_accumulators &&
+              !getenv("A3D_ICP_NOSOLVE");
+  for (uint32_t l = 0; l < levels_to_run; ++l) head = head && b->group[l] == 1;
+  HeadArgs prev{};
+  prev.mode = SOLVE_NONE;
+  uint32_t seq = 0;  // launches so far: launch `seq` reads state / partial buffer seq & 1 ... writes the other
+  const uint32_t job_stride = b->max_tiles * GN_PARTIAL;
   for (uint32_t l = levels_to_run; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
     const a3d_icp_params& prm = b->params[l];
     profile_level = l;
+    if (head) {
+      for (uint64_t it = 0; it < prm.max_iterations; ++it) {
+        const JobState* st_in = b->d_states + (size_t)(seq & 1u) * P;
+        JobState* st_out = b->d_states + (size_t)((seq + 1u) & 1u) * P;
+        const float* part_in = b->d_partials + (size_t)((seq + 1u) & 1u) * b->partials_half;  // written by launch seq - 1
+        float* part_out = b->d_partials + (size_t)(seq & 1u) * b->partials_half;
+        for (uint32_t g = 0; g < S; ++g) {
+          const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
+          hipStream_t gs = g == 0 ? s : b->aux_streams[g - 1];
+          A3D_TRY(profile_begin(gs));
+          hipLaunchKernelGGL(image_icp_head_kernel, dim3(b->tiles[l], p1 - p0), dim3(256), 0, gs,
+                             b->d_descs + (size_t)l * P + p0, st_in + p0, st_out + p0, b->gates[l],
+                             part_in + (size_t)p0 * job_stride, part_out + (size_t)p0 * job_stride, job_stride, prev,
+                             (int)b->ppt[l]);
+          A3D_HIP_TRY(hipGetLastError());
+          A3D_TRY(profile_end(gs));
+        }
+        prev.weight = prm.weight, prev.color_weight = prm.color_weight, prev.mode = SOLVE_IMAGE_ICP;
+        prev.tiles = b->tiles[l];
+        prev.first_in_level = it == 0, prev.last_in_level = it + 1 == prm.max_iterations;
+        prev.trace = d_trace, prev.trace_stride = trace_stride, prev.trace_index = trace_index;
+        ++trace_index;
+        ++seq;
+      }
+      continue;
+    }
     SolveArgs sa{};
     sa.weight = prm.weight, sa.color_weight = prm.color_weight;
     sa.mode = getenv("A3D_ICP_NOSOLVE") ? SOLVE_NONE : SOLVE_IMAGE_ICP;  // diagnostics: time the body alone
@@ -1035,7 +1128,12 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
     A3D_HIP_TRY(hipEventRecord(b->ev_join[g - 1], b->aux_streams[g - 1]));
     A3D_HIP_TRY(hipStreamWaitEvent(s, b->ev_join[g - 1], 0));
   }
-  A3D_TRY(launch_job_finish(s, b->d_states, b->d_poses, b->d_status, d_matrices, (int)P));
+  if (head)  // the last iteration is still pending: the finish kernel applies it
+    A3D_TRY(launch_job_finish_head(s, b->d_states + (size_t)(seq & 1u) * P,
+                                   b->d_partials + (size_t)((seq + 1u) & 1u) * b->partials_half, job_stride, prev,
+                                   b->d_poses, b->d_status, d_matrices, (int)P));
+  else
+    A3D_TRY(launch_job_finish(s, b->d_states, b->d_poses, b->d_status, d_matrices, (int)P));
   A3D_HIP_TRY(hipEventRecord(b->ev1, s));
   b->last_kernel_launches = kidx;
   return A3D_OK;
