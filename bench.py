@@ -66,7 +66,7 @@ def measured_traffic(name, **match):
     """HBM bytes per launch of a workload's dominant kernel from the committed PMC passes (scripts/traffic_pmc.sh;
     counters cannot be read from inside an unprofiled run).  Only a profile whose recorded workload keys equal
     `match` counts; otherwise (None, None)."""
-    names = [f"round*_{name}_traffic.json"] + (["round*_hbm_traffic.json"] if name == "bench" else [])
+    names = [f"round*_{name}_traffic*.json"] + (["round*_hbm_traffic.json"] if name == "bench" else [])
     files = sorted((f for n in names for f in glob.glob(os.path.join(ROOT, "profiles", n))), reverse=True)
     for f in files:
         try:
@@ -128,7 +128,9 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         "value": n / (ms * 1e-3), "unit": "queries/s", "ms_per_500k_queries": ms,
         "ms_per_500k_queries_stats": stats(per),
         "build_ms_incl_pcie": float(np.median(builds)),  # R3dTree::new from host points: upload + device sort levels
-        "roofline": roofline(alg_bytes, ms, traffic, src, kernel="kdtree_nearest_kernel"),
+        "roofline": roofline(alg_bytes, ms, traffic, src, kernel="kdtree_nearest_kernel",
+                             binding_resource="L2 / Infinity Cache gather rate and latency (HBM-nominal fraction: the 8 MB leaf "
+                                              "table and the 6 MB query array stay cache-resident between launches)"),
     }
 
 
@@ -181,7 +183,9 @@ def pcl_icp_bench(ctx, n=500_000):
         "align_wall_ms_incl_pcie": float(np.median(walls)),  # Icp::align from host clouds: 12 MB upload + 15 iterations
         "error_vs_synthetic_gt": {"angle_rad": float(np.arccos(np.clip((np.trace(dm[:3, :3]) - 1) / 2, -1, 1))),
                                   "translation_m": float(np.linalg.norm(dm[:3, 3]))},
-        "roofline": roofline(alg, ms / iters, traffic, tsrc, kernel="pcl_icp_kernel", launches_per_align=iters),
+        "roofline": roofline(alg, ms / iters, traffic, tsrc, kernel="pcl_icp_kernel", launches_per_align=iters,
+                             binding_resource="L2 / Infinity Cache gather rate and latency (HBM-nominal fraction: fabric "
+                                              "traffic is well below the algorithmic bytes, neighbouring queries share leaves)"),
     }, (tgt, src)
 
 
@@ -778,8 +782,9 @@ def main():
         achieved = step_alg_bytes / (rms * 1e-3) / 1e9
         traffic, traffic_src = (measured_traffic("bench", pairs_per_gpu=P, concurrent_launches=conc, distinct_frames=int(distinct))
                                 if (W, H) == (640, 480) else (None, None))
+        batch_kernel_name = "image_icp_kernel" if os.environ.get("A3D_ICP_HANDOFF") == "ticket" else "image_icp_head_kernel"
         roof = {
-            "bound": "hbm", "kernel": "image_icp_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": batch_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
             "traffic_source": traffic_src,
             "launches_per_step": int(launches), "concurrent_launches": conc,

@@ -33,7 +33,7 @@ out = {
     "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
     "traffic_bytes_per_launch": fetch_b + write_b,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate counter-only passes; KiB -> bytes; "
-              "FETCH_SIZE x2 (gfx950 wide-read correction); mean over every launch of the kernel in the run",
+              "FETCH_SIZE x2 (gfx950: every fabric read request is 128 B and is tallied as 64 B — validated for 16 / 12 / 8 / 4 / 1 byte-per-lane reads in profiles/round3_fetch_calibration.json); mean over every launch of the kernel in the run",
 }
 for kv in sys.argv[4:]:
     k, v = kv.split("=", 1)
