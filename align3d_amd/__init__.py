@@ -9,7 +9,21 @@ import os as _os
 # Streams beyond GPU_MAX_HW_QUEUES (HIP default: 4) share hardware queues and run one after the other; a batch
 # uses three, a context has four, an aligner + builder pair eight, PyTorch / RCCL in the same process their own.
 # Must be set before the HIP runtime initialises, which importing this package does not do yet.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    import sys as _sys
+
+    _torch = _sys.modules.get("torch")
+    try:
+        _late = bool(_torch is not None and _torch.cuda.is_initialized())
+    except Exception:
+        _late = False
+    if _late:  # the runtime has read its settings already: say so instead of silently losing a third of the throughput
+        import warnings as _warnings
+
+        _warnings.warn("align3d_amd: HIP was initialised before this import, so GPU_MAX_HW_QUEUES=16 cannot be applied; "
+                       "with the default of 4 hardware queues the pair groups of a batch alignment share queues and "
+                       "run one after the other (about -35 %).  Export GPU_MAX_HW_QUEUES=16 before the process starts.")
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 from ._abi import A3dError, InvalidParameter, load_library  # noqa: F401
 from .bilateral import BilateralFilter  # noqa: F401

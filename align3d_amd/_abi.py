@@ -140,6 +140,7 @@ SIGNATURES = {
     "a3d_icp_params_default": (None, [C.POINTER(IcpParamsC)]),
     "a3d_ms_icp_params_default": (None, [C.POINTER(IcpParamsC)]),
     "a3d_range_image_upload": (_ST, [_P, C.POINTER(RangeImageViewC), _PP]),
+    "a3d_range_image_upload_pyramid": (_ST, [_P, C.POINTER(RangeImageViewC), C.c_uint64, _PP]),
     "a3d_range_image_free": (_ST, [_P]),
     "a3d_range_image_compute_normals": (_ST, [_P]),
     "a3d_range_image_download_normals": (_ST, [_P, _P]),
@@ -162,6 +163,10 @@ SIGNATURES = {
         _ST,
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC), C.POINTER(GnStateC)],
     ),
+    "a3d_image_icp_accumulate_exact": (
+        _ST,
+        [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC), C.POINTER(GnStateC)],
+    ),
     "a3d_image_icp_accumulate_weighted": (
         _ST,
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC)],
@@ -171,6 +176,7 @@ SIGNATURES = {
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(PoseC), _P],
     ),
     "a3d_selftest_division": (_ST, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "a3d_selftest_transform": (_ST, [_P, _P, _P, _P, C.c_uint64, _P, _P, _P]),
     "a3d_multiscale_new": (_ST, [_P, C.POINTER(IcpParamsC), C.c_uint64, _PP, C.c_uint64, _PP]),
     "a3d_multiscale_align": (_ST, [_P, _PP, C.c_uint64, C.POINTER(PoseC)]),
     "a3d_multiscale_free": (_ST, [_P]),

@@ -5,18 +5,20 @@ from . import _abi
 
 
 class Context:
-    def __init__(self, device_index=0, priority=0, _handle=None):
+    def __init__(self, device_index=0, priority=0, _handle=None, pair=True):
         """priority < 0: the device's highest stream priority (a frame-builder context next to an aligning one),
         0: default, > 0: lowest.  A default-priority context is created together with its sibling (the builder context
         `sibling()` returns): a3d_context_create_pair puts the two contexts' streams on the GPU's compute pipes in a
-        fixed relation, which contexts created at unrelated moments do not have."""
+        fixed relation, which contexts created at unrelated moments do not have.  `pair=False` creates the aligning
+        context alone (four streams instead of eight, no second pinned block); `sibling()` then creates the builder on
+        first use, wherever the runtime places its streams at that moment."""
         self.lib = _abi.load_library()
         self.handle = C.c_void_p()
         self.device_index = int(device_index)
         self._sibling = None
         if _handle is not None:
             self.handle = _handle
-        elif int(priority) == 0:
+        elif int(priority) == 0 and pair:
             builder = C.c_void_p()
             _abi.check(self.lib.a3d_context_create_pair(int(device_index), C.byref(self.handle), C.byref(builder)),
                        "a3d_context_create")

@@ -205,4 +205,7 @@ struct a3d_device_image {
   uint8_t* colors = nullptr;             // [h][w][3] or null (kept by the device-side builder for the pyramid)
   bool has_normals = false, has_intensities = false, has_imap = false;
   a3d::DeviceArena* arena = nullptr;     // when set, the arrays above are carved out of it and not freed one by one
+  bool built = false;        // made by the device frame builder (its arena layout is fixed when it is planned)
+  bool own_normals = false;  // `normals` is its own hipMalloc although the image lives in an arena (uploaded without
+                             // normals, a3d_range_image_compute_normals called later)
 };

@@ -261,7 +261,9 @@ a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priori
   }
   A3D_REQUIRE(device_index >= 0 && device_index < count, A3D_INVALID_PARAMETER, "device index out of range");
   A3D_HIP_TRY(hipSetDevice(device_index));
-  a3d_context* ctx = new a3d_context();
+  // on any failure below, what has been created so far is released again (a3d_context_destroy tolerates the gaps)
+  std::unique_ptr<a3d_context, void (*)(a3d_context*)> guard(new a3d_context(), [](a3d_context* c) { a3d_context_destroy(c); });
+  a3d_context* ctx = guard.get();
   ctx->device = device_index;
   hipDeviceProp_t prop;
   A3D_HIP_TRY(hipGetDeviceProperties(&prop, device_index));
@@ -284,7 +286,14 @@ a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priori
     //    pairs/s with the main stream on any other pipe).
     // This holds while the process's streams are created by this library, context by context; other creators shift it.
     hipStream_t four[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int k = 0; k < 4; ++k) A3D_HIP_TRY(hipStreamCreateWithPriority(&four[k], hipStreamNonBlocking, prio));
+    for (int k = 0; k < 4; ++k) {
+      const hipError_t se = hipStreamCreateWithPriority(&four[k], hipStreamNonBlocking, prio);
+      if (se != hipSuccess) {
+        for (int j = 0; j < k; ++j) hipStreamDestroy(four[j]);
+        set_error("hipStreamCreateWithPriority failed: %s", hipGetErrorString(se));
+        return A3D_HIP_ERROR;
+      }
+    }
     if (priority < 0) {
       ctx->copy_stream = four[0], ctx->stream = four[3];
     } else {
@@ -297,7 +306,7 @@ a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priori
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_start));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_stop));
   A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, a3d_context::PINNED_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-  *out_ctx = ctx;
+  *out_ctx = guard.release();
   return A3D_OK;
 }
 
@@ -316,10 +325,10 @@ a3d_status a3d_context_create_pair(int32_t device_index, a3d_context** out_align
 a3d_status a3d_context_destroy(a3d_context* ctx) {
   if (!ctx) return A3D_OK;
   hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  hipStreamSynchronize(ctx->copy_stream);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);  // (a context whose creation failed half-way has gaps)
+  if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
   for (hipEvent_t e : ctx->copy_events) hipEventDestroy(e);
-  hipStreamDestroy(ctx->copy_stream);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
   for (hipStream_t st : ctx->side_streams) {
     hipStreamSynchronize(st);
@@ -333,9 +342,9 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   hipFree(ctx->scratch[0]);
   hipFree(ctx->scratch[1]);
   hipFree(ctx->scratch[2]);
-  hipEventDestroy(ctx->ev_start);
-  hipEventDestroy(ctx->ev_stop);
-  hipStreamDestroy(ctx->stream);
+  if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return A3D_OK;
 }

@@ -407,7 +407,7 @@ a3d_status chunk_prepare(a3d_context* ctx, const a3d_builder_params* prm, const 
     for (uint64_t l = 0; l < L; ++l) {
       const LevelLayout& Y = plan.layout.lv[l];
       a3d_device_image* im = new a3d_device_image();
-      im->ctx = ctx, im->arena = arena;
+      im->ctx = ctx, im->arena = arena, im->built = true;
       ++arena->refs;
       im->width = Y.w, im->height = Y.h;
       const double k = std::ldexp(1.0, -(int)l);  // CameraIntrinsics::scale(0.5) per level (camera.rs:119-127): exact

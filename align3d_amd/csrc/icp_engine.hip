@@ -65,7 +65,33 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// a3d_selftest_transform: item i -> T = exp(Se3(update_i)) * pose_i with the tail's own device functions
+// (tail_exp_se3 = the polynomial / libm trig switch + exp_se3_trig, compose), then T . point_i (transform_vector, as the
+// pixel kernels call it) and R . point_i (transform_normal, as Icp calls it on source normals).
+__global__ void transform_selftest_kernel(const float* __restrict__ updates6, const Pose* __restrict__ poses,
+                                          const float* __restrict__ points3, int n, Pose* __restrict__ out_composed,
+                                          float* __restrict__ out_points3, float* __restrict__ out_normals3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float u[6];
+  for (int k = 0; k < 6; ++k) u[k] = updates6[6 * i + k];
+  const Pose T = compose(tail_exp_se3(u), poses ? poses[i] : pose_eye());
+  out_composed[i] = T;
+  const V3 p{points3[3 * i], points3[3 * i + 1], points3[3 * i + 2]};
+  const V3 a = transform_vector(T, p), b = transform_normal(T, p);
+  out_points3[3 * i] = a.x, out_points3[3 * i + 1] = a.y, out_points3[3 * i + 2] = a.z;
+  out_normals3[3 * i] = b.x, out_normals3[3 * i + 1] = b.y, out_normals3[3 * i + 2] = b.z;
+}
+
 }  // namespace
+
+a3d_status launch_transform_selftest(hipStream_t stream, const float* updates6, const Pose* poses, const float* points3,
+                                     int n, Pose* out_composed, float* out_points3, float* out_normals3) {
+  hipLaunchKernelGGL(transform_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, updates6, poses, points3, n,
+                     out_composed, out_points3, out_normals3);
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
 
 a3d_status launch_job_finish_head(hipStream_t stream, const JobState* states_in, const float* partials_in,
                                   uint32_t partials_job_stride, const HeadArgs& head, Pose* poses_out,

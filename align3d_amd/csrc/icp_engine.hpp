@@ -61,6 +61,9 @@ a3d_status launch_job_finish_head(hipStream_t stream, const JobState* states_in,
                                   int32_t* status_out, float* matrices_out, int n_jobs);
 // Converts the 58 f64 sums of launch_gn_readback into the ABI's two a3d_gn_state.
 void gn_states_from_sums(const double sums[GN_PARTIAL], a3d_gn_state* geom, a3d_gn_state* color);
+// Device self-test of the pose arithmetic (a3d_selftest_transform): device arrays, n items.
+a3d_status launch_transform_selftest(hipStream_t stream, const float* updates6, const Pose* poses, const float* points3,
+                                     int n, Pose* out_composed, float* out_points3, float* out_normals3);
 
 // ---- block reduction of per-thread accumulators --------------------------------------------------
 // A wave-level reduce-scatter: after six exchange steps lane L holds the wave total of accumulator L.
@@ -223,6 +226,27 @@ __device__ __forceinline__ double rsqrt_f64(double x, double* root) {
   return h + h;
 }
 
+// sin(x), cos(x) for x = theta or theta / 2 in the iteration tail.  theta <= pi / 4 (every ICP update in practice): no
+// range reduction needed, the single-precision minimax kernels of the Cephes library (sinf / cosf, < 1 ulp on this
+// interval) — the device libm spends ~1 us of the single-lane tail in its general-argument path; above: the device libm.
+__device__ __forceinline__ void tail_sincos(float x, float theta, float* sx, float* cx) {
+  if (theta <= 0.78539816f) {
+    const float z = x * x;
+    *sx = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+    *cx = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+  } else {
+    *sx = sin_f32(x), *cx = cos_f32(x);
+  }
+}
+// Transform::exp(Se3(update)) as the iteration tail evaluates it (tail_sincos + exp_se3_trig).
+__device__ __forceinline__ Pose tail_exp_se3(const float update[6]) {
+  Se3Trig tg;
+  tg.theta = se3_theta(update);
+  tail_sincos(0.5f * tg.theta, tg.theta, &tg.sin_half, &tg.cos_half);
+  tail_sincos(tg.theta, tg.theta, &tg.sin_theta, &tg.cos_theta);
+  return exp_se3_trig(update, tg);
+}
+
 // One wave (threads 0..63 of the block).  Lane k < 18 holds word k of the job's state in `state_bits`; `sums` = the
 // 58 f64 totals of the iteration being finished (LDS).  Leaves the job's new state in s_state[0..18) (LDS) and, when
 // st_out is given, in global memory.  Same operations as gn_finish_block, except that the Cholesky's column scaling
@@ -318,16 +342,10 @@ __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const doubl
       }
       Se3Trig tg;
       tg.theta = se3_theta(update);
-      {  // sin and cos of theta / 2 (even lanes) and of theta (odd lanes) in one pass, as in gn_finish_block
+      {  // sin and cos of theta / 2 (even lanes) and of theta (odd lanes) in one pass
         const float x = (tid & 1) ? tg.theta : 0.5f * tg.theta;
         float sx, cx;
-        if (tg.theta <= 0.78539816f) {
-          const float z = x * x;
-          sx = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
-          cx = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
-        } else {
-          sx = sin_f32(x), cx = cos_f32(x);
-        }
+        tail_sincos(x, tg.theta, &sx, &cx);
         auto lane_of = [](float v, int lane) {
           return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
         };

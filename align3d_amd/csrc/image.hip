@@ -73,45 +73,86 @@ a3d_status compute_normals_device(a3d_context* ctx, const float* d_points, const
 
 extern "C" {
 
+// RangeImages as the host holds them -> HBM.  All levels of a pyramid share ONE arena from the context's pool (no
+// hipMalloc / hipFree in a steady stream of calls: each of those synchronises the whole device), every array is one
+// asynchronous copy on the context's stream straight from the caller's memory (a DMA at the PCIe rate when that is
+// page-locked: a3d_host_alloc), one synchronisation at the end.
+a3d_status a3d_range_image_upload_pyramid(a3d_context* ctx, const a3d_range_image_view* views, uint64_t n_levels,
+                                          a3d_device_image** out_images) {
+  A3D_REQUIRE(ctx && views && out_images && n_levels > 0 && n_levels <= 16, A3D_INVALID_PARAMETER, "bad argument");
+  size_t total = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = total;
+    total += ((bytes + 255) / 256) * 256;
+    return at;
+  };
+  struct Offsets {
+    size_t points, mask, normals, intensities, imap;
+  };
+  std::vector<Offsets> off(n_levels);
+  for (uint64_t l = 0; l < n_levels; ++l) {
+    const a3d_range_image_view* v = &views[l];
+    A3D_REQUIRE(v->points && v->mask, A3D_INVALID_PARAMETER, "RangeImage needs points and mask");
+    A3D_REQUIRE(v->width > 0 && v->height > 0 && v->width * v->height < (1ull << 28), A3D_INVALID_PARAMETER,
+                "bad image size (at most 2^28 pixels: the kernels address the arrays with 32-bit byte offsets)");
+    // the kernels form texel offsets with 24-bit multiplies
+    A3D_REQUIRE(v->width < (1ull << 23) && v->height < (1ull << 23), A3D_INVALID_PARAMETER, "image side too long");
+    const size_t n = (size_t)v->width * v->height;
+    off[l].points = take(n * 12), off[l].mask = take(n);
+    off[l].normals = v->normals ? take(n * 12) : 0;
+    off[l].intensities = v->intensities ? take(n) : 0;
+    off[l].imap = v->intensity_map ? take((size_t)(v->width + 2) * (v->height + 2) * 4) : 0;
+  }
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  DeviceArena* arena = new DeviceArena();
+  if (ctx_arena_acquire(ctx, total, arena) != A3D_OK) {
+    delete arena;
+    return A3D_HIP_ERROR;
+  }
+  char* base = (char*)arena->base;
+  hipStream_t s = ctx->stream;
+  bool ok = true;
+  auto copy = [&](void* dst, const void* src, size_t bytes) {
+    if (ok && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
+  };
+  for (uint64_t l = 0; l < n_levels; ++l) {
+    const a3d_range_image_view* v = &views[l];
+    a3d_device_image* im = new a3d_device_image();
+    im->ctx = ctx, im->arena = arena;
+    ++arena->refs;
+    im->width = (uint32_t)v->width, im->height = (uint32_t)v->height;
+    im->fx64 = v->fx, im->fy64 = v->fy, im->cx64 = v->cx, im->cy64 = v->cy;
+    im->fx = (float)v->fx, im->fy = (float)v->fy, im->cx = (float)v->cx, im->cy = (float)v->cy;
+    const size_t n = (size_t)im->width * im->height;
+    im->points = (float*)(base + off[l].points), im->mask = (uint8_t*)(base + off[l].mask);
+    copy(im->points, v->points, n * 12);
+    copy(im->mask, v->mask, n);
+    if (v->normals) {
+      im->normals = (float*)(base + off[l].normals), im->has_normals = true;
+      copy(im->normals, v->normals, n * 12);
+    }
+    if (v->intensities) {
+      im->intensities = (uint8_t*)(base + off[l].intensities), im->has_intensities = true;
+      copy(im->intensities, v->intensities, n);
+    }
+    if (v->intensity_map) {
+      im->imap = (float*)(base + off[l].imap), im->has_imap = true;
+      copy(im->imap, v->intensity_map, (size_t)(im->width + 2) * (im->height + 2) * 4);
+    }
+    out_images[l] = im;
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+  if (!ok) {
+    set_error("a3d_range_image_upload: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+    for (uint64_t l = 0; l < n_levels; ++l) a3d_range_image_free(out_images[l]), out_images[l] = nullptr;
+    return A3D_HIP_ERROR;
+  }
+  return A3D_OK;
+}
+
 a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* v, a3d_device_image** out) {
   A3D_REQUIRE(ctx && v && out, A3D_INVALID_PARAMETER, "null argument");
-  A3D_REQUIRE(v->points && v->mask, A3D_INVALID_PARAMETER, "RangeImage needs points and mask");
-  A3D_REQUIRE(v->width > 0 && v->height > 0 && v->width * v->height < (1ull << 28), A3D_INVALID_PARAMETER,
-              "bad image size (at most 2^28 pixels: the kernels address the arrays with 32-bit byte offsets)");
-  // the kernels form texel offsets with 24-bit multiplies
-  A3D_REQUIRE(v->width < (1ull << 23) && v->height < (1ull << 23), A3D_INVALID_PARAMETER, "image side too long");
-  A3D_HIP_TRY(hipSetDevice(ctx->device));
-  a3d_device_image* im = new a3d_device_image();
-  im->ctx = ctx;
-  im->width = (uint32_t)v->width;
-  im->height = (uint32_t)v->height;
-  im->fx64 = v->fx, im->fy64 = v->fy, im->cx64 = v->cx, im->cy64 = v->cy;
-  im->fx = (float)v->fx, im->fy = (float)v->fy, im->cx = (float)v->cx, im->cy = (float)v->cy;
-  const size_t n = (size_t)im->width * im->height;
-  a3d_status st = upload_array(ctx, v->points, n * 3, &im->points);
-  if (st == A3D_OK) st = upload_array(ctx, v->mask, n, &im->mask);
-  if (st == A3D_OK && v->normals) {
-    st = upload_array(ctx, v->normals, n * 3, &im->normals);
-    im->has_normals = true;
-  }
-  if (st == A3D_OK && v->intensities) {
-    st = upload_array(ctx, v->intensities, n, &im->intensities);
-    im->has_intensities = true;
-  }
-  if (st == A3D_OK && v->intensity_map) {
-    st = upload_array(ctx, v->intensity_map, (size_t)(im->width + 2) * (im->height + 2), &im->imap);
-    im->has_imap = true;
-  }
-  if (st == A3D_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    set_error("upload failed");
-    st = A3D_HIP_ERROR;
-  }
-  if (st != A3D_OK) {
-    a3d_range_image_free(im);
-    return st;
-  }
-  *out = im;
-  return A3D_OK;
+  return a3d_range_image_upload_pyramid(ctx, v, 1, out);
 }
 
 a3d_status a3d_range_image_free(a3d_device_image* im) {
@@ -121,6 +162,7 @@ a3d_status a3d_range_image_free(a3d_device_image* im) {
   // returns with its work complete, and hipFree (images without an arena) waits for the device by itself.  A thread
   // building the next frames on this context therefore does not stall the thread that frees the previous ones.
   if (im->arena) {  // arrays live in a shared arena: release it with its last user
+    if (im->own_normals) hipFree(im->normals);  // (waits for the device by itself)
     if (--im->arena->refs == 0) {
       ctx_arena_release(im->ctx, im->arena);
       delete im->arena;
@@ -141,9 +183,12 @@ a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
   if (im) hipSetDevice(im->ctx->device);
   A3D_REQUIRE(im, A3D_INVALID_PARAMETER, "image is null");
   const size_t n = (size_t)im->width * im->height;
-  A3D_REQUIRE(im->normals || !im->arena, A3D_INVALID_PARAMETER,
+  A3D_REQUIRE(im->normals || !im->arena || !im->built, A3D_INVALID_PARAMETER,
               "this image was built without normals (a3d_builder_params.with_normals = 0)");
-  if (!im->normals) A3D_HIP_TRY(hipMalloc((void**)&im->normals, n * 3 * sizeof(float)));
+  if (!im->normals) {  // an uploaded image that came without normals: they get their own allocation, freed with it
+    A3D_HIP_TRY(hipMalloc((void**)&im->normals, n * 3 * sizeof(float)));
+    im->own_normals = true;
+  }
   A3D_TRY(launch_compute_normals(im->ctx, im->points, im->mask, im->normals, im->width, im->height));
   if (im->arena) {  // enqueue-only: the arena must outlive the launch (a3d_range_image_free)
     im->ctx->self_fence->record(im->ctx->stream);

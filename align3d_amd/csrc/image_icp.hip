@@ -195,6 +195,10 @@ struct Terms {  // stage D: the two residuals and Jacobians of a live pixel
   float Jc[6], rc;
   bool color;
 };
+// EXACT = true (the cross-check kernel behind a3d_image_icp_accumulate_exact, never the product path): the Jacobians
+// and the geometric residual in the reference's own operations too — no fused multiply-adds, IEEE divisions — so
+// that every per-pixel value is the oracle's bit for bit and only the order of the sums differs.
+template <bool EXACT = false>
 __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, const ProjPx& px, const MapPx& m,
                                          uint8_t intensity, uint32_t mw) {
   // What decides whether a pixel counts — the transform, the projection, the gates above, and here the colour
@@ -207,9 +211,15 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
   const V3 P = px.p, n = px.tn;
   {  // PointPlaneDistance::jacobian (src/icp/cost_function.rs:33-41)
     const V3 df = px.tp - P;
-    t.rg = __builtin_fmaf(df.z, n.z, __builtin_fmaf(df.y, n.y, df.x * n.x));
     t.Jg[0] = n.x, t.Jg[1] = n.y, t.Jg[2] = n.z;
-    t.Jg[3] = fms(P.y, n.z, P.z, n.y), t.Jg[4] = fms(P.z, n.x, P.x, n.z), t.Jg[5] = fms(P.x, n.y, P.y, n.x);
+    if (EXACT) {
+      t.rg = dot(df, n);
+      const V3 tw = cross(P, n);
+      t.Jg[3] = tw.x, t.Jg[4] = tw.y, t.Jg[5] = tw.z;
+    } else {
+      t.rg = __builtin_fmaf(df.z, n.z, __builtin_fmaf(df.y, n.y, df.x * n.x));
+      t.Jg[3] = fms(P.y, n.z, P.z, n.y), t.Jg[4] = fms(P.z, n.x, P.x, n.z), t.Jg[5] = fms(P.x, n.y, P.y, n.x);
+    }
   }
   // IntensityMap::bilinear_grad (src/intensity_map.rs:184-210), H = 0.005
   const float uf = px.u - (float)m.ui, vf = px.v - (float)m.vi;
@@ -233,12 +243,20 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
   // CameraIntrinsics::project_grad (src/camera.rs:82-89): fx / z, -x fx / zz, fy / z, -y fy / zz through the
   // refined reciprocal of z (rcp + one Newton step)
   const float z = P.z;
+  t.rc = sc - value;
+  t.color = t.rc * t.rc <= gt.max_color_distance_sqr;  // image_icp.rs:136
+  if (EXACT) {
+    const float zz = z * z;
+    const float dfx = d.fx / z, dcx = -P.x * d.fx / zz, dfy = d.fy / z, dcy = -P.y * d.fy / zz;
+    const V3 gr{du * dfx, dv * dfy, du * dcx + dv * dcy};
+    const V3 tw = cross(P, gr);
+    t.Jc[0] = gr.x, t.Jc[1] = gr.y, t.Jc[2] = gr.z, t.Jc[3] = tw.x, t.Jc[4] = tw.y, t.Jc[5] = tw.z;
+    return t;
+  }
   const float r0 = __builtin_amdgcn_rcpf(z);
   const float rz = __builtin_fmaf(__builtin_fmaf(-z, r0, 1.0f), r0, r0), rzz = rz * rz;
   const float dfx = d.fx * rz, dfy = d.fy * rz, dcx = (-P.x * d.fx) * rzz, dcy = (-P.y * d.fy) * rzz;
   const V3 gr{du * dfx, dv * dfy, __builtin_fmaf(du, dcx, dv * dcy)};
-  t.rc = sc - value;
-  t.color = t.rc * t.rc <= gt.max_color_distance_sqr;  // image_icp.rs:136
   t.Jc[0] = gr.x, t.Jc[1] = gr.y, t.Jc[2] = gr.z;
   t.Jc[3] = fms(P.y, gr.z, P.z, gr.y), t.Jc[4] = fms(P.z, gr.x, P.x, gr.z), t.Jc[5] = fms(P.x, gr.y, P.y, gr.x);
   return t;
@@ -366,6 +384,49 @@ __global__ void __launch_bounds__(256, MERGED ? 5 : 1)
   if (st->status != A3D_OK) sa.mode = SOLVE_NONE;
   block_finish<NACC>(acc, partials + (size_t)pair * gridDim.x * GN_PARTIAL, tile, gridDim.x,
                      counters + pair, st, sa, pair);
+}
+
+// Cross-check kernel (a3d_image_icp_accumulate_exact): the same four stages with stage_d<EXACT>, one pixel at a time
+// and no software pipeline; the per-sample products of the accumulation are rounded separately (`a * b` then `+`),
+// like GaussNewton::step.  Only the order of the additions differs from the reference.
+__global__ void __launch_bounds__(256)
+    image_icp_exact_kernel(const LevelDesc* __restrict__ descs, const JobState* __restrict__ states, Gates gt,
+                           float* __restrict__ partials, int PPT) {
+  float acc[GN_PARTIAL];
+#pragma unroll
+  for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
+  const LevelDesc d = descs[0];
+  const Pose T = states[0].pose;
+  const uint32_t mw = d.tw + 2;
+  const float twf = (float)d.tw, thf = (float)d.th;
+  auto step_exact = [](float* a, float r, const float J[6]) {  // gaussnewton.rs:47-77, no fused multiply-adds
+    int t = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) {
+        const float m = J[i] * J[j];
+        a[t] = a[t] + m;
+        ++t;
+      }
+    for (int i = 0; i < 6; ++i) {
+      const float m = J[i] * r;
+      a[21 + i] = a[21 + i] + m;
+    }
+    const float rr = r * r;
+    a[27] = a[27] + rr;
+    a[28] += 1.0f;
+  };
+  for (int k0 = 0; k0 < PPT; ++k0) {
+    const uint32_t i = blockIdx.x * (256u * (uint32_t)PPT) + threadIdx.x + (uint32_t)k0 * 256u;
+    const SrcPx s0 = stage_a(d, i, i < d.src_n);
+    ProjPx px = stage_b(d, T, s0, twf, thf);
+    const MapPx mp = stage_c(d, gt, px, mw);
+    if (px.live) {
+      const Terms t = stage_d<true>(d, gt, px, mp, s0.intensity, mw);
+      step_exact(acc, t.rg, t.Jg);
+      if (t.color) step_exact(acc + GN_ACC, t.rc, t.Jc);
+    }
+  }
+  block_reduce_store<GN_PARTIAL, false>(acc, partials + (size_t)blockIdx.x * GN_PARTIAL);
 }
 
 // ---- head-solve form of the same kernel (icp_engine.hpp, "ticketless hand-off") --------------------------------
@@ -1139,6 +1200,16 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   return A3D_OK;
 }
 
+// batch_enqueue failed after some launches may already have been issued on the main and side streams: no fence
+// covers those kernels, so wait for them here — the caller's error cleanup typically frees the images at once, and
+// their arenas must not go back to the pool under running kernels.
+void batch_drain_after_failure(a3d_multiscale_batch* b) {
+  for (uint32_t g = 1; g < b->n_streams; ++g)
+    if (b->aux_streams[g - 1]) (void)hipStreamSynchronize(b->aux_streams[g - 1]);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  (void)hipGetLastError();
+}
+
 a3d_status batch_collect_timing(a3d_multiscale_batch* b) {
   A3D_HIP_TRY(hipEventSynchronize(b->ev1));
   A3D_HIP_TRY(hipEventElapsedTime(&b->last_total_ms, b->ev0, b->ev1));
@@ -1231,12 +1302,13 @@ a3d_status align_single(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     A3D_HIP_TRY(hipMemsetAsync(d_trace, 0, total_iters * 8 * sizeof(float), ctx->stream));
   }
   a3d_status st = batch_enqueue(b, d_init, n_levels, nullptr, d_trace, (int)total_iters);
+  if (st != A3D_OK) batch_drain_after_failure(b);
   a3d_status worst = A3D_OK;
   if (st == A3D_OK) st = read_results(b, out_pose, nullptr, &worst);
   if (st == A3D_OK && d_trace)
     if (hipMemcpy(host_trace, d_trace, total_iters * 8 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
       st = A3D_HIP_ERROR;
-  hipFree(d_trace);
+  if (d_trace) hipFree(d_trace);
   if (st != A3D_OK) return st;
   if (worst == A3D_SOLVE_FAILED) set_error("GaussNewton::solve() returned None (count == 0 or Cholesky failed)");
   return worst;
@@ -1293,6 +1365,40 @@ a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* para
   if (hipStreamSynchronize(s) != hipSuccess) st = A3D_HIP_ERROR;
   hipFree(d_pose);
   if (st == A3D_HIP_ERROR) set_error("a3d_image_icp_accumulate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  if (st != A3D_OK) return st;
+  gn_states_from_sums(sums, out_geom, out_color);
+  return A3D_OK;
+}
+
+// Test hook: the same pass through image_icp_exact_kernel (every per-pixel value in the reference's own unfused
+// operations): guards the product kernel's fused Jacobians against a real error hiding inside their tolerance.
+a3d_status a3d_image_icp_accumulate_exact(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
+                                          const a3d_device_image* source, const a3d_pose* pose, a3d_gn_state* out_geom,
+                                          a3d_gn_state* out_color) {
+  A3D_REQUIRE(ctx && params, A3D_INVALID_PARAMETER, "null argument");
+  std::unique_ptr<a3d_multiscale_batch> b;
+  A3D_TRY(batch_create(ctx, params, 1, 1, &b));
+  A3D_TRY(fill_desc(target, source, &b->h_descs[0]));
+  A3D_TRY(batch_commit_descs(b.get()));
+  Pose h_pose = pose ? pose_from_c(pose) : pose_eye();
+  Pose* d_pose = nullptr;
+  A3D_HIP_TRY(hipMalloc((void**)&d_pose, sizeof(Pose)));
+  a3d_status st = A3D_OK;
+  double sums[GN_PARTIAL];
+  hipStream_t s = ctx->stream;
+  if (hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess) st = A3D_HIP_ERROR;
+  if (st == A3D_OK) st = launch_job_init(s, b->d_states, d_pose, 1);
+  if (st == A3D_OK) {
+    hipLaunchKernelGGL(image_icp_exact_kernel, dim3(b->tiles[0]), dim3(256), 0, s, b->d_descs, b->d_states, b->gates[0],
+                       b->d_partials, (int)b->ppt[0]);
+    if (hipGetLastError() != hipSuccess) st = A3D_HIP_ERROR;
+  }
+  if (st == A3D_OK) st = launch_gn_readback(s, b->d_partials, (int)b->tiles[0], b->d_readback);
+  if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
+    st = A3D_HIP_ERROR;
+  if (hipStreamSynchronize(s) != hipSuccess) st = A3D_HIP_ERROR;
+  hipFree(d_pose);
+  if (st == A3D_HIP_ERROR) set_error("a3d_image_icp_accumulate_exact: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   if (st != A3D_OK) return st;
   gn_states_from_sums(sums, out_geom, out_color);
   return A3D_OK;
@@ -1433,7 +1539,11 @@ a3d_status a3d_multiscale_batch_align(a3d_multiscale_batch* b, a3d_pose* out_pos
                                       int32_t* out_status_host) {
   A3D_REQUIRE(b, A3D_INVALID_PARAMETER, "batch is null");
   A3D_HIP_TRY(hipSetDevice(b->ctx->device));
-  A3D_TRY(batch_enqueue(b, nullptr, b->n_levels, out_matrices_device, nullptr, 0));
+  const a3d_status enq = batch_enqueue(b, nullptr, b->n_levels, out_matrices_device, nullptr, 0);
+  if (enq != A3D_OK) {  // some launches may be running with no fence recorded behind them
+    batch_drain_after_failure(b);
+    return enq;
+  }
   b->fence->record(b->ctx->stream);  // the aux streams have been joined into the context stream by now
   if (!out_poses_host && !out_status_host) return A3D_OK;
   a3d_status worst;
@@ -1509,6 +1619,42 @@ a3d_status a3d_selftest_division(a3d_context* ctx, const float* numerators, cons
     return st;
   }
   *out_mismatches = h_m;
+  return A3D_OK;
+}
+
+// Instrumentation: the pose arithmetic of the iteration tail on the device (Transform::exp, Mul, transform_vector,
+// transform_normal; src/transform.rs:44-118,138-153,205-220) for n items: out_composed[i] = exp(Se3(update_i)) * pose_i,
+// out_points[i] = out_composed[i] . point_i, out_normals[i] = its rotation . point_i.  Host arrays in and out.
+a3d_status a3d_selftest_transform(a3d_context* ctx, const float* updates6, const a3d_pose* poses, const float* points3,
+                                  uint64_t n, a3d_pose* out_composed, float* out_points3, float* out_normals3) {
+  A3D_REQUIRE(ctx && updates6 && points3 && out_composed && out_points3 && out_normals3 && n > 0 && n < (1ull << 24),
+              A3D_INVALID_PARAMETER, "bad argument");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  std::vector<Pose> h_poses(n), h_out(n);
+  if (poses)
+    for (uint64_t i = 0; i < n; ++i) h_poses[i] = pose_from_c(&poses[i]);
+  char* d = nullptr;
+  const size_t o_u = 0, o_p = o_u + n * 24, o_x = o_p + n * sizeof(Pose), o_c = o_x + n * 12, o_a = o_c + n * sizeof(Pose),
+               o_b = o_a + n * 12, total = o_b + n * 12;
+  A3D_HIP_TRY(hipMalloc((void**)&d, total));
+  bool ok = hipMemcpyAsync(d + o_u, updates6, n * 24, hipMemcpyHostToDevice, s) == hipSuccess &&
+            hipMemcpyAsync(d + o_x, points3, n * 12, hipMemcpyHostToDevice, s) == hipSuccess &&
+            (!poses || hipMemcpyAsync(d + o_p, h_poses.data(), n * sizeof(Pose), hipMemcpyHostToDevice, s) == hipSuccess);
+  if (ok)
+    ok = launch_transform_selftest(s, (const float*)(d + o_u), poses ? (const Pose*)(d + o_p) : nullptr,
+                                   (const float*)(d + o_x), (int)n, (Pose*)(d + o_c), (float*)(d + o_a),
+                                   (float*)(d + o_b)) == A3D_OK;
+  ok = ok && hipMemcpyAsync(h_out.data(), d + o_c, n * sizeof(Pose), hipMemcpyDeviceToHost, s) == hipSuccess &&
+       hipMemcpyAsync(out_points3, d + o_a, n * 12, hipMemcpyDeviceToHost, s) == hipSuccess &&
+       hipMemcpyAsync(out_normals3, d + o_b, n * 12, hipMemcpyDeviceToHost, s) == hipSuccess;
+  if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+  hipFree(d);
+  if (!ok) {
+    set_error("a3d_selftest_transform: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+    return A3D_HIP_ERROR;
+  }
+  for (uint64_t i = 0; i < n; ++i) pose_to_c(h_out[i], &out_composed[i]);
   return A3D_OK;
 }
 

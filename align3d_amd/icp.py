@@ -5,7 +5,7 @@ import numpy as np
 
 from . import _abi
 from .icp_params import IcpParams, MsIcpParams
-from .range_image import DeviceRangeImage, RangeImage
+from .range_image import DeviceRangeImage, RangeImage, upload_pyramid
 from .transform import Transform
 
 
@@ -15,6 +15,15 @@ def _dev(ctx, image):
     if isinstance(image, RangeImage):
         return image.device(ctx)
     raise TypeError("expected a RangeImage or DeviceRangeImage")
+
+
+def _dev_pyramid(ctx, images):
+    """Device copies of a pyramid; host RangeImages that are not resident yet go up in ONE call sharing one arena."""
+    images = list(images)
+    missing = [im for im in images if isinstance(im, RangeImage) and (im._device is None or im._device.ctx is not ctx)]
+    if len(missing) > 1:
+        upload_pyramid(ctx, missing)
+    return [_dev(ctx, im) for im in images]
 
 
 def _handle_array(images):
@@ -70,6 +79,19 @@ class ImageIcp:
         )
         return g.as_dict(), c.as_dict()
 
+    def accumulate_exact(self, source, transform):
+        """The same pass through the cross-check kernel whose per-pixel arithmetic is the reference's operation for
+        operation (a3d_image_icp_accumulate_exact, test hook)."""
+        src = _dev(self.ctx, source)
+        p, t = self.params.to_c(), transform.to_c()
+        g, c = _abi.GnStateC(), _abi.GnStateC()
+        _abi.check(
+            self.ctx.lib.a3d_image_icp_accumulate_exact(self.ctx.handle, C.byref(p), self.target.handle, src.handle,
+                                                        C.byref(t), C.byref(g), C.byref(c)),
+            "ImageIcp accumulate_exact",
+        )
+        return g.as_dict(), c.as_dict()
+
     def accumulate_weighted(self, source, transform):
         """One pass of the opt-in merged accumulation (A3D_ICP_ACCUM=merged: a thread sums geom.add_weighted(color, w,
         cw) directly): the merged accumulator H, g, weighted residual sum, combined count (test hook)."""
@@ -89,7 +111,7 @@ class MultiscaleAlign:
     def __init__(self, ctx, params, target_pyramid):
         self.ctx = ctx
         self.params = params
-        self.targets = [_dev(ctx, t) for t in target_pyramid]
+        self.targets = _dev_pyramid(ctx, target_pyramid)
         self.handle = C.c_void_p()
         parr = params.to_c_array()
         tarr = _handle_array(self.targets)
@@ -104,7 +126,7 @@ class MultiscaleAlign:
         return MultiscaleAlign(ctx, params, target_pyramid)
 
     def align(self, source_pyramid):
-        srcs = [_dev(self.ctx, s) for s in source_pyramid]
+        srcs = _dev_pyramid(self.ctx, source_pyramid)
         out = _abi.PoseC()
         _abi.check(self.ctx.lib.a3d_multiscale_align(self.handle, _handle_array(srcs), len(srcs), C.byref(out)),
                    "MultiscaleAlign::align")

@@ -49,6 +49,9 @@ class MultiContext:
     def close(self):
         if self.handle:
             for v in self._views.values():
+                if v._sibling is not None:  # a builder context created through a borrowed view is owned by nobody else
+                    v._sibling.close()
+                    v._sibling = None
                 v.handle = C.c_void_p()
             self.lib.a3d_multi_context_destroy(self.handle)
             self.handle = C.c_void_p()

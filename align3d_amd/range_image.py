@@ -133,6 +133,22 @@ class DeviceRangeImage:
             pass
 
 
+def upload_pyramid(ctx, host_images):
+    """A `&[RangeImage]` as the host holds it -> resident images sharing one pooled arena
+    (a3d_range_image_upload_pyramid): what MultiscaleAlign::new / align do with host pyramids.  The device copies are
+    remembered by the host objects (`RangeImage.device`), so a pyramid is uploaded once."""
+    n = len(host_images)
+    views = (_abi.RangeImageViewC * max(1, n))(*[im.view() for im in host_images])
+    out = (C.c_void_p * max(1, n))()
+    _abi.check(ctx.lib.a3d_range_image_upload_pyramid(ctx.handle, views, n, out), "a3d_range_image_upload_pyramid")
+    devs = []
+    for im, h in zip(host_images, out):
+        d = DeviceRangeImage(ctx, handle=C.c_void_p(h))
+        im._device = d
+        devs.append(d)
+    return devs
+
+
 class RangeImageBuilder:
     """RangeImageBuilder (src/range_image/builder.rs:7-92)."""
 

@@ -266,6 +266,108 @@ def live_pixel_fractions(ctx, params, target_pyramid, source_pyramid, pose):
     return out
 
 
+def drop_in_bench(ctx, params, target_pyramid, source_pyramid, reps=15):
+    """The call the reference makes, literally: MultiscaleAlign::align(&[RangeImage]) (src/icp/multiscale.rs:51) with
+    the SOURCE pyramid in host memory — uploaded (a3d_range_image_upload_pyramid: one pooled arena, one copy per
+    array), aligned, freed, every call — and the target pyramid resident (MultiscaleAlign::new borrowed it once).
+    Beside it ImageIcp::align (image_icp.rs:43) on level 0 alone from a host RangeImage (bench10 shape).  Pageable
+    numpy arrays and page-locked ones (a3d_host_alloc)."""
+    from align3d_amd import ImageIcp, RangeImage
+
+    def host_copy(dev_level, pinned):
+        ri = dev_level.download(colors=False)
+        if pinned:  # the same arrays in page-locked memory (ascontiguousarray inside RangeImage does not copy them)
+            def pin(a):
+                b = ctx.pinned_empty(a.shape, a.dtype)
+                b[...] = a
+                return b
+            ri = RangeImage(pin(ri.points), pin(ri.mask), ri.intrinsics, normals=pin(ri.normals),
+                            intensities=pin(ri.intensities), intensity_map=pin(ri.intensity_map))
+        ri._device = None
+        return ri
+
+    out = {}
+    ms = MultiscaleAlign.new(ctx, params, target_pyramid)
+    icp0 = ImageIcp.new(ctx, IcpParams(max_iterations=10), target_pyramid[0])
+    resident = ms.align(source_pyramid)
+    for label, pinned in (("pageable", False), ("page_locked", True)):
+        host = [host_copy(lv, pinned) for lv in source_pyramid]
+        nbytes = sum(a.nbytes for h in host for a in (h.points, h.mask, h.normals, h.intensities, h.intensity_map))
+
+        def forget():
+            for h in host:
+                if h._device is not None:
+                    h._device.free()
+                h._device = None
+
+        def timed(fn):
+            for _ in range(3):
+                forget()
+                fn()
+            per = []
+            for _ in range(reps):
+                forget()
+                t0 = time.perf_counter()
+                T = fn()
+                per.append((time.perf_counter() - t0) * 1e3)
+            forget()
+            return T, per
+
+        T, per = timed(lambda: ms.align(host))
+        same = bool(np.array_equal(T.matrix(), resident.matrix()))
+        _, per0 = timed(lambda: icp0.align(host[0]))
+        out[label] = {"ms3x15_ms": float(np.median(per)), "ms3x15_ms_stats": stats(per),
+                      "equals_device_resident_result": same, "uploaded_bytes_per_call": int(nbytes),
+                      "image_icp_bench10_ms": float(np.median(per0)), "image_icp_bench10_ms_stats": stats(per0)}
+    ms.free()
+    out["workload"] = ("MultiscaleAlign::align(&[RangeImage]) with the 3-level 640x480 source pyramid in host memory "
+                       "(upload + 45 iterations + free per call), target pyramid resident; ImageIcp::align likewise on "
+                       "level 0 with 10 iterations")
+    return out
+
+
+def bench_icp_shape(ctx):
+    """benches/bench_icp.rs:9-39, the reference's own Icp bench: sample1 frames 0 (target) and 5 (source) as point
+    clouds (RangeImage::from_rgbd_frame + compute_normals + PointCloud::from, no bilateral filter), Icp::new(IcpParams {
+    max_iterations: 10, ..default }, &pcl0).align(&pcl1).  Needs the fixture frames (tests/golden)."""
+    from align3d_amd import Icp, PointCloud, SlamTbDataset
+
+    real = os.path.join(ROOT, "tests", "golden", "rgbd", "sample1")
+    if not os.path.isdir(real):
+        return None, None
+    ds = SlamTbDataset.load(real)
+    clouds = []
+    for i in (0, 5):
+        cam, depth, rgb, depth_scale = ds.get(i)
+        lv = RangeImageBuilder(ctx).pyramid_levels(1).with_intensity(False).build(cam, depth, rgb, depth_scale)[0]
+        clouds.append(PointCloud.from_range_image(lv.download(intensity=False)))
+        lv.free()
+    tgt, src = clouds
+    prm = IcpParams(max_iterations=10)
+    Icp.new(ctx, prm, tgt).free()
+    news = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        icp = Icp.new(ctx, prm, tgt)
+        news.append((time.perf_counter() - t0) * 1e3)
+        if len(news) < 3:
+            icp.free()
+    icp.align(src)
+    dev, wall = [], []
+    for _ in range(9):
+        t0 = time.perf_counter()
+        T = icp.align(src)
+        wall.append((time.perf_counter() - t0) * 1e3)
+        dev.append(icp.last_device_ms())
+    icp.free()
+    out = {"workload": f"benches/bench_icp.rs: sample1 0 <- 5 as clouds ({tgt.len()} target x {src.len()} source points), "
+                       "IcpParams{max_iterations: 10}",
+           "device_ms_per_align": float(np.median(dev)), "device_ms_per_align_stats": stats(dev),
+           "align_wall_ms_incl_pcie": float(np.median(wall)), "align_wall_ms_stats": stats(wall),
+           "icp_new_ms_incl_pcie": float(np.median(news)), "gpu_pose": [float(x) for x in T.matrix().reshape(-1)]}
+    return out, (tgt, src)
+
+
 def named_shapes_bench(ctx, targets, sources):
     """The other two ICP shapes BASELINE.md names, on the same resident pyramids: `bench10` = the reference's
     published bench (benches/bench_image_icp.rs: one 640x480 level, IcpParams::default() with 10 iterations; README:
@@ -523,7 +625,7 @@ def cpu_baseline_main(O, host_pyramids, pair_frames, params, n_pairs, gpu_poses,
     }
 
 
-def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clouds):
+def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clouds, bench_icp_clouds=None):
     """The reference's other benches (benches/bench_{kdtree,icp,compute_normals,bilateral,image_icp}.rs,
     README.md:130-134) on the oracle, threaded as the reference threads them, each bounded to a few seconds."""
     out = {}
@@ -567,6 +669,25 @@ def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clou
                            "ms_per_iteration": it_ms, "icp_new_ms": icp_new_ms,
                            "sample": "2 of the 15 iterations timed, single thread like Icp::align; x 7.5 for an align"}
     del ptree
+    # benches/bench_icp.rs on the oracle: sample1 0 <- 5 clouds, 10 iterations, single thread like the reference
+    if bench_icp_clouds is not None:
+        btgt, bsrc = bench_icp_clouds
+        t0 = time.perf_counter()
+        btree = O.KdTree(btgt.points)
+        bnew_ms = (time.perf_counter() - t0) * 1e3
+        bprm = O.params(max_iterations=10)
+        btv, bsv = O.pcl_view(btgt.points, btgt.normals), O.pcl_view(bsrc.points, bsrc.normals)
+        bpose = O.pose()
+
+        def bench_icp_align():
+            assert O.load().orc_pcl_icp_align(C.byref(bprm), btree.h, C.byref(btv), C.byref(bsv), C.byref(bpose), None) == 0
+
+        per = timed(bench_icp_align, 3)
+        out["bench_icp"] = {"value": float(np.median(per)), "unit": "ms per Icp::align (10 iterations)", "cores": 1,
+                            "kind": "port", "ms_stats": stats(per), "icp_new_ms": bnew_ms,
+                            "cpu_pose_t_q": [float(x) for x in list(bpose.t[:]) + list(bpose.q[:])],
+                            "sample": "3 repetitions, single thread like Icp::align (benches/bench_icp.rs:9-39)"}
+        del btree
     # compute_normals on one 640x480 frame (bench_compute_normals.rs; README: 1.1778 ms, rayon over 1024-px chunks)
     pts, msk = level0_host.points, level0_host.mask
     per_mt = timed(lambda: O.compute_normals(pts, msk, threads=cores), 20)
@@ -834,7 +955,7 @@ def main():
             errs.append((np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)), np.linalg.norm(d[:3, 3])))
         extra["mean_error_vs_synthetic_gt"] = {"angle_rad": float(np.mean([e[0] for e in errs])),
                                                "translation_m": float(np.mean([e[1] for e in errs]))}
-        level0_host = depth0 = clouds = None
+        level0_host = depth0 = clouds = bench_icp_clouds = None
         if not args.no_extras and world == 1:
             # configs[1]: one pair alone on the GPU (latency-bound: 45 dependent iterations)
             ms1 = MultiscaleAlign.new(ctx, params, targets[0])
@@ -847,7 +968,12 @@ def main():
                 lat.append((time.perf_counter() - t1) * 1e3)
             extra["single_pair_ms3x15_latency_ms"] = float(np.median(lat))
             extra["single_pair_ms3x15_latency_ms_stats"] = stats(lat)
+            extra["drop_in_from_host_range_images"] = drop_in_bench(ctx, params, targets[0], sources[0])
+            extra["drop_in_ms3x15_ms_from_host_range_images"] = extra["drop_in_from_host_range_images"]["page_locked"]["ms3x15_ms"]
             extra["named_shapes"] = named_shapes_bench(ctx, targets, sources)
+            bi, bench_icp_clouds = bench_icp_shape(ctx)
+            if bi is not None:
+                extra["named_shapes"]["bench_icp"] = bi
             extra["kdtree"] = kdtree_bench(ctx)
             extra["kdtree"]["x_vs_published_cpu_101.75ms"] = 101.75 / extra["kdtree"]["ms_per_500k_queries"]
             extra["pcl_icp"], clouds = pcl_icp_bench(ctx)
@@ -873,7 +999,7 @@ def main():
                     k = ri.intrinsics
                     return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
                 sec = cpu_baselines_secondary(O, cores, level0_host, depth0,
-                                              (oframe(targets[0][0]), oframe(sources[0][0])), clouds)
+                                              (oframe(targets[0][0]), oframe(sources[0][0])), clouds, bench_icp_clouds)
                 for v in sec.values():
                     v["cpu_model"], v["compiler_flags"] = model, flags
                 extra["cpu_baselines"] = sec
@@ -885,6 +1011,9 @@ def main():
                     "bilateral": sec["bilateral_640x480"]["value"] / extra["frame_prep"]["bilateral_filter_ms_host_to_host"],
                     "bench10_single_pair": sec["bench10"]["value"] / extra["named_shapes"]["bench10"]["single_pair_latency_ms"],
                 }
+                if "bench_icp" in sec and "bench_icp" in extra["named_shapes"]:
+                    extra["gpu_vs_cpu"]["bench_icp_align"] = (sec["bench_icp"]["value"]
+                                                              / extra["named_shapes"]["bench_icp"]["device_ms_per_align"])
         out = {
             "metric": "ICP frame-pairs/sec (640x480, 3-lvl, 15 iters)",
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

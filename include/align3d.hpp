@@ -174,6 +174,16 @@ class RangeImage {
   a3d_device_image* img_ = nullptr;
 };
 
+/// A whole host pyramid (`&[RangeImage]`) in one call: the levels share one pooled arena (a3d_range_image_upload_pyramid).
+inline std::vector<RangeImage> upload_pyramid(const Context& ctx, const std::vector<a3d_range_image_view>& host_views) {
+  std::vector<a3d_device_image*> raw(host_views.size(), nullptr);
+  if (!host_views.empty()) check(a3d_range_image_upload_pyramid(ctx.raw(), host_views.data(), host_views.size(), raw.data()));
+  std::vector<RangeImage> out;
+  out.reserve(raw.size());
+  for (a3d_device_image* im : raw) out.emplace_back(im);
+  return out;
+}
+
 inline std::vector<const a3d_device_image*> raw_pointers(const std::vector<RangeImage>& v) {
   std::vector<const a3d_device_image*> out;
   for (const auto& r : v) out.push_back(r.raw());

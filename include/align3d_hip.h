@@ -178,6 +178,12 @@ void a3d_ms_icp_params_default(a3d_icp_params out[3]);
  * `intensity_map` may be NULL; what is missing only matters to the call that needs it. */
 a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* view,
                                   a3d_device_image** out_image);
+/* The same for a whole pyramid (`&[RangeImage]` as MultiscaleAlign::align receives it, src/icp/multiscale.rs:51):
+ * `n_levels` views -> `n_levels` resident images that share ONE arena from the context's pool, one asynchronous copy
+ * per array straight from the caller's memory (DMA when it is page-locked, a3d_host_alloc), one synchronisation.
+ * A steady stream of upload / align / free calls allocates nothing.  Free each image with a3d_range_image_free. */
+a3d_status a3d_range_image_upload_pyramid(a3d_context* ctx, const a3d_range_image_view* views, uint64_t n_levels,
+                                          a3d_device_image** out_images);
 a3d_status a3d_range_image_free(a3d_device_image* image);
 
 /* RangeImage::compute_normals (src/range_image/structure.rs:184-262) on a resident image;
@@ -232,6 +238,13 @@ a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* para
                                     const a3d_pose* pose, a3d_gn_state* out_geom,
                                     a3d_gn_state* out_color);
 
+/* Test hook: a3d_image_icp_accumulate through a cross-check kernel in which EVERY per-pixel value — the Jacobians
+ * (src/icp/cost_function.rs:33-57), CameraIntrinsics::project_grad (src/camera.rs:82-89) and the products of
+ * GaussNewton::step (src/optim/gaussnewton.rs:47-77) — is computed with the reference's own unfused operations and
+ * IEEE divisions; only the order of the additions differs.  The product kernel fuses those (they only feed the sums). */
+a3d_status a3d_image_icp_accumulate_exact(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
+                                          const a3d_device_image* source, const a3d_pose* pose,
+                                          a3d_gn_state* out_geom, a3d_gn_state* out_color);
 /* The same pass through the opt-in merged-accumulator kernel (A3D_ICP_ACCUM=merged: a thread sums
  * geom.add_weighted(color, weight, color_weight) (src/optim/gaussnewton.rs:115-121) directly, from the weighted
  * Jacobians), returning that merged accumulator: H, g, the weighted residual sum and the combined count.  Test hook. */
@@ -246,6 +259,15 @@ a3d_status a3d_image_icp_align_trace(a3d_context* ctx, const a3d_icp_params* par
                                      const a3d_device_image* target, const a3d_device_image* source,
                                      const a3d_pose* init_pose, a3d_pose* out_pose, float* out_trace);
 
+/* Instrumentation: the pose arithmetic of the iteration tail run ON THE DEVICE for n items (host arrays in and out):
+ *   out_composed[i] = Transform::exp(&LieGroup::Se3(updates6[i])) * poses[i]   (src/transform.rs:44-108, 205-220;
+ *                     poses == NULL: identity), evaluated by the very device functions the ICP kernels' tail calls
+ *                     (minimax sin / cos up to theta = pi/4, libm above; the theta^2 < 1e-16 Taylor branch);
+ *   out_points3[i]  = Transform::transform_vector(out_composed[i], points3[i])  (src/transform.rs:138-145);
+ *   out_normals3[i] = Transform::transform_normal(out_composed[i], points3[i])  (src/transform.rs:147-153).
+ * Lets the reference's own known answers (src/transform.rs:321-411) be checked against the device code. */
+a3d_status a3d_selftest_transform(a3d_context* ctx, const float* updates6, const a3d_pose* poses, const float* points3,
+                                  uint64_t n, a3d_pose* out_composed, float* out_points3, float* out_normals3);
 /* Instrumentation: the ICP kernels divide with a reciprocal shared between the quotients of one pixel
  * (same arithmetic as a correctly rounded f32 division); this runs that routine on n caller-drawn
  * (numerator, denominator) pairs on the device and counts results that differ from IEEE `/`. */

@@ -108,6 +108,24 @@ impl DeviceImage {
     }
 }
 
+/// A whole `&[RangeImage]` pyramid in ONE call (a3d_range_image_upload_pyramid): the levels share one arena from the
+/// context's pool, so a steady stream of `align` calls allocates nothing on the device.
+pub fn upload_pyramid(ctx: *mut sys::a3d_context, pyramid: &[RangeImage]) -> Vec<DeviceImage> {
+    if pyramid.is_empty() {
+        return Vec::new();
+    }
+    for image in pyramid {
+        assert!(image.points.is_standard_layout() && image.mask.is_standard_layout());
+    }
+    let views: Vec<sys::a3d_range_image_view> = pyramid.iter().map(view_of).collect();
+    let mut out: Vec<*mut sys::a3d_device_image> = vec![std::ptr::null_mut(); pyramid.len()];
+    check(
+        unsafe { sys::a3d_range_image_upload_pyramid(ctx, views.as_ptr(), views.len() as u64, out.as_mut_ptr()) },
+        "a3d_range_image_upload_pyramid",
+    );
+    out.into_iter().map(DeviceImage).collect()
+}
+
 impl Drop for DeviceImage {
     fn drop(&mut self) {
         unsafe { sys::a3d_range_image_free(self.0) };

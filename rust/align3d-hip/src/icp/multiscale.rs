@@ -20,7 +20,7 @@ impl<'pyramid_lt> MultiscaleAlign<'pyramid_lt> {
             ));
         }
         let ctx = device::Context::current();
-        let device_targets: Vec<_> = target_pyramid.iter().map(|t| device::DeviceImage::upload(ctx, t)).collect();
+        let device_targets = device::upload_pyramid(ctx, target_pyramid);
         let c_params: Vec<_> = params.iter().map(device::params_of).collect();
         let handles: Vec<*const sys::a3d_device_image> = device_targets.iter().map(|d| d.0 as *const _).collect();
         let mut handle = std::ptr::null_mut();
@@ -41,7 +41,7 @@ impl<'pyramid_lt> MultiscaleAlign<'pyramid_lt> {
     pub fn align(&self, source_pyramid: &[RangeImage]) -> Transform {
         let _ = (&self.params, self.target_pyramid, &self.device_targets);
         let ctx = device::Context::current();
-        let sources: Vec<_> = source_pyramid.iter().map(|s| device::DeviceImage::upload(ctx, s)).collect();
+        let sources = device::upload_pyramid(ctx, source_pyramid); // one pooled arena, freed on drop
         let handles: Vec<*const sys::a3d_device_image> = sources.iter().map(|d| d.0 as *const _).collect();
         let mut pose = sys::a3d_pose::default();
         device::check(

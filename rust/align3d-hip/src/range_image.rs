@@ -91,6 +91,20 @@ impl RangeImageBuilder {
         }
         let k = &frames[0].camera;
         let (w, h) = (frames[0].image.width() as u64, frames[0].image.height() as u64);
+        let depth_scale = frames[0].image.depth_scale.expect("RangeImageBuilder::build: the frames need a depth scale");
+        // the C ABI receives bare pointers and ONE size, camera and depth scale for the whole slice: every frame must
+        // match frame 0 and hold its arrays in standard layout, or the library would read past a buffer
+        for (i, f) in frames.iter().enumerate() {
+            assert!(f.image.width() as u64 == w && f.image.height() as u64 == h,
+                    "InvalidParameter: frame {i} is not {w}x{h} like frame 0");
+            assert!(f.image.depth.is_standard_layout() && f.image.color.is_standard_layout(),
+                    "InvalidParameter: frame {i}: depth / color must be in standard layout");
+            assert!(f.image.depth.len() as u64 == w * h && f.image.color.len() as u64 == w * h * 3,
+                    "InvalidParameter: frame {i}: depth must hold h*w u16 and color h*w*3 u8");
+            assert!(f.image.depth_scale == Some(depth_scale), "InvalidParameter: frame {i} has another depth scale");
+            assert!(f.camera.fx == k.fx && f.camera.fy == k.fy && f.camera.cx == k.cx && f.camera.cy == k.cy,
+                    "InvalidParameter: frame {i} has other intrinsics than frame 0");
+        }
         let depth: Vec<*const u16> = frames.iter().map(|f| f.image.depth.as_ptr()).collect();
         let color: Vec<*const u8> = frames.iter().map(|f| f.image.color.as_ptr()).collect(); // [h][w][3] u8
         let mut out = vec![std::ptr::null_mut(); frames.len() * self.pyramid_levels];
@@ -98,7 +112,7 @@ impl RangeImageBuilder {
             unsafe {
                 sys::a3d_range_image_build_pyramids(device::Context::current(), &self.c_params(), frames.len() as u64,
                                                     depth.as_ptr(), color.as_ptr(), w, h, k.fx, k.fy, k.cx, k.cy,
-                                                    frames[0].image.depth_scale.unwrap(), out.as_mut_ptr())
+                                                    depth_scale, out.as_mut_ptr())
             },
             "RangeImageBuilder::build",
         );

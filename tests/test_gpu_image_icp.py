@@ -32,6 +32,16 @@ def _check_accumulators(ctx, prm, ft, fs, T):
     for gpu, ref in ((g_gpu, g_ref), (c_gpu, c_ref)):
         eh, eg, es = gn_rel_err(gpu, ref)
         assert eh < ACC_TOL and eg < ACC_TOL and es < ACC_TOL, (eh, eg, es)
+    # The cross-check kernel computes every per-pixel value in the reference's own unfused operations; both kernels add
+    # the same pixels in the same order, so their difference is exactly what the product kernel's fused Jacobians cost
+    # — a real Jacobian error could not hide in it (measured ~1e-7; an error in one term would show at 1e-3 or more)
+    g_ex, c_ex = icp.accumulate_exact(to_range_image(fs), T)
+    assert g_ex["count"] == g_ref["count"] and c_ex["count"] == c_ref["count"]
+    for ex, ref, gpu in ((g_ex, g_ref, g_gpu), (c_ex, c_ref, c_gpu)):
+        eh, eg, es = gn_rel_err(ex, ref)
+        assert eh < ACC_TOL and eg < ACC_TOL and es < ACC_TOL, ("exact kernel vs oracle", eh, eg, es)
+        fh, fg, fs_ = gn_rel_err(gpu, ex)
+        assert fh < 5e-7 and fg < 5e-7 and fs_ < 5e-7, ("fused vs exact kernel", fh, fg, fs_)
     # and close to the f32 accumulation order the reference itself would use
     st, g32, c32 = O.image_icp_accumulate(prm.to_c(), ft, fs, T.to_c(), accum_f64=False)
     eh, eg, es = gn_rel_err(g_gpu, g32.as_dict())
@@ -671,3 +681,40 @@ def test_two_batches_alternating_over_a_stream_of_rounds():
     finally:
         side.close()
         main.close()
+
+
+@pytest.mark.gpu
+def test_pyramid_upload_shares_one_arena_and_changes_nothing(ctx):
+    """a3d_range_image_upload_pyramid (the drop-in call's upload: one pooled arena for all levels) against level-by-
+    level uploads and against an alignment of the same pyramid resident on the device: bit-identical poses; arrays
+    read back equal what went up; images uploaded without normals can still compute them."""
+    from align3d_amd import DeviceRangeImage
+    from align3d_amd.range_image import upload_pyramid
+
+    tp, sp = oracle_pyramid("sample1", 0), oracle_pyramid("sample1", 1)
+    prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 4))
+    t_host, s_host = [to_range_image(f) for f in tp], [to_range_image(f) for f in sp]
+    t_one = [DeviceRangeImage(ctx, im) for im in t_host]           # one upload call per level
+    s_one = [DeviceRangeImage(ctx, im) for im in s_host]
+    T_one = MultiscaleAlign.new(ctx, prm, t_one).align(s_one)
+    T_pyr = MultiscaleAlign.new(ctx, prm, t_host).align(s_host)    # host pyramids: upload_pyramid inside
+    assert np.array_equal(T_one.matrix(), T_pyr.matrix())
+    for h, f in zip(s_host, sp):
+        back = h._device.download(colors=False)
+        assert np.array_equal(back.points.view(np.uint32), f.points.view(np.uint32)) and np.array_equal(back.mask, f.mask)
+        assert np.array_equal(back.normals.view(np.uint32), f.normals.view(np.uint32))
+        assert np.array_equal(back.intensity_map.view(np.uint32), f.intensity_map.view(np.uint32))
+    # many upload / free cycles: the arenas go back to the pool and come out again with the same contents
+    for _ in range(6):
+        for h in s_host:
+            h._device.free()
+            h._device = None
+        devs = upload_pyramid(ctx, s_host)
+        assert np.array_equal(MultiscaleAlign.new(ctx, prm, t_one).align(devs).matrix(), T_one.matrix())
+    # an image that went up without normals gets them from compute_normals (its own allocation inside an arena image)
+    bare = to_range_image(tp[0])
+    bare.normals = None
+    dev = upload_pyramid(ctx, [bare, to_range_image(tp[1])])[0]
+    dev.compute_normals()
+    assert np.array_equal(dev.download_normals().view(np.uint32), tp[0].normals.view(np.uint32))
+    dev.free()
