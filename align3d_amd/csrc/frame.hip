@@ -13,6 +13,7 @@
 // The RGB blur of the pyramid (image 0.24.7 imageops::blur) is restated from its published algorithm
 // like the oracle's: PARITY UNPINNED (no reference test pins its values).
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 #include "bilateral.hpp"
@@ -25,6 +26,44 @@ constexpr uint32_t MAX_BATCH = 16;  // frames per launch sequence
 struct FrameBases {
   char* arena[MAX_BATCH];
 };
+
+// One pyramid level as the kernels see it: size and the byte offsets of its arrays inside a frame's arena.
+struct LevelLayout {
+  uint32_t w, h;
+  size_t points, mask, normals, colors, intensities, imap;
+};
+constexpr uint32_t MAX_LEVELS = 16;
+struct PyramidLayout {
+  LevelLayout lv[MAX_LEVELS];
+};
+
+// get_neighborhood_mean_point (src/range_image/resize.rs:4-40) on the four candidates of a 2 x 2 block in block order
+// (00, 01, 10, 11): among the entries whose SOURCE mask is 1, the one nearest to their mean (strict <, first wins);
+// (0,0,0) when none is valid.  *n_valid = how many were.
+__device__ __forceinline__ V3 pick_nearest_to_mean(const V3 (&cand)[4], const bool (&ok)[4], int* n_valid) {
+  int n = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) n += ok[q] ? 1 : 0;
+  *n_valid = n;
+  V3 nearest{0.f, 0.f, 0.f};
+  if (n > 0) {
+    V3 sum{0.f, 0.f, 0.f};  // valid entries in block order, as the reference's `local` list
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ok[q]) sum = sum + cand[q];
+    const V3 mean = sum / (float)n;
+    float min_dist = 3.402823466e+38f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float d = norm_squared(cand[q] - mean);
+      if (ok[q] && d < min_dist) {  // strict <: the first minimum wins
+        min_dist = d;
+        nearest = cand[q];
+      }
+    }
+  }
+  return nearest;
+}
 
 // ---- level 0: bilateral slice + back-projection + normals in one pass ---------------------------------------
 // A block stages the points of a 32 x 16 patch (the 30 x 14 pixels it owns plus a one-pixel halo) in LDS: every
@@ -41,8 +80,10 @@ __global__ void __launch_bounds__(ST_W* ST_H)
     level0_kernel(const uint16_t* __restrict__ depth, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
                   const double* __restrict__ grids, unsigned long long capacity, uint32_t* __restrict__ scal, float fx,
                   float fy, float cx, float cy, float scale, FrameBases bases, size_t off_points, size_t off_mask,
-                  size_t off_normals, bool with_normals) {
+                  size_t off_normals, bool with_normals, LevelLayout L1, bool emit_l1) {
   __shared__ float sp[3][ST_H][ST_W + 1];
+  __shared__ float sn[3][OWN_H][OWN_W + 1];  // the owned pixels' normals, for the fused level-1 pick
+  __shared__ uint8_t sm[ST_H][ST_W];         // their masks (1: depth > 0)
   const uint32_t f = blockIdx.z;
   const int lx = threadIdx.x % ST_W, ly = threadIdx.x / ST_W;
   const int col = (int)blockIdx.x * OWN_W + lx - 1, row = (int)blockIdx.y * OWN_H + ly - 1;
@@ -69,20 +110,60 @@ __global__ void __launch_bounds__(ST_W* ST_H)
     }
   }
   sp[0][ly][lx] = px, sp[1][ly][lx] = py, sp[2][ly][lx] = pz;
+  sm[ly][lx] = d > 0 ? 1 : 0;
   __syncthreads();
-  if (!in || lx == 0 || lx == ST_W - 1 || ly == 0 || ly == ST_H - 1) return;  // halo
+  const bool owned = in && lx != 0 && lx != ST_W - 1 && ly != 0 && ly != ST_H - 1;  // (the rest is halo)
   char* base = bases.arena[f];
-  const size_t idx = (size_t)row * w + col;
-  float* points = (float*)(base + off_points);
-  points[3 * idx] = px, points[3 * idx + 1] = py, points[3 * idx + 2] = pz;
-  ((uint8_t*)(base + off_mask))[idx] = d > 0 ? 1 : 0;
-  if (!with_normals) return;
-  // an invalid neighbour's point is (0,0,0) already (= get_point(...).unwrap_or_else(zeros)); so is everything
-  // outside the image; the centre is used as stored, its mask is NOT checked (structure.rs:207)
   auto at = [&](int y, int x) { return V3{sp[0][y][x], sp[1][y][x], sp[2][y][x]}; };
-  const V3 nrm = normal_from_neighbours(V3{px, py, pz}, at(ly, lx - 1), at(ly, lx + 1), at(ly - 1, lx), at(ly + 1, lx));
-  float* normals = (float*)(base + off_normals);
-  normals[3 * idx] = nrm.x, normals[3 * idx + 1] = nrm.y, normals[3 * idx + 2] = nrm.z;
+  V3 nrm{0.f, 0.f, 0.f};
+  if (owned && with_normals) {
+    // an invalid neighbour's point is (0,0,0) already (= get_point(...).unwrap_or_else(zeros)); so is everything
+    // outside the image; the centre is used as stored, its mask is NOT checked (structure.rs:207)
+    nrm = normal_from_neighbours(V3{px, py, pz}, at(ly, lx - 1), at(ly, lx + 1), at(ly - 1, lx), at(ly + 1, lx));
+    if (emit_l1) sn[0][ly - 1][lx - 1] = nrm.x, sn[1][ly - 1][lx - 1] = nrm.y, sn[2][ly - 1][lx - 1] = nrm.z;
+  }
+  if (emit_l1) __syncthreads();  // (before the stores below: the level-1 picks then run under them)
+  if (owned) {
+    const size_t idx = (size_t)row * w + col;
+    float* points = (float*)(base + off_points);
+    points[3 * idx] = px, points[3 * idx + 1] = py, points[3 * idx + 2] = pz;
+    ((uint8_t*)(base + off_mask))[idx] = d > 0 ? 1 : 0;
+    if (with_normals) {
+      float* normals = (float*)(base + off_normals);
+      normals[3 * idx] = nrm.x, normals[3 * idx + 1] = nrm.y, normals[3 * idx + 2] = nrm.z;
+    }
+  }
+  if (!emit_l1) return;
+  // ---- level 1 of the pyramid from the staged level-0 patch (pyr_scale_down: resize_range_points / _normals,
+  // src/range_image/resize.rs:42-104): the patch origin is even and the image sides are even (the host checks), so the
+  // 2 x 2 blocks of the 30 x 14 owned pixels are whole and block (dv, du) is source pixels (2 dv .. 2 dv + 1, 2 du ..).
+  // Saves reading level 0's points, mask and normals again (123 of the 154 MB a separate kernel moves per 16 frames).
+  // 15 x 7 level-1 pixels per patch, each picked twice (points, normals): 210 tasks on the block's first 210 threads
+  constexpr int L1W = OWN_W / 2, L1N = (OWN_W / 2) * (OWN_H / 2);
+  const int t = (int)threadIdx.x;
+  const bool normals_task = t >= L1N;
+  const int task = normals_task ? t - L1N : t;
+  if (task >= L1N || (normals_task && !with_normals)) return;
+  const int oy = 2 * (task / L1W), ox = 2 * (task % L1W);  // owned coordinates of the 2 x 2 block's first pixel
+  const uint32_t r0 = blockIdx.y * OWN_H + (uint32_t)oy, c0 = blockIdx.x * OWN_W + (uint32_t)ox;
+  if (r0 >= h || c0 >= w) return;
+  V3 cand[4];
+  bool ok[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int q = a * 2 + b;
+      cand[q] = normals_task ? V3{sn[0][oy + a][ox + b], sn[1][oy + a][ox + b], sn[2][oy + a][ox + b]}
+                             : at(oy + 1 + a, ox + 1 + b);
+      ok[q] = sm[oy + 1 + a][ox + 1 + b] == 1;
+    }
+  int n_valid;
+  const V3 pk = pick_nearest_to_mean(cand, ok, &n_valid);
+  const size_t i1 = (size_t)(r0 >> 1) * L1.w + (size_t)(c0 >> 1);
+  float* dst = (float*)(base + (normals_task ? L1.normals : L1.points));
+  dst[3 * i1] = pk.x, dst[3 * i1 + 1] = pk.y, dst[3 * i1 + 2] = pk.z;
+  if (!normals_task) ((uint8_t*)(base + L1.mask))[i1] = n_valid > 0 ? 1 : 0;
 }
 
 // Colours that arrived as ONE upload for the whole chunk ([F][h][w][3] in the staging region) to each frame's arena.
@@ -102,43 +183,66 @@ __device__ __forceinline__ uint8_t luma_u8(const uint8_t* __restrict__ rgb, uint
   return l >= 255.0f ? 255 : (l <= 0.0f ? 0 : (uint8_t)l);
 }
 
-// One pyramid level as the kernels see it: size and the byte offsets of its arrays inside a frame's arena.
-struct LevelLayout {
-  uint32_t w, h;
-  size_t points, mask, normals, colors, intensities, imap;
-};
-constexpr uint32_t MAX_LEVELS = 16;
-struct PyramidLayout {
-  LevelLayout lv[MAX_LEVELS];
-};
-
 // compute_intensity + compute_intensity_map (structure.rs:266-297) for every level of every frame in one launch:
-// blockIdx.y = level, blockIdx.z = frame, one thread per cell of the (h+2) x (w+2) map.
+// blockIdx.y = level, blockIdx.z = frame.
 // IntensityMap::from_luma_image (src/intensity_map.rs:37-92) including the incomplete border: rows h, h+1 copy row
 // h-1 for cols < w-1; cols w, w+1 copy col w-1 for rows < h-1; (h, w) and (h+1, w+1) take the last pixel; the other
 // border cells stay 0.  The luma of a cell's pixel is computed from the level's colours on the fly; interior cells
 // also store it as the level's `intensities`.
+// QUADS (the width is a multiple of four): a thread takes four interior cells of a row — 12 colour bytes as three
+// aligned words, four lumas as one word, four map cells — and the threads behind the interior take the border cells
+// one each; otherwise one thread per cell of the (h+2) x (w+2) map.
+__device__ __forceinline__ uint8_t luma_of(uint32_t r, uint32_t g, uint32_t b) {
+  const float l = (float)r * 0.3f + (float)g * 0.59f + (float)b * 0.11f;
+  return l >= 255.0f ? 255 : (l <= 0.0f ? 0 : (uint8_t)l);
+}
+__device__ __forceinline__ float imap_border_cell(const uint8_t* __restrict__ rgb, uint32_t w, uint32_t h, uint32_t r, uint32_t c) {
+  if (r >= h && c + 1 < w) return (float)luma_u8(rgb, (h - 1) * w + c) / 255.0f;
+  if (c >= w && r + 1 < h) return (float)luma_u8(rgb, r * w + (w - 1)) / 255.0f;
+  if ((r == h && c == w) || (r == h + 1 && c == w + 1)) return (float)luma_u8(rgb, (h - 1) * w + (w - 1)) / 255.0f;
+  return 0.0f;
+}
+template <bool QUADS>
 __global__ void __launch_bounds__(256) luma_imap_kernel(PyramidLayout layout, FrameBases bases) {
   const LevelLayout L = layout.lv[blockIdx.y];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t w = L.w, h = L.h, mw = w + 2, mh = h + 2;
-  if (i >= mw * mh) return;
   char* base = bases.arena[blockIdx.z];
   const uint8_t* __restrict__ rgb = (const uint8_t*)(base + L.colors);
+  float* __restrict__ imap = (float*)(base + L.imap);
+  if (QUADS) {
+    const uint32_t qpr = w / 4, n_quads = h * qpr, n_border = 2 * mw + 2 * h;
+    if (i < n_quads) {
+      const uint32_t r = i / qpr, c = 4 * (i % qpr), px = r * w + c;
+      const uint32_t* src = (const uint32_t*)(rgb + (size_t)px * 3);  // 12 bytes at a multiple of 12: word-aligned
+      const uint32_t a = src[0], b = src[1], d = src[2];
+      const uint8_t l0 = luma_of(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+      const uint8_t l1 = luma_of(a >> 24, b & 255u, (b >> 8) & 255u);
+      const uint8_t l2 = luma_of((b >> 16) & 255u, b >> 24, d & 255u);
+      const uint8_t l3 = luma_of((d >> 8) & 255u, (d >> 16) & 255u, d >> 24);
+      *(uint32_t*)((uint8_t*)(base + L.intensities) + px) = (uint32_t)l0 | ((uint32_t)l1 << 8) | ((uint32_t)l2 << 16) | ((uint32_t)l3 << 24);
+      float* o = imap + (size_t)r * mw + c;
+      o[0] = (float)l0 / 255.0f, o[1] = (float)l1 / 255.0f, o[2] = (float)l2 / 255.0f, o[3] = (float)l3 / 255.0f;
+    } else if (i < n_quads + n_border) {
+      const uint32_t j = i - n_quads;
+      uint32_t r, c;
+      if (j < 2 * mw) r = h + j / mw, c = j % mw;
+      else r = (j - 2 * mw) / 2, c = w + ((j - 2 * mw) & 1u);
+      imap[(size_t)r * mw + c] = imap_border_cell(rgb, w, h, r, c);
+    }
+    return;
+  }
+  if (i >= mw * mh) return;
   const uint32_t r = i / mw, c = i % mw;
-  float v = 0.0f;
+  float v;
   if (r < h && c < w) {
     const uint8_t l = luma_u8(rgb, r * w + c);
     ((uint8_t*)(base + L.intensities))[r * w + c] = l;
     v = (float)l / 255.0f;
-  } else if (r >= h && c + 1 < w) {
-    v = (float)luma_u8(rgb, (h - 1) * w + c) / 255.0f;
-  } else if (c >= w && r + 1 < h) {
-    v = (float)luma_u8(rgb, r * w + (w - 1)) / 255.0f;
-  } else if ((r == h && c == w) || (r == h + 1 && c == w + 1)) {
-    v = (float)luma_u8(rgb, (h - 1) * w + (w - 1)) / 255.0f;
+  } else {
+    v = imap_border_cell(rgb, w, h, r, c);
   }
-  ((float*)(base + L.imap))[i] = v;
+  imap[i] = v;
 }
 
 // get_neighborhood_mean_point over every 2x2 block (src/range_image/resize.rs:4-40): among the entries
@@ -160,7 +264,6 @@ __global__ void __launch_bounds__(256) resize_pick_kernel(LevelLayout S, LevelLa
   const uint32_t sv = (uint32_t)((float)dv * hr), su = (uint32_t)((float)du * wr);
   V3 cand[4];
   bool ok[4];
-  int n = 0;
 #pragma unroll
   for (uint32_t a = 0; a < 2; ++a)
 #pragma unroll
@@ -170,25 +273,9 @@ __global__ void __launch_bounds__(256) resize_pick_kernel(LevelLayout S, LevelLa
       const uint32_t k = in ? r * sw + c : 0u;
       ok[q] = in && src_mask[k] == 1;
       cand[q] = V3{src[3 * k], src[3 * k + 1], src[3 * k + 2]};
-      n += ok[q] ? 1 : 0;
     }
-  V3 nearest{0.f, 0.f, 0.f};
-  if (n > 0) {
-    V3 sum{0.f, 0.f, 0.f};  // valid entries in block order, as the reference's `local` list
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (ok[q]) sum = sum + cand[q];
-    const V3 mean = sum / (float)n;
-    float min_dist = 3.402823466e+38f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float d = norm_squared(cand[q] - mean);
-      if (ok[q] && d < min_dist) {  // strict <: the first minimum wins
-        min_dist = d;
-        nearest = cand[q];
-      }
-    }
-  }
+  int n;
+  const V3 nearest = pick_nearest_to_mean(cand, ok, &n);
   dst[3 * i] = nearest.x, dst[3 * i + 1] = nearest.y, dst[3 * i + 2] = nearest.z;
   if (!normals) ((uint8_t*)(base + D.mask))[i] = n > 0 ? 1 : 0;
 }
@@ -206,7 +293,7 @@ struct TapRow {
 // (consecutive output rows share all but two of their source rows); the vertical sums (u8 -> f32, the crate's f32
 // intermediate) go to a second LDS array, then the horizontal pass, clamp and round-half-away (u8) read them back.
 // Per output the additions run in tap order from 0.0f in both passes, as in the crate.
-constexpr uint32_t BLUR_TILE = 64, BLUR_ROWS = 4;
+constexpr uint32_t BLUR_TILE = 64, BLUR_ROWS = 4;  // (8 rows per block measured slower: 37 against 31 us per 16 frames)
 constexpr uint32_t BLUR_SPAN = 3 * (2 * BLUR_TILE + MAX_TAPS + 2);   // bytes / vertical results a tile's row can need
 constexpr uint32_t RAW_ROWS = 2 * (BLUR_ROWS - 1) + MAX_TAPS;        // source rows under BLUR_ROWS output rows
 constexpr uint32_t RAW_PITCH = ((BLUR_SPAN + 3 + 3) / 4) * 4;        // bytes per staged source row (+ alignment slack)
@@ -345,17 +432,21 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   const PyramidLayout& P = plan.layout;
   const LevelLayout& L0 = P.lv[0];
   const dim3 grid0((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F);
+  // level 1's points / mask / normals come out of level0_kernel when the sides are even (2 x 2 blocks are whole and the
+  // resize's float index arithmetic is exactly 2 dv, 2 du); A3D_BUILDER_FUSE_L1=0 keeps the separate kernel (cross-check)
+  static const bool fuse_allowed = !(getenv("A3D_BUILDER_FUSE_L1") && atoi(getenv("A3D_BUILDER_FUSE_L1")) == 0);
+  const bool fuse_l1 = fuse_allowed && prm->pyramid_levels >= 2 && w % 2 == 0 && h % 2 == 0;
   if (prm->use_bilateral) {  // builder.rs:75-77
     GridBatch gb;
     A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb));
     hipLaunchKernelGGL(level0_kernel<true>, grid0, dim3(ST_W * ST_H), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
                        1.0 / prm->sigma_color, (const double*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
-                       bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0);
+                       bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1);
     A3D_HIP_TRY(hipMemcpyAsync(result, gb.scal, (size_t)F * SC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   } else {
     hipLaunchKernelGGL(level0_kernel<false>, grid0, dim3(ST_W * ST_H), 0, s, d_depth, w, h, 0.0, 0.0,
                        (const double*)nullptr, 0ull, (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points,
-                       L0.mask, L0.normals, prm->with_normals != 0);
+                       L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1);
   }
   // RangeImage::pyramid (structure.rs:342-351): normals exist at level 0 only (builder.rs:79-82), coarser levels
   // inherit picked normals; colours are blurred and halved level by level
@@ -363,17 +454,25 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   if (sigma <= 0.0f) sigma = 1.0f;
   for (uint64_t l = 1; l < prm->pyramid_levels; ++l) {
     const LevelLayout &S = P.lv[l - 1], &D = P.lv[l];
-    hipLaunchKernelGGL(resize_pick_kernel, dim3((D.w * D.h + 255) / 256, prm->with_normals ? 2 : 1, F), dim3(256), 0, s, S, D,
-                       bases);
+    if (!(l == 1 && fuse_l1))
+      hipLaunchKernelGGL(resize_pick_kernel, dim3((D.w * D.h + 255) / 256, prm->with_normals ? 2 : 1, F), dim3(256), 0, s, S,
+                         D, bases);
     TapRow *d_tv = nullptr, *d_th = nullptr;
     A3D_TRY(taps_for(ctx, S.h, D.h, sigma, &d_tv));
     A3D_TRY(taps_for(ctx, S.w, D.w, sigma, &d_th));
     hipLaunchKernelGGL(blur_halve_kernel, dim3((D.w + BLUR_TILE - 1) / BLUR_TILE, (D.h + BLUR_ROWS - 1) / BLUR_ROWS, F),
                        dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
   }
-  if (prm->with_intensity)
-    hipLaunchKernelGGL(luma_imap_kernel, dim3(((w + 2) * (h + 2) + 255) / 256, (uint32_t)prm->pyramid_levels, F), dim3(256),
-                       0, s, P, bases);
+  if (prm->with_intensity) {
+    bool quads = true;  // every level's width a multiple of four (the colour, intensity and map rows then stay word-aligned)
+    for (uint64_t l = 0; l < prm->pyramid_levels; ++l) quads = quads && P.lv[l].w % 4 == 0;
+    if (quads)
+      hipLaunchKernelGGL(luma_imap_kernel<true>, dim3((h * (w / 4) + 2 * (w + 2) + 2 * h + 255) / 256, (uint32_t)prm->pyramid_levels, F),
+                         dim3(256), 0, s, P, bases);
+    else
+      hipLaunchKernelGGL(luma_imap_kernel<false>, dim3(((w + 2) * (h + 2) + 255) / 256, (uint32_t)prm->pyramid_levels, F),
+                         dim3(256), 0, s, P, bases);
+  }
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }
