@@ -492,7 +492,7 @@ struct Chunk {
 // earlier chunk reads), followed by an event the compute stream waits for.
 a3d_status chunk_prepare(a3d_context* ctx, const a3d_builder_params* prm, const ArenaPlan& plan, Chunk& c,
                          const uint16_t* const* depth, const uint8_t* const* rgb, uint32_t w, uint32_t h, double fx,
-                         double fy, double cx, double cy, hipEvent_t uploaded) {
+                         double fy, double cx, double cy, hipEvent_t uploaded, bool mask_is_z) {
   const size_t n = (size_t)w * h;
   const uint64_t L = prm->pyramid_levels;
   for (uint32_t f = 0; f < c.F; ++f) {
@@ -507,6 +507,9 @@ a3d_status chunk_prepare(a3d_context* ctx, const a3d_builder_params* prm, const 
       const LevelLayout& Y = plan.layout.lv[l];
       a3d_device_image* im = new a3d_device_image();
       im->ctx = ctx, im->arena = arena, im->built = true;
+      // mask = (depth > 0) and z = (float)depth * scale: the two agree when the smallest depth unit already gives a
+      // non-zero z (a positive, normal f32 scale); picked pyramid levels inherit it (an invalid pick is (0, 0, 0))
+      im->mask_is_z = mask_is_z;
       ++arena->refs;
       im->width = Y.w, im->height = Y.h;
       const double k = std::ldexp(1.0, -(int)l);  // CameraIntrinsics::scale(0.5) per level (camera.rs:119-127): exact
@@ -597,7 +600,10 @@ a3d_status build_frames(a3d_context* ctx, const a3d_builder_params* prm, uint64_
     c.d_depth = (uint16_t*)staging + f0 * n;
     c.d_colors = (uint8_t*)staging + depth_bytes + f0 * n * 3;
     c.result = ctx->pinned_words + k * (MAX_BATCH * SC_STRIDE);
-    const a3d_status st = chunk_prepare(ctx, prm, plan, c, depth + f0, rgb + f0, w, h, fx, fy, cx, cy, ctx->copy_events[k]);
+    const float fscale = (float)depth_scale;
+    const bool mask_is_z = fscale >= 1.1754944e-38f && std::isfinite(fscale);  // 1.0f * scale != 0, and so is d * scale
+    const a3d_status st = chunk_prepare(ctx, prm, plan, c, depth + f0, rgb + f0, w, h, fx, fy, cx, cy, ctx->copy_events[k],
+                                        mask_is_z);
     if (st != A3D_OK) return fail(st);
   }
   std::vector<size_t> todo(n_chunks);

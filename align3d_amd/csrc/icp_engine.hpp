@@ -43,7 +43,6 @@ struct SolveArgs {
   int first_in_level, last_in_level;
   int trace_stride, trace_index;
   float* trace;  // nullable: [job][trace_stride][8] = residual, t, q
-  int reverse;   // image ICP: this launch walks pairs and tiles from the last to the first (cache reuse, image_icp.hip)
 };
 
 // Host launchers (kernels live in icp_engine.hip); all enqueue on `stream` and return immediately.

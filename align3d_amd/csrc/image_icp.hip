@@ -127,11 +127,19 @@ struct SrcPx {  // stage A: one source record
                        // so that the conversion does not wait for the load inside the step that issued it
   bool live;
 };
+// ZMASK: both images of the pair were made by the device frame builder with a depth scale that maps every depth
+// unit to a non-zero z, so a pixel's mask is 1 exactly when its point's z is not 0 (invalid pixels are stored as
+// (0, 0, 0), frame.hip) — the two mask bytes per pixel need not be read.  Decided per launch on the host.
+template <bool ZMASK = false>
 __device__ __forceinline__ SrcPx stage_a(const LevelDesc& d, uint32_t i, bool in_range) {
   const uint32_t ii = in_range ? i : 0u;
   SrcPx s;
   s.sp = ld_v3(d.src_points, ii);
   s.intensity = ld<uint8_t>(d.src_intensities, ii);
+  if (ZMASK) {
+    s.live = in_range & (s.sp.z != 0.0f);
+    return s;
+  }
   // the mask byte is loaded unconditionally: `in_range && load != 0` compiles to a branch around the load with an
   // s_waitcnt vmcnt(0) behind it, which drains every load in flight (the whole software pipeline) once per pixel
   const uint8_t mask = ld<uint8_t>(d.src_mask, ii);
@@ -146,6 +154,7 @@ struct ProjPx {  // stage B: transformed point, projection, the gathered target 
   uint8_t tmask;  // consumed in stage C, so that stage B only ISSUES the gathers
   bool live;
 };
+template <bool ZMASK = false>
 __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, const SrcPx& s, float twf, float thf) {
   ProjPx o;
   o.p = transform_vector(T, s.sp);
@@ -166,7 +175,7 @@ __device__ __forceinline__ ProjPx stage_b(const LevelDesc& d, const Pose& T, con
   const uint32_t tidx = o.live ? __umul24(row, d.tw) + col : 0u;
   o.tp = ld_v3(d.tgt_points, tidx);
   o.tn = ld_v3(d.tgt_normals, tidx);
-  o.tmask = ld<uint8_t>(d.tgt_mask, tidx);
+  o.tmask = ZMASK ? (uint8_t)0 : ld<uint8_t>(d.tgt_mask, tidx);
   return o;
 }
 
@@ -174,12 +183,13 @@ struct MapPx {  // stage C: gates passed, the intensity-map cell
   float t00, t10, t01, t11;
   uint32_t ui, vi;
 };
+template <bool ZMASK = false>
 __device__ __forceinline__ MapPx stage_c(const LevelDesc& d, const Gates& gt, ProjPx& px, uint32_t mw) {
   const V3 diff = px.tp - px.p;
   // angle_between_normals(&p, &n) >= max_normal_angle on the POINT p; NaN (|p.n| > 1) passes (image_icp.rs:118-123)
   const float pn = dot(px.p, px.tn);
   // (bitwise on purpose: the short-circuit form compiles to three nested exec-mask branches per pixel)
-  px.live = px.live & (px.tmask == 1)                               // RangeImage::get_point: mask == 1 (structure.rs:176)
+  px.live = px.live & (ZMASK ? px.tp.z != 0.0f : px.tmask == 1)    // RangeImage::get_point: mask == 1 (structure.rs:176)
             & !(norm_squared(diff) > gt.max_distance_sqr)        // image_icp.rs:114
             & !((pn >= -1.0f) & (pn <= gt.dot_reject_max));
   MapPx m;
@@ -276,11 +286,8 @@ template <int G, bool MERGED>
 __global__ void __launch_bounds__(256, MERGED ? 5 : 1)
     image_icp_kernel(const LevelDesc* __restrict__ descs, JobState* __restrict__ states, Gates gt,
                      float* __restrict__ partials, unsigned* __restrict__ counters, SolveArgs solve, int PPT) {
-  // Odd iterations walk the pairs (and a pair's tiles) backwards: the arrays touched last by iteration k are touched
-  // first by iteration k + 1, while they are still in the Infinity Cache (a forward sweep over a working set larger
-  // than the cache re-reads everything from HBM every iteration).
-  const int pair = solve.reverse ? (int)(gridDim.y - 1u - blockIdx.y) : (int)blockIdx.y;
-  const uint32_t tile = solve.reverse ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+  const int pair = blockIdx.y;
+  const uint32_t tile = blockIdx.x;
   constexpr int NACC = MERGED ? GN_MERGED : GN_PARTIAL;
   float acc[NACC];
 #pragma unroll
@@ -434,6 +441,7 @@ __global__ void __launch_bounds__(256)
 // launch and runs the solve (head_advance), then takes the pixel pass with the resulting pose and stores its own
 // partial with plain stores.  The source records of the first two pipeline steps do not depend on the pose and are in
 // flight during the head.  State and partials alternate between two buffers (in / out).
+template <bool ZMASK>
 __global__ void __launch_bounds__(256, 1)
     image_icp_head_kernel(const LevelDesc* __restrict__ descs, const JobState* __restrict__ states_in,
                           JobState* __restrict__ states_out, Gates gt, const float* __restrict__ partials_in,
@@ -450,7 +458,7 @@ __global__ void __launch_bounds__(256, 1)
   const uint32_t base = tile * (256u * (uint32_t)PPT) + threadIdx.x;
   auto src_at = [&](int k0) {
     const uint32_t i = base + (uint32_t)k0 * 256u;
-    return stage_a(d, i, (k0 < PPT) && (i < d.src_n));
+    return stage_a<ZMASK>(d, i, (k0 < PPT) && (i < d.src_n));
   };
   const SrcPx s0 = src_at(0);
   SrcPx sa = src_at(1), sb;
@@ -459,12 +467,12 @@ __global__ void __launch_bounds__(256, 1)
   if ((int)s_state[15] == A3D_OK) {  // a failed job stays frozen: its blocks contribute nothing
     auto uni = [&](int k) { return __uint_as_float(__builtin_amdgcn_readfirstlane(s_state[k])); };
     const Pose T{{uni(0), uni(1), uni(2)}, {uni(3), uni(4), uni(5), uni(6)}};
-    ProjPx pa = stage_b(d, T, s0, twf, thf), pb;
+    ProjPx pa = stage_b<ZMASK>(d, T, s0, twf, thf), pb;
     uint8_t ia = s0.intensity, ib;
     auto step = [&](ProjPx& cur, uint8_t cur_i, ProjPx& nxt, uint8_t& nxt_i, const SrcPx& s_next, SrcPx& s_new, int k0) {
       s_new = src_at(k0 + 2);                                     // issue source record k+2
-      const MapPx mp = stage_c(d, gt, cur, mw);                   // gathers(k) land; issue map cell(k)
-      nxt = stage_b(d, T, s_next, twf, thf);                      // issue gathers(k+1)
+      const MapPx mp = stage_c<ZMASK>(d, gt, cur, mw);                   // gathers(k) land; issue map cell(k)
+      nxt = stage_b<ZMASK>(d, T, s_next, twf, thf);                      // issue gathers(k+1)
       nxt_i = s_next.intensity;
       if (cur.live) {
         const Terms t = stage_d(d, gt, cur, mp, cur_i, mw);
@@ -793,13 +801,13 @@ struct a3d_multiscale_batch {
   // A3D_ICP_ACCUM=merged: 31 merged running sums (H and g of add_weighted directly) instead of 2 x 29: 96 VGPRs,
   // one more wave per SIMD — measured 18.5 k against 18.7 k pairs/s (occupancy is not what limits the kernel): opt-in
   bool merged_accumulators = false;
-  // bit l: the odd iterations of level l sweep the pairs and tiles backwards (Infinity-Cache reuse between iterations;
-  // A3D_ICP_REVERSE=mask, default: every level)
-  uint32_t reverse_mask = 0;  // (measured on MI355X: no effect on the 64-pair batch, off by default)
   // Head-solve hand-off (icp_engine.hpp): a launch finishes the PREVIOUS iteration at its head instead of the last
   // block of a pair finishing the current one at its tail.  Two state buffers ([2][P]) and two partial buffers
   // ([2][P][max_tiles][58]) alternate.  A3D_ICP_HANDOFF=ticket selects the last-block form.
   bool head_solve = true;
+  // every image of the batch was built on the device with masks that equal (z != 0): the head kernel skips the two
+  // mask bytes per pixel (A3D_ICP_ZMASK=0 reads them anyway: cross-check)
+  bool zmask = false;
   // Pair groups launched on separate streams: one group's launch ramp and last-block solve overlap the other
   // groups' streaming (pairs are independent, so the groups never synchronise until the final read-out).
   uint32_t n_streams = 1;
@@ -842,7 +850,7 @@ a3d_status fill_desc(const a3d_device_image* target, const a3d_device_image* sou
   d->tw = target->width;
   d->th = target->height;
   d->fx = target->fx, d->fy = target->fy, d->cx = target->cx, d->cy = target->cy;
-  d->pad = 0;
+  d->pad = (target->mask_is_z && source->mask_is_z) ? 1u : 0u;
   return A3D_OK;
 }
 
@@ -955,6 +963,8 @@ a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
     max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
   }
   b->max_tiles = (uint32_t)(max_partials / ((size_t)P * GN_PARTIAL));
+  b->zmask = !(getenv("A3D_ICP_ZMASK") && atoi(getenv("A3D_ICP_ZMASK")) == 0);
+  for (const LevelDesc& dsc : b->h_descs) b->zmask = b->zmask && (dsc.pad & 1u);
   b->partials_half = max_partials;  // floats per buffer: the head-solve form alternates between two
   if (b->partials_capacity < 2 * max_partials) {  // grow-only: a reused engine keeps its buffer
     if (b->d_partials) A3D_HIP_TRY(hipFree(b->d_partials));
@@ -1014,7 +1024,6 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   }
   A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
   if (const char* env = getenv("A3D_ICP_HANDOFF")) b->head_solve = strcmp(env, "ticket") != 0;  // cross-check knob
-  if (const char* env = getenv("A3D_ICP_REVERSE")) b->reverse_mask = (uint32_t)strtoul(env, nullptr, 0);  // tuning knob
   if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
   if (const char* env = getenv("A3D_ICP_PERSISTENT_LEVELS")) b->level_mask = (uint32_t)strtoul(env, nullptr, 0);
   // measured (scripts/streams_sweep*.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
@@ -1110,10 +1119,16 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
           const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
           hipStream_t gs = g == 0 ? s : b->aux_streams[g - 1];
           A3D_TRY(profile_begin(gs));
-          hipLaunchKernelGGL(image_icp_head_kernel, dim3(b->tiles[l], p1 - p0), dim3(256), 0, gs,
-                             b->d_descs + (size_t)l * P + p0, st_in + p0, st_out + p0, b->gates[l],
-                             part_in + (size_t)p0 * job_stride, part_out + (size_t)p0 * job_stride, job_stride, prev,
-                             (int)b->ppt[l]);
+          if (b->zmask)
+            hipLaunchKernelGGL(image_icp_head_kernel<true>, dim3(b->tiles[l], p1 - p0), dim3(256), 0, gs,
+                               b->d_descs + (size_t)l * P + p0, st_in + p0, st_out + p0, b->gates[l],
+                               part_in + (size_t)p0 * job_stride, part_out + (size_t)p0 * job_stride, job_stride, prev,
+                               (int)b->ppt[l]);
+          else
+            hipLaunchKernelGGL(image_icp_head_kernel<false>, dim3(b->tiles[l], p1 - p0), dim3(256), 0, gs,
+                               b->d_descs + (size_t)l * P + p0, st_in + p0, st_out + p0, b->gates[l],
+                               part_in + (size_t)p0 * job_stride, part_out + (size_t)p0 * job_stride, job_stride, prev,
+                               (int)b->ppt[l]);
           A3D_HIP_TRY(hipGetLastError());
           A3D_TRY(profile_end(gs));
         }
@@ -1174,7 +1189,6 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
     for (uint64_t it = 0; it < prm.max_iterations; ++it) {
       sa.first_in_level = it == 0, sa.last_in_level = it + 1 == prm.max_iterations;
       sa.trace_index = trace_index;
-      sa.reverse = (int)((it & 1u) && ((b->reverse_mask >> l) & 1u) && !d_trace);
       for (uint32_t g = 0; g < S; ++g) {
         const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
         hipStream_t gs = g == 0 ? s : b->aux_streams[g - 1];

@@ -85,3 +85,17 @@ def test_launcher_fails_loudly_when_a_rank_fails(tmp_path):
                    "--no-extras", "--cpu-pairs", "0"], timeout=600)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_c_host_gathers_poses_with_rccl_on_the_context_stream():
+    """RCCL below Python: examples/rccl_gather.cpp — a plain C-ABI host that aligns its pairs, then calls ncclAllGather
+    on a3d_context_stream with the device buffer a3d_multiscale_batch_align filled.  One rank here (the box has one
+    GPU and RCCL refuses two ranks on one device); the N-rank form only differs in the communicator's size."""
+    exe = os.path.join(ROOT, "tests", "cpp", "rccl_gather")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "rccl_gather"], stdout=subprocess.DEVNULL)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "rccl gather OK" in out.stdout, out.stdout + out.stderr

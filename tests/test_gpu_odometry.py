@@ -160,3 +160,50 @@ def test_batched_odometry_of_a_recorded_sequence_equals_the_frame_by_frame_loop(
     for x, y in zip(a.camera_to_world, b.camera_to_world):
         ang, tr = transform_diff(x, y)
         assert ang <= 1e-5 and tr <= 1e-5
+
+
+def test_masks_derived_from_z_change_nothing(ctx):
+    """Device-built pyramids carry mask == (z != 0), so the alignment kernel skips the two mask bytes per pixel
+    (A3D_ICP_ZMASK, image_icp.hip).  With the bytes read (A3D_ICP_ZMASK=0), with the same pyramids uploaded from host
+    arrays (which never take the short cut), and on frames with large invalid regions: bit-identical poses."""
+    from align3d_amd import MultiscaleAlignBatch
+
+    ds = SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1"))
+    builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
+    cam, _, _, scale = ds.get(0)
+    frames = []
+    for i in (0, 1, 4, 5):
+        _, depth, rgb, _ = ds.get(i)
+        depth = depth.copy()
+        depth[(i * 37) % 200:(i * 37) % 200 + 90, 100:400] = 0  # a large hole on top of the data's own 12 % invalid pixels
+        frames.append((depth, rgb))
+    pyr = builder.build_many(cam, frames, scale)
+    prm = MsIcpParams.default()
+    pairs = [(0, 1), (2, 3), (1, 2)]
+
+    def run(tp, sp):
+        b = MultiscaleAlignBatch(ctx, prm, tp, sp)
+        poses, status = b.align()
+        b.free()
+        assert not status.any()
+        return np.stack([p.matrix() for p in poses])
+
+    tp, sp = [pyr[a] for a, _ in pairs], [pyr[b] for _, b in pairs]
+    fast = run(tp, sp)
+    os.environ["A3D_ICP_ZMASK"] = "0"
+    try:
+        slow = run(tp, sp)
+    finally:
+        del os.environ["A3D_ICP_ZMASK"]
+    assert np.array_equal(fast.view(np.uint32), slow.view(np.uint32))
+    # the same pyramids as host RangeImages, uploaded (never flagged): the masks are read
+    host = [[lv.download(colors=False) for lv in p] for p in pyr]
+    for p in host:
+        for lv in p:
+            lv._device = None
+    up = run([host[a] for a, _ in pairs], [host[b] for _, b in pairs])
+    assert np.array_equal(fast.view(np.uint32), up.view(np.uint32))
+    # and the flag's premise, pixel by pixel: mask == (z != 0) on every level of every built frame
+    for p in host:
+        for lv in p:
+            assert np.array_equal(lv.mask != 0, lv.points[..., 2] != 0) and set(np.unique(lv.mask)) <= {0, 1}
