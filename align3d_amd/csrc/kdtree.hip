@@ -170,6 +170,41 @@ struct PclGates {
 
 // The body of Icp::align's point loop (src/icp/pcl_icp.rs:68-92); grid-stride.
 template <int BLOCK>
+__device__ __forceinline__ void pcl_point_loop(const KdSplits& sp, const float4* __restrict__ leaves,
+                                               const float4* __restrict__ leaf_normals, uint32_t n, uint32_t max_depth,
+                                               const float* __restrict__ src_points, const float* __restrict__ src_normals,
+                                               uint32_t m, const Pose& T, const PclGates& gates, float (&acc)[GN_ACC]) {
+  typedef float f32x3 __attribute__((ext_vector_type(3)));
+  typedef f32x3 __attribute__((aligned(4))) f32x3_u;
+  // every lane stays in the loop: the cooperative leaf scan needs the whole wave
+  const uint32_t rounds = (m + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t i = (r * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
+    const uint32_t ii = i < m ? i : m - 1;
+    const f32x3 pv = *(const f32x3_u*)(src_points + 3 * (size_t)ii), nv = *(const f32x3_u*)(src_normals + 3 * (size_t)ii);
+    const V3 p = transform_vector(T, V3{pv.x, pv.y, pv.z});
+    const uint32_t base = kdtree_descend(sp, n, max_depth, p);
+    uint32_t slot;
+    float d2;
+    kdtree_scan_leaves_coop(leaves, base, p, &slot, &d2);
+    // the winner's record and its normal: one 16-byte gather each (the point's line was just scanned)
+    const float4 win = leaves[slot], tn4 = leaf_normals[slot];
+    const V3 sn = transform_normal(T, V3{nv.x, nv.y, nv.z});
+    const V3 tn{tn4.x, tn4.y, tn4.z};
+    const float c = dot(sn, tn);
+    const bool keep = i < m && !(d2 > gates.max_distance_sqr) && !(c >= -1.0f && c <= gates.dot_reject_max);
+    if (keep) {
+      const V3 tp{win.x, win.y, win.z};
+      const float rr = dot(tp - p, tn);
+      const V3 tw = cross(p, tn);
+      const float J[6] = {tn.x, tn.y, tn.z, tw.x, tw.y, tw.z};
+      gn_step(acc, rr, J);
+    }
+  }
+}
+
+// Last-block form: the block that publishes the last partial finishes the iteration (icp_engine.hpp).
+template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
     pcl_icp_kernel(const float* __restrict__ split, const float4* __restrict__ leaves,
                    const float4* __restrict__ leaf_normals, uint32_t n, uint32_t max_depth, uint32_t lds_levels,
@@ -186,37 +221,41 @@ __global__ void __launch_bounds__(BLOCK)
   const int status = states->status;
   if (status == A3D_OK) {
     const Pose T = states->pose;
-    typedef float f32x3 __attribute__((ext_vector_type(3)));
-    typedef f32x3 __attribute__((aligned(4))) f32x3_u;
-    // every lane stays in the loop: the cooperative leaf scan needs the whole wave
-    const uint32_t rounds = (m + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
-    for (uint32_t r = 0; r < rounds; ++r) {
-      const uint32_t i = (r * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
-      const uint32_t ii = i < m ? i : m - 1;
-      const f32x3 pv = *(const f32x3_u*)(src_points + 3 * (size_t)ii), nv = *(const f32x3_u*)(src_normals + 3 * (size_t)ii);
-      const V3 p = transform_vector(T, V3{pv.x, pv.y, pv.z});
-      const uint32_t base = kdtree_descend(sp, n, max_depth, p);
-      uint32_t slot;
-      float d2;
-      kdtree_scan_leaves_coop(leaves, base, p, &slot, &d2);
-      // the winner's record and its normal: one 16-byte gather each (the point's line was just scanned)
-      const float4 win = leaves[slot], tn4 = leaf_normals[slot];
-      const V3 sn = transform_normal(T, V3{nv.x, nv.y, nv.z});
-      const V3 tn{tn4.x, tn4.y, tn4.z};
-      const float c = dot(sn, tn);
-      const bool keep = i < m && !(d2 > gates.max_distance_sqr) && !(c >= -1.0f && c <= gates.dot_reject_max);
-      if (keep) {
-        const V3 tp{win.x, win.y, win.z};
-        const float rr = dot(tp - p, tn);
-        const V3 tw = cross(p, tn);
-        const float J[6] = {tn.x, tn.y, tn.z, tw.x, tw.y, tw.z};
-        gn_step(acc, rr, J);
-      }
-    }
+    pcl_point_loop<BLOCK>(sp, leaves, leaf_normals, n, max_depth, src_points, src_normals, m, T, gates, acc);
   }
   SolveArgs sa = solve;
   if (status != A3D_OK) sa.mode = SOLVE_NONE;
   block_finish<GN_ACC, BLOCK / 64>(acc, partials, blockIdx.x, gridDim.x, counter, states, sa, 0);  // no colour term
+}
+
+// Head-solve form (icp_engine.hpp): the launch of iteration k first finishes iteration k - 1 — every block sums the
+// previous launch's partials and runs the solve while its split table is still arriving in LDS — then takes the point
+// loop with the resulting pose and stores its partial with plain stores.  State and partials alternate between two
+// buffers; job_finish_head applies the last iteration.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+    pcl_icp_head_kernel(const float* __restrict__ split, const float4* __restrict__ leaves,
+                        const float4* __restrict__ leaf_normals, uint32_t n, uint32_t max_depth, uint32_t lds_levels,
+                        const float* __restrict__ src_points, const float* __restrict__ src_normals, uint32_t m,
+                        const JobState* __restrict__ state_in, JobState* __restrict__ state_out, PclGates gates,
+                        const float* __restrict__ partials_in, float* __restrict__ partials_out, HeadArgs head) {
+  extern __shared__ __attribute__((aligned(16))) float kd_lds[];
+  __shared__ uint32_t s_state[JOB_WORDS];
+  const uint32_t n_split = (1u << max_depth) - 1u;
+  kd_stage_splits(split, n_split, lds_levels, kd_lds);
+  const KdSplits sp{split, kd_lds, lds_levels};
+  head_advance(state_in, blockIdx.x == 0 ? state_out : nullptr, partials_in, head, 0, s_state, blockIdx.x == 0);
+  float acc[GN_ACC];
+#pragma unroll
+  for (int k = 0; k < GN_ACC; ++k) acc[k] = 0.0f;
+  if ((int)s_state[15] == A3D_OK) {  // a failed job stays frozen
+    const float* f = (const float*)s_state;
+    const Pose T{{f[0], f[1], f[2]}, {f[3], f[4], f[5], f[6]}};
+    pcl_point_loop<BLOCK>(sp, leaves, leaf_normals, n, max_depth, src_points, src_normals, m, T, gates, acc);
+  }
+  float* out = partials_out + (size_t)blockIdx.x * GN_PARTIAL;
+  block_reduce_store<GN_ACC, false, BLOCK / 64>(acc, out);
+  if (threadIdx.x >= GN_ACC && threadIdx.x < GN_PARTIAL) out[threadIdx.x] = 0.0f;  // no colour term
 }
 
 template <typename K>
@@ -240,8 +279,10 @@ struct a3d_pcl_icp {
   bool target_has_normals = false;
   uint32_t blocks = 0;  // block partials (= grid size of the iteration kernel)
   KdLaunch launch{};
-  JobState* d_state = nullptr;
-  float* d_partials = nullptr;
+  JobState* d_state = nullptr;     // two buffers: the head-solve form alternates between them
+  float* d_partials = nullptr;    // [2][blocks][GN_PARTIAL]
+  Pose* d_out_pose = nullptr;     // what job_finish_head leaves for the host (one allocation with d_out_status)
+  int32_t* d_out_status = nullptr;
   unsigned* d_counter = nullptr;
   double* d_readback = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the iteration launches of the last align
@@ -415,8 +456,9 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
   icp->launch = kd_launch_config(t, 1ull << 31, "A3D_PCL", 1024, 15, 1);
   icp->blocks = icp->launch.blocks;
   if (st == A3D_OK &&
-      (hipMalloc((void**)&icp->d_state, sizeof(JobState)) != hipSuccess ||
-       hipMalloc((void**)&icp->d_partials, (size_t)icp->blocks * GN_PARTIAL * sizeof(float)) != hipSuccess ||
+      (hipMalloc((void**)&icp->d_state, 2 * sizeof(JobState)) != hipSuccess ||
+       hipMalloc((void**)&icp->d_partials, 2 * (size_t)icp->blocks * GN_PARTIAL * sizeof(float)) != hipSuccess ||
+       hipMalloc((void**)&icp->d_out_pose, 256) != hipSuccess ||
        hipMalloc((void**)&icp->d_readback, GN_PARTIAL * sizeof(double)) != hipSuccess ||
        hipMalloc((void**)&icp->d_counter, sizeof(unsigned)) != hipSuccess ||
        hipMemset(icp->d_counter, 0, sizeof(unsigned)) != hipSuccess))
@@ -470,6 +512,31 @@ static a3d_status pcl_launch_pass(a3d_pcl_icp* icp, const float* d_pts, const fl
   return A3D_OK;
 }
 
+static a3d_status pcl_launch_head_pass(a3d_pcl_icp* icp, const float* d_pts, const float* d_nrm, uint32_t m, uint32_t seq,
+                                       const HeadArgs& head) {
+  PclGates g;
+  g.max_distance_sqr = icp->params.max_distance * icp->params.max_distance;
+  g.dot_reject_max = acos_gate_threshold(icp->params.max_normal_angle, /*strict=*/true);
+  a3d_kdtree* t = icp->tree;
+  const KdLaunch& L = icp->launch;
+  const size_t half = (size_t)icp->blocks * GN_PARTIAL;
+  const JobState* st_in = icp->d_state + (seq & 1u);
+  JobState* st_out = icp->d_state + ((seq + 1u) & 1u);
+  const float* part_in = icp->d_partials + (size_t)((seq + 1u) & 1u) * half;  // written by launch seq - 1
+  float* part_out = icp->d_partials + (size_t)(seq & 1u) * half;
+#define A3D_PCL_LAUNCH(B)                                                                                          \
+  {                                                                                                                \
+    A3D_TRY(kd_allow_big_lds(pcl_icp_head_kernel<B>, L.lds_bytes));                                                \
+    hipLaunchKernelGGL(pcl_icp_head_kernel<B>, dim3(L.blocks), dim3(B), L.lds_bytes, icp->ctx->stream, t->d_split, \
+                       t->d_leaves, t->d_leaf_normals, t->n, t->max_depth, L.lds_levels, d_pts, d_nrm, m, st_in,   \
+                       st_out, g, part_in, part_out, head);                                                        \
+  }
+  if (L.block == 256) A3D_PCL_LAUNCH(256) else if (L.block == 512) A3D_PCL_LAUNCH(512) else A3D_PCL_LAUNCH(1024)
+#undef A3D_PCL_LAUNCH
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
+
 a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, a3d_pose* out_pose) {
   A3D_REQUIRE(icp && source && out_pose, A3D_INVALID_PARAMETER, "null argument");
   float *d_pts = nullptr, *d_nrm = nullptr;
@@ -483,24 +550,50 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
   }
   if (st == A3D_OK) hipEventRecord(icp->ev0, s);
   if (st == A3D_OK) st = launch_job_init(s, icp->d_state, nullptr, 1);
-  for (uint64_t it = 0; st == A3D_OK && it < icp->params.max_iterations; ++it) {
-    SolveArgs sa{};
-    sa.weight = icp->params.weight, sa.color_weight = 0.0f;
-    sa.mode = SOLVE_PCL_ICP;
-    sa.first_in_level = it == 0, sa.last_in_level = it + 1 == icp->params.max_iterations;
-    st = pcl_launch_pass(icp, d_pts, d_nrm, m, sa);
-  }
+  const char* handoff = getenv("A3D_ICP_HANDOFF");
+  const bool head_form = !(handoff && !strcmp(handoff, "ticket"));  // cross-check knob: the last-block form
+  icp->d_out_status = (int32_t*)((char*)icp->d_out_pose + 128);
   JobState h;
-  if (st == A3D_OK) hipEventRecord(icp->ev1, s);
-  if (st == A3D_OK && hipMemcpyAsync(&h, icp->d_state, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess)
-    st = A3D_HIP_ERROR;
+  Pose h_pose{};
+  int32_t h_status = A3D_OK;
+  if (head_form) {
+    HeadArgs prev{};
+    prev.mode = SOLVE_NONE;
+    uint32_t seq = 0;
+    for (uint64_t it = 0; st == A3D_OK && it < icp->params.max_iterations; ++it, ++seq) {
+      st = pcl_launch_head_pass(icp, d_pts, d_nrm, m, seq, prev);
+      prev.weight = icp->params.weight, prev.color_weight = 0.0f, prev.mode = SOLVE_PCL_ICP;
+      prev.tiles = icp->blocks;
+      prev.first_in_level = it == 0, prev.last_in_level = it + 1 == icp->params.max_iterations;
+    }
+    if (st == A3D_OK)  // the last iteration is still pending: the finish kernel applies it
+      st = launch_job_finish_head(s, icp->d_state + (seq & 1u),
+                                  icp->d_partials + (size_t)((seq + 1u) & 1u) * icp->blocks * GN_PARTIAL, 0, prev,
+                                  icp->d_out_pose, icp->d_out_status, nullptr, 1);
+    if (st == A3D_OK) hipEventRecord(icp->ev1, s);
+    if (st == A3D_OK && (hipMemcpyAsync(&h_pose, icp->d_out_pose, sizeof(Pose), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                         hipMemcpyAsync(&h_status, icp->d_out_status, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess))
+      st = A3D_HIP_ERROR;
+  } else {
+    for (uint64_t it = 0; st == A3D_OK && it < icp->params.max_iterations; ++it) {
+      SolveArgs sa{};
+      sa.weight = icp->params.weight, sa.color_weight = 0.0f;
+      sa.mode = SOLVE_PCL_ICP;
+      sa.first_in_level = it == 0, sa.last_in_level = it + 1 == icp->params.max_iterations;
+      st = pcl_launch_pass(icp, d_pts, d_nrm, m, sa);
+    }
+    if (st == A3D_OK) hipEventRecord(icp->ev1, s);
+    if (st == A3D_OK && hipMemcpyAsync(&h, icp->d_state, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess)
+      st = A3D_HIP_ERROR;
+  }
   if (hipStreamSynchronize(s) != hipSuccess && st == A3D_OK) st = A3D_HIP_ERROR;
+  if (!head_form) h_pose = h.pose, h_status = h.status;
   if (st == A3D_OK) hipEventElapsedTime(&icp->last_device_ms, icp->ev0, icp->ev1);
   if (st == A3D_HIP_ERROR) set_error("a3d_pcl_icp_align: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   if (st != A3D_OK) return st;
-  pose_to_c(h.pose, out_pose);
-  if (h.status == A3D_SOLVE_FAILED) set_error("GaussNewton::solve() returned None (count == 0 or Cholesky failed)");
-  return (a3d_status)h.status;
+  pose_to_c(h_pose, out_pose);
+  if (h_status == A3D_SOLVE_FAILED) set_error("GaussNewton::solve() returned None (count == 0 or Cholesky failed)");
+  return (a3d_status)h_status;
 }
 
 a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, const a3d_pose* pose,
@@ -544,6 +637,7 @@ a3d_status a3d_pcl_icp_free(a3d_pcl_icp* icp) {
   a3d_kdtree_free(icp->tree);
   hipFree(icp->d_state);
   hipFree(icp->d_partials);
+  hipFree(icp->d_out_pose);
   hipFree(icp->d_counter);
   hipFree(icp->d_readback);
   if (icp->ev0) hipEventDestroy(icp->ev0);

@@ -27,29 +27,28 @@ class Transform:
     # -- Isometry3 algebra in f32, nalgebra's formulas (src/transform.rs:138-153, :191, :205-220) -------------
     @staticmethod
     def _rotate(q, v):
-        """UnitQuaternion * Vector3: t = 2 (q_v x v); v' = (t w + q_v x t) + v"""
-        q = np.asarray(q, np.float32)
-        v = np.asarray(v, np.float32)
-        qv = q[:3]
-        t = np.cross(qv, v).astype(np.float32) * np.float32(2)
-        c = np.cross(qv, t).astype(np.float32)
-        return ((t * q[3] + c) + v).astype(np.float32)
+        """UnitQuaternion * Vector3: t = 2 (q_v x v); v' = (t w + q_v x t) + v — every operation rounded to f32, in
+        nalgebra's order (numpy f32 scalars: the odometry loop calls this once per frame, array temporaries cost 10x)."""
+        f = np.float32
+        qi, qj, qk, qw = f(q[0]), f(q[1]), f(q[2]), f(q[3])
+        vx, vy, vz = f(v[0]), f(v[1]), f(v[2])
+        two = f(2)
+        tx, ty, tz = (qj * vz - qk * vy) * two, (qk * vx - qi * vz) * two, (qi * vy - qj * vx) * two
+        cx, cy, cz = qj * tz - qk * ty, qk * tx - qi * tz, qi * ty - qj * tx
+        return np.array([(tx * qw + cx) + vx, (ty * qw + cy) + vy, (tz * qw + cz) + vz], np.float32)
 
     def transform_vector(self, v):
         return (self._rotate(self.q, v) + self.t).astype(np.float32)
 
     def __mul__(self, rhs):
         """self * rhs (rhs applied first): t = t1 + R1 t2, q = q1 q2 (Hamilton product, not renormalised)."""
-        a, b = self.q, rhs.q
-        q = np.array(
-            [
-                a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1],
-                a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0],
-                a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3],
-                a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2],
-            ],
-            np.float32,
-        )
+        f = np.float32
+        a0, a1, a2, a3 = f(self.q[0]), f(self.q[1]), f(self.q[2]), f(self.q[3])
+        b0, b1, b2, b3 = f(rhs.q[0]), f(rhs.q[1]), f(rhs.q[2]), f(rhs.q[3])
+        q = (a3 * b0 + a0 * b3 + a1 * b2 - a2 * b1,
+             a3 * b1 - a0 * b2 + a1 * b3 + a2 * b0,
+             a3 * b2 + a0 * b1 - a1 * b0 + a2 * b3,
+             a3 * b3 - a0 * b0 - a1 * b1 - a2 * b2)
         return Transform(self.t + self._rotate(self.q, rhs.t), q)
 
     def inverse(self):
