@@ -155,6 +155,7 @@ SIGNATURES = {
         [_P, C.POINTER(BuilderParamsC), C.c_uint64, _PP, _PP, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double,
          C.c_double, C.c_double, _PP],
     ),
+    "a3d_context_last_build_stats": (_ST, [_P, C.POINTER(C.c_uint64)]),
     "a3d_range_image_size": (_ST, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "a3d_range_image_download": (_ST, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double)]),
     "a3d_compute_normals": (_ST, [_P, _P, _P, C.c_uint64, C.c_uint64, _P]),

@@ -79,6 +79,12 @@ class Context:
         _abi.check(self.lib.a3d_memcpy_d2h(self.handle, _abi.ptr(arr), p, arr.nbytes))
         return arr
 
+    def last_build_stats(self):
+        """{frames, grid_cells, marked_tiles, zero_tiles} of the most recent RangeImageBuilder call on this context."""
+        v = (C.c_uint64 * 4)()
+        _abi.check(self.lib.a3d_context_last_build_stats(self.handle, v))
+        return {"frames": int(v[0]), "grid_cells": int(v[1]), "marked_tiles": int(v[2]), "zero_tiles": int(v[3])}
+
     def close(self):
         if self._sibling is not None:
             self._sibling.close()

@@ -124,6 +124,9 @@ struct a3d_context {
   int stream_priority = 0;
   std::mutex stream_mutex;
   std::vector<hipStream_t> side_streams;
+  // What the most recent a3d_range_image_build_pyramids call processed (a3d_context_last_build_stats): frames, cells of
+  // their bilateral grids, blur tiles marked by the splat, first-channel tiles written as zeros.
+  uint64_t build_stats[4] = {0, 0, 0, 0};
 };
 
 namespace a3d {

@@ -653,8 +653,16 @@ a3d_status build_frames(a3d_context* ctx, const a3d_builder_params* prm, uint64_
     return fail(A3D_HIP_ERROR);
   }
   size_t o = 0;
-  for (Chunk& c : chunks)
+  for (Chunk& c : chunks) {
     for (a3d_device_image* im : c.images) out_levels[o++] = im;
+    ctx->build_stats[0] += c.F;
+    if (prm->use_bilateral)
+      for (uint32_t f = 0; f < c.F; ++f) {
+        const uint32_t* r = c.result + f * SC_STRIDE;
+        ctx->build_stats[1] += (uint64_t)r[SC_GH] * r[SC_GW] * r[SC_GD];
+        ctx->build_stats[2] += r[SC_NLIST], ctx->build_stats[3] += r[SC_NZERO];
+      }
+  }
   return A3D_OK;
 }
 
@@ -705,6 +713,7 @@ a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_pa
                                                                              prm->sigma_color, 4096);
     chunk = std::max<uint64_t>(1, std::min<uint64_t>(MAX_BATCH, (2ull << 30) / (cap * 24 + 1)));
   }
+  for (uint64_t& v : ctx->build_stats) v = 0;
   // frames per pipelined pass: as many chunks as the page-locked result area has scalar blocks for
   const uint64_t pass = chunk * (a3d_context::PINNED_WORDS / (MAX_BATCH * SC_STRIDE));
   for (uint64_t f0 = 0; f0 < n_frames; f0 += pass) {
@@ -723,6 +732,13 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
                                          const uint8_t* rgb, uint64_t width, uint64_t height, double fx, double fy,
                                          double cx, double cy, double depth_scale, a3d_device_image** out_levels) {
   return a3d_range_image_build_pyramids(ctx, prm, 1, &depth, &rgb, width, height, fx, fy, cx, cy, depth_scale, out_levels);
+}
+
+// Instrumentation: what the most recent a3d_range_image_build_pyramids call on this context processed.
+a3d_status a3d_context_last_build_stats(a3d_context* ctx, uint64_t out_stats[4]) {
+  A3D_REQUIRE(ctx && out_stats, A3D_INVALID_PARAMETER, "null argument");
+  for (int k = 0; k < 4; ++k) out_stats[k] = ctx->build_stats[k];
+  return A3D_OK;
 }
 
 a3d_status a3d_range_image_size(const a3d_device_image* im, uint64_t* out_width, uint64_t* out_height) {

@@ -212,6 +212,10 @@ a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_pa
                                           const uint16_t* const* depth_frames, const uint8_t* const* rgb_frames,
                                           uint64_t width, uint64_t height, double fx, double fy, double cx, double cy,
                                           double depth_scale, a3d_device_image** out_levels);
+/* Instrumentation for the roofline of the frame builder: what the most recent a3d_range_image_build_pyramids call on
+ * this context processed — out_stats = {frames, cells of their bilateral grids (GH x GW x GD, src/bilateral/grid.rs:37-56),
+ * 12^3-cell blur tiles the splat marked, first-channel tiles written as zeros}. */
+a3d_status a3d_context_last_build_stats(a3d_context* ctx, uint64_t out_stats[4]);
 a3d_status a3d_range_image_size(const a3d_device_image* image, uint64_t* out_width, uint64_t* out_height);
 /* Reads resident arrays back (each pointer nullable): points [h][w][3], mask [h][w], normals [h][w][3],
  * intensities [h*w], intensity_map [(h+2)][(w+2)], colors [h][w][3] u8, intrinsics fx fy cx cy. */

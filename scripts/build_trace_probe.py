@@ -1,4 +1,5 @@
-"""10 batched frame builds of 16 frames on one context (for rocprofv3 --kernel-trace --stats)."""
+"""10 batched frame builds of 16 frames on one context (for rocprofv3 --kernel-trace --stats); prints what a build
+processed (bench.py's extra.frame_build.roofline uses the same figures)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from align3d_amd import BilateralFilter, Context, RangeImageBuilder, synth
@@ -10,3 +11,4 @@ for i in range(10):
     for p in b.build_many(cam, frames, synth.DEPTH_SCALE):
         for lv in p:
             lv.free()
+print("last build:", ctx.last_build_stats())

@@ -2,7 +2,7 @@
 # frame build) (1) rocprofv3 --kernel-trace --stats, (2) a per-grid summary, (3) FETCH_SIZE / WRITE_SIZE passes ->
 # HBM bytes per launch of its dominant kernel.  Outputs under gpurun_out/profile_<round>/; copy them into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ROUND=${ROUND:-round2}
+ROUND=${ROUND:-round3}
 OUT=gpurun_out/profile_$ROUND
 rm -rf $OUT && mkdir -p $OUT
 trace() {  # NAME program args...
@@ -15,9 +15,12 @@ trace bench python3 bench.py --steps 5 --warmup 2 --no-extras --cpu-pairs 0 &&
 trace kdtree python3 scripts/kd_probe.py &&
 trace pcl_icp python3 scripts/pcl_probe.py &&
 trace frame_build python3 scripts/build_trace_probe.py &&
-ROUND=$ROUND bash scripts/traffic_pmc.sh bench image_icp_kernel "pairs_per_gpu=64 concurrent_launches=${CONC:-3}" python3 bench.py --steps 2 --warmup 1 --no-extras --cpu-pairs 0 > /dev/null &&
+ROUND=$ROUND bash scripts/traffic_pmc.sh bench image_icp_head_kernel "pairs_per_gpu=64 concurrent_launches=${CONC:-3} distinct_frames=1" python3 bench.py --steps 2 --warmup 1 --no-extras --cpu-pairs 0 > /dev/null &&
+mv gpurun_out/${ROUND}_bench_traffic.json gpurun_out/${ROUND}_bench_traffic_distinct.json &&
+ROUND=$ROUND bash scripts/traffic_pmc.sh bench image_icp_head_kernel "pairs_per_gpu=64 concurrent_launches=${CONC:-3} distinct_frames=0" python3 bench.py --shared-frames --steps 2 --warmup 1 --no-extras --cpu-pairs 0 > /dev/null &&
+mv gpurun_out/${ROUND}_bench_traffic.json gpurun_out/${ROUND}_bench_traffic_shared.json &&
 ROUND=$ROUND bash scripts/traffic_pmc.sh kdtree kdtree_nearest_kernel "queries=500000 points=500000" python3 scripts/kd_probe.py > /dev/null &&
-ROUND=$ROUND bash scripts/traffic_pmc.sh pcl_icp pcl_icp_kernel "source_points=500000 target_points=500000" python3 scripts/pcl_probe.py > /dev/null &&
+ROUND=$ROUND bash scripts/traffic_pmc.sh pcl_icp pcl_icp_head_kernel "source_points=500000 target_points=500000" python3 scripts/pcl_probe.py > /dev/null &&
 cp gpurun_out/${ROUND}_*_traffic.json $OUT/ &&
 python3 bench.py > $OUT/${ROUND}_bench.json 2> $OUT/bench.err &&
 head -12 $OUT/${ROUND}_bench_per_grid.txt && cat $OUT/${ROUND}_*_traffic.json && tail -c 2500 $OUT/${ROUND}_bench.json
