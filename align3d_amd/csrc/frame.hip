@@ -27,6 +27,16 @@ struct FrameBases {
   char* arena[MAX_BATCH];
 };
 
+// One Vector3<f32> as ONE 12-byte store (global_store_dwordx3): three dword stores at a 12-byte lane stride make the
+// memory pipeline touch every line of the wave's span three times, each time partially.
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef f32x3 __attribute__((aligned(4))) f32x3_u;
+__device__ __forceinline__ void st_v3(float* base, size_t idx, V3 v) { *(f32x3_u*)(base + 3 * idx) = f32x3{v.x, v.y, v.z}; }
+__device__ __forceinline__ V3 ld_v3g(const float* base, size_t idx) {
+  const f32x3 v = *(const f32x3_u*)(base + 3 * idx);
+  return V3{v.x, v.y, v.z};
+}
+
 // One pyramid level as the kernels see it: size and the byte offsets of its arrays inside a frame's arena.
 struct LevelLayout {
   uint32_t w, h;
@@ -75,8 +85,12 @@ __device__ __forceinline__ V3 pick_nearest_to_mean(const V3 (&cand)[4], const bo
 // round trip of the filtered image through HBM and two more launches.
 constexpr int ST_W = 32, ST_H = 16, OWN_W = ST_W - 2, OWN_H = ST_H - 2;
 
+// 256 threads per block, TWO staged pixels per thread (rows ly and ly + 8 of the 32 x 16 patch): the kernel is bound by
+// the latency of its dependent phases (depth load -> eight grid gathers -> LDS -> normals -> stores) times the rounds of
+// resident blocks, so a wave that carries two independent pixel chains halves the rounds.
+constexpr int L0_PPT = 2, L0_THREADS = ST_W * ST_H / L0_PPT;
 template <bool FILTER>
-__global__ void __launch_bounds__(ST_W* ST_H)
+__global__ void __launch_bounds__(L0_THREADS)
     level0_kernel(const uint16_t* __restrict__ depth, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
                   const double* __restrict__ grids, unsigned long long capacity, uint32_t* __restrict__ scal, float fx,
                   float fy, float cx, float cy, float scale, FrameBases bases, size_t off_points, size_t off_mask,
@@ -85,54 +99,69 @@ __global__ void __launch_bounds__(ST_W* ST_H)
   __shared__ float sn[3][OWN_H][OWN_W + 1];  // the owned pixels' normals, for the fused level-1 pick
   __shared__ uint8_t sm[ST_H][ST_W];         // their masks (1: depth > 0)
   const uint32_t f = blockIdx.z;
-  const int lx = threadIdx.x % ST_W, ly = threadIdx.x / ST_W;
-  const int col = (int)blockIdx.x * OWN_W + lx - 1, row = (int)blockIdx.y * OWN_H + ly - 1;
-  const bool in = col >= 0 && col < (int)w && row >= 0 && row < (int)h;
-  float px = 0.f, py = 0.f, pz = 0.f;
-  uint32_t d = 0;
-  if (in) {
-    d = depth[(size_t)f * w * h + (size_t)row * w + col];
-    if (FILTER) {
-      uint32_t* sc = scal + f * SC_STRIDE;
-      GridDims g;
-      uint32_t cmin;
-      if (dyn_dims(sc, &g, &cmin)) {  // (false: this frame's grid did not fit; the host grows the region and repeats)
-        uint16_t v;
-        if (!slice_pixel(d, (uint32_t)row, (uint32_t)col, inv_ss, inv_sc, cmin, g, grids + f * capacity, &v))
-          atomicOr(&sc[SC_OVERFLOW], 1u);  // the reference's .unwrap() would panic
-        d = v;
+  const int lx = threadIdx.x % ST_W, ly0 = threadIdx.x / ST_W;
+  const int col = (int)blockIdx.x * OWN_W + lx - 1;
+  int ly[L0_PPT], row[L0_PPT];
+  bool in[L0_PPT];
+  uint32_t d[L0_PPT];
+  float px[L0_PPT], py[L0_PPT], pz[L0_PPT];
+#pragma unroll
+  for (int k = 0; k < L0_PPT; ++k) {
+    ly[k] = ly0 + k * (ST_H / L0_PPT);
+    row[k] = (int)blockIdx.y * OWN_H + ly[k] - 1;
+    in[k] = col >= 0 && col < (int)w && row[k] >= 0 && row[k] < (int)h;
+    d[k] = in[k] ? depth[(size_t)f * w * h + (size_t)row[k] * w + col] : 0u;  // (both loads issued before either is used)
+    px[k] = py[k] = pz[k] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < L0_PPT; ++k) {
+    if (in[k]) {
+      if (FILTER) {
+        uint32_t* sc = scal + f * SC_STRIDE;
+        GridDims g;
+        uint32_t cmin;
+        if (dyn_dims(sc, &g, &cmin)) {  // (false: this frame's grid did not fit; the host grows the region and repeats)
+          uint16_t v;
+          if (!slice_pixel(d[k], (uint32_t)row[k], (uint32_t)col, inv_ss, inv_sc, cmin, g, grids + f * capacity, &v))
+            atomicOr(&sc[SC_OVERFLOW], 1u);  // the reference's .unwrap() would panic
+          d[k] = v;
+        }
+      }
+      if (d[k] > 0) {
+        pz[k] = (float)d[k] * scale;
+        px[k] = ((float)col - cx) * pz[k] / fx;
+        py[k] = ((float)row[k] - cy) * pz[k] / fy;
       }
     }
-    if (d > 0) {
-      pz = (float)d * scale;
-      px = ((float)col - cx) * pz / fx;
-      py = ((float)row - cy) * pz / fy;
-    }
+    sp[0][ly[k]][lx] = px[k], sp[1][ly[k]][lx] = py[k], sp[2][ly[k]][lx] = pz[k];
+    sm[ly[k]][lx] = d[k] > 0 ? 1 : 0;
   }
-  sp[0][ly][lx] = px, sp[1][ly][lx] = py, sp[2][ly][lx] = pz;
-  sm[ly][lx] = d > 0 ? 1 : 0;
   __syncthreads();
-  const bool owned = in && lx != 0 && lx != ST_W - 1 && ly != 0 && ly != ST_H - 1;  // (the rest is halo)
   char* base = bases.arena[f];
   auto at = [&](int y, int x) { return V3{sp[0][y][x], sp[1][y][x], sp[2][y][x]}; };
-  V3 nrm{0.f, 0.f, 0.f};
-  if (owned && with_normals) {
-    // an invalid neighbour's point is (0,0,0) already (= get_point(...).unwrap_or_else(zeros)); so is everything
-    // outside the image; the centre is used as stored, its mask is NOT checked (structure.rs:207)
-    nrm = normal_from_neighbours(V3{px, py, pz}, at(ly, lx - 1), at(ly, lx + 1), at(ly - 1, lx), at(ly + 1, lx));
-    if (emit_l1) sn[0][ly - 1][lx - 1] = nrm.x, sn[1][ly - 1][lx - 1] = nrm.y, sn[2][ly - 1][lx - 1] = nrm.z;
-  }
-  if (emit_l1) __syncthreads();  // (before the stores below: the level-1 picks then run under them)
-  if (owned) {
-    const size_t idx = (size_t)row * w + col;
-    float* points = (float*)(base + off_points);
-    points[3 * idx] = px, points[3 * idx + 1] = py, points[3 * idx + 2] = pz;
-    ((uint8_t*)(base + off_mask))[idx] = d > 0 ? 1 : 0;
-    if (with_normals) {
-      float* normals = (float*)(base + off_normals);
-      normals[3 * idx] = nrm.x, normals[3 * idx + 1] = nrm.y, normals[3 * idx + 2] = nrm.z;
+  bool owned[L0_PPT];
+  V3 nrm[L0_PPT];
+#pragma unroll
+  for (int k = 0; k < L0_PPT; ++k) {
+    owned[k] = in[k] && lx != 0 && lx != ST_W - 1 && ly[k] != 0 && ly[k] != ST_H - 1;  // (the rest is halo)
+    nrm[k] = V3{0.f, 0.f, 0.f};
+    if (owned[k] && with_normals) {
+      // an invalid neighbour's point is (0,0,0) already (= get_point(...).unwrap_or_else(zeros)); so is everything
+      // outside the image; the centre is used as stored, its mask is NOT checked (structure.rs:207)
+      nrm[k] = normal_from_neighbours(V3{px[k], py[k], pz[k]}, at(ly[k], lx - 1), at(ly[k], lx + 1), at(ly[k] - 1, lx),
+                                      at(ly[k] + 1, lx));
+      if (emit_l1) sn[0][ly[k] - 1][lx - 1] = nrm[k].x, sn[1][ly[k] - 1][lx - 1] = nrm[k].y, sn[2][ly[k] - 1][lx - 1] = nrm[k].z;
     }
   }
+  if (emit_l1) __syncthreads();  // (before the stores below: the level-1 picks then run under them)
+#pragma unroll
+  for (int k = 0; k < L0_PPT; ++k)
+    if (owned[k]) {
+      const size_t idx = (size_t)row[k] * w + col;
+      st_v3((float*)(base + off_points), idx, V3{px[k], py[k], pz[k]});
+      ((uint8_t*)(base + off_mask))[idx] = d[k] > 0 ? 1 : 0;
+      if (with_normals) st_v3((float*)(base + off_normals), idx, nrm[k]);
+    }
   if (!emit_l1) return;
   // ---- level 1 of the pyramid from the staged level-0 patch (pyr_scale_down: resize_range_points / _normals,
   // src/range_image/resize.rs:42-104): the patch origin is even and the image sides are even (the host checks), so the
@@ -161,8 +190,7 @@ __global__ void __launch_bounds__(ST_W* ST_H)
   int n_valid;
   const V3 pk = pick_nearest_to_mean(cand, ok, &n_valid);
   const size_t i1 = (size_t)(r0 >> 1) * L1.w + (size_t)(c0 >> 1);
-  float* dst = (float*)(base + (normals_task ? L1.normals : L1.points));
-  dst[3 * i1] = pk.x, dst[3 * i1 + 1] = pk.y, dst[3 * i1 + 2] = pk.z;
+  st_v3((float*)(base + (normals_task ? L1.normals : L1.points)), i1, pk);
   if (!normals_task) ((uint8_t*)(base + L1.mask))[i1] = n_valid > 0 ? 1 : 0;
 }
 
@@ -272,11 +300,11 @@ __global__ void __launch_bounds__(256) resize_pick_kernel(LevelLayout S, LevelLa
       const bool in = r < sh && c < sw;
       const uint32_t k = in ? r * sw + c : 0u;
       ok[q] = in && src_mask[k] == 1;
-      cand[q] = V3{src[3 * k], src[3 * k + 1], src[3 * k + 2]};
+      cand[q] = ld_v3g(src, k);
     }
   int n;
   const V3 nearest = pick_nearest_to_mean(cand, ok, &n);
-  dst[3 * i] = nearest.x, dst[3 * i + 1] = nearest.y, dst[3 * i + 2] = nearest.z;
+  st_v3(dst, i, nearest);
   if (!normals) ((uint8_t*)(base + D.mask))[i] = n > 0 ? 1 : 0;
 }
 
@@ -439,12 +467,12 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   if (prm->use_bilateral) {  // builder.rs:75-77
     GridBatch gb;
     A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb));
-    hipLaunchKernelGGL(level0_kernel<true>, grid0, dim3(ST_W * ST_H), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
+    hipLaunchKernelGGL(level0_kernel<true>, grid0, dim3(L0_THREADS), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
                        1.0 / prm->sigma_color, (const double*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
                        bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1);
     A3D_HIP_TRY(hipMemcpyAsync(result, gb.scal, (size_t)F * SC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   } else {
-    hipLaunchKernelGGL(level0_kernel<false>, grid0, dim3(ST_W * ST_H), 0, s, d_depth, w, h, 0.0, 0.0,
+    hipLaunchKernelGGL(level0_kernel<false>, grid0, dim3(L0_THREADS), 0, s, d_depth, w, h, 0.0, 0.0,
                        (const double*)nullptr, 0ull, (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points,
                        L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1);
   }

@@ -306,3 +306,27 @@ def test_builder_rejects_bad_sigmas_and_mismatched_frames(ctx):
         RangeImageBuilder(ctx).build(cam, depth.reshape(-1), rgb, 0.001)   # depth not 2-D
     with pytest.raises(InvalidParameter):
         RangeImageBuilder(ctx).build_many(cam, [(depth, rgb), (depth[:24], rgb[:24])], 0.001)  # frames of two sizes
+
+
+def test_builder_reports_what_it_processed(ctx):
+    """a3d_context_last_build_stats (the figures bench.py's frame-build roofline is made of): frames, cells of their
+    bilateral grids, marked blur tiles; the grid cells equal the oracle's grid dimensions for each frame."""
+    from align3d_amd import CameraIntrinsics, RangeImageBuilder
+
+    s1 = SlamTbSample("sample1")
+    frames = [s1.load(0), s1.load(1), s1.load(4)]
+    built = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default()).build_many(
+        CameraIntrinsics(*s1.intrinsics(0), 640, 480), frames, s1.depth_scale(0))
+    st = ctx.last_build_stats()
+    want_cells = 0
+    for depth, _ in frames:
+        status, _, dims = O.bilateral(depth)
+        assert status == 0
+        want_cells += int(np.prod(dims))
+    assert st["frames"] == 3 and st["grid_cells"] == want_cells
+    assert 0 < st["marked_tiles"] * 12 ** 3 < 3 * want_cells and st["zero_tiles"] > 0
+    for p in built:
+        for lv in p:
+            lv.free()
+    RangeImageBuilder(ctx).build_many(CameraIntrinsics(*s1.intrinsics(0), 640, 480), frames[:1], s1.depth_scale(0))
+    assert ctx.last_build_stats() == {"frames": 1, "grid_cells": 0, "marked_tiles": 0, "zero_tiles": 0}
