@@ -194,6 +194,36 @@ A3D_HD bool gn_solve6(const float H[36], const float g[6], float out[6]) {
 // Index of (r, c), r <= c, in the packed upper triangle of a symmetric 6x6 (21 entries).
 A3D_HD constexpr int tri6(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
 
+#if defined(__HIPCC__)
+// ---- IEEE division with a shared reciprocal (device only) ---------------------------------------------------
+// Several quotients over ONE denominator (the projection's x / z and y / z in the ICP kernels, a normal's three
+// components over its length, a back-projection's division by fx).  a / z below is the arithmetic of the compiler's own
+// correctly rounded f32 division (reciprocal estimate, one Newton step, quotient, two fma corrections) minus its
+// range scaling, with the refined reciprocal computed once per denominator.  It returns the correctly rounded quotient for operands in `div_fast_ok` range (checked on
+// 2e8 random pairs against IEEE division, and on the device by a3d_selftest_division); anything else takes
+// the plain `/`.
+struct DivBy {
+  float negz, y;
+};
+__device__ __forceinline__ DivBy div_prepare(float z) {
+  const float r = __builtin_amdgcn_rcpf(z);
+  const float e = __builtin_fmaf(-z, r, 1.0f);
+  return {-z, __builtin_fmaf(e, r, r)};
+}
+__device__ __forceinline__ float div_by(float a, const DivBy d) {
+  const float q = a * d.y;
+  const float r1 = __builtin_fmaf(d.negz, q, a);
+  const float q1 = __builtin_fmaf(r1, d.y, q);
+  const float r2 = __builtin_fmaf(d.negz, q1, a);
+  return __builtin_fmaf(r2, d.y, q1);
+}
+// (bitwise on purpose: short-circuit forms compile to a chain of exec-mask branches in the pixel loop)
+__device__ __forceinline__ bool div_den_ok(float z) { return (fabsf(z) > 1e-9f) & (fabsf(z) < 1e9f); }
+__device__ __forceinline__ bool div_num_ok(float a) { return (a == 0.0f) | ((fabsf(a) > 1e-20f) & (fabsf(a) < 1e9f)); }
+
+
+#endif  // __HIPCC__
+
 // The per-pixel body of RangeImage::compute_normals (src/range_image/structure.rs:207-257): neighbours that are
 // out of range or masked out arrive as (0,0,0); ratio comparisons with NaN / inf are false like the reference's.
 A3D_HD V3 normal_from_neighbours(V3 center, V3 left, V3 right, V3 top, V3 bottom) {

@@ -89,6 +89,9 @@ constexpr int ST_W = 32, ST_H = 16, OWN_W = ST_W - 2, OWN_H = ST_H - 2;
 // the latency of its dependent phases (depth load -> eight grid gathers -> LDS -> normals -> stores) times the rounds of
 // resident blocks, so a wave that carries two independent pixel chains halves the rounds.
 constexpr int L0_PPT = 2, L0_THREADS = ST_W * ST_H / L0_PPT;
+#ifndef A3D_L0_PROBE  // diagnostic builds (scripts/build_variant.sh -DA3D_L0_PROBE=n): 1 no level-0 stores, 2 no normals,
+#define A3D_L0_PROBE 0  // 3 no level-1 picks, 4 nothing but the staging
+#endif
 template <bool FILTER>
 __global__ void __launch_bounds__(L0_THREADS)
     level0_kernel(const uint16_t* __restrict__ depth, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(L0_THREADS)
   for (int k = 0; k < L0_PPT; ++k) {
     owned[k] = in[k] && lx != 0 && lx != ST_W - 1 && ly[k] != 0 && ly[k] != ST_H - 1;  // (the rest is halo)
     nrm[k] = V3{0.f, 0.f, 0.f};
-    if (owned[k] && with_normals) {
+    if (owned[k] && with_normals && A3D_L0_PROBE != 2 && A3D_L0_PROBE != 4) {
       // an invalid neighbour's point is (0,0,0) already (= get_point(...).unwrap_or_else(zeros)); so is everything
       // outside the image; the centre is used as stored, its mask is NOT checked (structure.rs:207)
       nrm[k] = normal_from_neighbours(V3{px[k], py[k], pz[k]}, at(ly[k], lx - 1), at(ly[k], lx + 1), at(ly[k] - 1, lx),
@@ -156,13 +159,13 @@ __global__ void __launch_bounds__(L0_THREADS)
   if (emit_l1) __syncthreads();  // (before the stores below: the level-1 picks then run under them)
 #pragma unroll
   for (int k = 0; k < L0_PPT; ++k)
-    if (owned[k]) {
+    if (owned[k] && ((A3D_L0_PROBE != 1 && A3D_L0_PROBE != 4) || px[k] == 12345.678f)) {
       const size_t idx = (size_t)row[k] * w + col;
       st_v3((float*)(base + off_points), idx, V3{px[k], py[k], pz[k]});
       ((uint8_t*)(base + off_mask))[idx] = d[k] > 0 ? 1 : 0;
       if (with_normals) st_v3((float*)(base + off_normals), idx, nrm[k]);
     }
-  if (!emit_l1) return;
+  if (!emit_l1 || A3D_L0_PROBE == 3 || A3D_L0_PROBE == 4) return;
   // ---- level 1 of the pyramid from the staged level-0 patch (pyr_scale_down: resize_range_points / _normals,
   // src/range_image/resize.rs:42-104): the patch origin is even and the image sides are even (the host checks), so the
   // 2 x 2 blocks of the 30 x 14 owned pixels are whole and block (dv, du) is source pixels (2 dv .. 2 dv + 1, 2 du ..).

@@ -72,32 +72,7 @@ __device__ __forceinline__ V3 ld_v3(const float* base, uint32_t idx) {
   return {v.x, v.y, v.z};
 }
 
-// ---- IEEE division with a shared reciprocal -------------------------------------------------------------
-// The reference divides six times per pixel, four times by z and twice by z*z; the two quotients of the projection
-// decide which target pixel a source pixel meets and are IEEE here (the four of the projection gradient only feed the
-// Jacobian: stage D multiplies by a refined reciprocal).  a / z below is the arithmetic of the compiler's own
-// correctly rounded f32 division (reciprocal estimate, one Newton step, quotient, two fma corrections) minus its
-// range scaling, with the refined reciprocal computed once per denominator.  It returns the correctly rounded quotient for operands in `div_fast_ok` range (checked on
-// 2e8 random pairs against IEEE division, and on the device by a3d_selftest_division); anything else takes
-// the plain `/`.
-struct DivBy {
-  float negz, y;
-};
-__device__ __forceinline__ DivBy div_prepare(float z) {
-  const float r = __builtin_amdgcn_rcpf(z);
-  const float e = __builtin_fmaf(-z, r, 1.0f);
-  return {-z, __builtin_fmaf(e, r, r)};
-}
-__device__ __forceinline__ float div_by(float a, const DivBy d) {
-  const float q = a * d.y;
-  const float r1 = __builtin_fmaf(d.negz, q, a);
-  const float q1 = __builtin_fmaf(r1, d.y, q);
-  const float r2 = __builtin_fmaf(d.negz, q1, a);
-  return __builtin_fmaf(r2, d.y, q1);
-}
-// (bitwise on purpose: short-circuit forms compile to a chain of exec-mask branches in the pixel loop)
-__device__ __forceinline__ bool div_den_ok(float z) { return (fabsf(z) > 1e-9f) & (fabsf(z) < 1e9f); }
-__device__ __forceinline__ bool div_num_ok(float a) { return (a == 0.0f) | ((fabsf(a) > 1e-20f) & (fabsf(a) < 1e9f)); }
+// (IEEE division with a shared reciprocal: div_prepare / div_by / div_den_ok / div_num_ok live in devmath.hpp)
 
 // Byte offset of texel (row, col) in an f32 image `width` texels wide.  Written as a 24-bit multiply-add
 // (rows, columns and widths are far below 2^24): the generic 32-bit form compiles to v_mad_u64_u32 with a 64-bit

@@ -852,6 +852,11 @@ def main():
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         log(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to report a wrong n_gpus")
         sys.exit(2)
+    # Only the JSON line goes to stdout: RCCL's version banner and gloo's connection messages are printed to fd 1 by the
+    # libraries themselves, so fd 1 points at stderr for the whole run and the line is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1120,7 +1125,9 @@ def main():
     if multi:
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
