@@ -324,7 +324,7 @@ struct TapRow {
 // (consecutive output rows share all but two of their source rows); the vertical sums (u8 -> f32, the crate's f32
 // intermediate) go to a second LDS array, then the horizontal pass, clamp and round-half-away (u8) read them back.
 // Per output the additions run in tap order from 0.0f in both passes, as in the crate.
-constexpr uint32_t BLUR_TILE = 64, BLUR_ROWS = 4;  // (8 rows per block measured slower: 37 against 31 us per 16 frames)
+constexpr uint32_t BLUR_TILE = 64, BLUR_ROWS = 4;  // (2 / 4 / 8 rows per block measured 32 / 31 / 37 us per 16 frames)
 constexpr uint32_t BLUR_SPAN = 3 * (2 * BLUR_TILE + MAX_TAPS + 2);   // bytes / vertical results a tile's row can need
 constexpr uint32_t RAW_ROWS = 2 * (BLUR_ROWS - 1) + MAX_TAPS;        // source rows under BLUR_ROWS output rows
 constexpr uint32_t RAW_PITCH = ((BLUR_SPAN + 3 + 3) / 4) * 4;        // bytes per staged source row (+ alignment slack)
