@@ -209,6 +209,7 @@ struct a3d_device_image {
   bool has_normals = false, has_intensities = false, has_imap = false;
   a3d::DeviceArena* arena = nullptr;     // when set, the arrays above are carved out of it and not freed one by one
   bool built = false;        // made by the device frame builder (its arena layout is fixed when it is planned)
+  bool pending_self_work = false;  // its context enqueued work on it without waiting (compute_normals): fenced at free
   bool mask_is_z = false;    // built with a depth scale for which mask == (z != 0) on every pixel (frame.hip)
   bool own_normals = false;  // `normals` is its own hipMalloc although the image lives in an arena (uploaded without
                              // normals, a3d_range_image_compute_normals called later)
