@@ -113,7 +113,7 @@ int main() {
                 bad ? "FAILED" : "rccl gather OK", world, P, poses[0].t[0], poses[0].t[1], poses[0].t[2]);
   a3d_multiscale_batch_free(batch);
   for (a3d_device_image* im : levels) a3d_range_image_free(im);
-  hipFree(d_local), hipFree(d_all);
+  (void)hipFree(d_local), (void)hipFree(d_all);
   ncclCommDestroy(comm);
   a3d_context_destroy(ctx);
   return bad ? 1 : 0;
