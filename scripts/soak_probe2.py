@@ -85,3 +85,31 @@ cycle("run_odometry_batched(6 frames, windows of 2)", lambda: run_odometry_batch
 import bench
 cycle("streaming_bench (3 rounds of 16 pairs, two alternating batches, images freed behind fences)",
       lambda: bench.streaming_bench(ctx, prm, 16, 640, 480, rounds=3), groups=3, reps=4)
+
+
+# round 3: the drop-in call from host pyramids (pooled pyramid upload + align + free) and compute_normals on uploaded images
+from align3d_amd import MultiscaleAlign
+host_src = [lv.download(colors=False) for lv in pyr[1]]
+ms = MultiscaleAlign.new(ctx, prm, pyr[0])
+
+
+def drop_in_cycle():
+    for h in host_src:
+        if h._device is not None:
+            h._device.free()
+        h._device = None
+    ms.align(host_src)
+
+
+cycle("drop-in align from host pyramids", drop_in_cycle)
+
+
+def normals_cycle():
+    h = host_src[0]
+    if h._device is not None:
+        h._device.free()
+    h._device = None
+    h.device(ctx).compute_normals()
+
+
+cycle("upload + compute_normals + free", normals_cycle)
