@@ -763,3 +763,43 @@ def test_pyramid_upload_shares_one_arena_and_changes_nothing(ctx):
     dev.compute_normals()
     assert np.array_equal(dev.download_normals().view(np.uint32), tp[0].normals.view(np.uint32))
     dev.free()
+
+
+def test_head_solve_and_last_block_handoff_give_the_same_bits(ctx, monkeypatch):
+    """The two hand-off forms (icp_engine.hpp) add the same partials in the same order and run the same solve: a batch
+    of uploaded pyramids (masks read) and a batch of device-built ones (masks derived from z) must give bit-identical
+    poses with the default head-solve form and with A3D_ICP_HANDOFF=ticket; a single pair and a trace likewise."""
+    import bench
+    from align3d_amd import synth
+
+    prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 7))
+    pairs = [("sample1", 0, 5), ("sample2", 0, 4), ("sample1", 1, 4), ("sample1", 4, 5)]
+    tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs]
+    sps = [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in pairs]
+    built, _, _ = bench.build_stream_pyramids(ctx, 77, 9, 640, 480)
+
+    def run_all():
+        out = []
+        b = MultiscaleAlignBatch(ctx, prm, tps, sps)
+        poses, status = b.align()
+        b.free()
+        assert not status.any()
+        out.append(np.stack([p.matrix() for p in poses]))
+        b = MultiscaleAlignBatch(ctx, MsIcpParams.repeat(3, IcpParams.default()), built[:8], built[1:])
+        poses, status = b.align()
+        b.free()
+        assert not status.any()
+        out.append(np.stack([p.matrix() for p in poses]))
+        out.append(MultiscaleAlign.new(ctx, prm, tps[0]).align(sps[0]).matrix())
+        T, tr = ImageIcp.new(ctx, prm[0], tps[1][0]).align(sps[1][0], trace=True)
+        out.append(tr.copy())
+        return out
+
+    head = run_all()
+    monkeypatch.setenv("A3D_ICP_HANDOFF", "ticket")
+    ticket = run_all()
+    monkeypatch.delenv("A3D_ICP_HANDOFF")
+    for h, t in zip(head, ticket):
+        assert np.array_equal(h.view(np.uint32), t.view(np.uint32))
+    for lv in (lv for p in built for lv in p):
+        lv.free()
