@@ -385,6 +385,67 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same kernel when a colour row is a multiple of four bytes (w * 3 % 4 == 0: every staged row then starts at the
+// same offset `sh` inside its first word): the vertical pass works on whole 32-bit words — one LDS read, four
+// v_cvt_f32_ubyteN, four multiply / add pairs per word and tap instead of a byte-wide LDS read per output and tap — and
+// the staging loop has no integer division.  Same operations per output in the same order: same bits.
+__global__ void __launch_bounds__(256)
+    blur_halve_words_kernel(size_t off_src, uint32_t w, uint32_t dw, uint32_t dh, const TapRow* __restrict__ taps_v,
+                            const TapRow* __restrict__ taps_h, size_t off_dst, FrameBases bases) {
+  constexpr uint32_t PITCH_W = RAW_PITCH / 4;                    // words per staged row
+  __shared__ uint32_t s_raw[RAW_ROWS * PITCH_W];
+  __shared__ __attribute__((aligned(16))) float s_v[BLUR_ROWS * PITCH_W * 4];  // vertical sums, indexed by RAW byte position
+  const uint8_t* __restrict__ rgb = (const uint8_t*)(bases.arena[blockIdx.z] + off_src);  // blockIdx.z = frame
+  uint8_t* __restrict__ out = (uint8_t*)(bases.arena[blockIdx.z] + off_dst);
+  const uint32_t dy0 = blockIdx.y * BLUR_ROWS, rows = min(BLUR_ROWS, dh - dy0);
+  const uint32_t dx0 = blockIdx.x * BLUR_TILE, dx1 = min(dx0 + BLUR_TILE, dw) - 1;
+  const int32_t vtop = taps_v[dy0].left, vbot = taps_v[dy0 + rows - 1].left + taps_v[dy0 + rows - 1].count;
+  const int32_t cmin = taps_h[dx0].left, cmax = taps_h[dx1].left + taps_h[dx1].count;
+  const uint32_t span = (uint32_t)(cmax - cmin) * 3u, nraw = (uint32_t)(vbot - vtop);
+  const uint32_t sh = ((uint32_t)cmin * 3u) & 3u;               // the same for every row: w * 3 is a multiple of four
+  const uint32_t words = (span + sh + 3) / 4;
+  // ---- staging: thread = (row slot t / 128, word t % 128); a tile's row has at most 108 words ----
+  {
+    const uint32_t k = threadIdx.x & 127u, jj = threadIdx.x >> 7;
+    const size_t row_bytes = (size_t)w * 3;
+    const uint8_t* p = rgb + (((size_t)vtop * w + (size_t)cmin) * 3 & ~(size_t)3) + 4 * (size_t)k;
+    if (k < words)
+      for (uint32_t j = jj; j < nraw; j += 2) s_raw[j * PITCH_W + k] = *(const uint32_t*)(p + (size_t)j * row_bytes);
+  }
+  __syncthreads();
+  // ---- vertical pass, word-wise: item = (output row r, word q) ----
+  for (uint32_t e = threadIdx.x; e < rows * 128u; e += 256) {
+    const uint32_t r = e >> 7, q = e & 127u;
+    if (q >= words) continue;
+    const TapRow* tv = taps_v + dy0 + r;  // row 2 * (dy0 + r) of the source (table built with stride 2)
+    const int32_t j0 = tv->left - vtop, vcount = tv->count;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAX_TAPS; ++k)
+      if (k < vcount) {
+        const uint32_t word = s_raw[(uint32_t)(j0 + k) * PITCH_W + q];
+        const float wk = tv->w[k];
+        a0 += (float)(word & 255u) * wk, a1 += (float)((word >> 8) & 255u) * wk;
+        a2 += (float)((word >> 16) & 255u) * wk, a3 += (float)(word >> 24) * wk;
+      }
+    *(float4*)(s_v + (r * PITCH_W + q) * 4) = make_float4(a0, a1, a2, a3);
+  }
+  __syncthreads();
+  // ---- horizontal pass: a thread owns one (column, channel) of the tile for all its rows: taps read once ------
+  const uint32_t o = threadIdx.x, dx = dx0 + o / 3, ch = o % 3;
+  if (o >= BLUR_TILE * 3 || dx >= dw) return;
+  const TapRow th = taps_h[dx];
+  const uint32_t h0 = (uint32_t)(th.left - cmin) * 3u + ch + sh;
+  for (uint32_t r = 0; r < rows; ++r) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAX_TAPS; ++k)
+      if (k < th.count) acc += s_v[r * PITCH_W * 4 + h0 + 3u * (uint32_t)k] * th.w[k];
+    acc = fminf(fmaxf(acc, 0.0f), 255.0f);
+    out[((size_t)(dy0 + r) * dw + dx) * 3 + ch] = (uint8_t)roundf(acc);
+  }
+}
+
 // Tap tables of image::imageops::blur's sampling filter (support 2 sigma, weights renormalised over the
 // clamped range), computed on the host in f32 exactly as the oracle computes them.
 std::vector<TapRow> make_taps(uint32_t size, float sigma, uint32_t stride, uint32_t count) {
@@ -491,8 +552,12 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
     TapRow *d_tv = nullptr, *d_th = nullptr;
     A3D_TRY(taps_for(ctx, S.h, D.h, sigma, &d_tv));
     A3D_TRY(taps_for(ctx, S.w, D.w, sigma, &d_th));
-    hipLaunchKernelGGL(blur_halve_kernel, dim3((D.w + BLUR_TILE - 1) / BLUR_TILE, (D.h + BLUR_ROWS - 1) / BLUR_ROWS, F),
-                       dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
+    static const bool blur_words = !(getenv("A3D_BUILDER_BLUR") && !strcmp(getenv("A3D_BUILDER_BLUR"), "bytes"));  // cross-check knob
+    const dim3 blur_grid((D.w + BLUR_TILE - 1) / BLUR_TILE, (D.h + BLUR_ROWS - 1) / BLUR_ROWS, F);
+    if (blur_words && (S.w * 3) % 4 == 0 && (RAW_PITCH / 4) <= 128)
+      hipLaunchKernelGGL(blur_halve_words_kernel, blur_grid, dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
+    else
+      hipLaunchKernelGGL(blur_halve_kernel, blur_grid, dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
   }
   if (prm->with_intensity) {
     bool quads = true;  // every level's width a multiple of four (the colour, intensity and map rows then stay word-aligned)
