@@ -164,14 +164,6 @@ SIGNATURES = {
         _ST,
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC), C.POINTER(GnStateC)],
     ),
-    "a3d_image_icp_accumulate_exact": (
-        _ST,
-        [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC), C.POINTER(GnStateC)],
-    ),
-    "a3d_image_icp_accumulate_weighted": (
-        _ST,
-        [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC)],
-    ),
     "a3d_image_icp_align_trace": (
         _ST,
         [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(PoseC), _P],
@@ -194,6 +186,8 @@ SIGNATURES = {
     "a3d_multiscale_batch_set_profiling": (_ST, [_P, C.c_int32]),
     "a3d_multiscale_batch_last_kernel_ms": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_multiscale_batch_concurrency": (_ST, [_P, C.POINTER(C.c_uint32)]),
+    "a3d_multiscale_batch_persistent_levels": (_ST, [_P, C.POINTER(C.c_uint32)]),
+    "a3d_context_set_tiling": (_ST, [_P, C.c_uint32]),
     "a3d_multi_shard_range": (_ST, [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "a3d_multi_context_create": (_ST, [C.POINTER(C.c_int32), C.c_uint64, _PP]),
     "a3d_multi_context_destroy": (_ST, [_P]),
@@ -223,35 +217,57 @@ SIGNATURES = {
     ),
 }
 
-# A3D_LIBRARY selects another build of the same library (diagnostic builds); never a different implementation.
-LIB_PATH = os.environ.get("A3D_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
-                                                         "libalign3d_hip.so")
-_lib = None
+# Exported by the diagnostics build only (csrc/Makefile `diag`: -DA3D_DIAGNOSTICS).
+DIAG_SIGNATURES = {
+    "a3d_image_icp_accumulate_exact": (
+        _ST,
+        [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC), C.POINTER(GnStateC)],
+    ),
+    "a3d_image_icp_accumulate_weighted": (
+        _ST,
+        [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(GnStateC)],
+    ),
+}
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+# (A3D_LIBRARY: a probe script's own build of the same sources, scripts/build_variant.sh; never another implementation)
+LIB_PATH = os.environ.get("A3D_LIBRARY") or os.path.join(_CSRC, "libalign3d_hip.so")
+# The diagnostics build of the same sources: environment knobs, cross-check kernels and the variants that were measured
+# slower live only there (tests and probes load it through Context(library=DIAG_LIB_PATH); the product never does).
+DIAG_LIB_PATH = os.path.join(_CSRC, "libalign3d_hip_diag.so")
+_libs = {}
 
 
-def load_library():
-    """Loads libalign3d_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if it is
-    missing: there is deliberately no other implementation to fall back to."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(path=None):
+    """Loads libalign3d_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if it is missing: there is
+    deliberately no other implementation to fall back to.  `path`: another build of the same library (DIAG_LIB_PATH)."""
+    path = os.path.abspath(path or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: build the HIP extension first "
-            "(python -c 'import __graft_entry__ as g; g.build()' or make -C align3d_amd/csrc)"
+            f"{path} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C align3d_amd/csrc all)"
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
+    for name, (restype, argtypes) in DIAG_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = restype
+            fn.argtypes = argtypes
     if lib.a3d_abi_version() != 1:
         raise RuntimeError("libalign3d_hip.so ABI version mismatch")
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
 def check(status, what=""):
     if status != A3D_OK:
-        msg = load_library().a3d_last_error().decode("utf-8", "replace")
+        msg = ""
+        for lib in list(_libs.values()) or [load_library()]:  # the failing call's library holds the text
+            msg = msg or lib.a3d_last_error().decode("utf-8", "replace")
         raise A3dError(status, f"{what}: {msg}" if what else msg)

@@ -5,14 +5,16 @@ from . import _abi
 
 
 class Context:
-    def __init__(self, device_index=0, priority=0, _handle=None, pair=True):
+    def __init__(self, device_index=0, priority=0, _handle=None, pair=True, library=None):
         """priority < 0: the device's highest stream priority (a frame-builder context next to an aligning one),
         0: default, > 0: lowest.  A default-priority context is created together with its sibling (the builder context
         `sibling()` returns): a3d_context_create_pair puts the two contexts' streams on the GPU's compute pipes in a
         fixed relation, which contexts created at unrelated moments do not have.  `pair=False` creates the aligning
         context alone (four streams instead of eight, no second pinned block); `sibling()` then creates the builder on
-        first use, wherever the runtime places its streams at that moment."""
-        self.lib = _abi.load_library()
+        first use, wherever the runtime places its streams at that moment.  `library`: path of another build of the
+        library (_abi.DIAG_LIB_PATH: the diagnostics build that tests and probes use)."""
+        self.lib = _abi.load_library(library)
+        self._library = library
         self.handle = C.c_void_p()
         self.device_index = int(device_index)
         self._sibling = None
@@ -22,7 +24,7 @@ class Context:
             builder = C.c_void_p()
             _abi.check(self.lib.a3d_context_create_pair(int(device_index), C.byref(self.handle), C.byref(builder)),
                        "a3d_context_create")
-            self._sibling = Context(device_index, priority=-1, _handle=builder)
+            self._sibling = Context(device_index, priority=-1, _handle=builder, library=library)
         else:
             _abi.check(self.lib.a3d_context_create_with_priority(int(device_index), int(priority), C.byref(self.handle)),
                        "a3d_context_create")
@@ -31,8 +33,14 @@ class Context:
         """The builder context on the same GPU (its own streams and scratch, highest stream priority), created with this
         one and closed with it: frame builds run on it while this context aligns (align3d_amd.odometry, bench.py)."""
         if self._sibling is None:
-            self._sibling = Context(self.device_index, priority=-1)
+            self._sibling = Context(self.device_index, priority=-1, library=self._library)
         return self._sibling
+
+    def set_tiling(self, tiles_per_pair):
+        """a3d_context_set_tiling: 0 = throughput tiling (the cut of a pair's pixels into blocks follows the batch size);
+        n > 0 = pinned tiling: n blocks per (pair, level) whatever the batch, so that a pair's pose is bit-identical
+        alone and in any batch."""
+        _abi.check(self.lib.a3d_context_set_tiling(self.handle, int(tiles_per_pair)), "a3d_context_set_tiling")
 
     def synchronize(self):
         _abi.check(self.lib.a3d_context_synchronize(self.handle))

@@ -573,7 +573,7 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
     const size_t cells = (size_t)g.gh * g.gw * g.gd;
     const size_t grid_bytes = ((cells * sizeof(double2) + 255) / 256) * 256;
     // images below 2^24 pixels: packed integer splat + all six blur passes in one LDS-tiled kernel
-    const char* mode = getenv("A3D_BILATERAL");
+    const char* mode = A3D_DIAG_ENV("A3D_BILATERAL");  // diagnostics build: force the pass-per-launch path
     const bool fused = n < (1u << PACK_SHIFT) && !(mode && !strcmp(mode, "unfused"));
     // (growing the region synchronises; the stream is idle here anyway after the min/max read-back)
     if (ctx_scratch(ctx, 1, 256 + 2 * grid_bytes, &scratch) != A3D_OK) {
@@ -665,7 +665,7 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   // at most floor(sigma) + 1 image rows (columns) round to one grid row (column): 4-byte cells while a (row, column)
   // can not receive more than 255 pixels (A3D_BILATERAL_CELLS=wide: always 8-byte cells, a cross-check)
   const uint32_t reach = (uint32_t)std::min(sigma_space, 1e6) + 2;
-  const char* cells_mode = getenv("A3D_BILATERAL_CELLS");
+  const char* cells_mode = A3D_DIAG_ENV("A3D_BILATERAL_CELLS");
   const bool narrow = reach * reach <= 255 && !(cells_mode && !strcmp(cells_mode, "wide"));
   const uint32_t cell_bytes = narrow ? 4 : 8;
   const size_t packed_bytes = (((size_t)n_frames * capacity * cell_bytes + 255) / 256) * 256;
@@ -737,7 +737,7 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
     set_error("a3d_bilateral_filter_u16: upload: %s", hipGetErrorString(hipGetLastError()));
     st = A3D_HIP_ERROR;
   }
-  const char* mode = getenv("A3D_BILATERAL");
+  const char* mode = A3D_DIAG_ENV("A3D_BILATERAL");  // diagnostics build: force the pass-per-launch path
   const bool one_pass = n < (1u << PACK_SHIFT) && !(mode && (!strcmp(mode, "unfused") || !strcmp(mode, "sync")));
   if (st == A3D_OK && !one_pass) {  // the pass-per-launch path (huge images, cross-check): min / max via the host
     st = bilateral_filter_device(ctx, d_img, d_out, w, h, sigma_space, sigma_color, out_grid_dims);

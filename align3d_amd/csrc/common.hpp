@@ -17,6 +17,18 @@
 
 struct a3d_context;
 
+// Two builds of these sources (csrc/Makefile): the product library libalign3d_hip.so, and the diagnostics build
+// libalign3d_hip_diag.so (-DA3D_DIAGNOSTICS) which also holds what only tests and probes use: the environment knobs
+// that pick launch geometries and cross-check paths, the kernel variants that were measured slower (last-block
+// hand-off, one launch per level, MFMA / merged accumulation, G = 2 / 4 pipelines), the exact-arithmetic accumulate
+// kernel, the rocPRIM cross-check sort, the host kd-tree build, the pass-per-launch bilateral grid.  In the product
+// build a knob's name does not even reach the object file: A3D_DIAG_ENV(name) is a null constant there.
+#ifdef A3D_DIAGNOSTICS
+#define A3D_DIAG_ENV(name) getenv(name)
+#else
+#define A3D_DIAG_ENV(name) ((const char*)nullptr)
+#endif
+
 namespace a3d {
 
 void set_error(const char* fmt, ...);
@@ -113,10 +125,6 @@ struct a3d_context {
     void* d;
   };
   std::vector<CachedTable> tables;
-  // Everything this context has enqueued on its own stream without waiting for it (a3d_range_image_compute_normals on
-  // a built image): registered with the image's arena like a consumer's fence, so that a3d_range_image_free need not
-  // wait for the whole stream (another thread may be building the next frames on it).
-  std::shared_ptr<a3d::UseFence> self_fence;
   // Side streams (the pair groups of a batch alignment run on them), created on demand with the context's priority
   // and SHARED by every batch of the context: batches of one context are ordered on its main stream anyway (fork /
   // join events), and the runtime maps streams onto a handful of hardware queues — a process that gave every batch
@@ -127,6 +135,13 @@ struct a3d_context {
   // What the most recent a3d_range_image_build_pyramids call processed (a3d_context_last_build_stats): frames, cells of
   // their bilateral grids, blur tiles marked by the splat, first-channel tiles written as zeros.
   uint64_t build_stats[4] = {0, 0, 0, 0};
+  // a3d_context_set_tiling: 0 = the tiling of the ICP pixel pass follows the batch size (throughput); otherwise every
+  // (pair, level) is cut into this many blocks whatever the batch: a pair's pose bits no longer depend on its batch.
+  uint32_t tiles_per_pair = 0;
+  // Pyramid arenas held by live images.  a3d_context_destroy with arenas outstanding only marks the context (zombie);
+  // the release of the last arena destroys it (both under pool_mutex).
+  int live_arenas = 0;
+  bool zombie = false;
 };
 
 namespace a3d {
@@ -145,6 +160,9 @@ struct DeviceArena {
   // alignment enqueued without host outputs): the arena waits for them before it is recycled.
   std::mutex fence_mutex;
   std::vector<std::shared_ptr<struct UseFence>> fences;
+  // enqueue-only work of the arena's own context on its images (a3d_range_image_compute_normals): recorded right
+  // behind each such launch
+  std::shared_ptr<struct UseFence> self_fence;
 };
 
 // "Everything enqueued so far by this consumer": an event the consumer re-records after each enqueue.
@@ -184,6 +202,9 @@ a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void*
 // (up to 128 arenas / 4 GiB per context are kept) or frees it.
 a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out);
 void ctx_arena_release(a3d_context* ctx, DeviceArena* arena);
+// Tears the context down (streams, pools, scratch); called by a3d_context_destroy, or by the release of the last arena
+// of a context that was destroyed while images were alive.
+void ctx_destroy_now(a3d_context* ctx);
 }  // namespace a3d
 
 struct a3d_device_image;
@@ -209,7 +230,6 @@ struct a3d_device_image {
   bool has_normals = false, has_intensities = false, has_imap = false;
   a3d::DeviceArena* arena = nullptr;     // when set, the arrays above are carved out of it and not freed one by one
   bool built = false;        // made by the device frame builder (its arena layout is fixed when it is planned)
-  bool pending_self_work = false;  // its context enqueued work on it without waiting (compute_normals): fenced at free
   bool mask_is_z = false;    // built with a depth scale for which mask == (z != 0) on every pixel (frame.hip)
   bool own_normals = false;  // `normals` is its own hipMalloc although the image lives in an arena (uploaded without
                              // normals, a3d_range_image_compute_normals called later)

@@ -132,6 +132,7 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
   }();
   const size_t padded = ((bytes + 255) / 256) * 256;
   std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+  A3D_REQUIRE(!ctx->zombie, A3D_INVALID_PARAMETER, "this context has been destroyed");
   for (size_t i = 0; i < ctx->arena_pool.size(); ++i) {
     const size_t have = ctx->arena_pool[i].second;
     if (have >= bytes && have <= bytes + bytes / 4) {
@@ -139,6 +140,7 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
       out->bytes = have;
       out->slab_slice = in_slab(ctx, out->base);
       ctx->arena_pool.erase(ctx->arena_pool.begin() + (long)i);
+      ++ctx->live_arenas;
       return A3D_OK;
     }
   }
@@ -155,6 +157,7 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
       ctx->slab_bytes_total += per_slab * padded;
       for (size_t k = 1; k < per_slab; ++k) ctx->arena_pool.emplace_back((char*)slab + k * padded, padded);
       out->base = slab, out->bytes = padded, out->slab_slice = true;
+      ++ctx->live_arenas;
       return A3D_OK;
     }
     (void)hipGetLastError();  // fall back to a single allocation
@@ -167,6 +170,7 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
   ctx->single_arenas.push_back(out->base);
   out->bytes = bytes;
   out->slab_slice = false;
+  ++ctx->live_arenas;
   return A3D_OK;
 }
 
@@ -218,6 +222,13 @@ void ctx_arena_release(a3d_context* ctx, DeviceArena* arena) {
     hipFree(arena->base);
   }
   arena->base = nullptr;
+  bool last_of_a_destroyed_context = false;
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    last_of_a_destroyed_context = --ctx->live_arenas == 0 && ctx->zombie;
+  }
+  // a3d_context_destroy was called while images were alive: it deferred to the last of them (this one)
+  if (last_of_a_destroyed_context) ctx_destroy_now(ctx);
 }
 
 }  // namespace a3d
@@ -302,7 +313,6 @@ a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priori
     ctx->side_streams.push_back(four[1]);
     ctx->side_streams.push_back(four[2]);
   }
-  ctx->self_fence = std::make_shared<UseFence>();
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_start));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_stop));
   A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, a3d_context::PINNED_WORDS * sizeof(uint32_t), hipHostMallocDefault));
@@ -327,6 +337,36 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);  // (a context whose creation failed half-way has gaps)
   if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
+  {  // Images (pyramid arenas) created on this context are still alive: their free path needs the context's pool and
+     // stream, so the context lives on, unusable for new work, until the last of them is freed (ctx_arena_release).
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    if (ctx->live_arenas > 0) {
+      ctx->zombie = true;
+      return A3D_OK;
+    }
+  }
+  a3d::ctx_destroy_now(ctx);
+  return A3D_OK;
+}
+
+a3d_status a3d_context_set_tiling(a3d_context* ctx, uint32_t tiles_per_pair) {
+  A3D_REQUIRE(ctx && tiles_per_pair <= 65535, A3D_INVALID_PARAMETER, "bad argument");
+  ctx->tiles_per_pair = tiles_per_pair;
+  if (ctx->icp_engine && ctx->icp_engine_free) {  // the cached single-pair engine was planned under the other tiling
+    hipStreamSynchronize(ctx->stream);
+    ctx->icp_engine_free(ctx->icp_engine);
+    ctx->icp_engine = nullptr;
+  }
+  return A3D_OK;
+}
+
+}  // extern "C"
+
+namespace a3d {
+void ctx_destroy_now(a3d_context* ctx) {
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
   for (hipEvent_t e : ctx->copy_events) hipEventDestroy(e);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
@@ -346,8 +386,10 @@ a3d_status a3d_context_destroy(a3d_context* ctx) {
   if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
-  return A3D_OK;
 }
+}  // namespace a3d
+
+extern "C" {
 
 a3d_status a3d_context_synchronize(a3d_context* ctx) {
   A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");

@@ -89,7 +89,7 @@ constexpr int ST_W = 32, ST_H = 16, OWN_W = ST_W - 2, OWN_H = ST_H - 2;
 // the latency of its dependent phases (depth load -> eight grid gathers -> LDS -> normals -> stores) times the rounds of
 // resident blocks, so a wave that carries two independent pixel chains halves the rounds.
 constexpr int L0_PPT = 2, L0_THREADS = ST_W * ST_H / L0_PPT;
-#ifndef A3D_L0_PROBE  // diagnostic builds (scripts/build_variant.sh -DA3D_L0_PROBE=n): 1 no level-0 stores, 2 no normals,
+#if !defined(A3D_L0_PROBE) || !defined(A3D_DIAGNOSTICS)  // diagnostic builds (scripts/build_variant.sh -DA3D_L0_PROBE=n): 1 no level-0 stores, 2 no normals,
 #define A3D_L0_PROBE 0  // 3 no level-1 picks, 4 nothing but the staging
 #endif
 template <bool FILTER>
@@ -526,7 +526,7 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   const dim3 grid0((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F);
   // level 1's points / mask / normals come out of level0_kernel when the sides are even (2 x 2 blocks are whole and the
   // resize's float index arithmetic is exactly 2 dv, 2 du); A3D_BUILDER_FUSE_L1=0 keeps the separate kernel (cross-check)
-  static const bool fuse_allowed = !(getenv("A3D_BUILDER_FUSE_L1") && atoi(getenv("A3D_BUILDER_FUSE_L1")) == 0);
+  static const bool fuse_allowed = !(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L1") && atoi(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L1")) == 0);
   const bool fuse_l1 = fuse_allowed && prm->pyramid_levels >= 2 && w % 2 == 0 && h % 2 == 0;
   if (prm->use_bilateral) {  // builder.rs:75-77
     GridBatch gb;
@@ -552,7 +552,7 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
     TapRow *d_tv = nullptr, *d_th = nullptr;
     A3D_TRY(taps_for(ctx, S.h, D.h, sigma, &d_tv));
     A3D_TRY(taps_for(ctx, S.w, D.w, sigma, &d_th));
-    static const bool blur_words = !(getenv("A3D_BUILDER_BLUR") && !strcmp(getenv("A3D_BUILDER_BLUR"), "bytes"));  // cross-check knob
+    static const bool blur_words = !(A3D_DIAG_ENV("A3D_BUILDER_BLUR") && !strcmp(A3D_DIAG_ENV("A3D_BUILDER_BLUR"), "bytes"));  // cross-check knob
     const dim3 blur_grid((D.w + BLUR_TILE - 1) / BLUR_TILE, (D.h + BLUR_ROWS - 1) / BLUR_ROWS, F);
     if (blur_words && (S.w * 3) % 4 == 0 && (RAW_PITCH / 4) <= 128)
       hipLaunchKernelGGL(blur_halve_words_kernel, blur_grid, dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);

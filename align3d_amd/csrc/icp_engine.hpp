@@ -135,7 +135,7 @@ __device__ __forceinline__ void block_reduce_store(const float (&acc)[N], float*
   }
 }
 
-#ifdef A3D_TAIL_STAMPS
+#if defined(A3D_DIAGNOSTICS) && defined(A3D_TAIL_STAMPS)
 __device__ unsigned long long g_tail_stamps[16];
 #define A3D_STAMP(k)                                                                       \
   do {                                                                                     \
@@ -200,9 +200,12 @@ struct HeadArgs {
   int first_in_level, last_in_level;
   int trace_stride, trace_index;
   float* trace;  // nullable: [job][trace_stride][8]
+#ifdef A3D_DIAGNOSTICS
+  int exact_solve;  // A3D_ICP_SOLVE=exact: IEEE sqrt and divisions in the 6x6 solve, as nalgebra (cross-check of the rsqrt form)
+#endif
 };
 __host__ __device__ inline HeadArgs head_args_of(const SolveArgs& a) {
-  HeadArgs h;
+  HeadArgs h{};
   h.weight = a.weight, h.color_weight = a.color_weight, h.mode = a.mode, h.tiles = 0;
   h.first_in_level = a.first_in_level, h.last_in_level = a.last_in_level;
   h.trace_stride = a.trace_stride, h.trace_index = a.trace_index, h.trace = a.trace;
@@ -279,15 +282,27 @@ __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const doubl
     int ok = 1;
     const int src_c = cell ? c * 6 : 0, src_r = cell ? r * 6 : 0;
     double rinv[6];
+#ifdef A3D_DIAGNOSTICS
+    double lii[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+#endif
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const double diag = __shfl(v, k * 7, 64);
       if (diag == 0.0 || !(diag >= 0.0)) ok = 0;  // zero, negative or NaN pivot: Cholesky::new() == None (wave-uniform)
       double sq;
       rinv[k] = rsqrt_f64(diag, &sq);
-      if (tid == k * 7) v = sq;
+#ifdef A3D_DIAGNOSTICS
+      if (a.exact_solve) sq = __builtin_sqrt(diag), lii[k] = sq;
+      if (a.exact_solve && cell && c == k && r > k) v = v / sq;  // nalgebra: col /= sqrt(pivot)
+      else
+#endif
       if (cell && c == k && r > k) v = v * rinv[k];
+      if (tid == k * 7) v = sq;
       const double lck = __shfl(v, src_c + k, 64), lrk = __shfl(v, src_r + k, 64);
+#ifdef A3D_DIAGNOSTICS
+      if (a.exact_solve && cell && c > k && r >= c) v = v - lck * lrk;
+      else
+#endif
       if (cell && c > k && r >= c) v = __builtin_fma(-lck, lrk, v);
     }
     if (cell) Lm[tid] = v;
@@ -316,17 +331,41 @@ __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const doubl
 #define A3D_L(row, col) Lm[(row) * 6 + (col)]
 #pragma unroll
       for (int i = 0; i < 6; ++i) {  // solve_lower_triangular (column oriented)
+#ifdef A3D_DIAGNOSTICS
+        const double coeff = a.exact_solve ? bvec[i] / lii[i] : bvec[i] * rinv[i];
+#else
         const double coeff = bvec[i] * rinv[i];
+#endif
         bvec[i] = coeff;
 #pragma unroll
-        for (int rr = i + 1; rr < 6; ++rr) bvec[rr] = __builtin_fma(-coeff, A3D_L(rr, i), bvec[rr]);
+        for (int rr = i + 1; rr < 6; ++rr) {
+#ifdef A3D_DIAGNOSTICS
+          if (a.exact_solve) {
+            bvec[rr] = bvec[rr] - coeff * A3D_L(rr, i);
+            continue;
+          }
+#endif
+          bvec[rr] = __builtin_fma(-coeff, A3D_L(rr, i), bvec[rr]);
+        }
       }
 #pragma unroll
       for (int i = 5; i >= 0; --i) {  // ad_solve_lower_triangular: L^T x = b
         double d = 0.0;
 #pragma unroll
-        for (int rr = i + 1; rr < 6; ++rr) d = __builtin_fma(A3D_L(rr, i), bvec[rr], d);
+        for (int rr = i + 1; rr < 6; ++rr) {
+#ifdef A3D_DIAGNOSTICS
+          if (a.exact_solve) {
+            d = d + A3D_L(rr, i) * bvec[rr];
+            continue;
+          }
+#endif
+          d = __builtin_fma(A3D_L(rr, i), bvec[rr], d);
+        }
+#ifdef A3D_DIAGNOSTICS
+        bvec[i] = a.exact_solve ? (bvec[i] - d) / lii[i] : (bvec[i] - d) * rinv[i];
+#else
         bvec[i] = (bvec[i] - d) * rinv[i];
+#endif
       }
 #undef A3D_L
       float update[6];
@@ -382,6 +421,7 @@ __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const doubl
   }
 }
 
+#ifdef A3D_DIAGNOSTICS  // the last-block (ticket) hand-off: kept as the cross-check of the head-solve form
 // The last-block forms (block_publish_and_finish, the level kernel): called by every thread of the job's last block
 // with the 58 f64 totals in LDS; the state is read and written in place with agent-scope accesses.
 __device__ __forceinline__ void gn_finish_block(JobState* st, const double* sums, const SolveArgs& a, int job) {
@@ -504,17 +544,27 @@ __device__ __forceinline__ bool block_publish_and_finish(float* __restrict__ job
   return true;
 }
 
+#endif  // A3D_DIAGNOSTICS
+
 // ---- head-solve hand-off (the HeadArgs comment above): every block of the NEXT launch finishes the iteration ----
 // Every thread of the block calls it (blocks of >= 256 threads).  Sums the job's `h.tiles` partials of the previous
 // launch — thread (component pair cg, slice s) adds tiles s, s + 8, ... in tile order, then the eight slices in a
 // fixed order: the same order as the last-block form above, so both forms give the same bits — runs the solve on
 // wave 0 and leaves the job's state in s_state (LDS, JOB_WORDS words) behind a block barrier.
-__device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st_out, const float* prev_partials,
-                                             const HeadArgs& h, int job, uint32_t* s_state, bool write_trace) {
+// COHERENT: the partials were written by other blocks of the SAME launch (the persistent kernel): every load is an
+// agent-scope (sc1) load that bypasses this CU's L1.  Otherwise a kernel boundary published them: plain loads.
+template <bool COHERENT>
+__device__ __forceinline__ unsigned long long ld_partial_pair(const unsigned long long* p) {
+  if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+// `state_bits`: lane k < JOB_WORDS of wave 0 holds word k of the job's current state.
+template <bool COHERENT>
+__device__ __forceinline__ void head_sum_and_advance(uint32_t state_bits, const float* prev_partials, const HeadArgs& h,
+                                                     int job, uint32_t* s_state, bool write_trace,
+                                                     JobState* st_out = nullptr) {
   __shared__ double s_sums[8][64];
   const int tid = threadIdx.x;
-  uint32_t state_bits = 0;
-  if (tid < JOB_WORDS) state_bits = ((const uint32_t*)st_in)[tid];
   if (h.mode != SOLVE_NONE) {
     const int cg = tid & 31, slice = tid >> 5;
     const uint32_t tiles = h.tiles;
@@ -525,7 +575,7 @@ __device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st
       for (; t + 248 < tiles; t += 256) {
         unsigned long long v[32];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = base[(size_t)(t + 8 * k) * (GN_PARTIAL / 2)];
+        for (int k = 0; k < 32; ++k) v[k] = ld_partial_pair<COHERENT>(base + (size_t)(t + 8 * k) * (GN_PARTIAL / 2));
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
           sum0 += (double)__uint_as_float((unsigned)v[k]);
@@ -535,7 +585,7 @@ __device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st
       for (; t + 56 < tiles; t += 64) {
         unsigned long long v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(t + 8 * k) * (GN_PARTIAL / 2)];
+        for (int k = 0; k < 8; ++k) v[k] = ld_partial_pair<COHERENT>(base + (size_t)(t + 8 * k) * (GN_PARTIAL / 2));
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           sum0 += (double)__uint_as_float((unsigned)v[k]);
@@ -546,7 +596,7 @@ __device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t tt = t + 8 * k;
-        v[k] = tt < tiles ? base[(size_t)tt * (GN_PARTIAL / 2)] : 0ull;  // +0.0f, +0.0f: adds nothing
+        v[k] = tt < tiles ? ld_partial_pair<COHERENT>(base + (size_t)tt * (GN_PARTIAL / 2)) : 0ull;  // +0.0f, +0.0f
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -568,6 +618,13 @@ __device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st
   __syncthreads();
 }
 
+__device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st_out, const float* prev_partials,
+                                             const HeadArgs& h, int job, uint32_t* s_state, bool write_trace) {
+  uint32_t state_bits = 0;
+  if (threadIdx.x < JOB_WORDS) state_bits = ((const uint32_t*)st_in)[threadIdx.x];
+  head_sum_and_advance<false>(state_bits, prev_partials, h, job, s_state, write_trace, st_out);
+}
+
 // acc[0..21) += J J^T (upper triangle), acc[21..27) += J r, acc[27] += r^2, acc[28] += 1
 // (GaussNewton::step, src/optim/gaussnewton.rs:47-77).  The sums use fused multiply-adds: the sum over
 // samples is re-associated on the GPU anyway, and an fma only removes one rounding per term.
@@ -586,6 +643,7 @@ __device__ __forceinline__ void gn_step(float* __restrict__ acc, float r, const 
   acc[28] += 1.0f;
 }
 
+#ifdef A3D_DIAGNOSTICS
 // One pixel into the merged accumulator: Jg, Jc already multiplied by their weights (Jc and rc zero when the colour
 // term is rejected), rg / rc the plain residuals.  Same FMA count as two gn_step calls, 27 fewer live registers.
 __device__ __forceinline__ void gn_step_merged(float* __restrict__ acc, float rg, const float Jg[6], float rc,
@@ -605,5 +663,7 @@ __device__ __forceinline__ void gn_step_merged(float* __restrict__ acc, float rg
   acc[29] = __builtin_fmaf(rc, rc, acc[29]);
   acc[30] += color_live;
 }
+
+#endif  // A3D_DIAGNOSTICS
 
 }  // namespace a3d

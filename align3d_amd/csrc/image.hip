@@ -162,10 +162,6 @@ a3d_status a3d_range_image_free(a3d_device_image* im) {
   // returns with its work complete, and hipFree (images without an arena) waits for the device by itself.  A thread
   // building the next frames on this context therefore does not stall the thread that frees the previous ones.
   if (im->arena) {  // arrays live in a shared arena: release it with its last user
-    if (im->pending_self_work) {  // enqueue-only launches of this context on the image (compute_normals)
-      im->ctx->self_fence->record(im->ctx->stream);
-      attach_fence(im, im->ctx->self_fence);
-    }
     if (im->own_normals) hipFree(im->normals);  // (waits for the device by itself)
     if (--im->arena->refs == 0) {
       ctx_arena_release(im->ctx, im->arena);
@@ -194,9 +190,14 @@ a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
     im->own_normals = true;
   }
   A3D_TRY(launch_compute_normals(im->ctx, im->points, im->mask, im->normals, im->width, im->height));
-  // enqueue-only: the arena must outlive the launch.  The fence is recorded when the image is freed (everything this
-  // context has enqueued by then covers this launch), so that a call costs one launch and no event record.
-  if (im->arena) im->pending_self_work = true;
+  // enqueue-only: the arena must outlive the launch.  The arena's own fence is recorded right behind the launch
+  // (an event record costs ~1 us), so that freeing the image later waits for THIS launch only — not for whatever
+  // else (the next frames' builds) has been enqueued on the context's stream by then.
+  if (im->arena) {
+    if (!im->arena->self_fence) im->arena->self_fence = std::make_shared<UseFence>();
+    im->arena->self_fence->record(im->ctx->stream);
+    attach_fence(im, im->arena->self_fence);
+  }
   im->has_normals = true;
   return A3D_OK;
 }

@@ -24,8 +24,11 @@ struct LevelDesc {
   uint32_t src_n;
   uint32_t tw, th;
   float fx, fy, cx, cy;
+  uint32_t flags;  // bit 0: both images carry mask_is_z
+  uint32_t ppt;    // source pixels per thread at this level: the pair's tiles are ceil(src_n / (256 ppt)) blocks
   uint32_t pad;
 };
+static_assert(sizeof(LevelDesc) == 96, "LevelDesc layout");
 
 struct Gates {
   float max_distance_sqr;
@@ -247,6 +250,7 @@ __device__ __forceinline__ Terms stage_d(const LevelDesc& d, const Gates& gt, co
   return t;
 }
 
+#ifdef A3D_DIAGNOSTICS  // the round-2 last-block kernel (all its variants) and the exact-arithmetic cross-check kernel
 // grid = (tiles, pairs); block = 256.  A thread visits PPT source pixels, 256 apart (coalesced), through a
 // three-deep software pipeline: the source record of pixel k+2, the target gathers of pixel k+1 and the map cell of
 // pixel k are in flight while pixel k is accumulated (58 per-thread f32 accumulators, wave reduce-scatter at the
@@ -411,16 +415,61 @@ __global__ void __launch_bounds__(256)
   block_reduce_store<GN_PARTIAL, false>(acc, partials + (size_t)blockIdx.x * GN_PARTIAL);
 }
 
-// ---- head-solve form of the same kernel (icp_engine.hpp, "ticketless hand-off") --------------------------------
+#endif  // A3D_DIAGNOSTICS
+
+// ---- the pixel pass of one block (the reference's loop over its share of the source pixels) -----------------------
+// grid = (tiles, pairs); block = 256.  A thread visits `ppt` source pixels, 256 apart (coalesced), through a
+// three-deep software pipeline: the source record of pixel k+2, the target gathers of pixel k+1 and the map cell of
+// pixel k are in flight while pixel k is accumulated (58 per-thread f32 accumulators, wave reduce-scatter at the end).
+// The pipeline is unrolled by two with the buffers swapping roles, so that the rotation cur <- nxt, s1 <- s2 costs no
+// register copies.  Reading the loop's s_waitcnt's in the ISA is part of maintaining this code: a short-circuit `&&`
+// around a load, a u8 -> f32 conversion next to its load or a 64-bit multiply-add with a don't-care high half each
+// cost a full drain of the pipeline per pixel before they were found.
+// The first two source records do not depend on the pose: the callers issue them (pixel_source_at) BEFORE they wait
+// for the pose of the iteration, so those loads are in flight during the head.
+template <bool ZMASK>
+__device__ __forceinline__ SrcPx pixel_source_at(const LevelDesc& d, uint32_t base, int ppt, int k0) {
+  const uint32_t i = base + (uint32_t)k0 * 256u;
+  return stage_a<ZMASK>(d, i, (k0 < ppt) && (i < d.src_n));
+}
+template <bool ZMASK>
+__device__ __forceinline__ void pixel_pass(const LevelDesc& d, const Gates& gt, const Pose& T, uint32_t base, int ppt,
+                                           const SrcPx& s0, SrcPx sa, float (&acc)[GN_PARTIAL]) {
+  const uint32_t mw = d.tw + 2;
+  const float twf = (float)d.tw, thf = (float)d.th;
+  SrcPx sb;
+  ProjPx pa = stage_b<ZMASK>(d, T, s0, twf, thf), pb;
+  uint8_t ia = s0.intensity, ib;
+  // one step: `cur` holds the projected pixel k, `s_next` the source record of pixel k+1 (consumed here); leaves the
+  // projected pixel k+1 in `nxt` and the source record of pixel k+2 in `s_new`
+  auto step = [&](ProjPx& cur, uint8_t cur_i, ProjPx& nxt, uint8_t& nxt_i, const SrcPx& s_next, SrcPx& s_new, int k0) {
+    s_new = pixel_source_at<ZMASK>(d, base, ppt, k0 + 2);  // issue source record k+2
+    const MapPx mp = stage_c<ZMASK>(d, gt, cur, mw);        // gathers(k) land; issue map cell(k)
+    nxt = stage_b<ZMASK>(d, T, s_next, twf, thf);           // issue gathers(k+1)
+    nxt_i = s_next.intensity;
+    if (cur.live) {
+      const Terms t = stage_d(d, gt, cur, mp, cur_i, mw);
+      gn_step(acc, t.rg, t.Jg);  // the geometric term counts even when the colour term is rejected
+      if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
+    }
+  };
+#pragma unroll 1
+  for (int k0 = 0; k0 < ppt; k0 += 2) {  // ppt is even (plan_tiling); surplus pixels are out of range
+    step(pa, ia, pb, ib, sa, sb, k0);
+    step(pb, ib, pa, ia, sb, sa, k0 + 1);
+  }
+}
+
+// ---- one launch per iteration: head-solve hand-off (icp_engine.hpp, "ticketless hand-off") -----------------------
 // The launch of iteration k first finishes iteration k - 1: every block sums its pair's partials of the previous
 // launch and runs the solve (head_advance), then takes the pixel pass with the resulting pose and stores its own
-// partial with plain stores.  The source records of the first two pipeline steps do not depend on the pose and are in
-// flight during the head.  State and partials alternate between two buffers (in / out).
+// partial with plain stores.  State and partials alternate between two buffers (in / out).  A pair whose own tile
+// count is below the grid's (a smaller image in a mixed batch) leaves the surplus blocks to store zero partials.
 template <bool ZMASK>
 __global__ void __launch_bounds__(256, 1)
     image_icp_head_kernel(const LevelDesc* __restrict__ descs, const JobState* __restrict__ states_in,
                           JobState* __restrict__ states_out, Gates gt, const float* __restrict__ partials_in,
-                          float* __restrict__ partials_out, uint32_t job_stride, HeadArgs head, int PPT) {
+                          float* __restrict__ partials_out, uint32_t job_stride, HeadArgs head) {
   __shared__ uint32_t s_state[JOB_WORDS];
   const int pair = blockIdx.y;
   const uint32_t tile = blockIdx.x;
@@ -428,42 +477,176 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
   for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
   const LevelDesc d = descs[pair];
-  const uint32_t mw = d.tw + 2;
-  const float twf = (float)d.tw, thf = (float)d.th;
-  const uint32_t base = tile * (256u * (uint32_t)PPT) + threadIdx.x;
-  auto src_at = [&](int k0) {
-    const uint32_t i = base + (uint32_t)k0 * 256u;
-    return stage_a<ZMASK>(d, i, (k0 < PPT) && (i < d.src_n));
-  };
-  const SrcPx s0 = src_at(0);
-  SrcPx sa = src_at(1), sb;
+  const int ppt = (int)d.ppt;
+  const uint32_t base = tile * (256u * (uint32_t)ppt) + threadIdx.x;
+  const SrcPx s0 = pixel_source_at<ZMASK>(d, base, ppt, 0), s1 = pixel_source_at<ZMASK>(d, base, ppt, 1);
   head_advance(states_in + pair, tile == 0 ? states_out + pair : nullptr, partials_in + (size_t)pair * job_stride, head,
                pair, s_state, tile == 0);
   if ((int)s_state[15] == A3D_OK) {  // a failed job stays frozen: its blocks contribute nothing
     auto uni = [&](int k) { return __uint_as_float(__builtin_amdgcn_readfirstlane(s_state[k])); };
     const Pose T{{uni(0), uni(1), uni(2)}, {uni(3), uni(4), uni(5), uni(6)}};
-    ProjPx pa = stage_b<ZMASK>(d, T, s0, twf, thf), pb;
-    uint8_t ia = s0.intensity, ib;
-    auto step = [&](ProjPx& cur, uint8_t cur_i, ProjPx& nxt, uint8_t& nxt_i, const SrcPx& s_next, SrcPx& s_new, int k0) {
-      s_new = src_at(k0 + 2);                                     // issue source record k+2
-      const MapPx mp = stage_c<ZMASK>(d, gt, cur, mw);                   // gathers(k) land; issue map cell(k)
-      nxt = stage_b<ZMASK>(d, T, s_next, twf, thf);                      // issue gathers(k+1)
-      nxt_i = s_next.intensity;
-      if (cur.live) {
-        const Terms t = stage_d(d, gt, cur, mp, cur_i, mw);
-        gn_step(acc, t.rg, t.Jg);
-        if (t.color) gn_step(acc + GN_ACC, t.rc, t.Jc);
-      }
-    };
-#pragma unroll 1
-    for (int k0 = 0; k0 < PPT; k0 += 2) {  // PPT is even (batch_commit_descs)
-      step(pa, ia, pb, ib, sa, sb, k0);
-      step(pb, ib, pa, ia, sb, sa, k0 + 1);
-    }
+    pixel_pass<ZMASK>(d, gt, T, base, ppt, s0, s1, acc);
   }
   block_reduce_store<GN_PARTIAL, false>(acc, partials_out + (size_t)pair * job_stride + (size_t)tile * GN_PARTIAL);
 }
 
+// ---- many iterations in one launch: the persistent head-solve kernel ------------------------------------------------
+// What a kernel boundary costs between two dependent iterations (launch + completion, ~4.5 us on MI355X) is more than
+// the pixel pass of a coarse level or of a lone pair.  Here the blocks of a pair stay resident and run a whole schedule
+// of (level, iterations) entries.  The hand-off between two iterations is ONE hop: a block stores its partial
+// write-through, drains, and adds 1 to the pair's counter; every block of the pair waits until the counter shows that
+// all partials of the iteration are out, then sums them itself (same fixed order as head_advance: same bits) and runs
+// the solve redundantly — there is no last block, no published state and no second hop back (the round-1/2 level
+// kernel had both and lost to kernel boundaries).  The state of the pair lives in every block's LDS and never touches
+// memory until tile 0 stores it at the end; the partials alternate between the same two buffers as the per-iteration
+// launches use, so a launch of image_icp_head_kernel can continue where this kernel stops (and does, for level 0 of a
+// batch).  Pairs never wait for each other.
+//   * counter: monotonic per pair; `counter_base` = its value when the launch starts (the host advances it by the
+//     schedule's total, so nothing is reset between launches).
+//   * blocks whose tile index is beyond a level's tile count take no pixels at that level but follow every solve.
+//   * forward progress: all blocks of a pair must become resident while others of that pair spin.  Blocks are dispatched
+//     in index order (tiles of a pair are consecutive), so at most one pair per grid is partly resident and every
+//     other resident pair runs to completion and frees its slots; the host keeps a grid within what the chip holds at
+//     once whenever it can (plan_tiling), and a spin that exceeds its bound marks the pair A3D_HIP_ERROR and leaves.
+struct PersistLevel {
+  uint32_t desc_base;   // descs[desc_base + pair] describes this level
+  uint32_t iterations;
+  uint32_t tiles;       // blocks per pair that publish a partial at this level (<= gridDim.x)
+  float weight, color_weight;
+  Gates gates;
+};
+constexpr int PERSIST_MAX_LEVELS = 16;
+// How long a block waits for its pair's partners before it gives the pair up: 100 ms of the 100 MHz clock.  A level-0
+// pass of a full batch takes ~0.15 ms, so only a partner that is not resident at all (the chip shared with another
+// process's persistent grid) can be this late.
+constexpr unsigned long long PERSIST_SPIN_BOUND_TICKS = 10'000'000ull;
+struct PersistPlan {
+  uint32_t n_levels;       // schedule entries, in execution order (coarsest level first)
+  uint32_t seq0;           // launches / iterations that ran before this kernel (selects the buffer parity)
+  uint32_t counter_base;
+  uint32_t finish;         // 1: apply the last iteration too and write the outputs (no job_finish launch needed)
+  int trace_index0;
+  int trace_stride;
+  HeadArgs prev;           // the iteration that ran just before this kernel (mode SOLVE_NONE: none)
+  PersistLevel lv[PERSIST_MAX_LEVELS];
+};
+struct PersistOut {  // written by tile 0 when plan.finish (each nullable)
+  Pose* poses;
+  int32_t* status;
+  float* matrices;
+  unsigned long long* stamps;  // nullable: [pair][2 * n_levels] s_memrealtime at the start / end of each level (tile 0)
+};
+
+template <bool ZMASK>
+__global__ void __launch_bounds__(256, 4)  // four blocks per CU: what plan_tiling counts on for a 64-pair batch
+    image_icp_persistent_kernel(const LevelDesc* __restrict__ descs, uint32_t n_pairs_total, JobState* __restrict__ states,
+                                float* __restrict__ partials, uint32_t partials_half, uint32_t job_stride,
+                                unsigned* __restrict__ counters, PersistPlan plan, PersistOut out) {
+  __shared__ uint32_t s_state[JOB_WORDS];
+  __shared__ int s_go;
+  const int pair = blockIdx.y;
+  const uint32_t tile = blockIdx.x;
+  unsigned* const counter = counters + pair;
+  float* const job_partials = partials + (size_t)pair * job_stride;
+  // the pair's state: every block carries its own copy through the schedule (lane k < 18 of wave 0 <-> word k)
+  if (threadIdx.x < JOB_WORDS) s_state[threadIdx.x] = ((const uint32_t*)(states + (size_t)(plan.seq0 & 1u) * n_pairs_total + pair))[threadIdx.x];
+  __syncthreads();
+  HeadArgs prev = plan.prev;
+  uint32_t seq = plan.seq0;
+  uint32_t expected = plan.counter_base;  // the counter's value once every partial of the previous iteration is out
+  int trace_index = plan.trace_index0;
+  bool alive = true;
+  // waits for the previous iteration's partials, sums them and advances the state in LDS
+  auto head = [&](bool write_trace) {
+    if (prev.mode != SOLVE_NONE) {
+      if (threadIdx.x == 0) {
+        int go = 1;
+        unsigned long long t0 = 0;
+        while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+          if (!t0) t0 = now;
+          if (now - t0 > PERSIST_SPIN_BOUND_TICKS) {  // a partner that never became resident (the host falls back)
+            go = 0;
+            break;
+          }
+        }
+        s_go = go;
+      }
+      __syncthreads();
+      if (!s_go) {
+        alive = false;
+        return;
+      }
+    }
+    const uint32_t state_bits = threadIdx.x < JOB_WORDS ? s_state[threadIdx.x] : 0u;
+    head_sum_and_advance<true>(state_bits, job_partials + (size_t)((seq + 1u) & 1u) * partials_half, prev, pair, s_state,
+                               write_trace);
+  };
+#pragma unroll 1
+  for (uint32_t l = 0; l < plan.n_levels && alive; ++l) {
+    const PersistLevel lv = plan.lv[l];
+    const LevelDesc d = descs[lv.desc_base + pair];
+    const int ppt = (int)d.ppt;
+    const uint32_t own_tiles = (d.src_n + 256u * d.ppt - 1u) / (256u * d.ppt);
+    const bool works = tile < lv.tiles;
+    const uint32_t base = tile * (256u * (uint32_t)ppt) + threadIdx.x;
+    if (out.stamps && tile == 0 && threadIdx.x == 0) out.stamps[((size_t)pair * plan.n_levels + l) * 2] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (uint32_t it = 0; it < lv.iterations; ++it) {
+      SrcPx s0{}, s1{};
+      if (works) s0 = pixel_source_at<ZMASK>(d, base, ppt, 0), s1 = pixel_source_at<ZMASK>(d, base, ppt, 1);
+      head(tile == 0);
+      if (!alive) break;
+      if (works) {
+        float acc[GN_PARTIAL];  // (not live across the head: its partial loads want the registers)
+#pragma unroll
+        for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
+        if ((int)s_state[15] == A3D_OK && tile < own_tiles) {
+          auto uni = [&](int k) { return __uint_as_float(__builtin_amdgcn_readfirstlane(s_state[k])); };
+          const Pose T{{uni(0), uni(1), uni(2)}, {uni(3), uni(4), uni(5), uni(6)}};
+          pixel_pass<ZMASK>(d, lv.gates, T, base, ppt, s0, s1, acc);
+        }
+        // publish: write-through partial, drained by the storing wave, then one agent-scope add (Guideline 16, form R1)
+        block_reduce_store<GN_PARTIAL, true>(acc, job_partials + (size_t)(seq & 1u) * partials_half + (size_t)tile * GN_PARTIAL);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      expected += lv.tiles;
+      prev.weight = lv.weight, prev.color_weight = lv.color_weight, prev.mode = SOLVE_IMAGE_ICP;
+      prev.tiles = lv.tiles;
+      prev.first_in_level = it == 0, prev.last_in_level = it + 1 == lv.iterations;
+      prev.trace_index = trace_index++;
+      ++seq;
+    }
+    if (out.stamps && tile == 0 && threadIdx.x == 0) out.stamps[((size_t)pair * plan.n_levels + l) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (alive && plan.finish) head(tile == 0);
+  if (tile != 0) return;
+  if (!alive) {  // the spin bound was hit: tell the host (it resets the counters and runs the per-iteration launches)
+    if (threadIdx.x == 0) {
+      states[(size_t)(seq & 1u) * n_pairs_total + pair].status = A3D_HIP_ERROR;
+      if (out.status) out.status[pair] = A3D_HIP_ERROR;
+    }
+    return;
+  }
+  // leave the state where the next launch (image_icp_head_kernel / job_finish_head) reads it
+  if (threadIdx.x < JOB_WORDS) ((uint32_t*)(states + (size_t)(seq & 1u) * n_pairs_total + pair))[threadIdx.x] = s_state[threadIdx.x];
+  if (plan.finish && threadIdx.x == 0) {
+    const float* f = (const float*)s_state;
+    const Pose p{{f[0], f[1], f[2]}, {f[3], f[4], f[5], f[6]}};
+    if (out.poses) out.poses[pair] = p;
+    if (out.status) out.status[pair] = (int32_t)s_state[15];
+    if (out.matrices) {
+      float m[16];
+      pose_to_matrix(p, m);
+      for (int k = 0; k < 16; ++k) out.matrices[(size_t)pair * 16 + k] = m[k];
+    }
+  }
+}
+
+#ifdef A3D_DIAGNOSTICS  // measured slower than the default path (ruled out): kept as cross-checks
 // ---- one launch per pyramid level ------------------------------------------------------------------
 // When the grid of a level is exactly the set of blocks the chip holds at once (choose_tiling, waves = 1),
 // every block of every pair is resident for the whole launch, so the iterations of the level can run inside
@@ -728,6 +911,8 @@ __global__ void __launch_bounds__(256)
   block_publish_and_finish(job_partials, gridDim.x, counters + pair, st, sa, pair);
 }
 
+#endif  // A3D_DIAGNOSTICS
+
 // Device self-test of the shared-reciprocal division: counts pairs for which it differs from `/`.
 __global__ void division_selftest_kernel(const float* __restrict__ num, const float* __restrict__ den, uint32_t n,
                                          unsigned* __restrict__ mismatches) {
@@ -747,58 +932,73 @@ struct a3d_multiscale_batch {
   uint32_t n_pairs = 0, n_levels = 0;
   std::vector<a3d_icp_params> params;  // index 0 = finest
   std::vector<Gates> gates;
-  std::vector<uint32_t> tiles, ppt, group;  // per level: tiles per pair, pixels per thread, pixels in flight
+  // per level: blocks per pair of the grid (the largest of the pairs' own tile counts), pixels per thread of the
+  // largest pair (each pair's own value is in its descriptor), pixels per pipeline step (1; diagnostics builds: 2, 4)
+  std::vector<uint32_t> tiles, ppt, group;
   std::vector<LevelDesc> h_descs;      // [level][pair]
   void* d_block = nullptr;  // one allocation behind every small device array below
   LevelDesc* d_descs = nullptr;
-  JobState* d_states = nullptr;
-  float* d_partials = nullptr;
+  JobState* d_states = nullptr;    // [2][P]: the launches alternate between the two (icp_engine.hpp, head-solve hand-off)
+  float* d_partials = nullptr;     // [2][P][max_tiles][58]
   size_t partials_capacity = 0;  // floats
-  size_t partials_half = 0;      // floats per buffer of the two the head-solve form alternates between
-  uint32_t max_tiles = 1;        // largest tiles[level]: the per-pair stride of a stream group's slice of d_partials
-  unsigned* d_counters = nullptr;  // per pair: blocks that have published their partial in this launch
-  unsigned* d_epochs = nullptr;    // per pair: iterations completed (level kernel hand-off word)
-  bool use_level_kernel = false;   // one launch per level when the whole grid is resident (A3D_ICP_PERSISTENT)
-  uint32_t level_mask = 0;         // bit l: level l runs as ONE launch per stream group (A3D_ICP_PERSISTENT_LEVELS)
-  uint32_t level_resident_blocks = 0;  // blocks of image_icp_level_kernel the chip holds at once
+  size_t partials_half = 0;      // floats per buffer
+  uint32_t max_tiles = 1;        // largest tiles[level]: the per-pair stride of d_partials
+  // Persistent head-solve kernel: the levels in `persist_mask` run as ONE launch per stream group (image_icp.hip,
+  // image_icp_persistent_kernel); d_counters[pair] counts the partials the pair has published since the batch was
+  // created, counter_base is what every pair's counter shows between two alignments.
+  unsigned* d_counters = nullptr;
+  uint32_t counter_base = 0;
+  uint32_t persist_mask = 0;
+  uint32_t persist_resident_blocks = 0;  // blocks of the persistent kernel the chip holds at once
+  bool persist_disabled = false;  // a launch hit its spin bound once (the GPU is shared): per-iteration launches from now on
+  bool persist_used = false;      // by the most recent enqueue
+  std::vector<uint32_t> persist_levels;  // the levels its persistent launch ran, in execution order
+  uint32_t last_groups = 1;              // stream groups of the most recent enqueue
+  unsigned long long* d_stamps = nullptr;  // [P][2 L] level start / end stamps of the persistent kernel, when profiling
   Pose* d_poses = nullptr;
   Pose* d_init = nullptr;  // per-pair initial transforms when the caller supplies them
   int32_t* d_status = nullptr;
   double* d_readback = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;  // per pixel-kernel launch: start/stop pairs, when profiling
-  std::vector<uint8_t> kev_level;  // the pyramid level of each launch
+  std::vector<uint8_t> kev_level;  // the pyramid level of each launch (the finest one of a persistent launch)
   float last_level_ms[16] = {0};
   uint32_t last_level_launches[16] = {0};
   bool profile_kernels = false;
-  uint32_t resident_blocks = 1024;  // blocks of the per-pixel kernel the chip holds at once
-  bool use_mfma = false;  // VALU accumulation measured faster on MI355X so far (kernel variants)
-  // A3D_ICP_ACCUM=merged: 31 merged running sums (H and g of add_weighted directly) instead of 2 x 29: 96 VGPRs,
-  // one more wave per SIMD — measured 18.5 k against 18.7 k pairs/s (occupancy is not what limits the kernel): opt-in
-  bool merged_accumulators = false;
-  // Head-solve hand-off (icp_engine.hpp): a launch finishes the PREVIOUS iteration at its head instead of the last
-  // block of a pair finishing the current one at its tail.  Two state buffers ([2][P]) and two partial buffers
-  // ([2][P][max_tiles][58]) alternate.  A3D_ICP_HANDOFF=ticket selects the last-block form.
-  bool head_solve = true;
-  // every image of the batch was built on the device with masks that equal (z != 0): the head kernel skips the two
-  // mask bytes per pixel (A3D_ICP_ZMASK=0 reads them anyway: cross-check)
+  uint32_t resident_blocks = 1024;  // blocks of the per-iteration kernel the chip holds at once
+  // every image of the batch was built on the device with masks that equal (z != 0): the kernels skip the two mask
+  // bytes per pixel
   bool zmask = false;
-  // Pair groups launched on separate streams: one group's launch ramp and last-block solve overlap the other
-  // groups' streaming (pairs are independent, so the groups never synchronise until the final read-out).
+  // Pair groups launched on separate streams: one group's launch ramp and head overlap the other groups' streaming
+  // (pairs are independent, so the groups never synchronise until the final read-out).
   uint32_t n_streams = 1;
   hipStream_t aux_streams[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   float last_total_ms = 0.f, last_kernel_ms = 0.f;
   uint64_t last_kernel_launches = 0;
+  // what the most recent enqueue was asked for (a rerun after a spin-bound exit repeats it)
+  const Pose* last_init = nullptr;
+  uint32_t last_levels = 0;
+  float* last_matrices = nullptr;
   // "every launch this batch has enqueued so far": registered with the arenas of the images the batch reads, so
   // that an image freed after an enqueue-only align (no host synchronisation) is not recycled under the kernels
   std::shared_ptr<UseFence> fence = std::make_shared<UseFence>();
   std::shared_ptr<UseFence> descs_uploaded = std::make_shared<UseFence>();  // h_descs -> d_descs copy of the last rebind
+#ifdef A3D_DIAGNOSTICS
+  unsigned* d_epochs = nullptr;    // per pair: iterations completed (level kernel hand-off word)
+  bool use_level_kernel = false;   // one launch per level, last-block form (A3D_ICP_PERSISTENT)
+  uint32_t level_mask = 0;         // bit l: level l runs as ONE last-block-form launch per stream group
+  uint32_t level_resident_blocks = 0;
+  bool use_mfma = false, merged_accumulators = false;  // A3D_ICP_ACCUM
+  bool head_solve = true;          // A3D_ICP_HANDOFF=ticket selects the last-block form
+  bool exact_solve = false;        // A3D_ICP_SOLVE=exact
+#endif
 
   ~a3d_multiscale_batch() {
     fence->retire();
     hipFree(d_block);  // descs, states, counters, epochs, poses, init, status, readback
     hipFree(d_partials);
+    hipFree(d_stamps);
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
     for (auto e : kev) hipEventDestroy(e);
@@ -825,11 +1025,11 @@ a3d_status fill_desc(const a3d_device_image* target, const a3d_device_image* sou
   d->tw = target->width;
   d->th = target->height;
   d->fx = target->fx, d->fy = target->fy, d->cx = target->cx, d->cy = target->cy;
-  d->pad = (target->mask_is_z && source->mask_is_z) ? 1u : 0u;
+  d->flags = (target->mask_is_z && source->mask_is_z) ? 1u : 0u;
+  d->ppt = 2, d->pad = 0;
   return A3D_OK;
 }
 
-// The image's arena (if it has one) will wait for this batch's launches before it is recycled.
 Gates make_gates(const a3d_icp_params& p) {
   Gates g;
   g.max_distance_sqr = p.max_distance * p.max_distance;
@@ -838,21 +1038,91 @@ Gates make_gates(const a3d_icp_params& p) {
   return g;
 }
 
-// Tiling of one level: `tiles` blocks per pair, each thread visiting `ppt` pixels.  The grid is sized to
-// `waves` full rounds of the blocks the chip holds at once (CUs x blocks per CU), so that every block gets
-// the same amount of work and the launch does not end on a partly filled round.
-void choose_tiling(uint32_t n_pairs, uint32_t max_src_n, uint32_t resident_blocks, float waves, uint32_t group,
-                   uint32_t* tiles, uint32_t* ppt) {
-  const uint32_t max_tiles = (max_src_n + 256 * group - 1) / (256 * group);  // at least `group` pixels per thread
-  uint32_t t = (uint32_t)((float)resident_blocks * waves / (float)n_pairs + 0.5f);
-  t = std::max(1u, std::min(t, std::max(1u, max_tiles)));
-  uint32_t p = (max_src_n + 256 * t - 1) / (256 * t);
-  p = ((p + group - 1) / group) * group;
-  *ppt = std::max(p, group);
-  *tiles = (max_src_n + 256 * *ppt - 1) / (256 * *ppt);
+// Pixels per thread (even: the pipeline takes two steps per trip) for `n` pixels cut into at most `want` blocks, and
+// the number of blocks that makes.
+void tiling_for(uint32_t n, uint32_t want, uint32_t group, uint32_t* tiles, uint32_t* ppt) {
+  const uint32_t step = std::max(2u, group);
+  want = std::max(1u, std::min(want, std::max(1u, (n + 256 * step - 1) / (256 * step))));
+  uint32_t p = (n + 256 * want - 1) / (256 * want);
+  p = std::max(step, ((p + step - 1) / step) * step);
+  *ppt = p;
+  *tiles = std::max(1u, (n + 256 * p - 1) / (256 * p));
 }
 
-// Launches pairs [p0, p0 + count) of one level on stream `s`.
+// Which levels of a batch run inside the persistent kernel, and how every (pair, level) is cut into blocks.
+//  * throughput tiling (default): the block count follows the batch — a per-iteration launch fills the chip with whole
+//    rounds of blocks (1.5 rounds over three stream groups measured best), a persistent launch fits all
+//    its blocks on the chip at once; a handful of pairs is latency-bound and takes fewer, fatter blocks.
+//  * pinned tiling (a3d_context_set_tiling): `tiles_per_pair` blocks for every pair and level whatever the batch, each
+//    pair from its OWN size — the association of a pair's sums, hence every bit of its pose, no longer depends on the
+//    batch it is in (the persistent kernel is used where the pinned grid still fits the chip: same bits either way).
+void plan_tiling(a3d_multiscale_batch* b) {
+  const uint32_t P = b->n_pairs, L = b->n_levels;
+  const uint32_t pinned = b->ctx->tiles_per_pair;
+  float waves = P >= 8 ? (b->n_streams > 2 ? 1.5f : 1.0f) : 0.125f;
+  if (const char* env = A3D_DIAG_ENV("A3D_ICP_WAVES")) waves = (float)atof(env);
+  // persistent levels: a small batch is latency-bound on every level; a large one on all but the finest
+  uint32_t mask = P < 8 ? ((1u << L) - 1u) : (((1u << L) - 1u) & ~1u);
+  if (const char* env = A3D_DIAG_ENV("A3D_ICP_PERSIST")) mask = (uint32_t)strtoul(env, nullptr, 0) & ((1u << L) - 1u);
+  if (!b->persist_resident_blocks) mask = 0;
+  // (a batch that fell back to per-iteration launches keeps the tiling it had: same bits before and after)
+  const uint32_t persist_tiles_cap = std::max(1u, b->persist_resident_blocks / std::max(1u, P));
+  for (uint32_t l = 0; l < L; ++l) {
+    uint32_t max_n = 0;
+    for (uint32_t p = 0; p < P; ++p) max_n = std::max(max_n, b->h_descs[(size_t)l * P + p].src_n);
+    b->group[l] = 1;
+    float w = waves;
+#ifdef A3D_DIAGNOSTICS
+    if (const char* env = getenv("A3D_ICP_GROUP")) b->group[l] = atoi(env) == 2 ? 2 : 1;
+    if (const char* env = getenv("A3D_ICP_GROUP_LEVELS")) {  // per-level "g0,g1,g2"
+      unsigned gl[3] = {1, 1, 1};
+      sscanf(env, "%u,%u,%u", &gl[0], &gl[1], &gl[2]);
+      if (l < 3) b->group[l] = (gl[l] == 2 || gl[l] == 4) ? gl[l] : 1;
+    }
+    if (const char* env = getenv("A3D_ICP_WAVES_LEVELS")) {  // per-level "w0,w1,w2"
+      float wl[3] = {waves, waves, waves};
+      sscanf(env, "%f,%f,%f", &wl[0], &wl[1], &wl[2]);
+      if (l < 3) w = wl[l];
+    }
+#endif
+    uint32_t want = std::max(1u, (uint32_t)((float)b->resident_blocks * w / (float)P + 0.5f));
+    if ((mask >> l) & 1u) want = std::min(want, persist_tiles_cap);  // all blocks of the launch resident at once
+    if (pinned) want = pinned;
+    uint32_t tiles = 0, ppt = 0;
+    tiling_for(max_n, want, b->group[l], &tiles, &ppt);
+#ifdef A3D_DIAGNOSTICS
+    if (const char* env = getenv("A3D_ICP_VARIANT")) {  // "ppt,g"
+      unsigned ep = 0, eg = 0;
+      if (sscanf(env, "%u,%u", &ep, &eg) == 2 && ep && (eg == 1 || eg == 2)) {
+        b->group[l] = eg;
+        ppt = ((ep + 1) / 2) * 2;
+        tiles = (max_n + 256 * ppt - 1) / (256 * ppt);
+      }
+    }
+#endif
+    b->tiles[l] = tiles, b->ppt[l] = ppt;
+    for (uint32_t p = 0; p < P; ++p) {
+      LevelDesc& d = b->h_descs[(size_t)l * P + p];
+      d.ppt = ppt;
+      if (pinned) {  // from the pair's own size (a smaller pair's surplus blocks store zero partials)
+        uint32_t t_own = 0;
+        tiling_for(d.src_n, pinned, 1, &t_own, &d.ppt);
+      }
+    }
+    // a pinned grid that does not fit the chip at once runs as per-iteration launches (same bits)
+    if (((mask >> l) & 1u) && (uint64_t)tiles * P > b->persist_resident_blocks) mask &= ~(1u << l);
+  }
+  // the persistent levels are ONE launch: the coarsest contiguous run of the mask
+  uint32_t run = 0;
+  for (uint32_t l = L; l-- > 0;) {
+    if (!((mask >> l) & 1u)) break;
+    run |= 1u << l;
+  }
+  b->persist_mask = b->persist_disabled ? 0u : run;
+}
+
+#ifdef A3D_DIAGNOSTICS
+// Launches pairs [p0, p0 + count) of one level on stream `s`: the round-2 last-block kernel and its variants.
 a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const SolveArgs& solve, uint32_t p0,
                                uint32_t count, hipStream_t s) {
   dim3 grid(b->tiles[level], count), block(256);
@@ -889,58 +1159,39 @@ a3d_status launch_pixel_kernel(a3d_multiscale_batch* b, uint32_t level, const So
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }
+#endif  // A3D_DIAGNOSTICS
+
+// One per-iteration launch (head-solve form) of pairs [p0, p0 + count) at `level`: launch number `seq` of the sequence.
+a3d_status launch_head_kernel(a3d_multiscale_batch* b, uint32_t level, uint32_t seq, const HeadArgs& prev, uint32_t p0,
+                              uint32_t count, hipStream_t s) {
+  const uint32_t P = b->n_pairs;
+  const uint32_t job_stride = b->max_tiles * GN_PARTIAL;
+  const JobState* st_in = b->d_states + (size_t)(seq & 1u) * P + p0;
+  JobState* st_out = b->d_states + (size_t)((seq + 1u) & 1u) * P + p0;
+  const float* part_in = b->d_partials + (size_t)((seq + 1u) & 1u) * b->partials_half + (size_t)p0 * job_stride;
+  float* part_out = b->d_partials + (size_t)(seq & 1u) * b->partials_half + (size_t)p0 * job_stride;
+  const LevelDesc* descs = b->d_descs + (size_t)level * P + p0;
+  if (b->zmask)
+    hipLaunchKernelGGL(image_icp_head_kernel<true>, dim3(b->tiles[level], count), dim3(256), 0, s, descs, st_in, st_out,
+                       b->gates[level], part_in, part_out, job_stride, prev);
+  else
+    hipLaunchKernelGGL(image_icp_head_kernel<false>, dim3(b->tiles[level], count), dim3(256), 0, s, descs, st_in, st_out,
+                       b->gates[level], part_in, part_out, job_stride, prev);
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
+}
 
 // (Re)derives tiling from h_descs and uploads the descriptors.
 a3d_status batch_commit_descs(a3d_multiscale_batch* b) {
   const uint32_t P = b->n_pairs, L = b->n_levels;
+  plan_tiling(b);
   size_t max_partials = 1;
-  for (uint32_t l = 0; l < L; ++l) {
-    uint32_t max_n = 0;
-    for (uint32_t p = 0; p < P; ++p) max_n = std::max(max_n, b->h_descs[(size_t)l * P + p].src_n);
-    b->group[l] = 1;  // pixels per pipeline stage; 1 measured best on MI355X (kernel variants)
-    // a batch fills the chip with exactly one round of blocks; a handful of pairs is latency-bound, and fewer,
-    // fatter blocks shorten the last block's sum over the partials (measured: 0.82 vs 0.95 ms for one pair)
-    // with three pair groups on separate streams, 1.5 rounds in total measured best (scripts/streams_sweep*.sh)
-    float waves = P >= 8 ? (b->n_streams > 2 ? 1.5f : 1.0f) : 0.25f;
-    if (const char* env = getenv("A3D_ICP_WAVES")) waves = (float)atof(env);  // tuning knob
-    if (const char* env = getenv("A3D_ICP_GROUP")) b->group[l] = atoi(env) == 2 ? 2 : 1;
-    if (const char* env = getenv("A3D_ICP_GROUP_LEVELS")) {  // tuning knob: per-level "g0,g1,g2"
-      unsigned gl[3] = {1, 1, 1};
-      sscanf(env, "%u,%u,%u", &gl[0], &gl[1], &gl[2]);
-      if (l < 3) b->group[l] = (gl[l] == 2 || gl[l] == 4) ? gl[l] : 1;
-    }
-    if (const char* env = getenv("A3D_ICP_WAVES_LEVELS")) {  // tuning knob: per-level "w0,w1,w2"
-      float wl[3] = {waves, waves, waves};
-      sscanf(env, "%f,%f,%f", &wl[0], &wl[1], &wl[2]);
-      if (l < 3) waves = wl[l];
-    }
-    choose_tiling(P, max_n, b->resident_blocks, waves, b->group[l], &b->tiles[l], &b->ppt[l]);
-    if (b->group[l] == 1 && !b->use_mfma && (b->ppt[l] & 1u)) {  // image_icp_kernel<1> takes two pipeline steps per trip
-      ++b->ppt[l];
-      b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
-    }
-    if ((b->level_mask >> l) & 1u) {  // every block of every group must be resident at once for this level
-      b->group[l] = 1;
-      choose_tiling(P, max_n, b->level_resident_blocks, 1.0f, 1, &b->tiles[l], &b->ppt[l]);
-      while ((uint64_t)b->tiles[l] * P > b->level_resident_blocks && b->tiles[l] > 1) {
-        ++b->ppt[l];
-        b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
-      }
-    }
-    if (const char* env = getenv("A3D_ICP_VARIANT")) {  // tuning knob: "ppt,g"
-      unsigned ep = 0, eg = 0;
-      if (sscanf(env, "%u,%u", &ep, &eg) == 2 && ep && (eg == 1 || eg == 2)) {
-        b->group[l] = eg;
-        b->ppt[l] = ((ep + eg - 1) / eg) * eg;
-        b->tiles[l] = (max_n + 256 * b->ppt[l] - 1) / (256 * b->ppt[l]);
-      }
-    }
-    max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
-  }
+  for (uint32_t l = 0; l < L; ++l) max_partials = std::max(max_partials, (size_t)P * b->tiles[l] * GN_PARTIAL);
   b->max_tiles = (uint32_t)(max_partials / ((size_t)P * GN_PARTIAL));
-  b->zmask = !(getenv("A3D_ICP_ZMASK") && atoi(getenv("A3D_ICP_ZMASK")) == 0);
-  for (const LevelDesc& dsc : b->h_descs) b->zmask = b->zmask && (dsc.pad & 1u);
-  b->partials_half = max_partials;  // floats per buffer: the head-solve form alternates between two
+  const char* zenv = A3D_DIAG_ENV("A3D_ICP_ZMASK");
+  b->zmask = !(zenv && atoi(zenv) == 0);
+  for (const LevelDesc& dsc : b->h_descs) b->zmask = b->zmask && (dsc.flags & 1u);
+  b->partials_half = max_partials;  // floats per buffer: the launches alternate between two
   if (b->partials_capacity < 2 * max_partials) {  // grow-only: a reused engine keeps its buffer
     if (b->d_partials) A3D_HIP_TRY(hipFree(b->d_partials));
     b->d_partials = nullptr;
@@ -962,21 +1213,31 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
   b->params.assign(params, params + n_levels);
   for (uint32_t l = 0; l < n_levels; ++l) b->gates.push_back(make_gates(params[l]));
   b->tiles.assign(n_levels, 0);
-  b->ppt.assign(n_levels, 1);
+  b->ppt.assign(n_levels, 2);
   b->group.assign(n_levels, 1);
   b->h_descs.resize((size_t)n_levels * n_pairs);
-  if (const char* env = getenv("A3D_ICP_ACCUM")) {  // tuning knob
+  auto resident = [&](auto kernel, int fallback_per_cu) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1)
+      per_cu = fallback_per_cu;
+    return (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)std::max(0, per_cu);
+  };
+  b->resident_blocks = resident(image_icp_head_kernel<true>, 4);
+  b->persist_resident_blocks = resident(image_icp_persistent_kernel<true>, 0);
+#ifdef A3D_DIAGNOSTICS
+  if (const char* env = getenv("A3D_ICP_ACCUM")) {
     b->use_mfma = strcmp(env, "mfma") == 0;
     b->merged_accumulators = strcmp(env, "merged") == 0;
   }
-  {
-    int per_cu = 0;
-    const hipError_t e = b->merged_accumulators
-                             ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_kernel<1, true>, 256, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_kernel<1, false>, 256, 0);
-    if (e != hipSuccess || per_cu < 1) per_cu = 4;
-    b->resident_blocks = (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)per_cu;
-  }
+  if (const char* env = getenv("A3D_ICP_HANDOFF")) b->head_solve = strcmp(env, "ticket") != 0;
+  if (const char* env = getenv("A3D_ICP_SOLVE")) b->exact_solve = strcmp(env, "exact") == 0;
+  if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;
+  if (const char* env = getenv("A3D_ICP_PERSISTENT_LEVELS")) b->level_mask = (uint32_t)strtoul(env, nullptr, 0);
+  if (!b->head_solve) b->resident_blocks = resident(image_icp_kernel<1, false>, 4);
+  if (b->merged_accumulators) b->resident_blocks = resident(image_icp_kernel<1, true>, 4);
+  b->level_resident_blocks = resident(image_icp_level_kernel<1>, 0);
+  if (b->use_level_kernel && b->level_resident_blocks) b->resident_blocks = b->level_resident_blocks;
+#endif
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   {  // every small device array of the batch in ONE allocation (each hipMalloc / hipFree synchronises the device:
      // nine of them made creating and destroying a batch cost ~12 ms, six alignments' worth)
@@ -993,32 +1254,30 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     A3D_HIP_TRY(hipMalloc((void**)&b->d_block, total));
     char* base = (char*)b->d_block;
     b->d_descs = (LevelDesc*)(base + o_descs), b->d_states = (JobState*)(base + o_states);
-    b->d_counters = (unsigned*)(base + o_counters), b->d_epochs = (unsigned*)(base + o_epochs);
+    b->d_counters = (unsigned*)(base + o_counters);
+#ifdef A3D_DIAGNOSTICS
+    b->d_epochs = (unsigned*)(base + o_epochs);
+#else
+    (void)o_epochs;
+#endif
     b->d_poses = (Pose*)(base + o_poses), b->d_init = (Pose*)(base + o_init);
     b->d_status = (int32_t*)(base + o_status), b->d_readback = (double*)(base + o_readback);
   }
   A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
-  if (const char* env = getenv("A3D_ICP_HANDOFF")) b->head_solve = strcmp(env, "ticket") != 0;  // cross-check knob
-  if (const char* env = getenv("A3D_ICP_PERSISTENT")) b->use_level_kernel = atoi(env) != 0;  // tuning knob
-  if (const char* env = getenv("A3D_ICP_PERSISTENT_LEVELS")) b->level_mask = (uint32_t)strtoul(env, nullptr, 0);
-  // measured (scripts/streams_sweep*.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
+  // measured (scripts/sweep.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
   // stream), 2 groups at 8 pairs (+21 %); a handful of pairs stays on one stream
   b->n_streams = n_pairs >= 12 ? 3u : (n_pairs >= 8 ? 2u : 1u);
-  if (const char* env = getenv("A3D_ICP_STREAMS")) b->n_streams = (uint32_t)std::min(4, std::max(1, atoi(env)));
-  b->n_streams = b->use_level_kernel ? 1u : std::min(b->n_streams, n_pairs);
+  if (const char* env = A3D_DIAG_ENV("A3D_ICP_STREAMS")) b->n_streams = (uint32_t)std::min(4, std::max(1, atoi(env)));
+  b->n_streams = std::min(b->n_streams, n_pairs);
+#ifdef A3D_DIAGNOSTICS
+  if (b->use_level_kernel) b->n_streams = 1u;
+#endif
   if (b->n_streams > 1) {
     A3D_HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     for (uint32_t g = 1; g < b->n_streams; ++g) {
       A3D_TRY(ctx_side_stream(ctx, g - 1, &b->aux_streams[g - 1]));  // shared by the context's batches
       A3D_HIP_TRY(hipEventCreateWithFlags(&b->ev_join[g - 1], hipEventDisableTiming));
     }
-  }
-  {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, image_icp_level_kernel<1>, 256, 0) != hipSuccess)
-      per_cu = 0;
-    b->level_resident_blocks = (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)std::max(0, per_cu);
-    if (b->use_level_kernel && b->level_resident_blocks) b->resident_blocks = b->level_resident_blocks;
   }
   A3D_HIP_TRY(hipEventCreate(&b->ev0));
   A3D_HIP_TRY(hipEventCreate(&b->ev1));
@@ -1031,6 +1290,8 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
                          float* d_trace, int trace_stride) {
   hipStream_t s = b->ctx->stream;
   const uint32_t P = b->n_pairs;
+  b->last_init = d_init, b->last_levels = levels_to_run, b->last_matrices = d_matrices;
+  b->persist_used = false;
   A3D_HIP_TRY(hipEventRecord(b->ev0, s));
   A3D_TRY(launch_job_init(s, b->d_states, d_init, (int)P));
   size_t kidx = 0;
@@ -1055,7 +1316,10 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
     ++kidx;
     return A3D_OK;
   };
-  // one launch per level is only legal when every block of the level is resident at once
+  bool head = true;
+  uint32_t S = d_trace ? 1u : b->n_streams;  // (not with a trace: its rows are indexed by the pair number inside a launch)
+#ifdef A3D_DIAGNOSTICS
+  // one last-block-form launch per level is only legal when every block of the level is resident at once
   bool level_kernel = b->use_level_kernel && !b->use_mfma && b->level_resident_blocks > 0;
   for (uint32_t l = 0; l < levels_to_run; ++l)
     level_kernel = level_kernel && (uint64_t)b->tiles[l] * P <= b->level_resident_blocks && b->group[l] == 1;
@@ -1066,79 +1330,110 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
       if (((b->level_mask >> l) & 1u) && (uint64_t)b->tiles[l] * P <= b->level_resident_blocks && b->group[l] == 1)
         mask |= 1u << l;
   if (level_kernel || mask) A3D_HIP_TRY(hipMemsetAsync(b->d_epochs, 0, P * sizeof(unsigned), s));
-  // pair groups on separate streams (not with a trace: its rows are indexed by the pair number inside a launch)
-  const uint32_t S = (level_kernel || d_trace) ? 1u : b->n_streams;
+  if (level_kernel) S = 1u;
+  head = b->head_solve && !level_kernel && !mask && !b->use_mfma && !b->merged_accumulators && !getenv("A3D_ICP_NOSOLVE");
+  for (uint32_t l = 0; l < levels_to_run; ++l) head = head && b->group[l] == 1;
+  uint32_t epoch_base = 0;
+#endif
   if (S > 1) {
     A3D_HIP_TRY(hipEventRecord(b->ev_fork, s));
     for (uint32_t g = 1; g < S; ++g) A3D_HIP_TRY(hipStreamWaitEvent(b->aux_streams[g - 1], b->ev_fork, 0));
   }
-  uint32_t epoch_base = 0;
-  // head-solve form: launch k finishes iteration k - 1 at its head (HeadArgs describes iteration k - 1)
-  bool head = b->head_solve && !level_kernel && !mask && !b->use_mfma && !b->merged_accumulators &&
-              !getenv("A3D_ICP_NOSOLVE");
-  for (uint32_t l = 0; l < levels_to_run; ++l) head = head && b->group[l] == 1;
+  // head-solve hand-off: launch k finishes iteration k - 1 at its head (`prev` describes iteration k - 1)
   HeadArgs prev{};
   prev.mode = SOLVE_NONE;
-  uint32_t seq = 0;  // launches so far: launch `seq` reads state / partial buffer seq & 1 ... writes the other
+  prev.trace = d_trace, prev.trace_stride = trace_stride;
+#ifdef A3D_DIAGNOSTICS
+  prev.exact_solve = b->exact_solve;
+#endif
+  uint32_t seq = 0;  // iterations so far: launch `seq` reads state / partial buffer seq & 1 ... writes the other
   const uint32_t job_stride = b->max_tiles * GN_PARTIAL;
-  for (uint32_t l = levels_to_run; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
+  bool finished_in_kernel = false;
+  // ---- the persistent kernel takes the coarsest levels in persist_mask (all of them for a handful of pairs) ----
+  uint32_t first_per_iteration = levels_to_run;  // levels below this index run as per-iteration launches
+  uint32_t pmask = head ? (b->persist_mask & ((1u << levels_to_run) - 1u)) : 0u;
+  if (pmask && !((pmask >> (levels_to_run - 1)) & 1u)) pmask = 0;  // (a truncated pyramid: the run must start at its coarsest level)
+  if (pmask) {
+    PersistPlan plan{};
+    plan.seq0 = 0, plan.counter_base = b->counter_base, plan.trace_index0 = 0, plan.trace_stride = trace_stride;
+    plan.prev = prev;
+    uint32_t published = 0;
+    for (uint32_t l = levels_to_run; l-- > 0;) {
+      if (!((pmask >> l) & 1u) || plan.n_levels == PERSIST_MAX_LEVELS) break;
+      const a3d_icp_params& prm = b->params[l];
+      PersistLevel& lv = plan.lv[plan.n_levels++];
+      lv.desc_base = l * P, lv.iterations = (uint32_t)prm.max_iterations, lv.tiles = b->tiles[l];
+      lv.weight = prm.weight, lv.color_weight = prm.color_weight, lv.gates = b->gates[l];
+      published += lv.iterations * lv.tiles;
+      first_per_iteration = l;
+    }
+    plan.finish = first_per_iteration == 0 ? 1u : 0u;
+    uint32_t grid_x = 1;
+    for (uint32_t k = 0; k < plan.n_levels; ++k) grid_x = std::max(grid_x, plan.lv[k].tiles);
+    if (b->profile_kernels && !b->d_stamps)
+      A3D_HIP_TRY(hipMalloc((void**)&b->d_stamps, (size_t)P * 2 * PERSIST_MAX_LEVELS * sizeof(unsigned long long)));
+    profile_level = 255;  // (a persistent launch spans levels: its per-level times come from the kernel's stamps)
+    b->persist_levels.clear();
+    for (uint32_t k = 0; k < plan.n_levels; ++k) b->persist_levels.push_back(plan.lv[k].desc_base / P);
+    for (uint32_t g = 0; g < S; ++g) {
+      const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
+      hipStream_t gs = g == 0 ? s : b->aux_streams[g - 1];
+      PersistOut po{};
+      if (plan.finish) po.poses = b->d_poses + p0, po.status = b->d_status + p0, po.matrices = d_matrices ? d_matrices + (size_t)p0 * 16 : nullptr;
+      po.stamps = b->profile_kernels ? b->d_stamps + (size_t)p0 * 2 * plan.n_levels : nullptr;
+      PersistPlan gp = plan;
+      gp.prev.trace = d_trace;
+      A3D_TRY(profile_begin(gs));
+      if (b->zmask)
+        hipLaunchKernelGGL(image_icp_persistent_kernel<true>, dim3(grid_x, p1 - p0), dim3(256), 0, gs, b->d_descs + p0, P,
+                           b->d_states + p0, b->d_partials + (size_t)p0 * job_stride, (uint32_t)b->partials_half, job_stride,
+                           b->d_counters + p0, gp, po);
+      else
+        hipLaunchKernelGGL(image_icp_persistent_kernel<false>, dim3(grid_x, p1 - p0), dim3(256), 0, gs, b->d_descs + p0, P,
+                           b->d_states + p0, b->d_partials + (size_t)p0 * job_stride, (uint32_t)b->partials_half, job_stride,
+                           b->d_counters + p0, gp, po);
+      A3D_HIP_TRY(hipGetLastError());
+      A3D_TRY(profile_end(gs));
+    }
+    b->persist_used = true;
+    b->counter_base += published;
+    for (uint32_t k = 0; k < plan.n_levels; ++k) {  // what the next launch has to know about the last iteration run
+      const PersistLevel& lv = plan.lv[k];
+      if (!lv.iterations) continue;
+      prev.weight = lv.weight, prev.color_weight = lv.color_weight, prev.mode = SOLVE_IMAGE_ICP, prev.tiles = lv.tiles;
+      prev.first_in_level = lv.iterations == 1, prev.last_in_level = 1;
+      seq += lv.iterations, trace_index += (int)lv.iterations;
+      prev.trace_index = trace_index - 1;
+    }
+    finished_in_kernel = plan.finish != 0;
+  }
+  for (uint32_t l = first_per_iteration; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
     const a3d_icp_params& prm = b->params[l];
     profile_level = l;
     if (head) {
       for (uint64_t it = 0; it < prm.max_iterations; ++it) {
-        const JobState* st_in = b->d_states + (size_t)(seq & 1u) * P;
-        JobState* st_out = b->d_states + (size_t)((seq + 1u) & 1u) * P;
-        const float* part_in = b->d_partials + (size_t)((seq + 1u) & 1u) * b->partials_half;  // written by launch seq - 1
-        float* part_out = b->d_partials + (size_t)(seq & 1u) * b->partials_half;
         for (uint32_t g = 0; g < S; ++g) {
           const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
           hipStream_t gs = g == 0 ? s : b->aux_streams[g - 1];
           A3D_TRY(profile_begin(gs));
-          if (b->zmask)
-            hipLaunchKernelGGL(image_icp_head_kernel<true>, dim3(b->tiles[l], p1 - p0), dim3(256), 0, gs,
-                               b->d_descs + (size_t)l * P + p0, st_in + p0, st_out + p0, b->gates[l],
-                               part_in + (size_t)p0 * job_stride, part_out + (size_t)p0 * job_stride, job_stride, prev,
-                               (int)b->ppt[l]);
-          else
-            hipLaunchKernelGGL(image_icp_head_kernel<false>, dim3(b->tiles[l], p1 - p0), dim3(256), 0, gs,
-                               b->d_descs + (size_t)l * P + p0, st_in + p0, st_out + p0, b->gates[l],
-                               part_in + (size_t)p0 * job_stride, part_out + (size_t)p0 * job_stride, job_stride, prev,
-                               (int)b->ppt[l]);
-          A3D_HIP_TRY(hipGetLastError());
+          A3D_TRY(launch_head_kernel(b, l, seq, prev, p0, p1 - p0, gs));
           A3D_TRY(profile_end(gs));
         }
         prev.weight = prm.weight, prev.color_weight = prm.color_weight, prev.mode = SOLVE_IMAGE_ICP;
         prev.tiles = b->tiles[l];
         prev.first_in_level = it == 0, prev.last_in_level = it + 1 == prm.max_iterations;
-        prev.trace = d_trace, prev.trace_stride = trace_stride, prev.trace_index = trace_index;
+        prev.trace_index = trace_index;
         ++trace_index;
         ++seq;
       }
       continue;
     }
+#ifdef A3D_DIAGNOSTICS
     SolveArgs sa{};
     sa.weight = prm.weight, sa.color_weight = prm.color_weight;
-    sa.mode = getenv("A3D_ICP_NOSOLVE") ? SOLVE_NONE : SOLVE_IMAGE_ICP;  // diagnostics: time the body alone
+    sa.mode = getenv("A3D_ICP_NOSOLVE") ? SOLVE_NONE : SOLVE_IMAGE_ICP;  // times the body alone (poses meaningless)
     sa.trace = d_trace, sa.trace_stride = trace_stride;
-    if (level_kernel) {
-      if (prm.max_iterations == 0) continue;
-      A3D_TRY(profile_begin(s));
-      LevelPlan plan;
-      plan.iterations = (uint32_t)prm.max_iterations;
-      plan.epoch_base = epoch_base;
-      plan.trace_base = trace_index;
-      sa.first_in_level = sa.last_in_level = 0;
-      sa.trace_index = 0;
-      hipLaunchKernelGGL((image_icp_level_kernel<1>), dim3(b->tiles[l], P), dim3(256), 0, s,
-                         b->d_descs + (size_t)l * P, b->d_states, b->gates[l], b->d_partials, b->d_counters, b->d_epochs,
-                         sa, plan, (int)b->ppt[l]);
-      A3D_HIP_TRY(hipGetLastError());
-      A3D_TRY(profile_end(s));
-      epoch_base += plan.iterations;
-      trace_index += (int)plan.iterations;
-      continue;
-    }
-    if ((mask >> l) & 1u) {
+    if (level_kernel || ((mask >> l) & 1u)) {
       if (prm.max_iterations == 0) continue;
       LevelPlan plan;
       plan.iterations = (uint32_t)prm.max_iterations;
@@ -1173,19 +1468,24 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
       }
       ++trace_index;
     }
+#endif
   }
   for (uint32_t g = 1; g < S; ++g) {
     A3D_HIP_TRY(hipEventRecord(b->ev_join[g - 1], b->aux_streams[g - 1]));
     A3D_HIP_TRY(hipStreamWaitEvent(s, b->ev_join[g - 1], 0));
   }
-  if (head)  // the last iteration is still pending: the finish kernel applies it
+  if (finished_in_kernel) {
+    // the persistent kernel applied the last iteration and wrote the outputs
+  } else if (head) {  // the last iteration is still pending: the finish kernel applies it
     A3D_TRY(launch_job_finish_head(s, b->d_states + (size_t)(seq & 1u) * P,
                                    b->d_partials + (size_t)((seq + 1u) & 1u) * b->partials_half, job_stride, prev,
                                    b->d_poses, b->d_status, d_matrices, (int)P));
-  else
+  } else {
     A3D_TRY(launch_job_finish(s, b->d_states, b->d_poses, b->d_status, d_matrices, (int)P));
+  }
   A3D_HIP_TRY(hipEventRecord(b->ev1, s));
   b->last_kernel_launches = kidx;
+  b->last_groups = S;
   return A3D_OK;
 }
 
@@ -1197,6 +1497,9 @@ void batch_drain_after_failure(a3d_multiscale_batch* b) {
     if (b->aux_streams[g - 1]) (void)hipStreamSynchronize(b->aux_streams[g - 1]);
   (void)hipStreamSynchronize(b->ctx->stream);
   (void)hipGetLastError();
+  // a persistent launch may not have run to its end: start the pairs' counters afresh
+  (void)hipMemsetAsync(b->d_counters, 0, b->n_pairs * sizeof(unsigned), b->ctx->stream);
+  b->counter_base = 0;
 }
 
 a3d_status batch_collect_timing(a3d_multiscale_batch* b) {
@@ -1210,7 +1513,30 @@ a3d_status batch_collect_timing(a3d_multiscale_batch* b) {
       A3D_HIP_TRY(hipEventElapsedTime(&ms, b->kev[2 * k], b->kev[2 * k + 1]));
       b->last_kernel_ms += ms;
       const uint32_t l = k < b->kev_level.size() ? b->kev_level[k] : 0u;
-      b->last_level_ms[l & 15u] += ms, ++b->last_level_launches[l & 15u];
+      if (l < 16) b->last_level_ms[l] += ms, ++b->last_level_launches[l];
+    }
+    if (b->persist_used && b->d_stamps && !b->persist_levels.empty()) {
+      // the levels that ran inside the persistent kernel: per stream group, first start to last end of the level over
+      // the group's pairs (s_memrealtime: 100 MHz), summed over the groups like the launch durations above; the
+      // "launches" of such a level are its iterations x groups
+      const uint32_t P = b->n_pairs, nl = (uint32_t)b->persist_levels.size(), S = b->last_groups;
+      std::vector<unsigned long long> st((size_t)P * 2 * nl);
+      A3D_HIP_TRY(hipMemcpy(st.data(), b->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      for (uint32_t g = 0; g < S; ++g) {
+        const uint32_t p0 = (uint32_t)((uint64_t)P * g / S), p1 = (uint32_t)((uint64_t)P * (g + 1) / S);
+        for (uint32_t k = 0; k < nl; ++k) {
+          unsigned long long lo = ~0ull, hi = 0;
+          for (uint32_t p = p0; p < p1; ++p) {
+            lo = std::min(lo, st[((size_t)p * nl + k) * 2]);
+            hi = std::max(hi, st[((size_t)p * nl + k) * 2 + 1]);
+          }
+          const uint32_t l = b->persist_levels[k];
+          if (l < 16 && hi >= lo) {
+            b->last_level_ms[l] += (float)((double)(hi - lo) * 1e-5);
+            b->last_level_launches[l] += (uint32_t)b->params[l].max_iterations;
+          }
+        }
+      }
     }
   }
   return A3D_OK;
@@ -1223,14 +1549,30 @@ a3d_status read_results(a3d_multiscale_batch* b, a3d_pose* out_poses, int32_t* o
   const uint32_t P = b->n_pairs;
   std::vector<Pose> poses(P);
   std::vector<int32_t> status(P);
-  hipStream_t s = b->ctx->stream;
-  if (behind_fence) {
-    s = b->ctx->copy_stream;
-    A3D_REQUIRE(b->fence->wait_on(s), A3D_HIP_ERROR, "hipStreamWaitEvent failed");
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    hipStream_t s = b->ctx->stream;
+    if (behind_fence) {
+      s = b->ctx->copy_stream;
+      A3D_REQUIRE(b->fence->wait_on(s), A3D_HIP_ERROR, "hipStreamWaitEvent failed");
+    }
+    A3D_HIP_TRY(hipMemcpyAsync(poses.data(), b->d_poses, P * sizeof(Pose), hipMemcpyDeviceToHost, s));
+    A3D_HIP_TRY(hipMemcpyAsync(status.data(), b->d_status, P * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    A3D_HIP_TRY(hipStreamSynchronize(s));
+    bool spin_bound = false;
+    for (uint32_t p = 0; p < P; ++p) spin_bound = spin_bound || status[p] == A3D_HIP_ERROR;
+    if (!(spin_bound && b->persist_used) || attempt == 1) break;
+    // A pair's blocks waited for partners that never became resident (another process holds part of the chip): this
+    // batch goes back to one launch per iteration for good — same tiling, same bits — and the pass is repeated.
+    batch_drain_after_failure(b);
+    b->persist_disabled = true;
+    b->persist_mask = 0;
+    a3d_status st = batch_enqueue(b, b->last_init, b->last_levels, b->last_matrices, nullptr, 0);
+    if (st != A3D_OK) {
+      batch_drain_after_failure(b);
+      return st;
+    }
+    b->fence->record(b->ctx->stream);
   }
-  A3D_HIP_TRY(hipMemcpyAsync(poses.data(), b->d_poses, P * sizeof(Pose), hipMemcpyDeviceToHost, s));
-  A3D_HIP_TRY(hipMemcpyAsync(status.data(), b->d_status, P * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  A3D_HIP_TRY(hipStreamSynchronize(s));
   *worst = A3D_OK;
   for (uint32_t p = 0; p < P; ++p) {
     if (out_poses) pose_to_c(poses[p], &out_poses[p]);
@@ -1261,8 +1603,6 @@ a3d_status acquire_single_engine(a3d_context* ctx, const a3d_icp_params* params,
   } else {
     e->params.assign(params, params + n_levels);
     for (uint32_t l = 0; l < n_levels; ++l) e->gates[l] = make_gates(params[l]);
-    // a run that died half-way may have left tickets behind
-    A3D_HIP_TRY(hipMemsetAsync(e->d_counters, 0, sizeof(unsigned), ctx->stream));
   }
   *out = e;
   return A3D_OK;
@@ -1329,103 +1669,81 @@ a3d_status a3d_image_icp_align_trace(a3d_context* ctx, const a3d_icp_params* par
   return align_single(ctx, params, 1, &target, &source, init_pose, out_pose, out_trace);
 }
 
-a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
-                                    const a3d_device_image* source, const a3d_pose* pose, a3d_gn_state* out_geom,
-                                    a3d_gn_state* out_color) {
-  A3D_REQUIRE(ctx && params, A3D_INVALID_PARAMETER, "null argument");
+// One pass of the pixel loop from `pose` (image_icp.rs:76-148): the two accumulators as the product kernel sums them
+// (block partials added in f64).  `which`: 0 the product kernel; diagnostics builds: 1 the exact-arithmetic cross-check
+// kernel, 2 the merged-accumulator kernel.
+static a3d_status accumulate_pass(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
+                                  const a3d_device_image* source, const a3d_pose* pose, int which, double sums[GN_PARTIAL],
+                                  const char* what) {
   std::unique_ptr<a3d_multiscale_batch> b;
   A3D_TRY(batch_create(ctx, params, 1, 1, &b));
   A3D_TRY(fill_desc(target, source, &b->h_descs[0]));
   A3D_TRY(batch_commit_descs(b.get()));
   Pose h_pose = pose ? pose_from_c(pose) : pose_eye();
-  Pose* d_pose = nullptr;
-  A3D_HIP_TRY(hipMalloc((void**)&d_pose, sizeof(Pose)));
+  Pose* d_pose = b->d_init;
   a3d_status st = A3D_OK;
-  double sums[GN_PARTIAL];
   hipStream_t s = ctx->stream;
   if (hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess) st = A3D_HIP_ERROR;
   if (st == A3D_OK) st = launch_job_init(s, b->d_states, d_pose, 1);
-  SolveArgs none{};
-  none.mode = SOLVE_NONE;
-  if (st == A3D_OK) st = launch_pixel_kernel(b.get(), 0, none, 0, b->n_pairs, b->ctx->stream);
-  if (st == A3D_OK) st = launch_gn_readback(s, b->d_partials, (int)b->tiles[0], b->d_readback);
-  if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
-    st = A3D_HIP_ERROR;
-  if (hipStreamSynchronize(s) != hipSuccess) st = A3D_HIP_ERROR;
-  hipFree(d_pose);
-  if (st == A3D_HIP_ERROR) set_error("a3d_image_icp_accumulate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-  if (st != A3D_OK) return st;
-  gn_states_from_sums(sums, out_geom, out_color);
-  return A3D_OK;
-}
-
-// Test hook: the same pass through image_icp_exact_kernel (every per-pixel value in the reference's own unfused
-// operations): guards the product kernel's fused Jacobians against a real error hiding inside their tolerance.
-a3d_status a3d_image_icp_accumulate_exact(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
-                                          const a3d_device_image* source, const a3d_pose* pose, a3d_gn_state* out_geom,
-                                          a3d_gn_state* out_color) {
-  A3D_REQUIRE(ctx && params, A3D_INVALID_PARAMETER, "null argument");
-  std::unique_ptr<a3d_multiscale_batch> b;
-  A3D_TRY(batch_create(ctx, params, 1, 1, &b));
-  A3D_TRY(fill_desc(target, source, &b->h_descs[0]));
-  A3D_TRY(batch_commit_descs(b.get()));
-  Pose h_pose = pose ? pose_from_c(pose) : pose_eye();
-  Pose* d_pose = nullptr;
-  A3D_HIP_TRY(hipMalloc((void**)&d_pose, sizeof(Pose)));
-  a3d_status st = A3D_OK;
-  double sums[GN_PARTIAL];
-  hipStream_t s = ctx->stream;
-  if (hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess) st = A3D_HIP_ERROR;
-  if (st == A3D_OK) st = launch_job_init(s, b->d_states, d_pose, 1);
-  if (st == A3D_OK) {
+  if (st == A3D_OK && which == 0) {  // the per-iteration launch with nothing to finish at its head: partials in buffer 0
+    HeadArgs none{};
+    none.mode = SOLVE_NONE;
+    st = launch_head_kernel(b.get(), 0, 0, none, 0, 1, s);
+  }
+#ifdef A3D_DIAGNOSTICS
+  if (st == A3D_OK && which == 1) {
     hipLaunchKernelGGL(image_icp_exact_kernel, dim3(b->tiles[0]), dim3(256), 0, s, b->d_descs, b->d_states, b->gates[0],
                        b->d_partials, (int)b->ppt[0]);
     if (hipGetLastError() != hipSuccess) st = A3D_HIP_ERROR;
   }
-  if (st == A3D_OK) st = launch_gn_readback(s, b->d_partials, (int)b->tiles[0], b->d_readback);
-  if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
-    st = A3D_HIP_ERROR;
-  if (hipStreamSynchronize(s) != hipSuccess) st = A3D_HIP_ERROR;
-  hipFree(d_pose);
-  if (st == A3D_HIP_ERROR) set_error("a3d_image_icp_accumulate_exact: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-  if (st != A3D_OK) return st;
-  gn_states_from_sums(sums, out_geom, out_color);
-  return A3D_OK;
-}
-
-// Test hook for the merged-accumulator kernel (A3D_ICP_ACCUM=merged): one pass from `pose`, returning what it hands
-// to the solve: geom.add_weighted(color, weight, color_weight) (gaussnewton.rs:115-121) — H, g, the weighted residual
-// sum and the combined count.
-a3d_status a3d_image_icp_accumulate_weighted(a3d_context* ctx, const a3d_icp_params* params,
-                                             const a3d_device_image* target, const a3d_device_image* source,
-                                             const a3d_pose* pose, a3d_gn_state* out_state) {
-  A3D_REQUIRE(ctx && params && out_state, A3D_INVALID_PARAMETER, "null argument");
-  std::unique_ptr<a3d_multiscale_batch> b;
-  A3D_TRY(batch_create(ctx, params, 1, 1, &b));
-  A3D_TRY(fill_desc(target, source, &b->h_descs[0]));
-  A3D_TRY(batch_commit_descs(b.get()));
-  Pose h_pose = pose ? pose_from_c(pose) : pose_eye();
-  Pose* d_pose = nullptr;
-  A3D_HIP_TRY(hipMalloc((void**)&d_pose, sizeof(Pose)));
-  a3d_status st = A3D_OK;
-  double sums[GN_PARTIAL];
-  hipStream_t s = ctx->stream;
-  if (hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess) st = A3D_HIP_ERROR;
-  if (st == A3D_OK) st = launch_job_init(s, b->d_states, d_pose, 1);
-  if (st == A3D_OK) {  // the merged kernel, with its tail switched off: the partials stay as the blocks wrote them
+  if (st == A3D_OK && which == 2) {  // the merged kernel, with its tail switched off: the partials stay as the blocks wrote them
     SolveArgs sa{};
     sa.weight = params->weight, sa.color_weight = params->color_weight, sa.mode = SOLVE_NONE;
     hipLaunchKernelGGL((image_icp_kernel<1, true>), dim3(b->tiles[0], 1), dim3(256), 0, s, b->d_descs, b->d_states, b->gates[0],
                        b->d_partials, b->d_counters, sa, (int)b->ppt[0]);
     if (hipGetLastError() != hipSuccess) st = A3D_HIP_ERROR;
   }
+#endif
   if (st == A3D_OK) st = launch_gn_readback(s, b->d_partials, (int)b->tiles[0], b->d_readback);
-  if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
+  if (st == A3D_OK && hipMemcpyAsync(sums, b->d_readback, GN_PARTIAL * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
     st = A3D_HIP_ERROR;
   if (hipStreamSynchronize(s) != hipSuccess) st = A3D_HIP_ERROR;
-  hipFree(d_pose);
-  if (st == A3D_HIP_ERROR) set_error("a3d_image_icp_accumulate_weighted: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-  if (st != A3D_OK) return st;
+  if (st == A3D_HIP_ERROR) set_error("%s: HIP failure: %s", what, hipGetErrorString(hipGetLastError()));
+  return st;
+}
+
+a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
+                                    const a3d_device_image* source, const a3d_pose* pose, a3d_gn_state* out_geom,
+                                    a3d_gn_state* out_color) {
+  A3D_REQUIRE(ctx && params, A3D_INVALID_PARAMETER, "null argument");
+  double sums[GN_PARTIAL];
+  A3D_TRY(accumulate_pass(ctx, params, target, source, pose, 0, sums, "a3d_image_icp_accumulate"));
+  gn_states_from_sums(sums, out_geom, out_color);
+  return A3D_OK;
+}
+
+#ifdef A3D_DIAGNOSTICS
+// Diagnostics build only: the same pass through image_icp_exact_kernel (every per-pixel value in the reference's own
+// unfused operations): guards the product kernel's fused Jacobians against a real error hiding inside their tolerance.
+a3d_status a3d_image_icp_accumulate_exact(a3d_context* ctx, const a3d_icp_params* params, const a3d_device_image* target,
+                                          const a3d_device_image* source, const a3d_pose* pose, a3d_gn_state* out_geom,
+                                          a3d_gn_state* out_color) {
+  A3D_REQUIRE(ctx && params, A3D_INVALID_PARAMETER, "null argument");
+  double sums[GN_PARTIAL];
+  A3D_TRY(accumulate_pass(ctx, params, target, source, pose, 1, sums, "a3d_image_icp_accumulate_exact"));
+  gn_states_from_sums(sums, out_geom, out_color);
+  return A3D_OK;
+}
+
+// Diagnostics build only: the merged-accumulator kernel (A3D_ICP_ACCUM=merged), one pass from `pose`, returning what it
+// hands to the solve: geom.add_weighted(color, weight, color_weight) (gaussnewton.rs:115-121) — H, g, the weighted
+// residual sum and the combined count.
+a3d_status a3d_image_icp_accumulate_weighted(a3d_context* ctx, const a3d_icp_params* params,
+                                             const a3d_device_image* target, const a3d_device_image* source,
+                                             const a3d_pose* pose, a3d_gn_state* out_state) {
+  A3D_REQUIRE(ctx && params && out_state, A3D_INVALID_PARAMETER, "null argument");
+  double sums[GN_PARTIAL];
+  A3D_TRY(accumulate_pass(ctx, params, target, source, pose, 2, sums, "a3d_image_icp_accumulate_weighted"));
   int t = 0;
   for (int i = 0; i < 6; ++i)
     for (int j = i; j < 6; ++j) {
@@ -1437,6 +1755,7 @@ a3d_status a3d_image_icp_accumulate_weighted(a3d_context* ctx, const a3d_icp_par
   out_state->count = (uint64_t)sums[28] + (uint64_t)sums[30];
   return A3D_OK;
 }
+#endif  // A3D_DIAGNOSTICS
 
 a3d_status a3d_multiscale_new(a3d_context* ctx, const a3d_icp_params* params, uint64_t n_params,
                               const a3d_device_image* const* target_pyramid, uint64_t n_levels,
@@ -1573,9 +1892,17 @@ a3d_status a3d_multiscale_batch_last_level_ms(a3d_multiscale_batch* b, uint32_t 
   return A3D_OK;
 }
 
+a3d_status a3d_multiscale_batch_persistent_levels(a3d_multiscale_batch* b, uint32_t* out_mask) {
+  A3D_REQUIRE(b && out_mask, A3D_INVALID_PARAMETER, "null argument");
+  *out_mask = 0;
+  if (b->persist_used)
+    for (uint32_t l : b->persist_levels) *out_mask |= 1u << l;
+  return A3D_OK;
+}
+
 a3d_status a3d_multiscale_batch_concurrency(a3d_multiscale_batch* b, uint32_t* out_streams) {
   A3D_REQUIRE(b && out_streams, A3D_INVALID_PARAMETER, "null argument");
-  *out_streams = b->use_level_kernel ? 1u : b->n_streams;
+  *out_streams = b->n_streams;
   return A3D_OK;
 }
 
@@ -1647,7 +1974,7 @@ a3d_status a3d_selftest_transform(a3d_context* ctx, const float* updates6, const
   return A3D_OK;
 }
 
-#ifdef A3D_TAIL_STAMPS
+#if defined(A3D_DIAGNOSTICS) && defined(A3D_TAIL_STAMPS)
 extern "C" int a3d_debug_tail_stamps(unsigned long long out[16]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }

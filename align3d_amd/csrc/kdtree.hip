@@ -108,9 +108,12 @@ struct KdLaunch {
 KdLaunch kd_launch_config(const a3d_kdtree* t, uint64_t m, const char* env_prefix, uint32_t def_block,
                           uint32_t def_levels, uint32_t blocks_per_cu_cap) {
   auto env_u = [&](const char* suffix, uint32_t def) {
+#ifdef A3D_DIAGNOSTICS  // A3D_KD_* / A3D_PCL_* launch-geometry knobs (scripts/kd_sweep.sh)
     std::string name = std::string(env_prefix) + suffix;
-    const char* v = getenv(name.c_str());
-    return v ? (uint32_t)atoi(v) : def;
+    if (const char* v = getenv(name.c_str())) return (uint32_t)atoi(v);
+#endif
+    (void)suffix, (void)env_prefix;
+    return def;
   };
   KdLaunch L;
   L.block = env_u("_BLOCK", def_block);
@@ -143,12 +146,12 @@ __global__ void __launch_bounds__(BLOCK)
     const uint32_t ii = i < m ? i : m - 1;
     const f32x3 qv = *(const f32x3_u*)(queries + 3 * (size_t)ii);  // one dwordx3
     const V3 q{qv.x, qv.y, qv.z};
-#if defined(A3D_KD_PROBE) && A3D_KD_PROBE == 2  // phase probe (scripts/build_variant.sh): scan only, pseudo-random leaf
+#if defined(A3D_DIAGNOSTICS) && defined(A3D_KD_PROBE) && A3D_KD_PROBE == 2  // phase probe (scripts/build_variant.sh): scan only, pseudo-random leaf
     const uint32_t base = ((i * 2654435761u) >> (32u - max_depth)) * 16u;
 #else
     const uint32_t base = kdtree_descend(sp, n, max_depth, q);
 #endif
-#if defined(A3D_KD_PROBE) && A3D_KD_PROBE == 1  // phase probe: descent only
+#if defined(A3D_DIAGNOSTICS) && defined(A3D_KD_PROBE) && A3D_KD_PROBE == 1  // phase probe: descent only
     if (i < m) out_idx[i] = base, out_dist[i] = 0.0f;
     continue;
 #endif
@@ -203,6 +206,7 @@ __device__ __forceinline__ void pcl_point_loop(const KdSplits& sp, const float4*
   }
 }
 
+#ifdef A3D_DIAGNOSTICS
 // Last-block form: the block that publishes the last partial finishes the iteration (icp_engine.hpp).
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -227,6 +231,8 @@ __global__ void __launch_bounds__(BLOCK)
   if (status != A3D_OK) sa.mode = SOLVE_NONE;
   block_finish<GN_ACC, BLOCK / 64>(acc, partials, blockIdx.x, gridDim.x, counter, states, sa, 0);  // no colour term
 }
+
+#endif  // A3D_DIAGNOSTICS
 
 // Head-solve form (icp_engine.hpp): the launch of iteration k first finishes iteration k - 1 — every block sums the
 // previous launch's partials and runs the solve while its split table is still arriving in LDS — then takes the point
@@ -299,7 +305,7 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
   t->ctx = ctx;
   t->n = (uint32_t)n;
   A3D_HIP_TRY(hipSetDevice(ctx->device));
-  const char* mode = getenv("A3D_KDTREE_BUILD");
+  const char* mode = A3D_DIAG_ENV("A3D_KDTREE_BUILD");  // diagnostics build: "host" = std::stable_sort build (cross-check)
   if (!(mode && !strcmp(mode, "host"))) {  // device build: upload the points, sort level by level on the GPU
     kdtree_shape(t->n, &t->max_depth, &t->n_leaves, &t->n_internal);
     A3D_REQUIRE(t->max_depth <= 23, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout (leaf byte offsets are 32-bit)");
@@ -492,6 +498,7 @@ static a3d_status pcl_upload_source(a3d_pcl_icp* icp, const a3d_point_cloud_view
   return A3D_OK;
 }
 
+#ifdef A3D_DIAGNOSTICS  // the last-block (ticket) form: cross-check of the head-solve form
 static a3d_status pcl_launch_pass(a3d_pcl_icp* icp, const float* d_pts, const float* d_nrm, uint32_t m,
                                   const SolveArgs& solve) {
   PclGates g;
@@ -511,6 +518,8 @@ static a3d_status pcl_launch_pass(a3d_pcl_icp* icp, const float* d_pts, const fl
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }
+
+#endif  // A3D_DIAGNOSTICS
 
 static a3d_status pcl_launch_head_pass(a3d_pcl_icp* icp, const float* d_pts, const float* d_nrm, uint32_t m, uint32_t seq,
                                        const HeadArgs& head) {
@@ -550,8 +559,8 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
   }
   if (st == A3D_OK) hipEventRecord(icp->ev0, s);
   if (st == A3D_OK) st = launch_job_init(s, icp->d_state, nullptr, 1);
-  const char* handoff = getenv("A3D_ICP_HANDOFF");
-  const bool head_form = !(handoff && !strcmp(handoff, "ticket"));  // cross-check knob: the last-block form
+  const char* handoff = A3D_DIAG_ENV("A3D_ICP_HANDOFF");
+  const bool head_form = !(handoff && !strcmp(handoff, "ticket"));  // diagnostics build: the last-block form
   icp->d_out_status = (int32_t*)((char*)icp->d_out_pose + 128);
   JobState h;
   Pose h_pose{};
@@ -575,6 +584,7 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
                          hipMemcpyAsync(&h_status, icp->d_out_status, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess))
       st = A3D_HIP_ERROR;
   } else {
+#ifdef A3D_DIAGNOSTICS
     for (uint64_t it = 0; st == A3D_OK && it < icp->params.max_iterations; ++it) {
       SolveArgs sa{};
       sa.weight = icp->params.weight, sa.color_weight = 0.0f;
@@ -585,6 +595,7 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
     if (st == A3D_OK) hipEventRecord(icp->ev1, s);
     if (st == A3D_OK && hipMemcpyAsync(&h, icp->d_state, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess)
       st = A3D_HIP_ERROR;
+#endif
   }
   if (hipStreamSynchronize(s) != hipSuccess && st == A3D_OK) st = A3D_HIP_ERROR;
   if (!head_form) h_pose = h.pose, h_status = h.status;
@@ -609,9 +620,9 @@ a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* 
                        hipMemcpyAsync(d_pose, &h_pose, sizeof(Pose), hipMemcpyHostToDevice, s) != hipSuccess))
     st = A3D_HIP_ERROR;
   if (st == A3D_OK) st = launch_job_init(s, icp->d_state, d_pose, 1);
-  SolveArgs none{};
+  HeadArgs none{};  // the per-iteration launch with nothing to finish at its head: partials in buffer 0
   none.mode = SOLVE_NONE;
-  if (st == A3D_OK) st = pcl_launch_pass(icp, d_pts, d_nrm, (uint32_t)source->len, none);
+  if (st == A3D_OK) st = pcl_launch_head_pass(icp, d_pts, d_nrm, (uint32_t)source->len, 0, none);
   if (st == A3D_OK) st = launch_gn_readback(s, icp->d_partials, (int)icp->blocks, icp->d_readback);
   if (st == A3D_OK && hipMemcpyAsync(sums, icp->d_readback, sizeof(sums), hipMemcpyDeviceToHost, s) != hipSuccess)
     st = A3D_HIP_ERROR;

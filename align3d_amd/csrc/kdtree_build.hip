@@ -11,12 +11,14 @@
 // One workgroup per range (or per handful of short ranges) is right for the thousands of short ranges of the
 // deep levels but would leave the chip idle on the few long ranges at the top; those levels use ONE
 // device-wide stable radix sort instead, on 64-bit keys (range number << 32 | order-preserving key bits).
-// The sorts are hand-written (kdtree_sort.hip); rocPRIM's stable radix sorts (a ROCm header library) stay behind
-// A3D_KDTREE_SORT=rocprim as a cross-check.  Key gather, NaN detection, range tables, split extraction and leaf
-// packing are written here.  The result is bit-identical to the host build (kdtree.hip), which stays available
-// (A3D_KDTREE_BUILD=host) and is what the tests compare against.
+// The sorts are hand-written (kdtree_sort.hip).  Key gather, NaN detection, range tables, split extraction and leaf
+// packing are written here.  The result is bit-identical to the host build (kdtree.hip, std::stable_sort) — the
+// diagnostics build (-DA3D_DIAGNOSTICS) keeps that build (A3D_KDTREE_BUILD=host) and the same device build on
+// rocPRIM's stable radix sorts (A3D_KDTREE_SORT=rocprim) as cross-checks; the product library contains neither.
+#ifdef A3D_DIAGNOSTICS
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
+#endif
 
 #include <algorithm>
 #include <cstdlib>
@@ -164,7 +166,9 @@ namespace a3d {
 size_t kdtree_build_scratch_bytes(uint32_t n, uint32_t max_depth, hipStream_t s) {
   auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
   const size_t max_nodes = max_depth ? (1ull << (max_depth - 1)) : 1;
-  size_t sort_bytes = 0, wide_bytes = 0;
+  size_t sort_bytes = 0;
+#ifdef A3D_DIAGNOSTICS
+  size_t wide_bytes = 0;
   if (max_depth > 0) {
     (void)rocprim::segmented_radix_sort_pairs(nullptr, sort_bytes, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr,
                                               (uint32_t*)nullptr, n, (unsigned)max_nodes, (uint32_t*)nullptr,
@@ -173,6 +177,9 @@ size_t kdtree_build_scratch_bytes(uint32_t n, uint32_t max_depth, hipStream_t s)
                                     (uint32_t*)nullptr, n, 0, 64, s);
     sort_bytes = std::max(sort_bytes, wide_bytes);
   }
+#else
+  (void)s;
+#endif
   return 2 * pad((size_t)n * 4) + 2 * pad((size_t)n * 8) + 2 * pad(max_nodes * 4) + 256 + pad(sort_bytes) +
          pad(kdtree_sort_scratch_bytes(n)) + pad((size_t)n * 12);
 }
@@ -196,16 +203,23 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
   hipLaunchKernelGGL(fill_leaves_kernel, grid_for(n_slots), dim3(256), 0, s, t->d_leaves, n_slots);
 
   // Levels whose ranges are longer than this use the device-wide sort (no leaf can exist there: len > 16).
+  uint32_t wide_len = 4096u;
+#ifdef A3D_DIAGNOSTICS
   const char* sort_env = getenv("A3D_KDTREE_SORT");
   const bool use_rocprim = sort_env && !strcmp(sort_env, "rocprim");  // cross-check path; default: kdtree_sort.hip
-  uint32_t wide_len = getenv("A3D_KDTREE_WIDE_LEN") ? (uint32_t)atoi(getenv("A3D_KDTREE_WIDE_LEN")) : 4096u;
+  if (getenv("A3D_KDTREE_WIDE_LEN")) wide_len = (uint32_t)atoi(getenv("A3D_KDTREE_WIDE_LEN"));
   if (!use_rocprim) wide_len = std::min(wide_len, 4096u);  // the LDS sort holds at most 4096 points per range
+#else
+  constexpr bool use_rocprim = false;
+#endif
   auto max_len = [&](uint32_t level) { return (uint32_t)(((uint64_t)n + (1ull << level) - 1) >> level); };
   auto level_is_wide = [&](uint32_t level) { return max_len(level) > std::max(wide_len, 64u); };
 
   // scratch: two index buffers, two key buffers, offsets for the widest level, NaN flag, rocPRIM storage
   const size_t max_nodes = D ? (1ull << (D - 1)) : 1;
-  size_t sort_bytes = 0, wide_bytes = 0;
+  size_t sort_bytes = 0;
+#ifdef A3D_DIAGNOSTICS
+  size_t wide_bytes = 0;
   if (D > 0) {
     // size query with the widest level's segment count
     A3D_HIP_TRY(rocprim::segmented_radix_sort_pairs(nullptr, sort_bytes, (float*)nullptr, (float*)nullptr,
@@ -215,6 +229,7 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
                                           (uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 64, s));
     sort_bytes = std::max(sort_bytes, wide_bytes);
   }
+#endif
   auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
   const size_t hist_bytes = pad(kdtree_sort_scratch_bytes(n));
   const size_t total = 2 * pad((size_t)n * 4) + 2 * pad((size_t)n * 8) + 2 * pad(max_nodes * 4) + 256 +
@@ -259,6 +274,7 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
                          t->d_split);
       continue;
     }
+#ifdef A3D_DIAGNOSTICS  // the same build on rocPRIM's stable sorts
     if (level_is_wide(level)) {
       hipLaunchKernelGGL(gather_keys64_kernel, grid_for(n), dim3(256), 0, s, d_points, cur, n, level, k,
                          (uint64_t*)keys_a, nan_flag);
@@ -275,6 +291,7 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
     }
     hipLaunchKernelGGL(extract_splits_kernel, grid_for(nodes), dim3(256), 0, s, d_points, nxt, n, level, k, t->d_split);
     std::swap(cur, nxt);
+#endif
   }
   hipLaunchKernelGGL(pack_leaves_kernel, grid_for(n), dim3(256), 0, s, d_points, cur, n, D, t->d_leaves,
                      t->d_slot_of_point);

@@ -255,7 +255,8 @@ a3d_status kdtree_radix_sort_pairs(hipStream_t s, uint64_t* keys_a, uint64_t* ke
   for (int shift = 0; shift < end_bit; shift += 8) {
     const uint64_t* kin = flip ? keys_b : keys_a;
     const uint32_t* vin = flip ? vals_b : vals_a;
-    const bool force_unfused = getenv("A3D_KDTREE_SCAN") && !strcmp(getenv("A3D_KDTREE_SCAN"), "unfused");
+    const char* scan_env = A3D_DIAG_ENV("A3D_KDTREE_SCAN");  // diagnostics build: force the > 2 M-key form at test sizes
+    const bool force_unfused = scan_env && !strcmp(scan_env, "unfused");
     if (nblocks <= 1024 && !force_unfused) {  // up to 2M keys: every scatter block reads the whole table (at most 1 MiB, L2-resident)
       hipLaunchKernelGGL(radix_hist_kernel<true>, dim3(nblocks), dim3(256), 0, s, kin, n, shift, nblocks, hist);
       hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(256), 0, s, kin, vin, flip ? keys_a : keys_b,

@@ -213,6 +213,12 @@ class MultiscaleAlignBatch:
         _abi.check(self.ctx.lib.a3d_multiscale_batch_last_timing(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def persistent_levels(self):
+        """Bit mask of the levels the most recent align ran inside the persistent kernel."""
+        m = C.c_uint32()
+        _abi.check(self.ctx.lib.a3d_multiscale_batch_persistent_levels(self.handle, C.byref(m)))
+        return int(m.value)
+
     def concurrency(self):
         """Number of pair groups whose launches run on separate streams at the same time."""
         n = C.c_uint32()

@@ -123,7 +123,12 @@ typedef struct a3d_pcl_icp a3d_pcl_icp;                 /* Icp */
  * Lifetime of images: the objects that read images (a3d_multiscale, a3d_multiscale_batch) borrow them like the
  * reference's `&'a Vec<RangeImage>`; an image must not be freed while a host-synchronous call on it is running.
  * After an enqueue-only batch_align the images MAY be freed right away: a3d_range_image_free waits for the batch's
- * launches (also when batch and image live on different contexts / streams) before the memory is recycled. */
+ * launches (also when batch and image live on different contexts / streams) before the memory is recycled.
+ * Lifetime of contexts: every handle created on a context (a3d_multiscale, batches, kd-trees, Icp objects) must be
+ * freed before a3d_context_destroy.  Images are the exception — they are data and tend to outlive the code that made
+ * them: a3d_context_destroy with images of that context still alive waits for the context's work, refuses new work
+ * on it, and the context's memory (the pyramid arenas those images live in, its streams) is released when the last
+ * such image is freed; a3d_range_image_free on them stays valid. */
 
 uint32_t a3d_abi_version(void);
 /* Text of the most recent failure on the calling thread ("" if none). */
@@ -136,6 +141,19 @@ a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx);
  * that shares the GPU with a batch alignment wants the highest: its many short kernels are then dispatched ahead of
  * the alignment's long ones instead of queueing behind them (the build is the dependent chain of the two). */
 a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priority, a3d_context** out_ctx);
+/* How the ICP pixel pass of the alignments created on `ctx` is cut into blocks (no reference counterpart: the
+ * reference's own sums depend on the order rayon delivers its 75 chunks in, src/icp/image_icp.rs:96,143-148).
+ *   tiles_per_pair == 0 (default): throughput tiling — the number of blocks a (pair, level) is cut into follows the
+ *     batch size, so that every batch fills the chip; the f32 sums of a pair are then associated differently in a
+ *     batch of 64, a batch of 32 and alone, and its pose can differ in the last bits (more where the reference's
+ *     parameters are not contractive).
+ *   tiles_per_pair  > 0: pinned tiling — every pair's level is cut into that many blocks (fewer when the level is
+ *     small), from the pair's OWN size: a pair's pose is bit-identical alone, in any batch, at any position of a
+ *     batch, next to images of other sizes, on one stream group or three.  24 is what the throughput tiling gives a
+ *     64-pair batch of 640x480 images at level 0, so a 64-pair batch loses nothing at level 0; small batches lose
+ *     parallelism (a lone pair runs on 24 blocks instead of ~120).
+ * Takes effect for batches created or re-bound and single alignments started after the call. */
+a3d_status a3d_context_set_tiling(a3d_context* ctx, uint32_t tiles_per_pair);
 /* An aligning context and the builder context (highest priority) that feeds it, created back to back.  Which compute
  * pipe of the GPU a HIP stream lands on follows the order in which the process creates its streams, and a pipe
  * dispatches one big grid at a time: created as a pair, the builder's kernel stream sits on the pipe of the aligner's
@@ -236,13 +254,15 @@ a3d_status a3d_image_icp_align(a3d_context* ctx, const a3d_icp_params* params,
                                const a3d_pose* init_pose, a3d_pose* out_pose);
 
 /* One pass of the per-pixel body (src/icp/image_icp.rs:101-139) from `pose`, returning the two
- * merged accumulators before add_weighted.  Test hook for per-iteration parity. */
+ * merged accumulators before add_weighted (the state GaussNewton holds at image_icp.rs:148).  Used for per-iteration
+ * parity and by bench.py's live-pixel count. */
 a3d_status a3d_image_icp_accumulate(a3d_context* ctx, const a3d_icp_params* params,
                                     const a3d_device_image* target, const a3d_device_image* source,
                                     const a3d_pose* pose, a3d_gn_state* out_geom,
                                     a3d_gn_state* out_color);
 
-/* Test hook: a3d_image_icp_accumulate through a cross-check kernel in which EVERY per-pixel value — the Jacobians
+#ifdef A3D_DIAGNOSTICS /* exported by the diagnostics build only (csrc/Makefile `diag`: libalign3d_hip_diag.so) */
+/* a3d_image_icp_accumulate through a cross-check kernel in which EVERY per-pixel value — the Jacobians
  * (src/icp/cost_function.rs:33-57), CameraIntrinsics::project_grad (src/camera.rs:82-89) and the products of
  * GaussNewton::step (src/optim/gaussnewton.rs:47-77) — is computed with the reference's own unfused operations and
  * IEEE divisions; only the order of the additions differs.  The product kernel fuses those (they only feed the sums). */
@@ -255,6 +275,7 @@ a3d_status a3d_image_icp_accumulate_exact(a3d_context* ctx, const a3d_icp_params
 a3d_status a3d_image_icp_accumulate_weighted(a3d_context* ctx, const a3d_icp_params* params,
                                              const a3d_device_image* target, const a3d_device_image* source,
                                              const a3d_pose* pose, a3d_gn_state* out_state);
+#endif /* A3D_DIAGNOSTICS */
 
 /* Instrumentation (no reference counterpart): a3d_image_icp_align that also writes, per iteration,
  * [residual, t(3), q_ijkw(4)] of the transform after that iteration's update; out_trace holds
@@ -321,8 +342,13 @@ a3d_status a3d_multiscale_batch_free(a3d_multiscale_batch* batch);
  * time, so that sum can exceed the wall time reported by a3d_multiscale_batch_last_timing. */
 a3d_status a3d_multiscale_batch_set_profiling(a3d_multiscale_batch* batch, int32_t on);
 a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* batch, float* out_kernel_ms);
+/* The same sum for one pyramid level.  Levels that ran inside the persistent kernel (one launch per stream group
+ * for all their iterations) are timed by that kernel's own clock stamps: per group, from the first pair entering the
+ * level to the last pair leaving it; their `launches` are iterations x groups. */
 a3d_status a3d_multiscale_batch_last_level_ms(a3d_multiscale_batch* batch, uint32_t level, float* out_ms,
-                                              uint32_t* out_launches);  /* the same sum for one pyramid level */
+                                              uint32_t* out_launches);
+/* Which levels the most recent batch_align ran inside the persistent kernel (bit l = level l). */
+a3d_status a3d_multiscale_batch_persistent_levels(a3d_multiscale_batch* batch, uint32_t* out_mask);
 a3d_status a3d_multiscale_batch_concurrency(a3d_multiscale_batch* batch, uint32_t* out_streams);
 /* Time of the most recent batch_align on the device, between hipEvents recorded on the context
  * stream around its launches, and the share of it spent in the per-pixel kernel (sum of that

@@ -19,12 +19,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     lib = _abi.load_library()
     header = open(os.path.join(ROOT, "include", "align3d_hip.h")).read()
-    declared = set(re.findall(r"\b(a3d_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 40
+    # what the header declares under #ifdef A3D_DIAGNOSTICS is exported by the diagnostics build only
+    diag_part = "".join(re.findall(r"#ifdef A3D_DIAGNOSTICS(.*?)#endif /\* A3D_DIAGNOSTICS \*/", header, flags=re.S))
+    product_part = re.sub(r"#ifdef A3D_DIAGNOSTICS.*?#endif /\* A3D_DIAGNOSTICS \*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(a3d_[a-z0-9_]+)\s*\(", product_part))
+    diag_declared = set(re.findall(r"\b(a3d_[a-z0-9_]+)\s*\(", diag_part))
+    assert len(declared) >= 40 and diag_declared
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/align3d_hip.h but not exported"
     assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
+    assert diag_declared == set(_abi.DIAG_SIGNATURES), diag_declared ^ set(_abi.DIAG_SIGNATURES)
     assert lib.a3d_abi_version() == 1
+    for name in diag_declared:
+        assert not hasattr(lib, name), f"{name} is a diagnostics entry point but the product library exports it"
+    diag = _abi.load_library(_abi.DIAG_LIB_PATH)
+    for name in declared | diag_declared:
+        assert hasattr(diag, name), f"{name} missing from the diagnostics build"
+
+
+def test_product_library_carries_no_diagnostics():
+    """no environment knob, no rocPRIM, none of the slower kernel variants in libalign3d_hip.so."""
+    blob = open(_abi.LIB_PATH, "rb").read()
+    for needle in (b"A3D_ICP_NOSOLVE", b"A3D_ICP_", b"A3D_KD", b"A3D_BILATERAL", b"A3D_BUILDER", b"rocprim", b"mfma_kernel",
+                   b"image_icp_level_kernel", b"image_icp_exact_kernel"):
+        assert needle not in blob, needle
+    diag = open(_abi.DIAG_LIB_PATH, "rb").read()
+    assert b"A3D_ICP_NOSOLVE" in diag and b"rocprim" in diag
 
 
 def test_struct_layouts_match_header():

@@ -166,7 +166,7 @@ def test_device_pyramid_builder_ragged_sizes_and_blur_sigmas(ctx, w, h, sigma):
     assert e.value.status == 1
 
 
-def test_bilateral_fused_and_unfused_paths_agree(ctx, monkeypatch):
+def test_bilateral_fused_and_unfused_paths_agree(ctx, diag_ctx, monkeypatch):
     """The packed-integer splat + LDS-tiled six-pass blur and the original pass-per-launch path are the same
     function (and both are the oracle's): grids smaller than one tile, tiles cut by every grid face, deep grids."""
     rng = np.random.default_rng(11)
@@ -181,10 +181,13 @@ def test_bilateral_fused_and_unfused_paths_agree(ctx, monkeypatch):
         st, ref, dims = O.bilateral(img, ss, sc)
         outs = {}
         for mode in ("fused", "sync", "unfused"):  # one enqueue / min-max via the host / pass per launch
-            monkeypatch.setenv("A3D_BILATERAL", mode)
+            monkeypatch.setenv("A3D_BILATERAL", mode)  # (read by the diagnostics build only)
             f = BilateralFilter.new(ss, sc)
-            outs[mode] = f.filter(ctx, img)
+            outs[mode] = f.filter(diag_ctx, img)
             assert f.last_grid_dims == dims
+        f = BilateralFilter.new(ss, sc)
+        outs["product"] = f.filter(ctx, img)
+        assert f.last_grid_dims == dims
         assert st == 0 and all(np.array_equal(o, ref) for o in outs.values())
 
 

@@ -13,18 +13,18 @@ def _as_array(poses):
     return np.array([np.concatenate([t.t, t.q]) for t in poses], np.float32)
 
 
-def test_full_size_batch_properties(ctx, monkeypatch):
+def test_full_size_batch_properties(ctx):
     P, W, H = 64, 640, 480
     frames, gt = synth.frame_stream(1000, P + 1, W, H)  # the benchmark's rank-0 stream
     cam = synth.camera(W, H)
     builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
     pyr = [builder.build_device(cam, d, rgb, synth.DEPTH_SCALE) for d, rgb in frames]
     prm = MsIcpParams.repeat(3, IcpParams.default())
-    monkeypatch.setenv("A3D_ICP_WAVES", "1.5")  # pin the tiling: sub-batches then do the same arithmetic per pair
     batch = MultiscaleAlignBatch(ctx, prm, pyr[:P], pyr[1:])
     poses, status = batch.align()
     assert not status.any()
     full = _as_array(poses)
+    assert batch.persistent_levels() == 0b110  # the two coarse levels ran inside the persistent kernel
     # determinism: the same launch sequence gives the same bits
     again, _ = batch.align()
     assert np.array_equal(full.view(np.uint32), _as_array(again).view(np.uint32))
@@ -40,15 +40,35 @@ def test_full_size_batch_properties(ctx, monkeypatch):
     errs, idents = np.array(errs), np.array(idents)
     print(f"[full size] mean error {errs.mean(axis=0)}, identity {idents.mean(axis=0)}")
     assert errs[:, 0].mean() < 0.5 * idents[:, 0].mean() and errs[:, 1].mean() < 0.02 and errs[:, 1].max() < 0.05
-    # a pair's result does not depend on its neighbours: two half batches (same tiling knobs, so the per-pair
-    # tile count differs -> compare to rounding), and pair 5 alone through MultiscaleAlign
+    # Throughput tiling (the default): the cut of a pair into blocks follows the batch size, so two half batches and a
+    # lone pair associate their f32 sums differently; IcpParams::default() is not contractive, which can
+    # move a pose by ~1e-3 — reported here, asserted loosely.
     lo, _ = MultiscaleAlignBatch(ctx, prm, pyr[:32], pyr[1:33]).align()
     hi, _ = MultiscaleAlignBatch(ctx, prm, pyr[32:64], pyr[33:65]).align()
     halves = np.concatenate([_as_array(lo), _as_array(hi)])
-    # IcpParams::default() is not contractive: differently associated sums may move a pose by ~1e-3
+    print(f"[full size] throughput tiling: 64-batch vs two 32-batches max |d| = {np.abs(halves - full).max():.2e}")
     assert np.abs(halves - full).max() < 5e-3
-    single = MultiscaleAlign.new(ctx, prm, pyr[5]).align(pyr[6])
-    assert np.abs(np.concatenate([single.t, single.q]) - full[5]).max() < 5e-3
+    # Pinned tiling (a3d_context_set_tiling): a pair's pose is the same BITS in the 64-pair batch, in a 32-pair batch,
+    # in a 5-pair batch and alone.  24 blocks per pair = what the throughput tiling gives level 0 of
+    # the 64-pair batch.
+    ctx.set_tiling(24)
+    try:
+        b64 = MultiscaleAlignBatch(ctx, prm, pyr[:P], pyr[1:])
+        pinned, st = b64.align()
+        assert not st.any()
+        pinned = _as_array(pinned).view(np.uint32)
+        lo, _ = MultiscaleAlignBatch(ctx, prm, pyr[:32], pyr[1:33]).align()
+        hi, _ = MultiscaleAlignBatch(ctx, prm, pyr[32:64], pyr[33:65]).align()
+        assert np.array_equal(np.concatenate([_as_array(lo), _as_array(hi)]).view(np.uint32), pinned)
+        few, _ = MultiscaleAlignBatch(ctx, prm, pyr[3:8], pyr[4:9]).align()
+        assert np.array_equal(_as_array(few).view(np.uint32), pinned[3:8])
+        for p in (5, 40):
+            single = MultiscaleAlign.new(ctx, prm, pyr[p]).align(pyr[p + 1])
+            assert np.array_equal(np.concatenate([single.t, single.q]).view(np.uint32), pinned[p])
+        # and it is the throughput tiling's level-0 cut of this very batch: the poses stay within rounding of it
+        assert np.abs(pinned.view(np.float32) - full).max() < 5e-3
+    finally:
+        ctx.set_tiling(0)
     for p in pyr:
         for lv in p:
             lv.free()

@@ -21,7 +21,8 @@ TRANS_TOL = 1e-4  # m
 ACC_TOL = 1e-6  # relative, per-iteration accumulators vs f64-summed oracle
 
 
-def _check_accumulators(ctx, prm, ft, fs, T):
+def _check_accumulators(ctx, prm, ft, fs, T, diag_ctx=None):
+    """`diag_ctx`: also run the exact-arithmetic cross-check kernel, which only the diagnostics build contains."""
     icp = ImageIcp.new(ctx, prm, to_range_image(ft))
     g_gpu, c_gpu = icp.accumulate(to_range_image(fs), T)
     st, g_ref, c_ref = O.image_icp_accumulate(prm.to_c(), ft, fs, T.to_c(), accum_f64=True)
@@ -35,13 +36,14 @@ def _check_accumulators(ctx, prm, ft, fs, T):
     # The cross-check kernel computes every per-pixel value in the reference's own unfused operations; both kernels add
     # the same pixels in the same order, so their difference is exactly what the product kernel's fused Jacobians cost
     # — a real Jacobian error could not hide in it (measured ~1e-7; an error in one term would show at 1e-3 or more)
-    g_ex, c_ex = icp.accumulate_exact(to_range_image(fs), T)
-    assert g_ex["count"] == g_ref["count"] and c_ex["count"] == c_ref["count"]
-    for ex, ref, gpu in ((g_ex, g_ref, g_gpu), (c_ex, c_ref, c_gpu)):
-        eh, eg, es = gn_rel_err(ex, ref)
-        assert eh < ACC_TOL and eg < ACC_TOL and es < ACC_TOL, ("exact kernel vs oracle", eh, eg, es)
-        fh, fg, fs_ = gn_rel_err(gpu, ex)
-        assert fh < 5e-7 and fg < 5e-7 and fs_ < 5e-7, ("fused vs exact kernel", fh, fg, fs_)
+    if diag_ctx is not None:
+        g_ex, c_ex = ImageIcp.new(diag_ctx, prm, to_range_image(ft)).accumulate_exact(to_range_image(fs), T)
+        assert g_ex["count"] == g_ref["count"] and c_ex["count"] == c_ref["count"]
+        for ex, ref, gpu in ((g_ex, g_ref, g_gpu), (c_ex, c_ref, c_gpu)):
+            eh, eg, es = gn_rel_err(ex, ref)
+            assert eh < ACC_TOL and eg < ACC_TOL and es < ACC_TOL, ("exact kernel vs oracle", eh, eg, es)
+            fh, fg, fs_ = gn_rel_err(gpu, ex)
+            assert fh < 5e-7 and fg < 5e-7 and fs_ < 5e-7, ("fused vs exact kernel", fh, fg, fs_)
     # and close to the f32 accumulation order the reference itself would use
     st, g32, c32 = O.image_icp_accumulate(prm.to_c(), ft, fs, T.to_c(), accum_f64=False)
     eh, eg, es = gn_rel_err(g_gpu, g32.as_dict())
@@ -77,16 +79,16 @@ def _oracle_step(prm, ft, fs, T, accum_f64):
 
 @pytest.mark.parametrize("sample,tgt,src,bilateral", [("sample1", 0, 5, False), ("sample2", 0, 1, True)])
 @pytest.mark.parametrize("which", ["default", "ms"])
-def test_per_iteration_accumulators(ctx, sample, tgt, src, bilateral, which):
+def test_per_iteration_accumulators(ctx, diag_ctx, sample, tgt, src, bilateral, which):
     ft, fs = oracle_frame(sample, tgt, bilateral), oracle_frame(sample, src, bilateral)
     prm = IcpParams.default() if which == "default" else MsIcpParams.default()[0]
-    _check_accumulators(ctx, prm, ft, fs, Transform.eye())
-    _check_accumulators(ctx, prm, ft, fs, small_pose(1))
-    _check_merged_accumulator(ctx, prm, ft, fs, Transform.eye())
-    _check_merged_accumulator(ctx, prm, ft, fs, small_pose(1))
+    _check_accumulators(ctx, prm, ft, fs, Transform.eye(), diag_ctx)
+    _check_accumulators(ctx, prm, ft, fs, small_pose(1), diag_ctx)
+    _check_merged_accumulator(diag_ctx, prm, ft, fs, Transform.eye())
+    _check_merged_accumulator(diag_ctx, prm, ft, fs, small_pose(1))
 
 
-def test_teacher_forced_along_oracle_trajectory(ctx):
+def test_teacher_forced_along_oracle_trajectory(ctx, diag_ctx):
     # bench10 shape (benches/bench_image_icp.rs): sample1 0 <- 5, IcpParams::default, 10 iterations.
     ft, fs = oracle_frame("sample1", 0), oracle_frame("sample1", 5)
     prm = IcpParams(max_iterations=10)
@@ -94,8 +96,8 @@ def test_teacher_forced_along_oracle_trajectory(ctx):
     assert st == 0
     for it in (0, 3, 8):
         T = Transform(trace[it, 1:4], trace[it, 4:8])
-        _check_accumulators(ctx, prm, ft, fs, T)
-        _check_merged_accumulator(ctx, prm, ft, fs, T)
+        _check_accumulators(ctx, prm, ft, fs, T, diag_ctx)
+        _check_merged_accumulator(diag_ctx, prm, ft, fs, T)
     # end-to-end on this non-contractive configuration: reported only
     T_gpu, tr_gpu = ImageIcp.new(ctx, prm, to_range_image(ft)).align(to_range_image(fs), trace=True)
     ang, tr = transform_diff(T_gpu, T_ref)
@@ -207,8 +209,9 @@ def test_batch_matches_single_pairs(ctx):
     mats = ctx.to_host(d_mats, np.zeros((len(pairs), 4, 4), np.float32))
     for k in range(len(pairs)):
         single = MultiscaleAlign.new(ctx, prm, tps[k]).align(sps[k])
-        # same kernels, but the tiling (pixels per thread) depends on the batch size, so the f32 sums
-        # are associated differently: equal to rounding, not bit for bit
+        # same kernels, but under the default (throughput) tiling the cut into blocks follows the batch size, so the
+        # f32 sums are associated differently: equal to rounding, not bit for bit (pinned tiling: see
+        # test_pinned_tiling_makes_a_pair_independent_of_its_batch)
         assert np.allclose(single.t, poses[k].t, atol=2e-6) and np.allclose(single.q, poses[k].q, atol=2e-6)
         assert np.allclose(mats[k], poses[k].matrix(), atol=1e-6)
         s, a, b = pairs[k]
@@ -249,9 +252,10 @@ def test_cpp_host_mirror_on_gpu():
     assert out.returncode == 0 and "GPU checks OK" in out.stdout, out.stdout + out.stderr
 
 
-def test_level_kernel_matches_per_iteration_launches(ctx, monkeypatch):
-    """The opt-in persistent form (one launch per pyramid level, blocks wait on a per-pair epoch word instead of
-    exiting: A3D_ICP_PERSISTENT=1) computes the same alignment as the default one-launch-per-iteration form."""
+def test_level_kernel_matches_per_iteration_launches(diag_ctx, monkeypatch):
+    """The round-1 persistent form (diagnostics build: one last-block-form launch per pyramid level, blocks wait on a
+    per-pair epoch word instead of exiting: A3D_ICP_PERSISTENT=1) computes the same alignment as the default path."""
+    ctx = diag_ctx
     prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 6))
     pairs = [("sample1", 0, 5), ("sample2", 0, 4), ("sample1", 1, 4)]
     tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs]
@@ -286,7 +290,7 @@ def test_level_kernel_matches_per_iteration_launches(ctx, monkeypatch):
     assert np.allclose(p2[1].t, ref_poses[1].t, atol=2e-6)
 
 
-def test_stream_groups_do_not_change_any_pair(ctx, monkeypatch):
+def test_stream_groups_do_not_change_any_pair(diag_ctx, monkeypatch):
     """A batch of >= 12 pairs runs as three pair groups on three HIP streams.  With the tiling pinned, a pair's
     arithmetic does not depend on which group it is in, so the poses must equal the one-stream run bit for bit —
     on every repeat (the groups drift apart in time, so they must not share any scratch: regression test for
@@ -297,7 +301,8 @@ def test_stream_groups_do_not_change_any_pair(ctx, monkeypatch):
     pairs = (base * 3)[:20]
     tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs]
     sps = [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in pairs]
-    monkeypatch.setenv("A3D_ICP_WAVES", "1.5")
+    ctx = diag_ctx  # (A3D_ICP_STREAMS is a knob of the diagnostics build)
+    ctx.set_tiling(24)  # pinned: the cut of a pair into blocks must not follow the stream count
 
     def run(streams, repeats):
         monkeypatch.setenv("A3D_ICP_STREAMS", str(streams))
@@ -311,8 +316,15 @@ def test_stream_groups_do_not_change_any_pair(ctx, monkeypatch):
         batch.free()
         return outs
 
-    one = run(1, 1)[0]
-    for o in run(3, 6) + run(2, 3):
+    try:
+        one = run(1, 1)[0]
+        many = run(3, 6) + run(2, 3)
+        monkeypatch.setenv("A3D_ICP_PERSIST", "0")  # and without the persistent kernel: the same bits again
+        many += run(3, 2)
+        monkeypatch.delenv("A3D_ICP_PERSIST")
+    finally:
+        ctx.set_tiling(0)
+    for o in many:
         assert np.array_equal(o, one)
     # equal inputs give equal outputs wherever they sit in the batch
     for k in range(7, 20):
@@ -386,15 +398,21 @@ def test_ragged_small_images_per_iteration(ctx, w, h):
     {"A3D_ICP_WAVES": "0.1"},
     {"A3D_ICP_VARIANT": "7,1"},
     {"A3D_ICP_STREAMS": "2", "A3D_ICP_WAVES_LEVELS": "2,1,0.5"},
+    {"A3D_ICP_PERSIST": "0"},
+    {"A3D_ICP_PERSIST": "7"},
+    {"A3D_ICP_PERSIST": "4", "A3D_ICP_STREAMS": "1"},
+    {"A3D_ICP_SOLVE": "exact"},
+    {"A3D_ICP_HANDOFF": "ticket"},
 ])
-def test_opt_in_kernel_variants_keep_parity(ctx, monkeypatch, knobs):
+def test_opt_in_kernel_variants_keep_parity(diag_ctx, monkeypatch, knobs):
     """The tuning knobs select other kernels / tilings (MFMA accumulation, 2 or 4 pixels per pipeline step, odd
     pixel counts per thread, more or fewer blocks): none may change what is computed beyond the association of
     the f32 sums."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
+    ctx = diag_ctx
     ft, fs = oracle_frame("sample1", 0, False), oracle_frame("sample1", 5, False)
-    _check_accumulators(ctx, MsIcpParams.default()[0], ft, fs, small_pose(1))
+    _check_accumulators(ctx, MsIcpParams.default()[0], ft, fs, small_pose(1), diag_ctx)
     prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 5))
     pairs = [("sample1", 0, 5), ("sample2", 0, 4)] * 7  # 14 pairs: the stream groups are in play
     tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs]
@@ -765,13 +783,14 @@ def test_pyramid_upload_shares_one_arena_and_changes_nothing(ctx):
     dev.free()
 
 
-def test_head_solve_and_last_block_handoff_give_the_same_bits(ctx, monkeypatch):
+def test_head_solve_and_last_block_handoff_give_the_same_bits(diag_ctx, monkeypatch):
     """The two hand-off forms (icp_engine.hpp) add the same partials in the same order and run the same solve: a batch
     of uploaded pyramids (masks read) and a batch of device-built ones (masks derived from z) must give bit-identical
     poses with the default head-solve form and with A3D_ICP_HANDOFF=ticket; a single pair and a trace likewise."""
     import bench
     from align3d_amd import synth
 
+    ctx = diag_ctx  # (the last-block form exists in the diagnostics build only)
     prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 7))
     pairs = [("sample1", 0, 5), ("sample2", 0, 4), ("sample1", 1, 4), ("sample1", 4, 5)]
     tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in pairs]
@@ -799,7 +818,154 @@ def test_head_solve_and_last_block_handoff_give_the_same_bits(ctx, monkeypatch):
     monkeypatch.setenv("A3D_ICP_HANDOFF", "ticket")
     ticket = run_all()
     monkeypatch.delenv("A3D_ICP_HANDOFF")
-    for h, t in zip(head, ticket):
+    monkeypatch.setenv("A3D_ICP_PERSIST", "0")  # head-solve form, one launch per iteration (no persistent kernel)
+    per_iteration = run_all()
+    monkeypatch.delenv("A3D_ICP_PERSIST")
+    for h, t, q in zip(head, ticket, per_iteration):
         assert np.array_equal(h.view(np.uint32), t.view(np.uint32))
+        assert np.array_equal(h.view(np.uint32), q.view(np.uint32))
     for lv in (lv for p in built for lv in p):
         lv.free()
+
+
+def _pose_bits(poses):
+    return np.array([np.concatenate([t.t, t.q]) for t in poses], np.float32).view(np.uint32)
+
+
+def test_pinned_tiling_makes_a_pair_independent_of_its_batch(ctx):
+    """a3d_context_set_tiling(n): every (pair, level) is cut into n blocks from the pair's OWN size, so a pair's pose is
+    the same bits alone, at any position of any batch, and next to images of another size.  Uses
+    the non-contractive IcpParams::default() on purpose: there a re-associated sum moves the pose visibly."""
+    from align3d_amd import synth
+
+    prm = MsIcpParams.repeat(3, IcpParams.default()).customize(lambda i, p: setattr(p, "max_iterations", 6))
+    base = [("sample1", 0, 5), ("sample2", 0, 4), ("sample1", 1, 4), ("sample1", 4, 5), ("sample2", 1, 0)]
+    tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in base]
+    sps = [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in base]
+    # a pair of another size (320x240 synthetic frames, 3 levels): mixed batches must not change anybody
+    frames, _ = synth.frame_stream(5, 2, 320, 240)
+    cam = synth.camera(320, 240)
+    small = [[to_range_image(f) for f in O.build_pyramid(d, rgb, cam.fx, cam.fy, cam.cx, cam.cy, synth.DEPTH_SCALE)]
+             for d, rgb in frames]
+    for tiles in (8, 24):
+        ctx.set_tiling(tiles)
+        try:
+            alone = [MultiscaleAlign.new(ctx, prm, tps[k]).align(sps[k]) for k in range(len(base))]
+            alone_small = MultiscaleAlign.new(ctx, prm, small[0]).align(small[1])
+            ref = _pose_bits(alone)
+            b5, st = MultiscaleAlignBatch(ctx, prm, tps, sps).align()
+            assert not st.any() and np.array_equal(_pose_bits(b5), ref)
+            # 17 pairs (three stream groups), rotated order, the small pair in the middle
+            order = [(k * 3 + 1) % 5 for k in range(16)]
+            t17 = [tps[k] for k in order[:8]] + [small[0]] + [tps[k] for k in order[8:]]
+            s17 = [sps[k] for k in order[:8]] + [small[1]] + [sps[k] for k in order[8:]]
+            b17, st = MultiscaleAlignBatch(ctx, prm, t17, s17).align()
+            assert not st.any()
+            got = _pose_bits(b17)
+            assert np.array_equal(got[8], _pose_bits([alone_small])[0])
+            assert np.array_equal(np.delete(got, 8, axis=0), ref[order])
+        finally:
+            ctx.set_tiling(0)
+    # under the default tiling the same comparison only holds to rounding (that is what the mode is for)
+    alone = MultiscaleAlign.new(ctx, prm, tps[0]).align(sps[0])
+    b5, _ = MultiscaleAlignBatch(ctx, prm, tps, sps).align()
+    print("[tiling] throughput tiling, pair alone vs in a batch of 5: max |d| =",
+          float(np.abs(np.concatenate([alone.t, alone.q]) - np.concatenate([b5[0].t, b5[0].q])).max()))
+
+
+def test_persistent_kernel_and_per_iteration_launches_give_the_same_bits(ctx, diag_ctx, monkeypatch):
+    """The persistent head-solve kernel (image_icp.hip: many iterations in one launch, one-hop counter hand-off, every
+    block sums the pair's partials itself) adds the same partials in the same order and runs the same solve as the
+    per-iteration launches: under one tiling both give the same bits — for a lone pair (all levels persistent, outputs
+    written by the kernel), a trace, a small batch and a three-group batch (coarse levels persistent).  The product
+    library must agree with the diagnostics build's per-iteration run."""
+    prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 7))
+    base = [("sample1", 0, 5), ("sample2", 0, 4), ("sample1", 1, 4), ("sample1", 4, 5)]
+    tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in base]
+    sps = [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in base]
+    t14, s14 = (tps * 4)[:14], (sps * 4)[:14]
+
+    def run_all(c):
+        out = []
+        out.append(MultiscaleAlign.new(c, prm, tps[0]).align(sps[0]).matrix())
+        T, tr = ImageIcp.new(c, prm[0], tps[1][0]).align(sps[1][0], trace=True)
+        out.append(tr.copy())
+        for t, s in ((tps, sps), (t14, s14)):
+            b = MultiscaleAlignBatch(c, prm, t, s)
+            poses, status = b.align()
+            again, _ = b.align()  # the pairs' counters keep counting across alignments of one batch
+            masks = b.persistent_levels()
+            b.free()
+            assert not status.any() and np.array_equal(_pose_bits(poses), _pose_bits(again))
+            out.append(_pose_bits(poses))
+            out.append(np.array([masks]))
+        return out
+
+    for c in (ctx, diag_ctx):
+        c.set_tiling(12)
+    try:
+        product = run_all(ctx)
+        persistent = run_all(diag_ctx)
+        monkeypatch.setenv("A3D_ICP_PERSIST", "0")
+        per_iteration = run_all(diag_ctx)
+        monkeypatch.delenv("A3D_ICP_PERSIST")
+    finally:
+        for c in (ctx, diag_ctx):
+            c.set_tiling(0)
+    assert product[3][0] == 0b111 and product[5][0] == 0b110 and per_iteration[3][0] == 0 and per_iteration[5][0] == 0
+    for k in (0, 1, 2, 4):
+        assert np.array_equal(product[k].view(np.uint32), per_iteration[k].view(np.uint32)), k
+        assert np.array_equal(product[k].view(np.uint32), persistent[k].view(np.uint32)), k
+
+
+def test_rsqrt_solve_and_ieee_solve_round_to_the_same_update(diag_ctx, monkeypatch):
+    """The 6x6 solve multiplies by a refined 1/sqrt(pivot) instead of nalgebra's sqrt and divisions (icp_engine.hpp);
+    A3D_ICP_SOLVE=exact (diagnostics build) runs the IEEE sqrt / divide / unfused form.  From identical states both must
+    round to the same f32 update: one-iteration alignments from several initial poses on the golden pairs."""
+    ctx = diag_ctx
+    cases = [("sample1", 0, 5, IcpParams.default()), ("sample2", 0, 1, IcpParams.default()),
+             ("sample1", 0, 1, MsIcpParams.default()[0]), ("sample2", 0, 4, MsIcpParams.default()[0])]
+    same = total = 0
+    for s, a, b, prm in cases:
+        prm.max_iterations = 1
+        ft, fs = to_range_image(oracle_frame(s, a)), to_range_image(oracle_frame(s, b))
+        for seed in range(6):
+            icp = ImageIcp.new(ctx, prm, ft)
+            icp.initial_transform = small_pose(seed) if seed else Transform.eye()
+            fast = icp.align(fs)
+            monkeypatch.setenv("A3D_ICP_SOLVE", "exact")
+            icp2 = ImageIcp.new(ctx, prm, ft)
+            icp2.initial_transform = icp.initial_transform
+            exact = icp2.align(fs)
+            monkeypatch.delenv("A3D_ICP_SOLVE")
+            x, y = np.concatenate([fast.t, fast.q]), np.concatenate([exact.t, exact.q])
+            total += 1
+            same += bool(np.array_equal(x.view(np.uint32), y.view(np.uint32)))
+            assert np.abs(x - y).max() <= 2.4e-7, (s, a, b, seed, x, y)  # at most last-bit ties of the f32 update
+    print(f"[solve] rsqrt vs IEEE solve: {same} of {total} one-iteration poses bit-identical")
+    assert same >= total - 3
+
+
+def test_context_destroyed_before_its_images_defers_to_the_last_image():
+    """a3d_context_destroy with images alive must not free their arenas; the context goes when the
+    last image is freed (C and Rust callers are not protected by Python's handle check)."""
+    import ctypes as C
+    from align3d_amd import Context, _abi
+
+    c = Context(0, pair=False)
+    fr = oracle_pyramid("sample1", 0)
+    devs = [to_range_image(f).device(c) for f in fr]
+    handles = [d.handle for d in devs]
+    lib, ch = c.lib, c.handle
+    assert lib.a3d_context_destroy(ch) == 0  # deferred: the images keep it alive
+    c.handle = C.c_void_p()                  # (Python's own guard would skip the frees below)
+    # a zombie context refuses new work that needs an arena ...
+    v = to_range_image(fr[0]).view()
+    h = C.c_void_p()
+    assert lib.a3d_range_image_upload(ch, C.byref(v), C.byref(h)) != 0
+    # ... its images are still readable and freeable; the last free tears the context down
+    w, hh = C.c_uint64(), C.c_uint64()
+    assert lib.a3d_range_image_size(handles[0], C.byref(w), C.byref(hh)) == 0 and (w.value, hh.value) == (640, 480)
+    for d, hd in zip(devs, handles):
+        assert lib.a3d_range_image_free(hd) == 0
+        d.handle = C.c_void_p()

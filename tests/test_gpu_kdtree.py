@@ -122,23 +122,28 @@ def _kd_cases():
 @pytest.mark.parametrize("case", ["n1", "n16", "n17", "n33", "n1000", "dup", "neg", "n270213"])
 @pytest.mark.parametrize("wide_len", [None, 64, 1 << 30])
 @pytest.mark.parametrize("sort", [None, "rocprim"])
-def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, monkeypatch, case, wide_len, sort):
+def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monkeypatch, case, wide_len, sort):
     """The device build (hand-written device-wide radix sort for the long ranges + LDS bitonic sort on
     (key, position) words for the short ones; rocPRIM's stable sorts as the cross-check) lays out exactly the tree
     of the host build (std::stable_sort per node = R3dTree::new, src/kdtree.rs:28-58): split table and every leaf
     slot."""
     db = _kd_cases()[case]
-    host = _build(ctx, db, "host", monkeypatch)
-    dev = _build(ctx, db, "device", monkeypatch, wide_len, sort)
+    host = _build(diag_ctx, db, "host", monkeypatch)  # (the host build and the knobs exist in the diagnostics build only)
+    dev = _build(diag_ctx, db, "device", monkeypatch, wide_len, sort)
     assert dev.stats() == host.stats()
     hs, hl = host.download()
     ds, dl = dev.download()
     assert np.array_equal(ds, hs)
     assert np.array_equal(dl, hl)
+    if wide_len is None and sort is None:  # and the PRODUCT library's build (no knobs) is that tree too
+        prod = R3dTree.new(ctx, db)
+        ps, pl = prod.download()
+        assert prod.stats() == host.stats() and np.array_equal(ps, hs) and np.array_equal(pl, hl)
 
 
 @pytest.mark.parametrize("case", ["n1000", "dup", "n270213"])
-def test_kdtree_device_build_with_the_separate_scan_kernel(ctx, monkeypatch, case):
+def test_kdtree_device_build_with_the_separate_scan_kernel(diag_ctx, monkeypatch, case):
+    ctx = diag_ctx
     """Above 4M keys the radix passes keep their digit-major table and one-block scan kernel instead of deriving the
     offsets inside the scatter blocks; A3D_KDTREE_SCAN=unfused forces that form at test sizes.  Same tree."""
     db = _kd_cases()[case]

@@ -162,10 +162,10 @@ def test_batched_odometry_of_a_recorded_sequence_equals_the_frame_by_frame_loop(
         assert ang <= 1e-5 and tr <= 1e-5
 
 
-def test_masks_derived_from_z_change_nothing(ctx):
+def test_masks_derived_from_z_change_nothing(ctx, diag_ctx):
     """Device-built pyramids carry mask == (z != 0), so the alignment kernel skips the two mask bytes per pixel
-    (A3D_ICP_ZMASK, image_icp.hip).  With the bytes read (A3D_ICP_ZMASK=0), with the same pyramids uploaded from host
-    arrays (which never take the short cut), and on frames with large invalid regions: bit-identical poses."""
+    (ZMASK, image_icp.hip).  With the bytes read (diagnostics build, A3D_ICP_ZMASK=0), with the same pyramids uploaded
+    from host arrays (which never take the short cut), and on frames with large invalid regions: bit-identical poses."""
     from align3d_amd import MultiscaleAlignBatch
 
     ds = SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1"))
@@ -181,8 +181,8 @@ def test_masks_derived_from_z_change_nothing(ctx):
     prm = MsIcpParams.default()
     pairs = [(0, 1), (2, 3), (1, 2)]
 
-    def run(tp, sp):
-        b = MultiscaleAlignBatch(ctx, prm, tp, sp)
+    def run(tp, sp, c=ctx):
+        b = MultiscaleAlignBatch(c, prm, tp, sp)
         poses, status = b.align()
         b.free()
         assert not status.any()
@@ -190,9 +190,14 @@ def test_masks_derived_from_z_change_nothing(ctx):
 
     tp, sp = [pyr[a] for a, _ in pairs], [pyr[b] for _, b in pairs]
     fast = run(tp, sp)
+    # the same frames built by the diagnostics build of the library (its own pyramids): masks derived, then masks read
+    dbuilder = RangeImageBuilder(diag_ctx).with_bilateral_filter(BilateralFilter.default())
+    dpyr = dbuilder.build_many(cam, frames, scale)
+    dtp, dsp = [dpyr[a] for a, _ in pairs], [dpyr[b] for _, b in pairs]
+    assert np.array_equal(fast.view(np.uint32), run(dtp, dsp, diag_ctx).view(np.uint32))
     os.environ["A3D_ICP_ZMASK"] = "0"
     try:
-        slow = run(tp, sp)
+        slow = run(dtp, dsp, diag_ctx)
     finally:
         del os.environ["A3D_ICP_ZMASK"]
     assert np.array_equal(fast.view(np.uint32), slow.view(np.uint32))

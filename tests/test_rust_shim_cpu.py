@@ -31,6 +31,8 @@ def test_sys_rs_is_the_generators_output_for_the_current_header():
 
 def test_every_header_symbol_is_bound_with_the_right_arity_and_pointer_kinds():
     header = open(os.path.join(ROOT, "include", "align3d_hip.h")).read()
+    # (the entry points of the diagnostics build are not part of what a Rust host binds)
+    header = re.sub(r"#ifdef A3D_DIAGNOSTICS.*?#endif /\* A3D_DIAGNOSTICS \*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(a3d_[a-z0-9_]+)\s*\(", header))
     text, fns = _rust_functions()
     assert set(fns) == declared == set(_abi.SIGNATURES)
