@@ -582,26 +582,32 @@ __device__ __forceinline__ void head_sum_and_advance(uint32_t state_bits, const 
           sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
         }
       }
-      for (; t + 56 < tiles; t += 64) {
+      // what is left (at most 256 tiles for this launch geometry) in ONE round of loads: up to 32 in flight per thread,
+      // masked — a lone pair's 150-200 tiles took four dependent rounds of eight; tile order as before, so the same bits
+      if (t + 56 < tiles) {
+        unsigned long long v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const uint32_t tt = t + 8 * k;
+          v[k] = tt < tiles ? ld_partial_pair<COHERENT>(base + (size_t)tt * (GN_PARTIAL / 2)) : 0ull;  // +0.0f, +0.0f
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          sum0 += (double)__uint_as_float((unsigned)v[k]);
+          sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
+        }
+      } else {
         unsigned long long v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = ld_partial_pair<COHERENT>(base + (size_t)(t + 8 * k) * (GN_PARTIAL / 2));
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t tt = t + 8 * k;
+          v[k] = tt < tiles ? ld_partial_pair<COHERENT>(base + (size_t)tt * (GN_PARTIAL / 2)) : 0ull;  // +0.0f, +0.0f
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           sum0 += (double)__uint_as_float((unsigned)v[k]);
           sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
         }
-      }
-      unsigned long long v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t tt = t + 8 * k;
-        v[k] = tt < tiles ? ld_partial_pair<COHERENT>(base + (size_t)tt * (GN_PARTIAL / 2)) : 0ull;  // +0.0f, +0.0f
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        sum0 += (double)__uint_as_float((unsigned)v[k]);
-        sum1 += (double)__uint_as_float((unsigned)(v[k] >> 32));
       }
       s_sums[slice][2 * cg] = sum0;
       s_sums[slice][2 * cg + 1] = sum1;

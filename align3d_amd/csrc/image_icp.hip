@@ -490,67 +490,110 @@ __global__ void __launch_bounds__(256, 1)
   block_reduce_store<GN_PARTIAL, false>(acc, partials_out + (size_t)pair * job_stride + (size_t)tile * GN_PARTIAL);
 }
 
-// ---- many iterations in one launch: the persistent head-solve kernel ------------------------------------------------
+#ifdef A3D_DIAGNOSTICS
+// ---- many iterations in one launch: the persistent head-solve kernel (round 4; measured SLOWER than kernel
+// boundaries on MI355X — DESIGN.md, ruled out — and therefore only in the diagnostics build: A3D_ICP_PERSIST=mask) ----
 // What a kernel boundary costs between two dependent iterations (launch + completion, ~4.5 us on MI355X) is more than
 // the pixel pass of a coarse level or of a lone pair.  Here the blocks of a pair stay resident and run a whole schedule
-// of (level, iterations) entries.  The hand-off between two iterations is ONE hop: a block stores its partial
-// write-through, drains, and adds 1 to the pair's counter; every block of the pair waits until the counter shows that
-// all partials of the iteration are out, then sums them itself (same fixed order as head_advance: same bits) and runs
-// the solve redundantly — there is no last block, no published state and no second hop back (the round-1/2 level
-// kernel had both and lost to kernel boundaries).  The state of the pair lives in every block's LDS and never touches
-// memory until tile 0 stores it at the end; the partials alternate between the same two buffers as the per-iteration
-// launches use, so a launch of image_icp_head_kernel can continue where this kernel stops (and does, for level 0 of a
-// batch).  Pairs never wait for each other.
-//   * counter: monotonic per pair; `counter_base` = its value when the launch starts (the host advances it by the
-//     schedule's total, so nothing is reset between launches).
-//   * blocks whose tile index is beyond a level's tile count take no pixels at that level but follow every solve.
-//   * forward progress: all blocks of a pair must become resident while others of that pair spin.  Blocks are dispatched
-//     in index order (tiles of a pair are consecutive), so at most one pair per grid is partly resident and every
-//     other resident pair runs to completion and frees its slots; the host keeps a grid within what the chip holds at
-//     once whenever it can (plan_tiling), and a spin that exceeds its bound marks the pair A3D_HIP_ERROR and leaves.
+// of (level, iterations) entries.  The hand-off between two iterations is ONE hop: a block stores its partials
+// write-through, drains, and adds their number to the pair's counter; every block of the pair waits until the counter
+// shows that all partials of the iteration are out, then sums them itself (same fixed order as head_advance: same
+// bits) and runs the solve redundantly — there is no last block, no published state and no second hop back (the
+// round-1/2 level kernel had both and lost to kernel boundaries).  The state of the pair lives in every block's LDS and
+// never touches memory until one block stores it at the end; the partials alternate between the same two buffers as
+// the per-iteration launches use, so a launch of image_icp_head_kernel can continue where this kernel stops (and
+// does, for level 0 of a batch).  Pairs never wait for each other.
+//   * forward progress without assuming that the whole grid is resident: the blocks of a pair REGISTER when they start
+//     (one atomic add on the pair's roster word, which also hands out ranks).  The roster closes when all blocks of the
+//     pair have arrived — at once on a GPU the process has to itself — or when a registered block has waited
+//     ROSTER_WAIT_TICKS for the rest (the chip is shared and some blocks have no slot yet): the R blocks registered by
+//     then share the pair's tiles (rank r takes tiles r, r + R, ...), a block that arrives later leaves at once.
+//     Everybody a block ever waits for is therefore running.  Which block computes a tile does not change the tile's
+//     partial, and the partials are summed in tile order: the result does not depend on R.
+//   * control words per pair (PAIR_CTRL_WORDS, 256 bytes apart so that the pairs' polls spread over the memory
+//     channels): [0] counter, monotonic — `counter_base` = its value when the launch starts (the host advances it by the
+//     schedule's total, so nothing is reset between launches); [1 + parity] roster (count | closed bit), [3 + parity]
+//     R, published by whoever closed the roster.  Launches alternate the parity; rank 0 of a launch zeroes the other
+//     parity's words for the next one.
+//   * a pair's own tile count below the level's (a smaller image in a mixed batch): the surplus tiles are zero partials.
 struct PersistLevel {
   uint32_t desc_base;   // descs[desc_base + pair] describes this level
   uint32_t iterations;
-  uint32_t tiles;       // blocks per pair that publish a partial at this level (<= gridDim.x)
+  uint32_t tiles;       // partials per pair and iteration at this level (<= gridDim.x)
   float weight, color_weight;
   Gates gates;
 };
 constexpr int PERSIST_MAX_LEVELS = 16;
-// How long a block waits for its pair's partners before it gives the pair up: 100 ms of the 100 MHz clock.  A level-0
-// pass of a full batch takes ~0.15 ms, so only a partner that is not resident at all (the chip shared with another
-// process's persistent grid) can be this late.
-constexpr unsigned long long PERSIST_SPIN_BOUND_TICKS = 10'000'000ull;
+constexpr uint32_t PAIR_CTRL_WORDS = 64;  // 256 bytes per pair
+constexpr uint32_t ROSTER_CLOSED = 0x80000000u;
+// s_memrealtime ticks (100 MHz).  The roster wait only matters on a shared GPU; the spin bound is a safety net (a
+// registered partner is running by construction, so only a fault elsewhere can make it this late).
+constexpr unsigned long long ROSTER_WAIT_TICKS = 2000ull, PERSIST_SPIN_BOUND_TICKS = 200'000'000ull;
 struct PersistPlan {
   uint32_t n_levels;       // schedule entries, in execution order (coarsest level first)
   uint32_t seq0;           // launches / iterations that ran before this kernel (selects the buffer parity)
   uint32_t counter_base;
   uint32_t finish;         // 1: apply the last iteration too and write the outputs (no job_finish launch needed)
+  uint32_t parity;         // which roster words this launch uses
   int trace_index0;
   int trace_stride;
   HeadArgs prev;           // the iteration that ran just before this kernel (mode SOLVE_NONE: none)
   PersistLevel lv[PERSIST_MAX_LEVELS];
 };
-struct PersistOut {  // written by tile 0 when plan.finish (each nullable)
+struct PersistOut {  // written by rank 0 when plan.finish (each nullable)
   Pose* poses;
   int32_t* status;
   float* matrices;
-  unsigned long long* stamps;  // nullable: [pair][2 * n_levels] s_memrealtime at the start / end of each level (tile 0)
+  unsigned long long* stamps;  // nullable: [pair][n_levels][2] s_memrealtime at the start / end of each level (rank 0)
 };
 
 template <bool ZMASK>
 __global__ void __launch_bounds__(256, 4)  // four blocks per CU: what plan_tiling counts on for a 64-pair batch
     image_icp_persistent_kernel(const LevelDesc* __restrict__ descs, uint32_t n_pairs_total, JobState* __restrict__ states,
                                 float* __restrict__ partials, uint32_t partials_half, uint32_t job_stride,
-                                unsigned* __restrict__ counters, PersistPlan plan, PersistOut out) {
+                                unsigned* __restrict__ ctrl, PersistPlan plan, PersistOut out) {
   __shared__ uint32_t s_state[JOB_WORDS];
+  __shared__ uint32_t s_rank, s_members;
   __shared__ int s_go;
   const int pair = blockIdx.y;
-  const uint32_t tile = blockIdx.x;
-  unsigned* const counter = counters + pair;
+  unsigned* const counter = ctrl + (size_t)pair * PAIR_CTRL_WORDS;
+  unsigned* const roster = counter + 1 + plan.parity;
+  unsigned* const members = counter + 3 + plan.parity;
   float* const job_partials = partials + (size_t)pair * job_stride;
+  // ---- register; learn the rank and how many blocks share the pair ----
+  if (threadIdx.x == 0) {
+    const uint32_t old = __hip_atomic_fetch_add(roster, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t rank = old & 0xffffu, R = 0;
+    if (old & ROSTER_CLOSED) {
+      rank = 0xffffffffu;  // the pair started without this block
+    } else {
+      unsigned long long t0 = 0;
+      for (uint32_t spin = 0;; ++spin) {
+        R = __hip_atomic_load(members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (R) break;
+        uint32_t cur = __hip_atomic_load(roster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool close = !(cur & ROSTER_CLOSED) && (cur & 0xffffu) >= gridDim.x;
+        if (!close && !(cur & ROSTER_CLOSED) && (spin & 15u) == 15u) {
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          if (!t0) t0 = now;
+          close = now - t0 > ROSTER_WAIT_TICKS;
+        }
+        if (close && __hip_atomic_compare_exchange_strong(roster, &cur, cur | ROSTER_CLOSED, __ATOMIC_RELAXED,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          R = cur & 0xffffu;
+          __hip_atomic_store(members, R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    s_rank = rank, s_members = R;
+  }
   // the pair's state: every block carries its own copy through the schedule (lane k < 18 of wave 0 <-> word k)
   if (threadIdx.x < JOB_WORDS) s_state[threadIdx.x] = ((const uint32_t*)(states + (size_t)(plan.seq0 & 1u) * n_pairs_total + pair))[threadIdx.x];
   __syncthreads();
+  const uint32_t rank = s_rank, R = s_members;
+  if (rank == 0xffffffffu) return;
   HeadArgs prev = plan.prev;
   uint32_t seq = plan.seq0;
   uint32_t expected = plan.counter_base;  // the counter's value once every partial of the previous iteration is out
@@ -562,13 +605,15 @@ __global__ void __launch_bounds__(256, 4)  // four blocks per CU: what plan_tili
       if (threadIdx.x == 0) {
         int go = 1;
         unsigned long long t0 = 0;
-        while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) < 0) {
-          __builtin_amdgcn_s_sleep(2);
-          const unsigned long long now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-          if (!t0) t0 = now;
-          if (now - t0 > PERSIST_SPIN_BOUND_TICKS) {  // a partner that never became resident (the host falls back)
-            go = 0;
-            break;
+        for (uint32_t spin = 0; (int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) < 0; ++spin) {
+          __builtin_amdgcn_s_sleep(1);
+          if ((spin & 255u) == 255u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (!t0) t0 = now;
+            if (now - t0 > PERSIST_SPIN_BOUND_TICKS) {
+              go = 0;
+              break;
+            }
           }
         }
         s_go = go;
@@ -589,29 +634,35 @@ __global__ void __launch_bounds__(256, 4)  // four blocks per CU: what plan_tili
     const LevelDesc d = descs[lv.desc_base + pair];
     const int ppt = (int)d.ppt;
     const uint32_t own_tiles = (d.src_n + 256u * d.ppt - 1u) / (256u * d.ppt);
-    const bool works = tile < lv.tiles;
-    const uint32_t base = tile * (256u * (uint32_t)ppt) + threadIdx.x;
-    if (out.stamps && tile == 0 && threadIdx.x == 0) out.stamps[((size_t)pair * plan.n_levels + l) * 2] = __builtin_amdgcn_s_memrealtime();
+    const uint32_t mine = rank < lv.tiles ? (lv.tiles - rank + R - 1u) / R : 0u;  // tiles rank, rank + R, ...
+    if (out.stamps && rank == 0 && threadIdx.x == 0) out.stamps[((size_t)pair * plan.n_levels + l) * 2] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
     for (uint32_t it = 0; it < lv.iterations; ++it) {
+      const uint32_t base0 = rank * (256u * (uint32_t)ppt) + threadIdx.x;
       SrcPx s0{}, s1{};
-      if (works) s0 = pixel_source_at<ZMASK>(d, base, ppt, 0), s1 = pixel_source_at<ZMASK>(d, base, ppt, 1);
-      head(tile == 0);
+      if (mine) s0 = pixel_source_at<ZMASK>(d, base0, ppt, 0), s1 = pixel_source_at<ZMASK>(d, base0, ppt, 1);
+      head(rank == 0);
       if (!alive) break;
-      if (works) {
+      const bool ok = (int)s_state[15] == A3D_OK;  // (a failed pair stays frozen: its blocks publish zeros)
+      auto uni = [&](int k) { return __uint_as_float(__builtin_amdgcn_readfirstlane(s_state[k])); };
+      const Pose T{{uni(0), uni(1), uni(2)}, {uni(3), uni(4), uni(5), uni(6)}};
+#pragma unroll 1
+      for (uint32_t tile = rank; tile < lv.tiles; tile += R) {
         float acc[GN_PARTIAL];  // (not live across the head: its partial loads want the registers)
 #pragma unroll
         for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
-        if ((int)s_state[15] == A3D_OK && tile < own_tiles) {
-          auto uni = [&](int k) { return __uint_as_float(__builtin_amdgcn_readfirstlane(s_state[k])); };
-          const Pose T{{uni(0), uni(1), uni(2)}, {uni(3), uni(4), uni(5), uni(6)}};
+        if (ok && tile < own_tiles) {
+          const uint32_t base = tile * (256u * (uint32_t)ppt) + threadIdx.x;
+          if (tile != rank) s0 = pixel_source_at<ZMASK>(d, base, ppt, 0), s1 = pixel_source_at<ZMASK>(d, base, ppt, 1);
           pixel_pass<ZMASK>(d, lv.gates, T, base, ppt, s0, s1, acc);
         }
-        // publish: write-through partial, drained by the storing wave, then one agent-scope add (Guideline 16, form R1)
         block_reduce_store<GN_PARTIAL, true>(acc, job_partials + (size_t)(seq & 1u) * partials_half + (size_t)tile * GN_PARTIAL);
+        __syncthreads();  // (the reduction's LDS is reused by the next tile)
+      }
+      if (mine) {  // publish: write-through partials, drained by the storing wave, then one agent-scope add (Guideline 16, form R1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       expected += lv.tiles;
       prev.weight = lv.weight, prev.color_weight = lv.color_weight, prev.mode = SOLVE_IMAGE_ICP;
@@ -620,11 +671,15 @@ __global__ void __launch_bounds__(256, 4)  // four blocks per CU: what plan_tili
       prev.trace_index = trace_index++;
       ++seq;
     }
-    if (out.stamps && tile == 0 && threadIdx.x == 0) out.stamps[((size_t)pair * plan.n_levels + l) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (out.stamps && rank == 0 && threadIdx.x == 0) out.stamps[((size_t)pair * plan.n_levels + l) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
   }
-  if (alive && plan.finish) head(tile == 0);
-  if (tile != 0) return;
-  if (!alive) {  // the spin bound was hit: tell the host (it resets the counters and runs the per-iteration launches)
+  if (alive && plan.finish) head(rank == 0);
+  if (rank != 0) return;
+  if (threadIdx.x == 0) {  // the other parity's roster words, for the next launch
+    __hip_atomic_store(counter + 1 + (plan.parity ^ 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(counter + 3 + (plan.parity ^ 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!alive) {  // the spin bound was hit (a fault elsewhere): the pair fails loudly
     if (threadIdx.x == 0) {
       states[(size_t)(seq & 1u) * n_pairs_total + pair].status = A3D_HIP_ERROR;
       if (out.status) out.status[pair] = A3D_HIP_ERROR;
@@ -645,6 +700,8 @@ __global__ void __launch_bounds__(256, 4)  // four blocks per CU: what plan_tili
     }
   }
 }
+
+#endif  // A3D_DIAGNOSTICS (persistent head-solve kernel)
 
 #ifdef A3D_DIAGNOSTICS  // measured slower than the default path (ruled out): kept as cross-checks
 // ---- one launch per pyramid level ------------------------------------------------------------------
@@ -926,6 +983,14 @@ __global__ void division_selftest_kernel(const float* __restrict__ num, const fl
 
 }  // namespace
 
+// Control words per pair of the diagnostics build's in-launch hand-offs (persistent kernel: counter + roster; the
+// last-block forms use the first word of the array as a plain per-pair ticket counter).  The product has none.
+#ifdef A3D_DIAGNOSTICS
+constexpr uint32_t CTRL_WORDS_PER_PAIR = PAIR_CTRL_WORDS;
+#else
+constexpr uint32_t CTRL_WORDS_PER_PAIR = 0;
+#endif
+
 // P independent coarse-to-fine alignments.  Owns only small state; the images are borrowed.
 struct a3d_multiscale_batch {
   a3d_context* ctx = nullptr;
@@ -944,10 +1009,12 @@ struct a3d_multiscale_batch {
   size_t partials_half = 0;      // floats per buffer
   uint32_t max_tiles = 1;        // largest tiles[level]: the per-pair stride of d_partials
   // Persistent head-solve kernel: the levels in `persist_mask` run as ONE launch per stream group (image_icp.hip,
-  // image_icp_persistent_kernel); d_counters[pair] counts the partials the pair has published since the batch was
-  // created, counter_base is what every pair's counter shows between two alignments.
+  // image_icp_persistent_kernel); d_counters holds PAIR_CTRL_WORDS control words per pair (counter, roster): the
+  // counter counts the partials the pair has published since the batch was created, counter_base is what every
+  // pair's counter shows between two alignments, persist_parity which roster words the next launch uses.
   unsigned* d_counters = nullptr;
   uint32_t counter_base = 0;
+  uint32_t persist_parity = 0;
   uint32_t persist_mask = 0;
   uint32_t persist_resident_blocks = 0;  // blocks of the persistent kernel the chip holds at once
   bool persist_disabled = false;  // a launch hit its spin bound once (the GPU is shared): per-iteration launches from now on
@@ -1059,11 +1126,14 @@ void tiling_for(uint32_t n, uint32_t want, uint32_t group, uint32_t* tiles, uint
 void plan_tiling(a3d_multiscale_batch* b) {
   const uint32_t P = b->n_pairs, L = b->n_levels;
   const uint32_t pinned = b->ctx->tiles_per_pair;
-  float waves = P >= 8 ? (b->n_streams > 2 ? 1.5f : 1.0f) : 0.125f;
-  if (const char* env = A3D_DIAG_ENV("A3D_ICP_WAVES")) waves = (float)atof(env);
-  // persistent levels: a small batch is latency-bound on every level; a large one on all but the finest
-  uint32_t mask = P < 8 ? ((1u << L) - 1u) : (((1u << L) - 1u) & ~1u);
-  if (const char* env = A3D_DIAG_ENV("A3D_ICP_PERSIST")) mask = (uint32_t)strtoul(env, nullptr, 0) & ((1u << L) - 1u);
+  float waves = P >= 8 ? (b->n_streams > 2 ? 1.5f : 1.0f) : 0.25f;
+  if (const char* env = A3D_DIAG_ENV("A3D_ICP_WAVES"))
+    if (*env) waves = (float)atof(env);
+  // levels that run inside the persistent kernel: none by default (it lost to kernel boundaries: DESIGN.md, ruled
+  // out); diagnostics build: A3D_ICP_PERSIST=mask
+  uint32_t mask = 0;
+  if (const char* env = A3D_DIAG_ENV("A3D_ICP_PERSIST"))
+    if (*env) mask = (uint32_t)strtoul(env, nullptr, 0) & ((1u << L) - 1u);
   if (!b->persist_resident_blocks) mask = 0;
   // (a batch that fell back to per-iteration launches keeps the tiling it had: same bits before and after)
   const uint32_t persist_tiles_cap = std::max(1u, b->persist_resident_blocks / std::max(1u, P));
@@ -1223,8 +1293,8 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     return (uint32_t)std::max(1, ctx->num_cus) * (uint32_t)std::max(0, per_cu);
   };
   b->resident_blocks = resident(image_icp_head_kernel<true>, 4);
-  b->persist_resident_blocks = resident(image_icp_persistent_kernel<true>, 0);
 #ifdef A3D_DIAGNOSTICS
+  b->persist_resident_blocks = resident(image_icp_persistent_kernel<true>, 0);
   if (const char* env = getenv("A3D_ICP_ACCUM")) {
     b->use_mfma = strcmp(env, "mfma") == 0;
     b->merged_accumulators = strcmp(env, "merged") == 0;
@@ -1248,7 +1318,7 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
       return at;
     };
     const size_t o_descs = take(b->h_descs.size() * sizeof(LevelDesc)), o_states = take(2 * n_pairs * sizeof(JobState)),
-                 o_counters = take(n_pairs * sizeof(unsigned)), o_epochs = take(n_pairs * sizeof(unsigned)),
+                 o_counters = take((size_t)n_pairs * CTRL_WORDS_PER_PAIR * sizeof(unsigned)), o_epochs = take(n_pairs * sizeof(unsigned)),
                  o_poses = take(n_pairs * sizeof(Pose)), o_init = take(n_pairs * sizeof(Pose)),
                  o_status = take(n_pairs * sizeof(int32_t)), o_readback = take(GN_PARTIAL * sizeof(double));
     A3D_HIP_TRY(hipMalloc((void**)&b->d_block, total));
@@ -1263,7 +1333,8 @@ a3d_status batch_create(a3d_context* ctx, const a3d_icp_params* params, uint32_t
     b->d_poses = (Pose*)(base + o_poses), b->d_init = (Pose*)(base + o_init);
     b->d_status = (int32_t*)(base + o_status), b->d_readback = (double*)(base + o_readback);
   }
-  A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, n_pairs * sizeof(unsigned), ctx->stream));
+  if (CTRL_WORDS_PER_PAIR)
+    A3D_HIP_TRY(hipMemsetAsync(b->d_counters, 0, (size_t)n_pairs * CTRL_WORDS_PER_PAIR * sizeof(unsigned), ctx->stream));
   // measured (scripts/sweep.sh): 3 groups best from 16 to 128 pairs (+14 % at 64, +24 % at 16 over one
   // stream), 2 groups at 8 pairs (+21 %); a handful of pairs stays on one stream
   b->n_streams = n_pairs >= 12 ? 3u : (n_pairs >= 8 ? 2u : 1u);
@@ -1351,11 +1422,14 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   bool finished_in_kernel = false;
   // ---- the persistent kernel takes the coarsest levels in persist_mask (all of them for a handful of pairs) ----
   uint32_t first_per_iteration = levels_to_run;  // levels below this index run as per-iteration launches
+#ifdef A3D_DIAGNOSTICS
   uint32_t pmask = head ? (b->persist_mask & ((1u << levels_to_run) - 1u)) : 0u;
   if (pmask && !((pmask >> (levels_to_run - 1)) & 1u)) pmask = 0;  // (a truncated pyramid: the run must start at its coarsest level)
   if (pmask) {
     PersistPlan plan{};
     plan.seq0 = 0, plan.counter_base = b->counter_base, plan.trace_index0 = 0, plan.trace_stride = trace_stride;
+    plan.parity = b->persist_parity;
+    b->persist_parity ^= 1u;
     plan.prev = prev;
     uint32_t published = 0;
     for (uint32_t l = levels_to_run; l-- > 0;) {
@@ -1387,11 +1461,11 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
       if (b->zmask)
         hipLaunchKernelGGL(image_icp_persistent_kernel<true>, dim3(grid_x, p1 - p0), dim3(256), 0, gs, b->d_descs + p0, P,
                            b->d_states + p0, b->d_partials + (size_t)p0 * job_stride, (uint32_t)b->partials_half, job_stride,
-                           b->d_counters + p0, gp, po);
+                           b->d_counters + (size_t)p0 * PAIR_CTRL_WORDS, gp, po);
       else
         hipLaunchKernelGGL(image_icp_persistent_kernel<false>, dim3(grid_x, p1 - p0), dim3(256), 0, gs, b->d_descs + p0, P,
                            b->d_states + p0, b->d_partials + (size_t)p0 * job_stride, (uint32_t)b->partials_half, job_stride,
-                           b->d_counters + p0, gp, po);
+                           b->d_counters + (size_t)p0 * PAIR_CTRL_WORDS, gp, po);
       A3D_HIP_TRY(hipGetLastError());
       A3D_TRY(profile_end(gs));
     }
@@ -1407,6 +1481,7 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
     }
     finished_in_kernel = plan.finish != 0;
   }
+#endif  // A3D_DIAGNOSTICS
   for (uint32_t l = first_per_iteration; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
     const a3d_icp_params& prm = b->params[l];
     profile_level = l;
@@ -1498,8 +1573,9 @@ void batch_drain_after_failure(a3d_multiscale_batch* b) {
   (void)hipStreamSynchronize(b->ctx->stream);
   (void)hipGetLastError();
   // a persistent launch may not have run to its end: start the pairs' counters afresh
-  (void)hipMemsetAsync(b->d_counters, 0, b->n_pairs * sizeof(unsigned), b->ctx->stream);
-  b->counter_base = 0;
+  if (CTRL_WORDS_PER_PAIR)
+    (void)hipMemsetAsync(b->d_counters, 0, (size_t)b->n_pairs * CTRL_WORDS_PER_PAIR * sizeof(unsigned), b->ctx->stream);
+  b->counter_base = 0, b->persist_parity = 0;
 }
 
 a3d_status batch_collect_timing(a3d_multiscale_batch* b) {

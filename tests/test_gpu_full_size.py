@@ -24,7 +24,6 @@ def test_full_size_batch_properties(ctx):
     poses, status = batch.align()
     assert not status.any()
     full = _as_array(poses)
-    assert batch.persistent_levels() == 0b110  # the two coarse levels ran inside the persistent kernel
     # determinism: the same launch sequence gives the same bits
     again, _ = batch.align()
     assert np.array_equal(full.view(np.uint32), _as_array(again).view(np.uint32))

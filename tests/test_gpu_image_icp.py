@@ -874,23 +874,25 @@ def test_pinned_tiling_makes_a_pair_independent_of_its_batch(ctx):
 
 
 def test_persistent_kernel_and_per_iteration_launches_give_the_same_bits(ctx, diag_ctx, monkeypatch):
-    """The persistent head-solve kernel (image_icp.hip: many iterations in one launch, one-hop counter hand-off, every
-    block sums the pair's partials itself) adds the same partials in the same order and runs the same solve as the
-    per-iteration launches: under one tiling both give the same bits — for a lone pair (all levels persistent, outputs
-    written by the kernel), a trace, a small batch and a three-group batch (coarse levels persistent).  The product
-    library must agree with the diagnostics build's per-iteration run."""
+    """The persistent head-solve kernel (diagnostics build, A3D_ICP_PERSIST=mask: many iterations in one launch, one-hop
+    counter hand-off, every block sums the pair's partials itself; measured slower than kernel boundaries)
+    adds the same partials in the same order and runs the same solve as the per-iteration launches: under one tiling both
+    give the same bits — for a lone pair (all levels persistent, outputs written by the kernel), a trace, a small batch
+    and a three-group batch (coarse levels persistent) — and so does the product library."""
     prm = MsIcpParams.default().customize(lambda i, p: setattr(p, "max_iterations", 7))
     base = [("sample1", 0, 5), ("sample2", 0, 4), ("sample1", 1, 4), ("sample1", 4, 5)]
     tps = [[to_range_image(f) for f in oracle_pyramid(s, a)] for s, a, b in base]
     sps = [[to_range_image(f) for f in oracle_pyramid(s, b)] for s, a, b in base]
     t14, s14 = (tps * 4)[:14], (sps * 4)[:14]
 
-    def run_all(c):
+    def run_all(c, mask14):
         out = []
         out.append(MultiscaleAlign.new(c, prm, tps[0]).align(sps[0]).matrix())
         T, tr = ImageIcp.new(c, prm[0], tps[1][0]).align(sps[1][0], trace=True)
         out.append(tr.copy())
-        for t, s in ((tps, sps), (t14, s14)):
+        for t, s, mask in ((tps, sps, None), (t14, s14, mask14)):
+            if mask is not None:
+                monkeypatch.setenv("A3D_ICP_PERSIST", mask)
             b = MultiscaleAlignBatch(c, prm, t, s)
             poses, status = b.align()
             again, _ = b.align()  # the pairs' counters keep counting across alignments of one batch
@@ -904,15 +906,17 @@ def test_persistent_kernel_and_per_iteration_launches_give_the_same_bits(ctx, di
     for c in (ctx, diag_ctx):
         c.set_tiling(12)
     try:
-        product = run_all(ctx)
-        persistent = run_all(diag_ctx)
+        product = run_all(ctx, None)
+        monkeypatch.setenv("A3D_ICP_PERSIST", "7")
+        persistent = run_all(diag_ctx, "6")
         monkeypatch.setenv("A3D_ICP_PERSIST", "0")
-        per_iteration = run_all(diag_ctx)
+        per_iteration = run_all(diag_ctx, "0")
         monkeypatch.delenv("A3D_ICP_PERSIST")
     finally:
         for c in (ctx, diag_ctx):
             c.set_tiling(0)
-    assert product[3][0] == 0b111 and product[5][0] == 0b110 and per_iteration[3][0] == 0 and per_iteration[5][0] == 0
+    assert persistent[3][0] == 0b111 and persistent[5][0] == 0b110
+    assert product[3][0] == 0 and product[5][0] == 0 and per_iteration[3][0] == 0 and per_iteration[5][0] == 0
     for k in (0, 1, 2, 4):
         assert np.array_equal(product[k].view(np.uint32), per_iteration[k].view(np.uint32)), k
         assert np.array_equal(product[k].view(np.uint32), persistent[k].view(np.uint32)), k
