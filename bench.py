@@ -643,63 +643,74 @@ def load_cpu_oracle():
     return O, ("-O3 -march=native" if os.path.exists(native) else "-O2 (portable)")
 
 
-def cpu_baseline_main(O, host_pyramids, pair_frames, params, n_pairs, gpu_poses, cores, budget_s=20.0):
-    """ms3x15 on the first n_pairs pairs, threaded like the reference (4096-pixel chunks over the host's cores)."""
-    def frame(dev_level):
-        ri = dev_level.download(colors=False)  # the very arrays the GPU path reads
-        k = ri.intrinsics
-        return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
+def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_poses, cores, orders=13, budget_s=25.0):
+    """ms3x15 on the batch's pairs, threaded like the reference (4096-pixel chunks over the host's cores).
+    TIMED: the chunk-order run of every pair (until `budget_s` of CPU work is spent) -> `value`.
+    UNTIMED (parity of the headline): every pair also under `orders` - 1 seeded chunk-merge orders
+    (what rayon's par_bridge() does to the reference, image_icp.rs:96,143-148) -> per-pair GPU-vs-oracle difference,
+    the oracle's own spread and the GPU's rank inside it; then the two most sensitive pairs teacher-forced at all 45
+    iterations (tests/headline_parity.py)."""
+    import headline_parity as HP
 
     parr = params.to_c_array()
-    worst_ang = worst_tr = 0.0
-    host = {}
-    per = []
-    envelope = []
+    per, entries = [], []
+    keep = {}
     for p in range(n_pairs):
         fa, fb = pair_frames[p]
-        for q in (fa, fb):
-            if q not in host:
-                host[q] = [frame(r) for r in host_pyramids[q]]
+        ta, tb = [HP.host_frame(r) for r in host_pyramids[fa]], [HP.host_frame(r) for r in host_pyramids[fb]]
         t0 = time.perf_counter()
-        st, T = O.multiscale_align(parr, len(params), host[fa], host[fb], threads=cores)
-        per.append(time.perf_counter() - t0)
-        if st == 0 and gpu_poses is not None:
-            ang, tr = O.transform_metrics(gpu_poses[p].to_c(), T)
-            worst_ang, worst_tr = max(worst_ang, abs(ang)), max(worst_tr, tr)
-            # the reference's own run-to-run envelope on this pair: rayon's par_bridge() delivers the 75 chunk
-            # accumulators in arbitrary order (image_icp.rs:96,143-148); the oracle replays two other orders (untimed)
-            env_ang = env_tr = 0.0
-            for seed in (1, 2):
+        st, T = O.multiscale_align(parr, len(params), ta, tb, threads=cores)
+        dt = time.perf_counter() - t0
+        if sum(per) <= budget_s:
+            per.append(dt)
+        if st != 0 or gpu_poses is None:
+            continue
+        runs = [T]
+        try:
+            for seed in range(1, orders):
                 O.set_chunk_merge_order(seed)
-                st2, T2 = O.multiscale_align(parr, len(params), host[fa], host[fb], threads=cores)
+                st2, T2 = O.multiscale_align(parr, len(params), ta, tb, threads=cores)
                 if st2 == 0:
-                    a2, t2 = O.transform_metrics(T, T2)
-                    env_ang, env_tr = max(env_ang, abs(a2)), max(env_tr, t2)
+                    runs.append(T2)
+        finally:
             O.set_chunk_merge_order(0)
-            envelope.append({"pair": p, "gpu_vs_cpu_angle_rad": abs(ang), "gpu_vs_cpu_translation_m": tr,
-                             "cpu_vs_cpu_other_merge_orders_angle_rad": env_ang,
-                             "cpu_vs_cpu_other_merge_orders_translation_m": env_tr})
-        if sum(per) > budget_s:
-            break
+        e = HP.envelope(gpu_poses[p], runs)
+        e["pair"] = p
+        entries.append(e)
+        keep[p] = (ta, tb)
+        if len(keep) > 4:  # host copies of the most sensitive pairs only
+            best = sorted(keep, key=lambda q: -next(x for x in entries if x["pair"] == q)["gpu_vs_cpu_translation_m"])[:2]
+            keep = {q: keep[q] for q in best}
+    fa, fb = pair_frames[0]
     t0 = time.perf_counter()
-    O.multiscale_align(parr, len(params), host[pair_frames[0][0]], host[pair_frames[0][1]], threads=1)
+    O.multiscale_align(parr, len(params), [HP.host_frame(r) for r in host_pyramids[fa]],
+                       [HP.host_frame(r) for r in host_pyramids[fb]], threads=1)
     single_ms = (time.perf_counter() - t0) * 1e3
-    return {
+    out = {
         "value": len(per) / sum(per), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-        "sample": f"{len(per)} of the batch's frame pairs, same ms3x15 workload, oracle threaded over {cores} host "
-                  f"threads (4096-pixel chunks like the reference's rayon loop)",
+        "sample": f"{len(per)} of the batch's {n_pairs} frame pairs, same ms3x15 workload, oracle threaded over {cores} host "
+                  f"threads (4096-pixel chunks like the reference's rayon loop); parity (untimed) on {len(entries)} pairs x "
+                  f"{orders} chunk-merge orders",
         "ms_per_pair_stats": stats([t * 1e3 for t in per]), "single_thread_ms_per_pair": single_ms,
-        "max_gpu_vs_cpu_angle_rad": worst_ang, "max_gpu_vs_cpu_translation_m": worst_tr,
+    }
+    if entries:
+        out.update(HP.summarize(entries))
         # ms3x15 = IcpParams::default() per level, which is not contractive on every pair (SURVEY §0-11): where the GPU
         # differs from the oracle by more than 1e-4 the oracle differs from ITSELF as much under another chunk-merge order
-        "max_cpu_vs_cpu_other_merge_orders_angle_rad": max([e["cpu_vs_cpu_other_merge_orders_angle_rad"] for e in envelope], default=0.0),
-        "max_cpu_vs_cpu_other_merge_orders_translation_m": max([e["cpu_vs_cpu_other_merge_orders_translation_m"] for e in envelope], default=0.0),
-        "pairs_where_gpu_exceeds_1e-4_and_twice_the_cpu_envelope": sum(
-            1 for e in envelope
-            if (e["gpu_vs_cpu_angle_rad"] > max(1e-4, 2 * e["cpu_vs_cpu_other_merge_orders_angle_rad"])
-                or e["gpu_vs_cpu_translation_m"] > max(1e-4, 2 * e["cpu_vs_cpu_other_merge_orders_translation_m"]))),
-        "per_pair_parity": envelope,
-    }
+        out["per_pair_parity"] = entries
+        worst = sorted(keep, key=lambda q: -next(x for x in entries if x["pair"] == q)["gpu_vs_cpu_translation_m"])[:2]
+        tfs = []
+        for p in worst:
+            fa, fb = pair_frames[p]
+            ta, tb = keep[p]
+            tf = HP.teacher_forced(ctx, params, ta, tb, host_pyramids[fa], host_pyramids[fb], threads=cores)
+            tf["pair"] = p
+            tfs.append(tf)
+        out["teacher_forced_most_sensitive_pairs"] = tfs
+        out["teacher_forced_count_mismatches"] = sum(t["count_mismatches"] for t in tfs)
+        out["teacher_forced_max_rel_err_sums"] = max((t["max_rel_err_sums"] for t in tfs), default=0.0)
+        out["teacher_forced_max_one_step_translation_m"] = max((t["max_one_step_translation_m"] for t in tfs), default=0.0)
+    return out
 
 
 def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clouds, bench_icp_clouds=None):
@@ -829,7 +840,10 @@ def main():
     ap.add_argument("--pairs-per-gpu", type=int, default=PAIRS_PER_STREAM)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--cpu-pairs", type=int, default=64,
+                    help="pairs run on the CPU oracle (rank 0, N=1 only): timed in chunk order until ~25 s of CPU work, and "
+                         "(untimed) under --cpu-orders chunk-merge orders for the parity envelope")
+    ap.add_argument("--cpu-orders", type=int, default=13, help="chunk-merge orders per pair of the parity envelope")
     ap.add_argument("--no-extras", action="store_true", help="skip the kd-tree / single-pair secondary numbers")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (gloo + --device 0 rehearses the multi-rank path on one GPU)")
@@ -1074,7 +1088,8 @@ def main():
         if world == 1 and args.cpu_pairs > 0:
             O, flags = load_cpu_oracle()
             model, cores = cpu_info()
-            cpu = cpu_baseline_main(O, host_pyramids, pair_frames, params, min(args.cpu_pairs, P), poses, cores)
+            cpu = cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, min(args.cpu_pairs, P), poses, cores,
+                                    orders=max(1, args.cpu_orders))
             cpu["cpu_model"], cpu["compiler_flags"] = model, flags
             if level0_host is not None:
                 def oframe(dev_level):

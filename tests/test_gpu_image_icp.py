@@ -488,49 +488,7 @@ def test_ms3x15_end_to_end_on_benchmark_pairs(ctx):
         lv.free()
 
 
-def test_ms3x15_on_the_headline_distinct_pairs_stays_inside_the_reference_envelope(ctx):
-    """The headline's own pairs (bench.py default: stream 1000, pair p = frames 2p -> 2p + 1).  ms3x15 runs
-    IcpParams::default() on every level, which is not contractive on every pair (SURVEY §0-11): on frames 10 -> 11 the
-    oracle differs from ITSELF by 7e-5 rad / 1.7e-4 m when only the order in which the 75 chunk accumulators are merged
-    changes (what rayon's par_bridge() does to the reference, image_icp.rs:96,143-148).  So: every pair within 1e-4 of
-    the oracle, or no farther from it than twice the oracle's own spread over four merge orders."""
-    import bench
-
-    P = 8
-    pyr, _, _ = bench.build_stream_pyramids(ctx, 1000, 2 * P, 640, 480)
-    prm = MsIcpParams.repeat(3, IcpParams.default())
-    pairs = [(2 * p, 2 * p + 1) for p in range(P)]
-    batch = MultiscaleAlignBatch(ctx, prm, [pyr[a] for a, _ in pairs], [pyr[b] for _, b in pairs])
-    poses, status = batch.align()
-    batch.free()
-    assert not np.any(status)
-
-    def frame(dev_level):
-        ri = dev_level.download(colors=False)
-        k = ri.intrinsics
-        return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
-
-    tight = 0
-    try:
-        for p, (a, b) in enumerate(pairs):
-            ta, tb = [frame(lv) for lv in pyr[a]], [frame(lv) for lv in pyr[b]]
-            runs = []
-            for seed in range(4):
-                O.set_chunk_merge_order(seed)
-                st, T = O.multiscale_align(prm.to_c_array(), 3, ta, tb, threads=8)
-                assert st == 0
-                runs.append(T)
-            spread = [O.transform_metrics(runs[0], r) for r in runs[1:]]
-            s_ang, s_tr = max(abs(x[0]) for x in spread), max(x[1] for x in spread)
-            ang, tr = transform_diff(poses[p], runs[0])
-            print(f"[ms3x15 distinct pair {p}] GPU vs oracle {ang:.2e} rad {tr:.2e} m; oracle vs oracle {s_ang:.2e} rad {s_tr:.2e} m")
-            assert ang <= max(ROT_TOL, 2 * s_ang) and tr <= max(TRANS_TOL, 2 * s_tr), (p, ang, tr, s_ang, s_tr)
-            tight += ang <= ROT_TOL and tr <= TRANS_TOL
-    finally:
-        O.set_chunk_merge_order(0)
-    assert tight >= P - 2  # the sensitive pairs are the exception
-    for lv in (lv for q in pyr for lv in q):
-        lv.free()
+# (the headline's own 64 distinct pairs against the oracle and its 13-order envelope: tests/test_gpu_headline_parity.py)
 
 
 def test_images_may_be_freed_right_after_an_enqueue_only_align():
