@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../include/align3d_hip.h"
@@ -34,19 +35,30 @@ int main() {
   A3D(a3d_context_create(device, &ctx));
   hipStream_t stream = (hipStream_t)a3d_context_stream(ctx);
 
-  // RCCL communicator: rank 0 makes the id, the others read it from a file both can see
+  // RCCL communicator: rank 0 makes the id and writes it to a file every rank can see; EVERY rank (rank 0 too) then reads
+  // the id from that file — so a one-rank run with A3D_NCCL_ID_FILE set goes through the whole N-rank rendezvous and only
+  // the communicator's size differs from the 8-GPU launch.  Without the variable (one rank only): no file.
   ncclUniqueId id;
+  const char* id_file = std::getenv("A3D_NCCL_ID_FILE");
+  if (world > 1 && !id_file) {
+    std::printf("WORLD_SIZE > 1 needs A3D_NCCL_ID_FILE\n");
+    return 5;
+  }
   if (rank == 0) {
     NCCL(ncclGetUniqueId(&id));
-    if (world > 1) {
-      FILE* f = std::fopen(std::getenv("A3D_NCCL_ID_FILE"), "wb");
+    if (id_file) {  // written under a temporary name and renamed: a reader never sees half an id
+      const std::string tmp = std::string(id_file) + ".tmp";
+      FILE* f = std::fopen(tmp.c_str(), "wb");
       if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) return 5;
       std::fclose(f);
+      if (std::rename(tmp.c_str(), id_file) != 0) return 5;
     }
-  } else {
+  }
+  if (id_file) {
+    std::memset(&id, 0, sizeof(id));
     FILE* f = nullptr;
     for (int tries = 0; tries < 600 && !f; ++tries) {
-      f = std::fopen(std::getenv("A3D_NCCL_ID_FILE"), "rb");
+      f = std::fopen(id_file, "rb");
       if (!f) usleep(100000);
     }
     if (!f || std::fread(&id, sizeof(id), 1, f) != 1) return 5;

@@ -18,7 +18,7 @@ import numpy as np, torch, torch.distributed as dist
 from align3d_amd.distributed import gather_poses, shard_range
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-n_pairs = 10
+n_pairs = 5 * world
 lo, hi = shard_range(n_pairs, world, rank)
 assert hi - lo == n_pairs // world
 # stand-in for the local alignments: pose matrix of global pair j is filled with j + k/100
@@ -43,15 +43,20 @@ def test_shard_range_covers_everything_once():
     assert [owner_of(j, 512, 8) for j in (0, 63, 64, 511)] == [0, 0, 1, 7]
 
 
-def test_two_rank_gloo_gather(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_ranks_gather_in_global_pair_order(tmp_path, world):
+    """world = 8: the rank count of BASELINE configs[4] (512 pairs over 8 GPUs), as host logic on CPU."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", RANK=str(rank),
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
                    LOCAL_RANK=str(rank), A3D_ROOT=ROOT, OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))

@@ -95,7 +95,63 @@ def test_c_host_gathers_poses_with_rccl_on_the_context_stream():
     exe = os.path.join(ROOT, "tests", "cpp", "rccl_gather")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "rccl_gather"], stdout=subprocess.DEVNULL)
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "A3D_NCCL_ID_FILE")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "rccl gather OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_goes_through_the_n_rank_rendezvous_with_one_rank(tmp_path):
+    """The same program launched the way an N-rank job launches it (RANK / WORLD_SIZE / LOCAL_RANK / A3D_NCCL_ID_FILE
+    set): rank 0 writes the RCCL unique id to the file and every rank — here the only one — reads it back before
+    ncclCommInitRank.  What the 8-GPU launch adds is the communicator's size, nothing else."""
+    exe = os.path.join(ROOT, "tests", "cpp", "rccl_gather")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "rccl_gather"], stdout=subprocess.DEVNULL)
+    id_file = tmp_path / "nccl_id"
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", A3D_NCCL_ID_FILE=str(id_file))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "rccl gather OK" in out.stdout, out.stdout + out.stderr
+    assert id_file.exists() and id_file.stat().st_size == 128  # sizeof(ncclUniqueId)
+    # a rank that is told WORLD_SIZE > 1 without the file refuses instead of inventing an id
+    bad = subprocess.run([exe], capture_output=True, text=True, timeout=120,
+                         env={k: v for k, v in dict(env, WORLD_SIZE="2").items() if k != "A3D_NCCL_ID_FILE"})
+    assert bad.returncode == 5
+
+
+@pytest.mark.gpu
+def test_four_fresh_ranks_keep_global_pair_order(ctx, tmp_path):
+    """`bench.py --gpus 4` (gloo, all ranks on device 0: the box has one GPU and allows six GPU processes): four fresh
+    rank processes, 2 pairs each.  One JSON line; ranks_in_collective == 4; the gathered buffer is in global pair order —
+    rank r's block is stream 1000 + r, checked bit for bit against single-process batches of those streams."""
+    P, N = 2, 4
+    dump = str(tmp_path / "gathered.npy")
+    r = run_bench(["--gpus", str(N), "--backend", "gloo", "--device", "0", "--pairs-per-gpu", str(P), "--steps", "2",
+                   "--warmup", "1", "--no-extras", "--cpu-pairs", "0", "--dump-gathered", dump])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == N and out["config"]["ranks_in_collective"] == N and out["config"]["gathered_pairs"] == N * P
+    assert out["config"]["gather_matches_local_poses"] is True and out["roofline"]["failed_pairs"] == 0
+    gathered = np.load(dump)
+    assert gathered.shape == (N * P, 16)
+    sys.path.insert(0, ROOT)
+    import bench
+    from align3d_amd import IcpParams, MsIcpParams, MultiscaleAlignBatch
+
+    for rank in range(N):
+        pyr, _, _ = bench.build_stream_pyramids(ctx, seed=1000 + rank, n_frames=2 * P, width=640, height=480)
+        batch = MultiscaleAlignBatch(ctx, MsIcpParams.repeat(3, IcpParams.default()), [pyr[2 * p] for p in range(P)],
+                                     [pyr[2 * p + 1] for p in range(P)])
+        d = ctx.malloc(P * 64)
+        _, status = batch.align(matrices_device=d)
+        mats = ctx.to_host(d, np.zeros((P, 16), np.float32))
+        ctx.free(d)
+        batch.free()
+        for lv in (lv for q in pyr for lv in q):
+            lv.free()
+        assert not status.any()
+        assert np.array_equal(gathered[rank * P:(rank + 1) * P].view(np.uint32), mats.view(np.uint32)), rank
