@@ -32,7 +32,8 @@ from .icp import Icp, ImageIcp, MultiscaleAlign, MultiscaleAlignBatch, PointClou
 from .icp_params import IcpParams, MsIcpParams  # noqa: F401
 from .kdtree import R3dTree  # noqa: F401
 from .multi import MultiContext, MultiscaleAlignMultiBatch  # noqa: F401
-from .range_image import CameraIntrinsics, DeviceRangeImage, RangeImage, RangeImageBuilder  # noqa: F401
+from .range_image import (CameraIntrinsics, DeviceRangeImage, RangeImage, RangeImageBuilder,  # noqa: F401
+                          compute_normals_batch)
 from .transform import Transform  # noqa: F401
 from .dataset import (DatasetError, IndoorLidarDataset, SlamTbDataset, SubsetDataset, SyntheticDataset,  # noqa: F401
                       TumRgbdDataset, load_dataset)

@@ -156,9 +156,12 @@ SIGNATURES = {
          C.c_double, C.c_double, _PP],
     ),
     "a3d_context_last_build_stats": (_ST, [_P, C.POINTER(C.c_uint64)]),
+    "a3d_context_set_build_profiling": (_ST, [_P, C.c_int32]),
+    "a3d_context_last_build_kernel_ms": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_range_image_size": (_ST, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "a3d_range_image_download": (_ST, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double)]),
     "a3d_compute_normals": (_ST, [_P, _P, _P, C.c_uint64, C.c_uint64, _P]),
+    "a3d_range_image_compute_normals_batch": (_ST, [_PP, C.c_uint64]),
     "a3d_image_icp_align": (_ST, [_P, C.POINTER(IcpParamsC), _P, _P, C.POINTER(PoseC), C.POINTER(PoseC)]),
     "a3d_image_icp_accumulate": (
         _ST,

@@ -93,6 +93,15 @@ class Context:
         _abi.check(self.lib.a3d_context_last_build_stats(self.handle, v))
         return {"frames": int(v[0]), "grid_cells": int(v[1]), "marked_tiles": int(v[2]), "zero_tiles": int(v[3])}
 
+    def set_build_profiling(self, on):
+        _abi.check(self.lib.a3d_context_set_build_profiling(self.handle, 1 if on else 0))
+
+    def last_build_kernel_ms(self):
+        """Device time of the builder's kernels in the most recent build (set_build_profiling(True) first)."""
+        ms = C.c_float()
+        _abi.check(self.lib.a3d_context_last_build_kernel_ms(self.handle, C.byref(ms)))
+        return ms.value
+
     def close(self):
         if self._sibling is not None:
             self._sibling.close()

@@ -111,13 +111,19 @@ constexpr int PACK_SHIFT = 24;
 // clear, to add into and to load in the blur.
 template <typename CELL>
 struct Pack;
+// Weight: the type the blur carries a cell's COUNT in.  Six unnormalised [1 2 1] passes multiply a count by at most
+// 4^6, so a count below 2^8 stays below 2^20: every intermediate is an integer that f32 holds exactly, and the weight
+// channel of the narrow cells runs on the full-rate f32 pipe (one DPP move per shift instead of two) while the value
+// channel (sums up to 2^24 x 4^6 = 2^36) stays in f64.  Wide cells count up to 2^24: f64 for both.
 template <>
 struct Pack<unsigned long long> {
   static constexpr int SHIFT = PACK_SHIFT;
+  typedef double Weight;
 };
 template <>
 struct Pack<uint32_t> {
   static constexpr int SHIFT = 8;
+  typedef float Weight;
 };
 constexpr int BT = 12, BR = BT + 4;  // blur tiles: 16^3 cells per tile, 12^3 of them final
 
@@ -309,23 +315,23 @@ constexpr int BCELLS = BR * BR * BZP;  // x 16 B = 64 KiB of LDS
 // scales by 2^-12 once, when it writes the cell: bit-identical, at half the f64 instructions.
 // `ok(i)`: cell i is one the reference writes (otherwise it is zero after every pass).  MASKED = false: the tile
 // lies inside the written box on this axis and the other two, ok is true everywhere (no selects).
-template <bool MASKED, typename OK>
-__device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok) {
+template <bool MASKED, typename W, typename OK>
+__device__ __forceinline__ void blur_line_twice(double (&vx)[BR], W (&vw)[BR], OK ok) {
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
     // left of the tile: stale layers, never part of the final 12^3 (at grid channel 0 the reference's "previous" read
     // aliases an always-zero cell: also zero)
-    double2 prev = make_double2(0.0, 0.0);
+    double prev_x = 0.0;
+    W prev_w = (W)0;
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      const double2 cur = v[i];
-      const double2 next = i + 1 < BR ? v[i + 1] : make_double2(0.0, 0.0);
-      double2 o;
-      o.x = __builtin_fma(2.0, cur.x, prev.x + next.x);  // exact (integers below 2^53): same as (p + n) + 2 c
-      o.y = __builtin_fma(2.0, cur.y, prev.y + next.y);
-      if (MASKED && !ok(i)) o = make_double2(0.0, 0.0);
-      v[i] = o;
-      prev = cur;
+      const double cur_x = vx[i], next_x = i + 1 < BR ? vx[i + 1] : 0.0;
+      const W cur_w = vw[i], next_w = i + 1 < BR ? vw[i + 1] : (W)0;
+      double ox = __builtin_fma(2.0, cur_x, prev_x + next_x);  // exact (integers below 2^53): same as (p + n) + 2 c
+      W ow = (W)2 * cur_w + (prev_w + next_w);                 // exact likewise (Pack<CELL>::Weight)
+      if (MASKED && !ok(i)) ox = 0.0, ow = (W)0;
+      vx[i] = ox, vw[i] = ow;
+      prev_x = cur_x, prev_w = cur_w;
     }
   }
 }
@@ -333,7 +339,8 @@ __device__ __forceinline__ void blur_line_twice(double2 (&v)[BR], OK ok) {
 // One tile.  `known_occupied`: the tile comes from the splat's list of marked windows; otherwise emptiness is decided
 // from the loaded window.  `zeros_only`: an unmarked first-channel tile, written as zeros (see below).
 template <typename CELL>
-__device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const CELL* __restrict__ packed,
+__device__ __forceinline__ void blur_tile(double* tile_x, typename Pack<CELL>::Weight* tile_w, uint32_t tile_id,
+                                          const CELL* __restrict__ packed,
                                           const GridDims g, double* __restrict__ out, bool known_occupied,
                                           bool zeros_only) {
   const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT;
@@ -358,7 +365,9 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
   auto chan_ok = [&](int gz) { return gz >= 0 && gz <= gd - 2; };
   // a tile whose 16^3 window lies inside the box of cells the reference writes needs no masks (block-uniform)
   const bool inside = r0 >= 1 && r0 + BR - 1 <= gh - 2 && c0 >= 1 && c0 + BR - 1 <= gw - 2 && z0 >= 0 && z0 + BR - 1 <= gd - 2;
-  double2 v[BR];
+  typedef typename Pack<CELL>::Weight W;
+  double vx[BR];
+  W vw[BR];
   // ---- axis 0: thread = (column hi, channel lo) owns the 16 rows; read straight from the packed grid -------
   {
     const int gc = c0 + hi, gz = z0 + lo;
@@ -368,7 +377,7 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
       const int gr = r0 + i;
       CELL u = 0;
       if (line_in && gr >= 0 && gr < gh) u = packed[((size_t)gr * gw + gc) * gd + gz];
-      v[i] = make_double2((double)(u >> Pack<CELL>::SHIFT), (double)(u & (((CELL)1 << Pack<CELL>::SHIFT) - 1)));
+      vx[i] = (double)(u >> Pack<CELL>::SHIFT), vw[i] = (W)(u & (((CELL)1 << Pack<CELL>::SHIFT) - 1));
     }
     // Empty windows: a depth image occupies ~1 % of its grid's cells and 20-30 % of its tiles.  A tile whose whole
     // 16^3 window holds no splat blurs to zero, and the slice never reads it: a pixel's eight cells lie within one cell
@@ -378,14 +387,14 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
     // always written (zeros when empty).  Skipped tiles keep stale cells that nothing reads.
     bool mine = false;
 #pragma unroll
-    for (int i = 0; i < BR; ++i) mine |= (v[i].x != 0.0) | (v[i].y != 0.0);
+    for (int i = 0; i < BR; ++i) mine |= (vx[i] != 0.0) | (vw[i] != (W)0);
     if (!known_occupied && !__syncthreads_or(mine ? 1 : 0)) {  // (no list from the splat: decided from the loaded window)
       if (z0 == -2) write_zeros();
       return;
     }
     const bool line_ok = col_ok(gc) && chan_ok(gz) && gz < gd;
-    if (inside) blur_line_twice<false>(v, [](int) { return true; });
-    else blur_line_twice<true>(v, [&](int i) { return line_ok && row_ok(r0 + i); });
+    if (inside) blur_line_twice<false>(vx, vw, [](int) { return true; });
+    else blur_line_twice<true>(vx, vw, [&](int i) { return line_ok && row_ok(r0 + i); });
     // ---- axis 2 (channels) in the same layout: the 16 channels of a (row, column) line sit in the 16 lanes of one
     // DPP row, so "previous" and "next" are row shifts by one lane (zero shifted in at the ends of the window: stale
     // layers there, and the reference's aliased always-zero "previous" at grid channel 0).  The axes commute exactly:
@@ -403,32 +412,41 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
         }
         return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi32 << 32) | (uint32_t)lo32));
       };
+      auto shifted_w = [&](W x, bool from_lower_lane) -> W {
+        if constexpr (sizeof(W) == 8) {
+          return (W)shifted((double)x, from_lower_lane);
+        } else {
+          const int b = (int)__float_as_uint((float)x);
+          return (W)__uint_as_float((unsigned)(from_lower_lane ? __builtin_amdgcn_update_dpp(0, b, 0x111, 0xF, 0xF, true)
+                                                               : __builtin_amdgcn_update_dpp(0, b, 0x101, 0xF, 0xF, true)));
+        }
+      };
       const bool lane_ok = col_ok(gc) && chan_ok(gz);
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         const bool ok = inside || (lane_ok && row_ok(r0 + i));
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
-          const double2 cur = v[i];
-          double2 o;
-          o.x = __builtin_fma(2.0, cur.x, shifted(cur.x, true) + shifted(cur.x, false));
-          o.y = __builtin_fma(2.0, cur.y, shifted(cur.y, true) + shifted(cur.y, false));
-          v[i] = ok ? o : make_double2(0.0, 0.0);
+          const double cx_ = vx[i];
+          const W cw_ = vw[i];
+          const double ox = __builtin_fma(2.0, cx_, shifted(cx_, true) + shifted(cx_, false));
+          const W ow = (W)2 * cw_ + (shifted_w(cw_, true) + shifted_w(cw_, false));
+          vx[i] = ok ? ox : 0.0, vw[i] = ok ? ow : (W)0;
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) tile[at(i, hi, lo)] = v[i];
+    for (int i = 0; i < BR; ++i) tile_x[at(i, hi, lo)] = vx[i], tile_w[at(i, hi, lo)] = vw[i];
   }
   __syncthreads();
   // ---- axis 1: thread = (row hi, channel lo) owns the 16 columns; the central 12^3 cells go straight to the grid ----
   {
 #pragma unroll
-    for (int i = 0; i < BR; ++i) v[i] = tile[at(hi, i, lo)];
+    for (int i = 0; i < BR; ++i) vx[i] = tile_x[at(hi, i, lo)], vw[i] = tile_w[at(hi, i, lo)];
     const int gr = r0 + hi, gz = z0 + lo;
     const bool line_ok = row_ok(gr) && chan_ok(gz);
-    if (inside) blur_line_twice<false>(v, [](int) { return true; });
-    else blur_line_twice<true>(v, [&](int i) { return line_ok && col_ok(c0 + i); });
+    if (inside) blur_line_twice<false>(vx, vw, [](int) { return true; });
+    else blur_line_twice<true>(vx, vw, [&](int i) { return line_ok && col_ok(c0 + i); });
     // (a wave stores 4 rows x 12 channels = four 192-byte runs per column)
     if (hi >= 2 && hi < BR - 2 && lo >= 2 && lo < BR - 2 && gr < gh && gz < gd) {
 #pragma unroll
@@ -436,7 +454,7 @@ __device__ __forceinline__ void blur_tile(double2* tile, uint32_t tile_id, const
         const int gc = c0 + i;
         // normalised (grid.rs:90-104): value / weight — the common factor 4^6 cancels exactly — or, where the weight
         // is zero, the value itself (x 4^-6: the six divisions by four)
-        if (gc < gw) out[((size_t)gr * gw + gc) * gd + gz] = v[i].y > 0.0 ? v[i].x / v[i].y : v[i].x * 0x1p-12;
+        if (gc < gw) out[((size_t)gr * gw + gc) * gd + gz] = vw[i] > (W)0 ? vx[i] / (double)vw[i] : vx[i] * 0x1p-12;
       }
     }
   }
@@ -478,7 +496,9 @@ __global__ void __launch_bounds__(256)
     blur_fused_kernel(const CELL* __restrict__ packed, GridDims g, double* __restrict__ out,
                       const uint32_t* __restrict__ dyn, unsigned long long capacity,
                       const uint32_t* __restrict__ lists, uint32_t flags_stride) {
-  __shared__ double2 tile[BCELLS];
+  typedef typename Pack<CELL>::Weight W;
+  __shared__ double tile_x[BCELLS];  // 32 KiB
+  __shared__ W tile_w[BCELLS];       // 16 KiB (narrow cells) / 32 KiB
   if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
   packed += blockIdx.y * capacity;
   out += blockIdx.y * capacity;
@@ -486,14 +506,14 @@ __global__ void __launch_bounds__(256)
   if (!lists) {
     // 1-D launch (the host may not know the dimensions): block -> tile (row, column, channel), channel fastest
     const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
-    if (blockIdx.x < tx * ty * tz) blur_tile(tile, blockIdx.x, packed, g, out, false, false);
+    if (blockIdx.x < tx * ty * tz) blur_tile<CELL>(tile_x, tile_w, blockIdx.x, packed, g, out, false, false);
     return;
   }
   lists += (size_t)blockIdx.y * 2 * flags_stride;
   const uint32_t n_work = dyn[SC_NLIST], n_zero = dyn[SC_NZERO];
   for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {
     const bool work = j < n_work;
-    blur_tile(tile, work ? lists[j] : lists[flags_stride + (j - n_work)], packed, g, out, true, !work);
+    blur_tile<CELL>(tile_x, tile_w, work ? lists[j] : lists[flags_stride + (j - n_work)], packed, g, out, true, !work);
     __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
   }
 }
@@ -692,8 +712,17 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   const GridDims none{0, 0, 0};
   // (gh and gw depend on the image size only: the launch covers every (row, column) pixels can splat into)
   const dim3 splat_grid(((gh - 3) * (gw - 3) + 255) / 256, n_frames);
-  // two blocks of the blur fit a CU (64 KiB of LDS each): one resident round, shared out over the frames
-  const uint32_t resident = 2u * (uint32_t)std::max(1, ctx->num_cus);
+  // one resident round of blur blocks, shared out over the frames: three blocks per CU with the narrow cells (48 KiB of
+  // LDS and 133 VGPRs each), two with the wide ones (64 KiB, 224 VGPRs)
+  static const int blur_per_cu[2] = {[] {
+                                       int n = 0;
+                                       return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<unsigned long long>, 256, 0) == hipSuccess && n > 0 ? n : 2;
+                                     }(),
+                                     [] {
+                                       int n = 0;
+                                       return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<uint32_t>, 256, 0) == hipSuccess && n > 0 ? n : 2;
+                                     }()};
+  const uint32_t resident = (uint32_t)blur_per_cu[narrow ? 1 : 0] * (uint32_t)std::max(1, ctx->num_cus);
   const uint32_t per_frame = std::max(8u, std::min(std::max(1u, tiles), (resident + n_frames - 1) / n_frames));
   const dim3 list_grid((std::max(1u, tiles) + 255) / 256, n_frames);
   if (narrow) {

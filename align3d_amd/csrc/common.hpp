@@ -135,6 +135,11 @@ struct a3d_context {
   // What the most recent a3d_range_image_build_pyramids call processed (a3d_context_last_build_stats): frames, cells of
   // their bilateral grids, blur tiles marked by the splat, first-channel tiles written as zeros.
   uint64_t build_stats[4] = {0, 0, 0, 0};
+  // a3d_context_set_build_profiling: every chunk of a build is bracketed by a hipEvent pair on the context stream (behind
+  // the wait for its upload), and last_build_kernel_ms is the sum of those brackets: the builder's kernels without PCIe.
+  bool build_profiling = false;
+  std::vector<hipEvent_t> build_events;
+  float last_build_kernel_ms = 0.f;
   // a3d_context_set_tiling: 0 = the tiling of the ICP pixel pass follows the batch size (throughput); otherwise every
   // (pair, level) is cut into this many blocks whatever the batch: a pair's pose bits no longer depend on its batch.
   uint32_t tiles_per_pair = 0;

@@ -368,6 +368,7 @@ void ctx_destroy_now(a3d_context* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
   for (hipEvent_t e : ctx->copy_events) hipEventDestroy(e);
+  for (hipEvent_t e : ctx->build_events) hipEventDestroy(e);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->icp_engine && ctx->icp_engine_free) ctx->icp_engine_free(ctx->icp_engine);
   for (hipStream_t st : ctx->side_streams) {

@@ -704,16 +704,26 @@ a3d_status build_frames(a3d_context* ctx, const a3d_builder_params* prm, uint64_
   }
   std::vector<size_t> todo(n_chunks);
   for (size_t k = 0; k < n_chunks; ++k) todo[k] = k;
+  size_t n_profiled = 0;
   for (int attempt = 0; attempt < 3 && !todo.empty(); ++attempt) {
     for (size_t k : todo) {
       Chunk& c = chunks[k];
       if (attempt == 0 && hipStreamWaitEvent(s, ctx->copy_events[k], 0) != hipSuccess) return fail(A3D_HIP_ERROR);
+      if (ctx->build_profiling) {
+        while (ctx->build_events.size() < 2 * (n_profiled + 1)) {
+          hipEvent_t e;
+          if (hipEventCreate(&e) != hipSuccess) return fail(A3D_HIP_ERROR);
+          ctx->build_events.push_back(e);
+        }
+        (void)hipEventRecord(ctx->build_events[2 * n_profiled], s);
+      }
       if (attempt == 0 && c.colors_staged)
         hipLaunchKernelGGL(scatter_colors_kernel, dim3((uint32_t)((n * 3 / 16 + 255) / 256), 1, c.F), dim3(256), 0, s,
                            (const uint4*)c.d_colors, n * 3, plan.layout.lv[0].colors, c.bases);
       const a3d_status st = enqueue_chunk(ctx, prm, c.F, c.d_depth, w, h, (float)fx, (float)fy, (float)cx, (float)cy,
                                           (float)depth_scale, plan, c.bases, c.result);
       if (st != A3D_OK) return fail(st);
+      if (ctx->build_profiling) (void)hipEventRecord(ctx->build_events[2 * n_profiled++ + 1], s);
     }
     if (hipStreamSynchronize(s) != hipSuccess) {
       set_error("a3d_range_image_build_pyramids: %s", hipGetErrorString(hipGetLastError()));
@@ -747,6 +757,10 @@ a3d_status build_frames(a3d_context* ctx, const a3d_builder_params* prm, uint64_
   if (!todo.empty()) {
     set_error("a3d_range_image_build_pyramids: the bilateral grid kept outgrowing its scratch region");
     return fail(A3D_HIP_ERROR);
+  }
+  for (size_t k = 0; k < n_profiled; ++k) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->build_events[2 * k], ctx->build_events[2 * k + 1]) == hipSuccess) ctx->last_build_kernel_ms += ms;
   }
   size_t o = 0;
   for (Chunk& c : chunks) {
@@ -810,6 +824,7 @@ a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_pa
     chunk = std::max<uint64_t>(1, std::min<uint64_t>(MAX_BATCH, (2ull << 30) / (cap * 24 + 1)));
   }
   for (uint64_t& v : ctx->build_stats) v = 0;
+  ctx->last_build_kernel_ms = 0.f;
   // frames per pipelined pass: as many chunks as the page-locked result area has scalar blocks for
   const uint64_t pass = chunk * (a3d_context::PINNED_WORDS / (MAX_BATCH * SC_STRIDE));
   for (uint64_t f0 = 0; f0 < n_frames; f0 += pass) {
@@ -834,6 +849,18 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
 a3d_status a3d_context_last_build_stats(a3d_context* ctx, uint64_t out_stats[4]) {
   A3D_REQUIRE(ctx && out_stats, A3D_INVALID_PARAMETER, "null argument");
   for (int k = 0; k < 4; ++k) out_stats[k] = ctx->build_stats[k];
+  return A3D_OK;
+}
+
+// Instrumentation: device time of the builder's kernels in the most recent build (see a3d_context::build_profiling).
+a3d_status a3d_context_set_build_profiling(a3d_context* ctx, int32_t on) {
+  A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");
+  ctx->build_profiling = on != 0;
+  return A3D_OK;
+}
+a3d_status a3d_context_last_build_kernel_ms(a3d_context* ctx, float* out_ms) {
+  A3D_REQUIRE(ctx && out_ms, A3D_INVALID_PARAMETER, "null argument");
+  *out_ms = ctx->last_build_kernel_ms;
   return A3D_OK;
 }
 

@@ -1,4 +1,6 @@
 // Range images resident in HBM: upload and RangeImage::compute_normals (src/range_image/structure.rs:184-262) as an LDS-tiled stencil.
+#include <algorithm>
+
 #include "common.hpp"
 
 using namespace a3d;
@@ -6,44 +8,81 @@ using namespace a3d;
 namespace {
 
 // ---- compute_normals ----------------------------------------------------------------------------
-constexpr int TILE_W = 32, TILE_H = 8;  // 256 threads; LDS tile (TILE_W+2) x (TILE_H+2) with 1-px halo
+// One block = a 64 x 16 pixel tile of one frame (blockIdx.z = frame of a batch), 256 threads, four pixels per thread
+// (rows ty, ty + 4, ty + 8, ty + 12).  Every point is ONE 12-byte load (global_load_dwordx3: three dword loads at a
+// 12-byte lane stride make the L1 look up every line of the wave's span three times) and every normal ONE 12-byte
+// store; the tile + a one-pixel halo (16 % more loads) is staged in LDS as SoA planes with the mask applied
+// (get_point(...).unwrap_or_else(zeros): neighbours that are out of range or whose mask != 1 read as (0,0,0)); the
+// centre is used raw from the thread's own registers — its mask is NOT checked (structure.rs:207).
+// 25 algorithmic bytes per pixel (12 + 1 read, 12 written).
+constexpr int NT_W = 64, NT_H = 16, NT_PPT = 4, NT_THREADS = NT_W * NT_H / NT_PPT;
+constexpr int NORMALS_MAX_BATCH = 64;
+struct NormalsBatch {
+  const float* points[NORMALS_MAX_BATCH];
+  const uint8_t* mask[NORMALS_MAX_BATCH];
+  float* normals[NORMALS_MAX_BATCH];
+};
+typedef float nf32x3 __attribute__((ext_vector_type(3)));
+typedef nf32x3 __attribute__((aligned(4))) nf32x3_u;
 
-// get_point(...).unwrap_or_else(zeros): the point if in range and mask == 1, else (0,0,0).
-__device__ __forceinline__ V3 masked_point(const float* __restrict__ points, const uint8_t* __restrict__ mask,
-                                           int w, int h, int row, int col) {
-  if (row < 0 || col < 0 || row >= h || col >= w) return {0.f, 0.f, 0.f};
-  int idx = row * w + col;
-  if (mask[idx] != 1) return {0.f, 0.f, 0.f};
-  return {points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
-}
-
-__global__ void __launch_bounds__(TILE_W* TILE_H)
-    compute_normals_kernel(const float* __restrict__ points, const uint8_t* __restrict__ mask,
-                           float* __restrict__ normals, int w, int h) {
-  __shared__ float tile[3][TILE_H + 2][TILE_W + 3];  // SoA planes; +3 keeps rows off the same banks
-  const int tx = threadIdx.x % TILE_W, ty = threadIdx.x / TILE_W;
-  const int col0 = blockIdx.x * TILE_W, row0 = blockIdx.y * TILE_H;
-  // cooperative load of the haloed tile, masked (neighbour semantics)
-  for (int t = threadIdx.x; t < (TILE_W + 2) * (TILE_H + 2); t += TILE_W * TILE_H) {
-    int lx = t % (TILE_W + 2), ly = t / (TILE_W + 2);
-    V3 p = masked_point(points, mask, w, h, row0 + ly - 1, col0 + lx - 1);
-    tile[0][ly][lx] = p.x;
-    tile[1][ly][lx] = p.y;
-    tile[2][ly][lx] = p.z;
+__global__ void __launch_bounds__(NT_THREADS)
+    compute_normals_kernel(NormalsBatch batch, int w, int h) {
+  __shared__ float tile[3][NT_H + 2][NT_W + 3];  // SoA planes; +3 keeps rows off the same banks
+  const float* __restrict__ points = batch.points[blockIdx.z];
+  const uint8_t* __restrict__ mask = batch.mask[blockIdx.z];
+  float* __restrict__ normals = batch.normals[blockIdx.z];
+  const int tx = threadIdx.x % NT_W, ty = threadIdx.x / NT_W;  // ty in 0..3
+  const int col0 = blockIdx.x * NT_W, row0 = blockIdx.y * NT_H;
+  const int col = col0 + tx;
+  // ---- the thread's own four pixels: raw centre kept in registers, masked copy into the tile ----
+  V3 center[NT_PPT];
+  bool inside[NT_PPT];
+#pragma unroll
+  for (int k = 0; k < NT_PPT; ++k) {
+    const int row = row0 + ty + k * (NT_H / NT_PPT);
+    inside[k] = col < w && row < h;
+    const int idx = inside[k] ? row * w + col : 0;
+    const nf32x3 p = *(const nf32x3_u*)(points + 3 * (size_t)idx);  // (unconditional loads: all four in flight at once)
+    const uint8_t m = mask[idx];
+    center[k] = V3{p.x, p.y, p.z};
+    const bool ok = inside[k] && m == 1;
+    const int ly = ty + k * (NT_H / NT_PPT) + 1;
+    tile[0][ly][tx + 1] = ok ? p.x : 0.f, tile[1][ly][tx + 1] = ok ? p.y : 0.f, tile[2][ly][tx + 1] = ok ? p.z : 0.f;
+  }
+  // ---- the halo ring: 2 (NT_W + 2) + 2 NT_H = 164 pixels, one per thread of the first 164 ----
+  {
+    constexpr int RING = 2 * (NT_W + 2) + 2 * NT_H;
+    const int t = (int)threadIdx.x;
+    if (t < RING) {
+      int ly, lx;
+      if (t < NT_W + 2) ly = 0, lx = t;
+      else if (t < 2 * (NT_W + 2)) ly = NT_H + 1, lx = t - (NT_W + 2);
+      else ly = 1 + (t - 2 * (NT_W + 2)) / 2, lx = ((t - 2 * (NT_W + 2)) & 1) ? NT_W + 1 : 0;
+      const int row = row0 + ly - 1, c = col0 + lx - 1;
+      const bool in = row >= 0 && c >= 0 && row < h && c < w;
+      const int idx = in ? row * w + c : 0;
+      const nf32x3 p = *(const nf32x3_u*)(points + 3 * (size_t)idx);
+      const bool ok = in && mask[idx] == 1;
+      tile[0][ly][lx] = ok ? p.x : 0.f, tile[1][ly][lx] = ok ? p.y : 0.f, tile[2][ly][lx] = ok ? p.z : 0.f;
+    }
   }
   __syncthreads();
-  const int col = col0 + tx, row = row0 + ty;
-  if (col >= w || row >= h) return;
-  const int idx = row * w + col;
-  // the centre is read raw: its mask is NOT checked (structure.rs:207)
-  V3 center{points[3 * idx], points[3 * idx + 1], points[3 * idx + 2]};
   auto at = [&](int ly, int lx) { return V3{tile[0][ly][lx], tile[1][ly][lx], tile[2][ly][lx]}; };
-  V3 left = at(ty + 1, tx), right = at(ty + 1, tx + 2);
-  V3 top = at(ty, tx + 1), bottom = at(ty + 2, tx + 1);
-  const V3 out = normal_from_neighbours(center, left, right, top, bottom);
-  normals[3 * idx] = out.x;
-  normals[3 * idx + 1] = out.y;
-  normals[3 * idx + 2] = out.z;
+#pragma unroll
+  for (int k = 0; k < NT_PPT; ++k) {
+    if (!inside[k]) continue;
+    const int ly = ty + k * (NT_H / NT_PPT) + 1, lx = tx + 1;
+    const V3 out = normal_from_neighbours(center[k], at(ly, lx - 1), at(ly, lx + 1), at(ly - 1, lx), at(ly + 1, lx));
+    const int row = row0 + ly - 1;
+    *(nf32x3_u*)(normals + 3 * ((size_t)row * w + col)) = nf32x3{out.x, out.y, out.z};
+  }
+}
+
+a3d_status launch_compute_normals_batch(a3d_context* ctx, const NormalsBatch& batch, uint32_t frames, uint32_t w, uint32_t h) {
+  dim3 grid((w + NT_W - 1) / NT_W, (h + NT_H - 1) / NT_H, frames);
+  hipLaunchKernelGGL(compute_normals_kernel, grid, dim3(NT_THREADS), 0, ctx->stream, batch, (int)w, (int)h);
+  A3D_HIP_TRY(hipGetLastError());
+  return A3D_OK;
 }
 
 template <typename T>
@@ -55,11 +94,9 @@ a3d_status upload_array(a3d_context* ctx, const T* host, size_t count, T** dev) 
 
 a3d_status launch_compute_normals(a3d_context* ctx, const float* points, const uint8_t* mask, float* normals,
                                   uint32_t w, uint32_t h) {
-  dim3 grid((w + TILE_W - 1) / TILE_W, (h + TILE_H - 1) / TILE_H);
-  hipLaunchKernelGGL(compute_normals_kernel, grid, dim3(TILE_W * TILE_H), 0, ctx->stream, points, mask, normals,
-                     (int)w, (int)h);
-  A3D_HIP_TRY(hipGetLastError());
-  return A3D_OK;
+  NormalsBatch b{};
+  b.points[0] = points, b.mask[0] = mask, b.normals[0] = normals;
+  return launch_compute_normals_batch(ctx, b, 1, w, h);
 }
 
 }  // namespace
@@ -199,6 +236,51 @@ a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
     attach_fence(im, im->arena->self_fence);
   }
   im->has_normals = true;
+  return A3D_OK;
+}
+
+// RangeImage::compute_normals for n resident images of one size in ONE launch per 64 images (enqueue-only, like the
+// single-image call): the stencil's launch cost is paid once instead of per frame.
+a3d_status a3d_range_image_compute_normals_batch(a3d_device_image* const* images, uint64_t n) {
+  A3D_REQUIRE(images || n == 0, A3D_INVALID_PARAMETER, "null argument");
+  if (n == 0) return A3D_OK;
+  for (uint64_t i = 0; i < n; ++i) {
+    A3D_REQUIRE(images[i], A3D_INVALID_PARAMETER, "image is null");
+    A3D_REQUIRE(images[i]->ctx == images[0]->ctx && images[i]->width == images[0]->width &&
+                    images[i]->height == images[0]->height,
+                A3D_INVALID_PARAMETER, "a3d_range_image_compute_normals_batch: the images must share a context and a size");
+    A3D_REQUIRE(images[i]->normals || !images[i]->arena || !images[i]->built, A3D_INVALID_PARAMETER,
+                "this image was built without normals (a3d_builder_params.with_normals = 0)");
+  }
+  a3d_context* ctx = images[0]->ctx;
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t px = (size_t)images[0]->width * images[0]->height;
+  for (uint64_t i = 0; i < n; ++i) {  // uploaded without normals: they get their own allocation, freed with the image
+    a3d_device_image* im = images[i];
+    if (!im->normals) {
+      A3D_HIP_TRY(hipMalloc((void**)&im->normals, px * 3 * sizeof(float)));
+      im->own_normals = true;
+    }
+  }
+  for (uint64_t first = 0; first < n; first += NORMALS_MAX_BATCH) {
+    const uint32_t count = (uint32_t)std::min<uint64_t>(NORMALS_MAX_BATCH, n - first);
+    NormalsBatch b{};
+    for (uint32_t k = 0; k < count; ++k) {
+      a3d_device_image* im = images[first + k];
+      b.points[k] = im->points, b.mask[k] = im->mask, b.normals[k] = im->normals;
+    }
+    A3D_TRY(launch_compute_normals_batch(ctx, b, count, images[0]->width, images[0]->height));
+  }
+  // enqueue-only: each arena's own fence is recorded behind the launches (see a3d_range_image_compute_normals)
+  for (uint64_t i = 0; i < n; ++i) {
+    a3d_device_image* im = images[i];
+    im->has_normals = true;
+    if (im->arena) {
+      if (!im->arena->self_fence) im->arena->self_fence = std::make_shared<UseFence>();
+      im->arena->self_fence->record(ctx->stream);
+      attach_fence(im, im->arena->self_fence);
+    }
+  }
   return A3D_OK;
 }
 

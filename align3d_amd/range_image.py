@@ -133,6 +133,16 @@ class DeviceRangeImage:
             pass
 
 
+def compute_normals_batch(images):
+    """RangeImage::compute_normals on a list of resident images of one size (a3d_range_image_compute_normals_batch: one
+    launch per 64 images, enqueue-only)."""
+    if not images:
+        return
+    arr = (C.c_void_p * len(images))(*[im.handle for im in images])
+    _abi.check(images[0].ctx.lib.a3d_range_image_compute_normals_batch(arr, len(images)),
+               "a3d_range_image_compute_normals_batch")
+
+
 def upload_pyramid(ctx, host_images):
     """A `&[RangeImage]` as the host holds it -> resident images sharing one pooled arena
     (a3d_range_image_upload_pyramid): what MultiscaleAlign::new / align do with host pyramids.  The device copies are

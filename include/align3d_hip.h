@@ -234,12 +234,25 @@ a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_pa
  * this context processed — out_stats = {frames, cells of their bilateral grids (GH x GW x GD, src/bilateral/grid.rs:37-56),
  * 12^3-cell blur tiles the splat marked, first-channel tiles written as zeros}. */
 a3d_status a3d_context_last_build_stats(a3d_context* ctx, uint64_t out_stats[4]);
+/* Instrumentation: when on, every chunk (up to 16 frames) of a3d_range_image_build_pyramids is bracketed by a hipEvent
+ * pair on the context's stream, recorded behind the wait for the chunk's upload: a3d_context_last_build_kernel_ms is the
+ * sum of those brackets for the most recent build — the device time of the builder's kernels without the PCIe copies
+ * (a live figure for the builder's roofline; rocprofv3 --kernel-trace shows the same kernels one by one). */
+a3d_status a3d_context_set_build_profiling(a3d_context* ctx, int32_t on);
+a3d_status a3d_context_last_build_kernel_ms(a3d_context* ctx, float* out_ms);
 a3d_status a3d_range_image_size(const a3d_device_image* image, uint64_t* out_width, uint64_t* out_height);
 /* Reads resident arrays back (each pointer nullable): points [h][w][3], mask [h][w], normals [h][w][3],
  * intensities [h*w], intensity_map [(h+2)][(w+2)], colors [h][w][3] u8, intrinsics fx fy cx cy. */
 a3d_status a3d_range_image_download(a3d_device_image* image, float* points, uint8_t* mask, float* normals,
                                     uint8_t* intensities, float* intensity_map, uint8_t* colors,
                                     double out_intrinsics[4]);
+
+/* RangeImage::compute_normals (src/range_image/structure.rs:184-262) on n resident images of one size and one context
+ * in ONE launch per 64 images; enqueue-only like a3d_range_image_compute_normals (results are ordered on the context's
+ * stream; a3d_range_image_download_normals / a3d_context_synchronize wait).  An odometry or mapping host that keeps its
+ * range images resident recomputes the normals of a whole window of frames at the stencil's HBM rate instead of paying
+ * one launch per frame. */
+a3d_status a3d_range_image_compute_normals_batch(a3d_device_image* const* images, uint64_t n);
 
 /* RangeImage::compute_normals, host in / host out convenience form. */
 a3d_status a3d_compute_normals(a3d_context* ctx, const float* points, const uint8_t* mask,

@@ -27,6 +27,41 @@ def test_compute_normals_bit_exact(ctx, sample, frame):
     assert np.array_equal(_bits(dev.download_normals()), _bits(fr.normals))
 
 
+def test_compute_normals_batch_bit_exact(ctx):
+    """a3d_range_image_compute_normals_batch: many resident images in one launch (more than one 64-image launch here),
+    every image bit for bit the oracle's normals (structure.rs:184-262) — real frames, and a ragged size that is neither
+    a multiple of the 64 x 16 tile nor of a wave."""
+    from align3d_amd import compute_normals_batch
+
+    frames = [oracle_frame("sample1", k) for k in (0, 1, 4, 5)] + [oracle_frame("sample2", k) for k in (0, 1)]
+    devs, refs = [], []
+    for rep in range(11):  # 66 images of 640 x 480
+        for fr in frames:
+            ri = RangeImage(fr.points, fr.mask, CameraIntrinsics(fr.fx, fr.fy, fr.cx, fr.cy, fr.w, fr.h))
+            devs.append(ri.device(ctx))
+            refs.append(fr.normals)
+    compute_normals_batch(devs)
+    for k in (0, 5, 63, 64, 65):
+        assert np.array_equal(devs[k].download_normals().view(np.uint32), refs[k].view(np.uint32)), k
+    for d in devs:
+        d.free()
+    rng = np.random.default_rng(5)
+    small = []
+    for k in range(5):
+        pts = rng.normal(size=(37, 131, 3)).astype(np.float32)
+        mask = (rng.random((37, 131)) > 0.2).astype(np.uint8) * rng.integers(1, 3, size=(37, 131)).astype(np.uint8)
+        small.append((pts, mask))
+    devs = [RangeImage(p, m, CameraIntrinsics(100, 100, 65, 18, 131, 37)).device(ctx) for p, m in small]
+    compute_normals_batch(devs)
+    for d, (p, m) in zip(devs, small):
+        assert np.array_equal(d.download_normals().view(np.uint32), O.compute_normals(p, m).view(np.uint32))
+    # images of different sizes in one call are refused
+    from align3d_amd import A3dError
+    other = RangeImage(frames[0].points, frames[0].mask, CameraIntrinsics(1, 1, 0, 0, 640, 480)).device(ctx)
+    with pytest.raises(A3dError):
+        compute_normals_batch([devs[0], other])
+
+
 def test_compute_normals_ragged_and_empty_inputs(ctx):
     # sizes that are not multiples of the tile, all-invalid mask, NaN points, single row / column
     rng = np.random.default_rng(7)
