@@ -15,7 +15,8 @@ namespace {
 // (get_point(...).unwrap_or_else(zeros): neighbours that are out of range or whose mask != 1 read as (0,0,0)); the
 // centre is used raw from the thread's own registers — its mask is NOT checked (structure.rs:207).
 // 25 algorithmic bytes per pixel (12 + 1 read, 12 written).
-constexpr int NT_W = 64, NT_H = 16, NT_PPT = 4, NT_THREADS = NT_W * NT_H / NT_PPT;
+// Two shapes: 64 x 16 tiles with four pixels per thread for a batch (16 % halo loads), 32 x 8 tiles with one pixel per
+// thread for a frame or two (1200 blocks for a 640 x 480 frame instead of 300: a lone frame is latency-bound).
 constexpr int NORMALS_MAX_BATCH = 64;
 struct NormalsBatch {
   const float* points[NORMALS_MAX_BATCH];
@@ -25,8 +26,10 @@ struct NormalsBatch {
 typedef float nf32x3 __attribute__((ext_vector_type(3)));
 typedef nf32x3 __attribute__((aligned(4))) nf32x3_u;
 
-__global__ void __launch_bounds__(NT_THREADS)
+template <int NT_W, int NT_H, int NT_PPT>
+__global__ void __launch_bounds__(256)
     compute_normals_kernel(NormalsBatch batch, int w, int h) {
+  static_assert(NT_W * NT_H / NT_PPT == 256, "256 threads per block");
   __shared__ float tile[3][NT_H + 2][NT_W + 3];  // SoA planes; +3 keeps rows off the same banks
   const float* __restrict__ points = batch.points[blockIdx.z];
   const uint8_t* __restrict__ mask = batch.mask[blockIdx.z];
@@ -79,10 +82,35 @@ __global__ void __launch_bounds__(NT_THREADS)
 }
 
 a3d_status launch_compute_normals_batch(a3d_context* ctx, const NormalsBatch& batch, uint32_t frames, uint32_t w, uint32_t h) {
-  dim3 grid((w + NT_W - 1) / NT_W, (h + NT_H - 1) / NT_H, frames);
-  hipLaunchKernelGGL(compute_normals_kernel, grid, dim3(NT_THREADS), 0, ctx->stream, batch, (int)w, (int)h);
+  if ((uint64_t)frames * w * h >= 4ull * 640 * 480)
+    hipLaunchKernelGGL((compute_normals_kernel<64, 16, 4>), dim3((w + 63) / 64, (h + 15) / 16, frames), dim3(256), 0, ctx->stream,
+                       batch, (int)w, (int)h);
+  else
+    hipLaunchKernelGGL((compute_normals_kernel<32, 8, 1>), dim3((w + 31) / 32, (h + 7) / 8, frames), dim3(256), 0, ctx->stream,
+                       batch, (int)w, (int)h);
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
+}
+
+// Enqueue-only work of a context on images that live in arenas: ONE fence (one event record) per call, shared by the
+// arenas of all the images the call touched; it replaces the fence an earlier call left on an arena (a later event on
+// the same stream covers the earlier work), so repeated calls do not pile fences up.
+void fence_self_work(a3d_context* ctx, a3d_device_image* const* images, uint64_t n) {
+  std::shared_ptr<UseFence> fence;
+  for (uint64_t i = 0; i < n; ++i) {
+    DeviceArena* a = images[i]->arena;
+    if (!a) continue;
+    if (!fence) {
+      fence = std::make_shared<UseFence>();
+      fence->record(ctx->stream);
+    }
+    std::lock_guard<std::mutex> lock(a->fence_mutex);
+    bool replaced = false;
+    for (auto& f : a->fences)
+      if (a->self_fence && f == a->self_fence) f = fence, replaced = true;
+    if (!replaced && a->self_fence != fence) a->fences.push_back(fence);
+    a->self_fence = fence;
+  }
 }
 
 template <typename T>
@@ -227,14 +255,10 @@ a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
     im->own_normals = true;
   }
   A3D_TRY(launch_compute_normals(im->ctx, im->points, im->mask, im->normals, im->width, im->height));
-  // enqueue-only: the arena must outlive the launch.  The arena's own fence is recorded right behind the launch
-  // (an event record costs ~1 us), so that freeing the image later waits for THIS launch only — not for whatever
-  // else (the next frames' builds) has been enqueued on the context's stream by then.
-  if (im->arena) {
-    if (!im->arena->self_fence) im->arena->self_fence = std::make_shared<UseFence>();
-    im->arena->self_fence->record(im->ctx->stream);
-    attach_fence(im, im->arena->self_fence);
-  }
+  // enqueue-only: the arena must outlive the launch.  A fence is recorded right behind the launch (one event record),
+  // so that freeing the image later waits for THIS launch only — not for whatever else (the next frames' builds) has
+  // been enqueued on the context's stream by then.
+  fence_self_work(im->ctx, &im, 1);
   im->has_normals = true;
   return A3D_OK;
 }
@@ -271,16 +295,8 @@ a3d_status a3d_range_image_compute_normals_batch(a3d_device_image* const* images
     }
     A3D_TRY(launch_compute_normals_batch(ctx, b, count, images[0]->width, images[0]->height));
   }
-  // enqueue-only: each arena's own fence is recorded behind the launches (see a3d_range_image_compute_normals)
-  for (uint64_t i = 0; i < n; ++i) {
-    a3d_device_image* im = images[i];
-    im->has_normals = true;
-    if (im->arena) {
-      if (!im->arena->self_fence) im->arena->self_fence = std::make_shared<UseFence>();
-      im->arena->self_fence->record(ctx->stream);
-      attach_fence(im, im->arena->self_fence);
-    }
-  }
+  for (uint64_t i = 0; i < n; ++i) images[i]->has_normals = true;
+  fence_self_work(ctx, images, n);  // enqueue-only: one fence behind the launches (see a3d_range_image_compute_normals)
   return A3D_OK;
 }
 

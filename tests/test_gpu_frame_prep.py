@@ -31,7 +31,7 @@ def test_compute_normals_batch_bit_exact(ctx):
     """a3d_range_image_compute_normals_batch: many resident images in one launch (more than one 64-image launch here),
     every image bit for bit the oracle's normals (structure.rs:184-262) — real frames, and a ragged size that is neither
     a multiple of the 64 x 16 tile nor of a wave."""
-    from align3d_amd import compute_normals_batch
+    from align3d_amd import CameraIntrinsics, RangeImage, compute_normals_batch
 
     frames = [oracle_frame("sample1", k) for k in (0, 1, 4, 5)] + [oracle_frame("sample2", k) for k in (0, 1)]
     devs, refs = [], []
