@@ -222,6 +222,48 @@ __device__ __forceinline__ bool div_den_ok(float z) { return (fabsf(z) > 1e-9f) 
 __device__ __forceinline__ bool div_num_ok(float a) { return (a == 0.0f) | ((fabsf(a) > 1e-20f) & (fabsf(a) < 1e9f)); }
 
 
+// The per-pixel body of RangeImage::compute_normals (src/range_image/structure.rs:207-257) as the kernels evaluate it:
+// the same decisions and the same bits as normal_from_neighbours below (the reference's operations in the reference's
+// order), with the two ratio tests and the three quotients n / |n| rewritten so that they cost a third of the
+// instructions (the stand-alone stencil is VALU-issue bound, not byte-bound):
+//  * `ld / rd < 4 && ld / rd > 1/4` == `ld < 4 rd && 4 ld > rd` for every pair of f32 (4 x is exact; a quotient below
+//    4 is at most pred(4) = 4 (1 - 2^-24), which is representable, so round-to-nearest cannot lift it to 4; a quotient
+//    above 1/4 is at least (1/4) succ(rd) / rd > the midpoint of 1/4 and succ(1/4), so it cannot be rounded down to 1/4;
+//    rd == 0, NaN, inf, overflow and underflow give `false` / the same truth value on both sides);
+//  * n / |n|: three IEEE quotients through ONE refined reciprocal (div_prepare / div_by: bit-identical to `/` inside
+//    their operand range, checked on the device by a3d_selftest_division), plain `/` for the rare lanes outside it.
+__device__ __forceinline__ V3 normal_from_neighbours_dev(V3 center, V3 left, V3 right, V3 top, V3 bottom) {
+  const float ld = norm_squared(left - center), rd = norm_squared(right - center);
+  V3 left_to_right;
+  if ((ld < 4.0f * rd) & (4.0f * ld > rd))
+    left_to_right = right - left;
+  else if (ld < rd)
+    left_to_right = center - left;
+  else
+    left_to_right = right - center;
+  const float bd = norm_squared(bottom - center), td = norm_squared(top - center);
+  V3 bottom_to_top;
+  if ((bd < 4.0f * td) & (4.0f * bd > td))
+    bottom_to_top = top - bottom;
+  else if (bd < td)
+    bottom_to_top = center - bottom;
+  else
+    bottom_to_top = top - center;
+  const V3 n = cross(left_to_right, bottom_to_top);
+  const float mag = sqrtf(norm_squared(n));
+  V3 out{0.f, 0.f, 0.f};
+  const bool keep = mag > 1e-6f;
+  const bool fast = div_den_ok(mag) & div_num_ok(n.x) & div_num_ok(n.y) & div_num_ok(n.z);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(keep & !fast) != 0ull, 0)) {
+    if (keep) out = n / mag;
+  } else if (keep) {
+    const DivBy d = div_prepare(mag);
+    // (a zero numerator keeps its sign: -0 / |n| = -0, which the fused corrections of div_by would turn into +0)
+    out = V3{n.x == 0.0f ? n.x : div_by(n.x, d), n.y == 0.0f ? n.y : div_by(n.y, d), n.z == 0.0f ? n.z : div_by(n.z, d)};
+  }
+  return out;
+}
+
 #endif  // __HIPCC__
 
 // The per-pixel body of RangeImage::compute_normals (src/range_image/structure.rs:207-257): neighbours that are

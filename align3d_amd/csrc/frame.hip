@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(L0_THREADS)
     if (owned[k] && with_normals && A3D_L0_PROBE != 2 && A3D_L0_PROBE != 4) {
       // an invalid neighbour's point is (0,0,0) already (= get_point(...).unwrap_or_else(zeros)); so is everything
       // outside the image; the centre is used as stored, its mask is NOT checked (structure.rs:207)
-      nrm[k] = normal_from_neighbours(V3{px[k], py[k], pz[k]}, at(ly[k], lx - 1), at(ly[k], lx + 1), at(ly[k] - 1, lx),
+      nrm[k] = normal_from_neighbours_dev(V3{px[k], py[k], pz[k]}, at(ly[k], lx - 1), at(ly[k], lx + 1), at(ly[k] - 1, lx),
                                       at(ly[k] + 1, lx));
       if (emit_l1) sn[0][ly[k] - 1][lx - 1] = nrm[k].x, sn[1][ly[k] - 1][lx - 1] = nrm[k].y, sn[2][ly[k] - 1][lx - 1] = nrm[k].z;
     }

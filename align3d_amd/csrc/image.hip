@@ -1,5 +1,6 @@
 // Range images resident in HBM: upload and RangeImage::compute_normals (src/range_image/structure.rs:184-262) as an LDS-tiled stencil.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -55,8 +56,8 @@ __global__ void __launch_bounds__(256)
   // ---- the halo ring: 2 (NT_W + 2) + 2 NT_H = 164 pixels, one per thread of the first 164 ----
   {
     constexpr int RING = 2 * (NT_W + 2) + 2 * NT_H;
-    const int t = (int)threadIdx.x;
-    if (t < RING) {
+    static_assert(RING <= 2 * 256, "the halo ring takes at most two pixels per thread");
+    for (int t = (int)threadIdx.x; t < RING; t += 256) {
       int ly, lx;
       if (t < NT_W + 2) ly = 0, lx = t;
       else if (t < 2 * (NT_W + 2)) ly = NT_H + 1, lx = t - (NT_W + 2);
@@ -75,14 +76,25 @@ __global__ void __launch_bounds__(256)
   for (int k = 0; k < NT_PPT; ++k) {
     if (!inside[k]) continue;
     const int ly = ty + k * (NT_H / NT_PPT) + 1, lx = tx + 1;
-    const V3 out = normal_from_neighbours(center[k], at(ly, lx - 1), at(ly, lx + 1), at(ly - 1, lx), at(ly + 1, lx));
+    const V3 out = normal_from_neighbours_dev(center[k], at(ly, lx - 1), at(ly, lx + 1), at(ly - 1, lx), at(ly + 1, lx));
     const int row = row0 + ly - 1;
     *(nf32x3_u*)(normals + 3 * ((size_t)row * w + col)) = nf32x3{out.x, out.y, out.z};
   }
 }
 
 a3d_status launch_compute_normals_batch(a3d_context* ctx, const NormalsBatch& batch, uint32_t frames, uint32_t w, uint32_t h) {
-  if ((uint64_t)frames * w * h >= 4ull * 640 * 480)
+  int shape = (uint64_t)frames * w * h >= 4ull * 640 * 480 ? 1 : 0;
+  if (const char* env = A3D_DIAG_ENV("A3D_NORMALS_SHAPE")) shape = atoi(env);  // diagnostics build: tile shape sweep
+  if (shape == 2)
+    hipLaunchKernelGGL((compute_normals_kernel<64, 32, 8>), dim3((w + 63) / 64, (h + 31) / 32, frames), dim3(256), 0, ctx->stream,
+                       batch, (int)w, (int)h);
+  else if (shape == 3)
+    hipLaunchKernelGGL((compute_normals_kernel<128, 8, 4>), dim3((w + 127) / 128, (h + 7) / 8, frames), dim3(256), 0, ctx->stream,
+                       batch, (int)w, (int)h);
+  else if (shape == 4)
+    hipLaunchKernelGGL((compute_normals_kernel<64, 8, 2>), dim3((w + 63) / 64, (h + 7) / 8, frames), dim3(256), 0, ctx->stream,
+                       batch, (int)w, (int)h);
+  else if (shape == 1)
     hipLaunchKernelGGL((compute_normals_kernel<64, 16, 4>), dim3((w + 63) / 64, (h + 15) / 16, frames), dim3(256), 0, ctx->stream,
                        batch, (int)w, (int)h);
   else

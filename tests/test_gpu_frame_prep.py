@@ -368,3 +368,30 @@ def test_builder_reports_what_it_processed(ctx):
             lv.free()
     RangeImageBuilder(ctx).build_many(CameraIntrinsics(*s1.intrinsics(0), 640, 480), frames[:1], s1.depth_scale(0))
     assert ctx.last_build_stats() == {"frames": 1, "grid_cells": 0, "marked_tiles": 0, "zero_tiles": 0}
+
+
+def test_compute_normals_wide_dynamic_range_and_signed_zeros(ctx):
+    """The kernels decide the two ratio tests by exact comparisons and take n / |n| through a shared reciprocal
+    (devmath.hpp, normal_from_neighbours_dev): point clouds scaled from 1e-12 to 1e12 (quotients outside the fast
+    division's range take the plain one), axis-aligned planes (cross products with -0.0 components), zero and huge
+    neighbour distances (ratios 0, inf, NaN, exactly 4 and exactly 1/4) — all bit for bit the oracle's."""
+    from align3d_amd import CameraIntrinsics, RangeImage
+
+    rng = np.random.default_rng(99)
+    h, w = 48, 80
+    cases = []
+    for scale in (1e-12, 1e-6, 1e-3, 1.0, 1e4, 1e9, 1e12):
+        cases.append((rng.normal(size=(h, w, 3)) * scale).astype(np.float32))
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    for plane in ((xx, yy, np.zeros_like(xx)), (-xx, yy, np.full_like(xx, 2.0)), (xx, -yy, xx * 0), (yy * 0, xx, -yy)):
+        cases.append(np.stack(plane, axis=-1).astype(np.float32))
+    # neighbour distances in exact ratios 4, 1/4, 1 and with repeated points (0 / 0)
+    steps = np.array([1.0, 2.0, 1.0, 0.5, 0.0, 4.0, 1.0, 1.0], np.float32)
+    xs = np.concatenate([[0.0], np.cumsum(np.tile(steps, w // 8 + 1))])[:w].astype(np.float32)
+    cases.append(np.stack([np.broadcast_to(xs, (h, w)), np.broadcast_to(xs[:h, None], (h, w)) if h <= w else yy, np.ones((h, w), np.float32)], axis=-1).astype(np.float32))
+    for k, pts in enumerate(cases):
+        pts = np.ascontiguousarray(pts)
+        mask = (rng.random((h, w)) > 0.1).astype(np.uint8)
+        ref = O.compute_normals(pts, mask)
+        got = RangeImage(pts, mask, CameraIntrinsics(100, 100, w / 2, h / 2, w, h)).compute_normals(ctx).normals
+        assert np.array_equal(_bits(got), _bits(ref)), (k, int(np.sum(_bits(got) != _bits(ref))))
