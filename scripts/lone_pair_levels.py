@@ -3,6 +3,8 @@ A3D_ICP_WAVES values (rounds of resident blocks the grid makes; fewer = fewer, f
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the A3D_ICP_* knobs exist in the diagnostics build only
+os.environ.setdefault("A3D_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "align3d_amd", "csrc", "libalign3d_hip_diag.so"))
 from align3d_amd import Context, IcpParams, MsIcpParams, MultiscaleAlignBatch
 from bench import build_stream_pyramids
 ctx = Context(0)

@@ -10,7 +10,6 @@ for f in glob.glob("gpurun_out/pmc_icp/**/*counter_collection.csv", recursive=Tr
     for r in csv.DictReader(open(f)):
         if "image_icp" not in r["Kernel_Name"]:
             continue
-        level = {6144: 0, 5632: 1, 4864: 2}.get(int(r["Grid_Size"]) // max(1, int(r["Grid_Size"]) // 6144 if False else 1), None)
         gx = int(r["Grid_Size"])
         name = f"image_icp_head_kernel grid={gx}"
         rows[name][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -3,6 +3,7 @@
 # by "--" and extra bench.py flags.  Run on an MI355X from the repository root, e.g.
 #   bash scripts/sweep.sh "A3D_ICP_STREAMS=1" "A3D_ICP_STREAMS=3 A3D_ICP_WAVES=1.5" "A3D_ICP_STREAMS=3 -- --pairs-per-gpu 128"
 #   bash scripts/sweep.sh "A3D_ICP_VARIANT=8,1" "A3D_ICP_ACCUM=mfma A3D_ICP_VARIANT=16,2" "A3D_ICP_PERSISTENT_LEVELS=4"
+export A3D_LIBRARY=${A3D_LIBRARY:-$(cd "$(dirname "$0")/.." && pwd)/align3d_amd/csrc/libalign3d_hip_diag.so}  # the knobs exist in the diagnostics build only
 STEPS=${STEPS:-20}
 WARMUP=${WARMUP:-5}
 for cfg in "$@"; do

@@ -22,6 +22,7 @@ def load(path=None):
     global _lib
     if _lib is not None:
         return _lib
+    path = path or os.environ.get("A3D_ORACLE_SO")  # tests/test_oracle_sanitized_cpu.py: the ASan + UBSan build
     if path is None and not os.path.exists(ORACLE_SO):
         subprocess.check_call(["make", "-C", ORACLE_DIR])
     lib = C.CDLL(path or ORACLE_SO)
