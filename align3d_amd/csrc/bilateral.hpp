@@ -38,20 +38,31 @@ __device__ __forceinline__ double cell_value(const double* __restrict__ grid, Gr
   return grid[((size_t)r * g.gw + c) * g.gd + z];
 }
 
-// BilateralGrid::slice for one pixel (grid.rs:106-130, trilinear :132-162): every pixel, zeros included.
-// Returns false when the value is not representable as u16 (num::cast::<f64,u16>().unwrap() would panic).
-__device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t c, double inv_ss, double inv_sc,
-                                            uint32_t color_min, GridDims g, const double* __restrict__ grid,
-                                            uint16_t* out) {
-  const double row = (double)r * inv_ss + 2.0;
-  const double col = (double)c * inv_ss + 2.0;
-  const double channel = (double)(color - color_min) * inv_sc + 2.0;
-  const uint32_t z = clampu(f64_as_usize(channel), g.gd - 1), zz = clampu(f64_as_usize(channel + 1.0), g.gd - 1);
-  const double za = channel - (double)z;
-  const uint32_t y = clampu(f64_as_usize(row), g.gh - 1), yy = clampu(f64_as_usize(row + 1.0), g.gh - 1);
-  const double ya = row - (double)y;
-  const uint32_t x = clampu(f64_as_usize(col), g.gw - 1), xx = clampu(f64_as_usize(col + 1.0), g.gw - 1);
-  const double xa = col - (double)x;
+// One axis of the trilinear slice (grid.rs:132-146): the cell below, the cell above (both clamped) and the fraction.
+// The row and column parts depend on the pixel's row / column only: the frame builder computes them once per tile row and
+// tile column (level0_kernel) instead of once per pixel — the same f64 operations on the same operands.
+struct SliceAxis {
+  uint32_t lo, hi;
+  double frac;
+};
+__device__ __forceinline__ SliceAxis slice_axis(double coord, uint32_t cells) {
+  SliceAxis a;
+  a.lo = clampu(f64_as_usize(coord), cells - 1), a.hi = clampu(f64_as_usize(coord + 1.0), cells - 1);
+  a.frac = coord - (double)a.lo;
+  return a;
+}
+__device__ __forceinline__ SliceAxis slice_axis_spatial(uint32_t pixel, double inv_ss, uint32_t cells) {
+  return slice_axis((double)pixel * inv_ss + 2.0, cells);
+}
+
+// BilateralGrid::slice for one pixel (grid.rs:106-130, trilinear :132-162) from its row and column parts: every pixel,
+// zeros included.  Returns false when the value is not representable as u16 (num::cast::<f64,u16>().unwrap() would panic).
+__device__ __forceinline__ bool slice_pixel_axes(uint32_t color, const SliceAxis& ry, const SliceAxis& cx, double inv_sc,
+                                                 uint32_t color_min, GridDims g, const double* __restrict__ grid,
+                                                 uint16_t* out) {
+  const SliceAxis cz = slice_axis((double)(color - color_min) * inv_sc + 2.0, g.gd);
+  const uint32_t z = cz.lo, zz = cz.hi, y = ry.lo, yy = ry.hi, x = cx.lo, xx = cx.hi;
+  const double za = cz.frac, ya = ry.frac, xa = cx.frac;
   const double value = (1.0 - ya) * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, y, x, z) +
                        (1.0 - ya) * xa * (1.0 - za) * cell_value(grid, g, y, xx, z) +
                        ya * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, yy, x, z) +
@@ -66,6 +77,12 @@ __device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t
   }
   *out = 0;
   return false;
+}
+__device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t c, double inv_ss, double inv_sc,
+                                            uint32_t color_min, GridDims g, const double* __restrict__ grid,
+                                            uint16_t* out) {
+  return slice_pixel_axes(color, slice_axis_spatial(r, inv_ss, g.gh), slice_axis_spatial(c, inv_ss, g.gw), inv_sc, color_min,
+                          g, grid, out);
 }
 
 // Where the blurred grids of a batch of frames live (the context's grid scratch region):
