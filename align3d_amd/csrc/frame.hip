@@ -103,10 +103,6 @@ __global__ void __launch_bounds__(L0_THREADS)
   __shared__ float sp[3][ST_H][ST_W + 1];
   __shared__ float sn[3][OWN_H][OWN_W + 1];  // the owned pixels' normals, for the fused level-1 pick
   __shared__ uint8_t sm[ST_H][ST_W];         // their masks (1: depth > 0)
-  // the row / column parts of the slice's trilinear weights, once per tile row and column (48 threads) instead of once
-  // per pixel: the f64 conversions they are made of issue at a quarter of the f32 rate and the kernel is VALU-issue bound
-  __shared__ SliceAxis s_row[ST_H], s_col[ST_W];
-  __shared__ uint32_t s_grid[4];  // gh, gw, gd, colour minimum (0 dims: the frame's grid did not fit)
   const uint32_t f = blockIdx.z;
   const int lx = threadIdx.x % ST_W, ly0 = threadIdx.x / ST_W;
   const int col = (int)blockIdx.x * OWN_W + lx - 1;
@@ -122,31 +118,18 @@ __global__ void __launch_bounds__(L0_THREADS)
     d[k] = in[k] ? depth[(size_t)f * w * h + (size_t)row[k] * w + col] : 0u;  // (both loads issued before either is used)
     px[k] = py[k] = pz[k] = 0.f;
   }
-  if (FILTER) {
-    uint32_t* sc = scal + f * SC_STRIDE;
-    GridDims g{0, 0, 0};
-    uint32_t cmin = 0;
-    const bool fits = dyn_dims(sc, &g, &cmin);  // (false: this frame's grid did not fit; the host grows the region and repeats)
-    const int t = (int)threadIdx.x;
-    if (fits && t < ST_H) {
-      const int r = (int)blockIdx.y * OWN_H + t - 1;
-      s_row[t] = slice_axis_spatial((uint32_t)(r < 0 ? 0 : r), inv_ss, g.gh);
-    } else if (fits && t >= 64 && t < 64 + ST_W) {
-      const int c = (int)blockIdx.x * OWN_W + (t - 64) - 1;
-      s_col[t - 64] = slice_axis_spatial((uint32_t)(c < 0 ? 0 : c), inv_ss, g.gw);
-    }
-    if (t == 0) s_grid[0] = fits ? g.gh : 0u, s_grid[1] = g.gw, s_grid[2] = g.gd, s_grid[3] = cmin;
-    __syncthreads();
-  }
 #pragma unroll
   for (int k = 0; k < L0_PPT; ++k) {
     if (in[k]) {
       if (FILTER) {
         uint32_t* sc = scal + f * SC_STRIDE;
-        const GridDims g{s_grid[0], s_grid[1], s_grid[2]};
-        if (g.gh) {
+        GridDims g;
+        uint32_t cmin;
+        if (dyn_dims(sc, &g, &cmin)) {  // (false: this frame's grid did not fit; the host grows the region and repeats)
+          // (the column part of the slice is shared by the thread's two pixels: the compiler keeps one copy; moving the row
+          // and column parts to per-tile LDS tables was measured in round 4: 75.3 against 73.4 us per 16 frames, dropped)
           uint16_t v;
-          if (!slice_pixel_axes(d[k], s_row[ly[k]], s_col[lx], inv_sc, s_grid[3], g, grids + f * capacity, &v))
+          if (!slice_pixel(d[k], (uint32_t)row[k], (uint32_t)col, inv_ss, inv_sc, cmin, g, grids + f * capacity, &v))
             atomicOr(&sc[SC_OVERFLOW], 1u);  // the reference's .unwrap() would panic
           d[k] = v;
         }
