@@ -288,6 +288,44 @@ def live_pixel_fractions(ctx, params, target_pyramid, source_pyramid, pose):
     return out
 
 
+def pinned_tiling_bench(ctx, params, targets, sources, lone_ms_default, step_ms_default, tiles=24):
+    """What a3d_context_set_tiling(24) costs: with the cut of every (pair, level) into blocks pinned, a
+    pair's pose is the same bits alone and in any batch; 24 blocks per pair is the throughput tiling's own level-0 cut of a
+    64-pair batch, so the batch pays only for the coarse levels' fixed cut, a lone pair for running on 24 blocks."""
+    P = len(targets)
+    ctx.set_tiling(tiles)
+    try:
+        batch = MultiscaleAlignBatch(ctx, params, targets, sources)
+        for _ in range(5):
+            batch.enqueue()
+        ctx.synchronize()
+        reps = []
+        for _ in range(10):
+            t1 = time.perf_counter()
+            for _ in range(20):
+                batch.enqueue()
+            ctx.synchronize()
+            reps.append((time.perf_counter() - t1) / 20 * 1e3)
+        poses, status = batch.align()
+        batch.free()
+        ms1 = MultiscaleAlign.new(ctx, params, targets[5 % P])
+        alone = ms1.align(sources[5 % P])
+        lat = []
+        for _ in range(15):
+            t1 = time.perf_counter()
+            ms1.align(sources[5 % P])
+            lat.append((time.perf_counter() - t1) * 1e3)
+    finally:
+        ctx.set_tiling(0)
+    a = np.concatenate([alone.t, alone.q]).view(np.uint32)
+    b = np.concatenate([poses[5 % P].t, poses[5 % P].q]).view(np.uint32)
+    step = float(np.median(reps))
+    return {"tiles_per_pair": tiles, "ms_per_step": step, "ms_per_step_stats": stats(reps), "pairs_per_s": P / step * 1e3,
+            "cost_vs_throughput_tiling": step / step_ms_default - 1.0,
+            "lone_pair_latency_ms": float(np.median(lat)), "lone_pair_latency_ms_throughput_tiling": lone_ms_default,
+            "pair_alone_equals_pair_in_batch_bit_for_bit": bool(np.array_equal(a, b)), "failed_pairs": int(np.count_nonzero(status))}
+
+
 def drop_in_bench(ctx, params, target_pyramid, source_pyramid, reps=15):
     """The call the reference makes, literally: MultiscaleAlign::align(&[RangeImage]) (src/icp/multiscale.rs:51) with
     the SOURCE pyramid in host memory — uploaded (a3d_range_image_upload_pyramid: one pooled arena, one copy per
@@ -1096,6 +1134,7 @@ def main():
                 lat.append((time.perf_counter() - t1) * 1e3)
             extra["single_pair_ms3x15_latency_ms"] = float(np.median(lat))
             extra["single_pair_ms3x15_latency_ms_stats"] = stats(lat)
+            extra["pinned_tiling"] = pinned_tiling_bench(ctx, params, targets, sources, float(np.median(lat)), ms_per_step)
             extra["drop_in_from_host_range_images"] = drop_in_bench(ctx, params, targets[0], sources[0])
             extra["drop_in_ms3x15_ms_from_host_range_images"] = extra["drop_in_from_host_range_images"]["page_locked"]["ms3x15_ms"]
             extra["named_shapes"] = named_shapes_bench(ctx, targets, sources)

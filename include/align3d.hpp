@@ -72,6 +72,9 @@ class Context {
   Context& operator=(const Context&) = delete;
   a3d_context* raw() const { return ctx_; }
   void synchronize() const { check(a3d_context_synchronize(ctx_)); }
+  /// a3d_context_set_tiling: 0 = throughput tiling (a pair's cut into blocks follows its batch); n > 0 = pinned tiling
+  /// (n blocks per pair and level whatever the batch: a pair's pose is bit-identical alone and in any batch).
+  void set_tiling(uint32_t tiles_per_pair) const { check(a3d_context_set_tiling(ctx_, tiles_per_pair)); }
 
  private:
   Context(a3d_context* raw, bool owned) : ctx_(raw), owned_(owned) {}
@@ -173,6 +176,15 @@ class RangeImage {
  private:
   a3d_device_image* img_ = nullptr;
 };
+
+/// RangeImage::compute_normals on many resident images of one size in one launch per 64 images
+/// (a3d_range_image_compute_normals_batch; enqueue-only).
+inline void compute_normals_batch(const std::vector<RangeImage*>& images) {
+  std::vector<a3d_device_image*> raw;
+  raw.reserve(images.size());
+  for (RangeImage* im : images) raw.push_back(const_cast<a3d_device_image*>(im->raw()));
+  check(a3d_range_image_compute_normals_batch(raw.data(), raw.size()));
+}
 
 /// A whole host pyramid (`&[RangeImage]`) in one call: the levels share one pooled arena (a3d_range_image_upload_pyramid).
 inline std::vector<RangeImage> upload_pyramid(const Context& ctx, const std::vector<a3d_range_image_view>& host_views) {
