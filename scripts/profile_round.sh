@@ -2,7 +2,7 @@
 # frame build) (1) rocprofv3 --kernel-trace --stats, (2) a per-grid summary, (3) FETCH_SIZE / WRITE_SIZE passes ->
 # HBM bytes per launch of its dominant kernel.  Outputs under gpurun_out/profile_<round>/; copy them into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ROUND=${ROUND:-round3}
+ROUND=${ROUND:-round4}
 OUT=gpurun_out/profile_$ROUND
 rm -rf $OUT && mkdir -p $OUT
 trace() {  # NAME program args...
