@@ -115,16 +115,56 @@ struct Pack;
 // 4^6, so a count below 2^8 stays below 2^20: every intermediate is an integer that f32 holds exactly, and the weight
 // channel of the narrow cells runs on the full-rate f32 pipe (one DPP move per shift instead of two) while the value
 // channel (sums up to 2^24 x 4^6 = 2^36) stays in f64.  Wide cells count up to 2^24: f64 for both.
+// Narrow cells go further: a value sum is below 255 x 65535 < 2^24, so after FOUR unnormalised passes (x 4^4) it is
+// still below 2^32: the first two axes of the blur (rows, channels) run on u32 integers — full-rate adds, one DPP move
+// per shift, 4-byte LDS cells — and only the last axis, whose results reach 2^36, runs in f64 (value) / f32 (weight).
+// The conversions u32 -> f64 the tile needs anyway simply happen after four passes instead of before the first.
 template <>
 struct Pack<unsigned long long> {
   static constexpr int SHIFT = PACK_SHIFT;
-  typedef double Weight;
+  typedef double EarlyValue;   // first two axes
+  typedef double EarlyWeight;
+  typedef double Weight;       // last axis
 };
 template <>
 struct Pack<uint32_t> {
   static constexpr int SHIFT = 8;
+  typedef uint32_t EarlyValue;
+  typedef uint32_t EarlyWeight;
   typedef float Weight;
 };
+// 2 c + (p + n) in the line's own type: exact in every type the blur uses it with (see above)
+__device__ __forceinline__ double blur3(double p, double c, double n) { return __builtin_fma(2.0, c, p + n); }
+__device__ __forceinline__ float blur3(float p, float c, float n) { return 2.0f * c + (p + n); }
+__device__ __forceinline__ uint32_t blur3(uint32_t p, uint32_t c, uint32_t n) { return 2u * c + (p + n); }
+// the value of the lane one below (from_lower_lane) / above in the same 16-lane DPP row; 0 at the row's ends
+template <typename T>
+__device__ __forceinline__ T row_neighbour(T x, bool from_lower_lane) {
+  if constexpr (sizeof(T) == 8) {
+    unsigned long long b;
+    __builtin_memcpy(&b, &x, 8);
+    int lo32 = (int)(uint32_t)b, hi32 = (int)(uint32_t)(b >> 32);
+    if (from_lower_lane) {  // row_shr:1 = 0x111, bound_ctrl: lanes without a source get 0
+      lo32 = __builtin_amdgcn_update_dpp(0, lo32, 0x111, 0xF, 0xF, true);
+      hi32 = __builtin_amdgcn_update_dpp(0, hi32, 0x111, 0xF, 0xF, true);
+    } else {                // row_shl:1 = 0x101
+      lo32 = __builtin_amdgcn_update_dpp(0, lo32, 0x101, 0xF, 0xF, true);
+      hi32 = __builtin_amdgcn_update_dpp(0, hi32, 0x101, 0xF, 0xF, true);
+    }
+    b = ((unsigned long long)(uint32_t)hi32 << 32) | (uint32_t)lo32;
+    T r;
+    __builtin_memcpy(&r, &b, 8);
+    return r;
+  } else {
+    int b;
+    __builtin_memcpy(&b, &x, 4);
+    b = from_lower_lane ? __builtin_amdgcn_update_dpp(0, b, 0x111, 0xF, 0xF, true)
+                        : __builtin_amdgcn_update_dpp(0, b, 0x101, 0xF, 0xF, true);
+    T r;
+    __builtin_memcpy(&r, &b, 4);
+    return r;
+  }
+}
 constexpr int BT = 12, BR = BT + 4;  // blur tiles: 16^3 cells per tile, 12^3 of them final
 
 // grid.rs:37-56 on the device (same f64 arithmetic as the host path), plus the capacity check
@@ -315,21 +355,21 @@ constexpr int BCELLS = BR * BR * BZP;  // x 16 B = 64 KiB of LDS
 // scales by 2^-12 once, when it writes the cell: bit-identical, at half the f64 instructions.
 // `ok(i)`: cell i is one the reference writes (otherwise it is zero after every pass).  MASKED = false: the tile
 // lies inside the written box on this axis and the other two, ok is true everywhere (no selects).
-template <bool MASKED, typename W, typename OK>
-__device__ __forceinline__ void blur_line_twice(double (&vx)[BR], W (&vw)[BR], OK ok) {
+template <bool MASKED, typename V, typename W, typename OK>
+__device__ __forceinline__ void blur_line_twice(V (&vx)[BR], W (&vw)[BR], OK ok) {
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
     // left of the tile: stale layers, never part of the final 12^3 (at grid channel 0 the reference's "previous" read
     // aliases an always-zero cell: also zero)
-    double prev_x = 0.0;
+    V prev_x = (V)0;
     W prev_w = (W)0;
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      const double cur_x = vx[i], next_x = i + 1 < BR ? vx[i + 1] : 0.0;
+      const V cur_x = vx[i], next_x = i + 1 < BR ? vx[i + 1] : (V)0;
       const W cur_w = vw[i], next_w = i + 1 < BR ? vw[i + 1] : (W)0;
-      double ox = __builtin_fma(2.0, cur_x, prev_x + next_x);  // exact (integers below 2^53): same as (p + n) + 2 c
-      W ow = (W)2 * cur_w + (prev_w + next_w);                 // exact likewise (Pack<CELL>::Weight)
-      if (MASKED && !ok(i)) ox = 0.0, ow = (W)0;
+      V ox = blur3(prev_x, cur_x, next_x);  // exact: same as (p + n) + 2 c in the reference's f64
+      W ow = blur3(prev_w, cur_w, next_w);
+      if (MASKED && !ok(i)) ox = (V)0, ow = (W)0;
       vx[i] = ox, vw[i] = ow;
       prev_x = cur_x, prev_w = cur_w;
     }
@@ -339,7 +379,8 @@ __device__ __forceinline__ void blur_line_twice(double (&vx)[BR], W (&vw)[BR], O
 // One tile.  `known_occupied`: the tile comes from the splat's list of marked windows; otherwise emptiness is decided
 // from the loaded window.  `zeros_only`: an unmarked first-channel tile, written as zeros (see below).
 template <typename CELL>
-__device__ __forceinline__ void blur_tile(double* tile_x, typename Pack<CELL>::Weight* tile_w, uint32_t tile_id,
+__device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_x, typename Pack<CELL>::EarlyWeight* tile_w,
+                                          uint32_t tile_id,
                                           const CELL* __restrict__ packed,
                                           const GridDims g, double* __restrict__ out, bool known_occupied,
                                           bool zeros_only) {
@@ -365,11 +406,13 @@ __device__ __forceinline__ void blur_tile(double* tile_x, typename Pack<CELL>::W
   auto chan_ok = [&](int gz) { return gz >= 0 && gz <= gd - 2; };
   // a tile whose 16^3 window lies inside the box of cells the reference writes needs no masks (block-uniform)
   const bool inside = r0 >= 1 && r0 + BR - 1 <= gh - 2 && c0 >= 1 && c0 + BR - 1 <= gw - 2 && z0 >= 0 && z0 + BR - 1 <= gd - 2;
+  typedef typename Pack<CELL>::EarlyValue EV;
+  typedef typename Pack<CELL>::EarlyWeight EW;
   typedef typename Pack<CELL>::Weight W;
-  double vx[BR];
-  W vw[BR];
   // ---- axis 0: thread = (column hi, channel lo) owns the 16 rows; read straight from the packed grid -------
   {
+    EV vx[BR];
+    EW vw[BR];
     const int gc = c0 + hi, gz = z0 + lo;
     const bool line_in = gc >= 0 && gc < gw && gz >= 0 && gz < gd;
 #pragma unroll
@@ -377,7 +420,7 @@ __device__ __forceinline__ void blur_tile(double* tile_x, typename Pack<CELL>::W
       const int gr = r0 + i;
       CELL u = 0;
       if (line_in && gr >= 0 && gr < gh) u = packed[((size_t)gr * gw + gc) * gd + gz];
-      vx[i] = (double)(u >> Pack<CELL>::SHIFT), vw[i] = (W)(u & (((CELL)1 << Pack<CELL>::SHIFT) - 1));
+      vx[i] = (EV)(u >> Pack<CELL>::SHIFT), vw[i] = (EW)(u & (((CELL)1 << Pack<CELL>::SHIFT) - 1));
     }
     // Empty windows: a depth image occupies ~1 % of its grid's cells and 20-30 % of its tiles.  A tile whose whole
     // 16^3 window holds no splat blurs to zero, and the slice never reads it: a pixel's eight cells lie within one cell
@@ -387,7 +430,7 @@ __device__ __forceinline__ void blur_tile(double* tile_x, typename Pack<CELL>::W
     // always written (zeros when empty).  Skipped tiles keep stale cells that nothing reads.
     bool mine = false;
 #pragma unroll
-    for (int i = 0; i < BR; ++i) mine |= (vx[i] != 0.0) | (vw[i] != (W)0);
+    for (int i = 0; i < BR; ++i) mine |= (vx[i] != (EV)0) | (vw[i] != (EW)0);
     if (!known_occupied && !__syncthreads_or(mine ? 1 : 0)) {  // (no list from the splat: decided from the loaded window)
       if (z0 == -2) write_zeros();
       return;
@@ -400,38 +443,17 @@ __device__ __forceinline__ void blur_tile(double* tile_x, typename Pack<CELL>::W
     // layers there, and the reference's aliased always-zero "previous" at grid channel 0).  The axes commute exactly:
     // every intermediate grid is zero outside the box of written cells, and the arithmetic is exact.
     {
-      auto shifted = [](double x, bool from_lower_lane) {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-        int lo32 = (int)(uint32_t)b, hi32 = (int)(uint32_t)(b >> 32);
-        if (from_lower_lane) {  // row_shr:1 = 0x111, bound_ctrl: lanes without a source get 0
-          lo32 = __builtin_amdgcn_update_dpp(0, lo32, 0x111, 0xF, 0xF, true);
-          hi32 = __builtin_amdgcn_update_dpp(0, hi32, 0x111, 0xF, 0xF, true);
-        } else {                // row_shl:1 = 0x101
-          lo32 = __builtin_amdgcn_update_dpp(0, lo32, 0x101, 0xF, 0xF, true);
-          hi32 = __builtin_amdgcn_update_dpp(0, hi32, 0x101, 0xF, 0xF, true);
-        }
-        return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi32 << 32) | (uint32_t)lo32));
-      };
-      auto shifted_w = [&](W x, bool from_lower_lane) -> W {
-        if constexpr (sizeof(W) == 8) {
-          return (W)shifted((double)x, from_lower_lane);
-        } else {
-          const int b = (int)__float_as_uint((float)x);
-          return (W)__uint_as_float((unsigned)(from_lower_lane ? __builtin_amdgcn_update_dpp(0, b, 0x111, 0xF, 0xF, true)
-                                                               : __builtin_amdgcn_update_dpp(0, b, 0x101, 0xF, 0xF, true)));
-        }
-      };
       const bool lane_ok = col_ok(gc) && chan_ok(gz);
 #pragma unroll
       for (int i = 0; i < BR; ++i) {
         const bool ok = inside || (lane_ok && row_ok(r0 + i));
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
-          const double cx_ = vx[i];
-          const W cw_ = vw[i];
-          const double ox = __builtin_fma(2.0, cx_, shifted(cx_, true) + shifted(cx_, false));
-          const W ow = (W)2 * cw_ + (shifted_w(cw_, true) + shifted_w(cw_, false));
-          vx[i] = ok ? ox : 0.0, vw[i] = ok ? ow : (W)0;
+          const EV cx_ = vx[i];
+          const EW cw_ = vw[i];
+          const EV ox = blur3(row_neighbour(cx_, true), cx_, row_neighbour(cx_, false));
+          const EW ow = blur3(row_neighbour(cw_, true), cw_, row_neighbour(cw_, false));
+          vx[i] = ok ? ox : (EV)0, vw[i] = ok ? ow : (EW)0;
         }
       }
     }
@@ -441,8 +463,10 @@ __device__ __forceinline__ void blur_tile(double* tile_x, typename Pack<CELL>::W
   __syncthreads();
   // ---- axis 1: thread = (row hi, channel lo) owns the 16 columns; the central 12^3 cells go straight to the grid ----
   {
+    double vx[BR];  // (results up to 2^36: f64 from here on; the counts, below 2^20, in Pack<CELL>::Weight)
+    W vw[BR];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) vx[i] = tile_x[at(hi, i, lo)], vw[i] = tile_w[at(hi, i, lo)];
+    for (int i = 0; i < BR; ++i) vx[i] = (double)tile_x[at(hi, i, lo)], vw[i] = (W)tile_w[at(hi, i, lo)];
     const int gr = r0 + hi, gz = z0 + lo;
     const bool line_ok = row_ok(gr) && chan_ok(gz);
     if (inside) blur_line_twice<false>(vx, vw, [](int) { return true; });
@@ -496,9 +520,8 @@ __global__ void __launch_bounds__(256)
     blur_fused_kernel(const CELL* __restrict__ packed, GridDims g, double* __restrict__ out,
                       const uint32_t* __restrict__ dyn, unsigned long long capacity,
                       const uint32_t* __restrict__ lists, uint32_t flags_stride) {
-  typedef typename Pack<CELL>::Weight W;
-  __shared__ double tile_x[BCELLS];  // 32 KiB
-  __shared__ W tile_w[BCELLS];       // 16 KiB (narrow cells) / 32 KiB
+  __shared__ typename Pack<CELL>::EarlyValue tile_x[BCELLS];   // 16 KiB (narrow cells) / 32 KiB
+  __shared__ typename Pack<CELL>::EarlyWeight tile_w[BCELLS];  // 16 KiB / 32 KiB
   if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
   packed += blockIdx.y * capacity;
   out += blockIdx.y * capacity;
