@@ -162,6 +162,22 @@ def test_batched_odometry_of_a_recorded_sequence_equals_the_frame_by_frame_loop(
         assert ang <= 1e-5 and tr <= 1e-5
 
 
+def test_alignments_in_flight_give_the_same_trajectory_bit_for_bit(ctx):
+    """run_odometry(in_flight=2, 3): the alignment of frames i -> i + 1 starts while frames i - 1 -> i are still being
+    aligned (each on its own aligning context; every alignment starts from Transform::eye(), multiscale.rs:52, so they
+    do not depend on each other).  Same pairs, same tiling, same kernels: the trajectory is the sequential loop's, bit
+    for bit, on the 20 real sample1 frames and on a synthetic stream."""
+    for ds in (SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1")), SyntheticDataset(11, 9)):
+        seq, m_seq = run_odometry(ctx, ds, prefetch=False)
+        for k in (2, 3):
+            pred, m = run_odometry(ctx, ds, in_flight=k)
+            assert pred.len() == seq.len()
+            for a, b in zip(pred.camera_to_world, seq.camera_to_world):
+                assert np.array_equal(np.asarray(a.t).view(np.uint32), np.asarray(b.t).view(np.uint32))
+                assert np.array_equal(np.asarray(a.q).view(np.uint32), np.asarray(b.q).view(np.uint32))
+            assert m.angle == m_seq.angle and m.translation == m_seq.translation
+
+
 def test_masks_derived_from_z_change_nothing(ctx, diag_ctx):
     """Device-built pyramids carry mask == (z != 0), so the alignment kernel skips the two mask bytes per pixel
     (ZMASK, image_icp.hip).  With the bytes read (diagnostics build, A3D_ICP_ZMASK=0), with the same pyramids uploaded
