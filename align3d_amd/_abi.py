@@ -191,6 +191,7 @@ SIGNATURES = {
     "a3d_multiscale_batch_concurrency": (_ST, [_P, C.POINTER(C.c_uint32)]),
     "a3d_multiscale_batch_persistent_levels": (_ST, [_P, C.POINTER(C.c_uint32)]),
     "a3d_context_set_tiling": (_ST, [_P, C.c_uint32]),
+    "a3d_context_create_on_pipe": (_ST, [C.c_int32, C.c_int32, C.c_int32, _PP]),
     "a3d_multi_shard_range": (_ST, [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "a3d_multi_context_create": (_ST, [C.POINTER(C.c_int32), C.c_uint64, _PP]),
     "a3d_multi_context_destroy": (_ST, [_P]),

@@ -5,7 +5,7 @@ from . import _abi
 
 
 class Context:
-    def __init__(self, device_index=0, priority=0, _handle=None, pair=True, library=None):
+    def __init__(self, device_index=0, priority=0, _handle=None, pair=True, library=None, main_slot=-1):
         """priority < 0: the device's highest stream priority (a frame-builder context next to an aligning one),
         0: default, > 0: lowest.  A default-priority context is created together with its sibling (the builder context
         `sibling()` returns): a3d_context_create_pair puts the two contexts' streams on the GPU's compute pipes in a
@@ -25,9 +25,9 @@ class Context:
             _abi.check(self.lib.a3d_context_create_pair(int(device_index), C.byref(self.handle), C.byref(builder)),
                        "a3d_context_create")
             self._sibling = Context(device_index, priority=-1, _handle=builder, library=library)
-        else:
-            _abi.check(self.lib.a3d_context_create_with_priority(int(device_index), int(priority), C.byref(self.handle)),
-                       "a3d_context_create")
+        else:  # (main_slot: a3d_context_create_on_pipe — a further aligning context beside the first one)
+            _abi.check(self.lib.a3d_context_create_on_pipe(int(device_index), int(priority), int(main_slot),
+                                                           C.byref(self.handle)), "a3d_context_create")
 
     def sibling(self):
         """The builder context on the same GPU (its own streams and scratch, highest stream priority), created with this

@@ -108,59 +108,76 @@ def _finish(tb, dataset, n):
 
 
 def _run_pipelined(ctx, frames, params, tb, in_flight):
-    """The loop of run_odometry with up to `in_flight` alignments enqueued at once, each on its own aligning context
-    (one-pair MultiscaleAlignBatch objects, re-bound from frame to frame: nothing is allocated per frame)."""
+    """The loop of run_odometry with up to `in_flight` alignments running at once: one lane per alignment in flight, each
+    a worker thread with its own aligning context (its own HIP stream, on a compute pipe of its own:
+    a3d_context_create_on_pipe) that runs the ordinary synchronous MultiscaleAlign::align.  An alignment is ~70 dependent
+    launches: ~0.25 ms of host launch time and ~0.64 ms of an almost idle GPU; lanes overlap both.  Pairs are dealt to
+    the lanes round robin and collected in frame order."""
     from .context import Context
 
     aligners = getattr(ctx, "_extra_aligners", None)
     if aligners is None or len(aligners) < in_flight - 1:
-        aligners = (aligners or []) + [Context(ctx.device_index, pair=False, library=ctx._library)
-                                       for _ in range(in_flight - 1 - len(aligners or []))]
+        have = len(aligners or [])  # (each further aligner's main stream on a pipe of its own: 1, 2, 1, ...)
+        aligners = (aligners or []) + [Context(ctx.device_index, pair=False, library=ctx._library, main_slot=1 + (have + k) % 2)
+                                       for k in range(in_flight - 1 - have)]
         ctx._extra_aligners = aligners  # kept with the context (closed with it)
     ctxs = [ctx] + aligners[:in_flight - 1]
-    batches = [None] * in_flight
-    pending = []  # (batch, frame index, target pyramid to free once the result is in)
+    jobs = [queue.Queue() for _ in ctxs]
+    done = [queue.Queue() for _ in ctxs]
+
+    def lane(k):
+        while True:
+            job = jobs[k].get()
+            if job is None:
+                return
+            i, target, source = job
+            try:
+                icp = MultiscaleAlign.new(ctxs[k], params, target)  # the previous frame's pyramid is the target
+                T = icp.align(source)
+                icp.free()
+            except BaseException as e:  # hand the failure to the collector
+                T = e
+            done[k].put((i, T))
+
+    workers = [threading.Thread(target=lane, args=(k,), name=f"a3d-aligner-{k}", daemon=True) for k in range(len(ctxs))]
+    for w in workers:
+        w.start()
+    pending = []  # (frame index, lane, target pyramid to free once the result is in)
     last = None
 
     def collect():
-        b, i, target = pending.pop(0)
-        poses, status = b.results()
-        if status[0] != 0:
-            raise _abi.A3dError(int(status[0]), f"alignment of frames {i - 1} and {i}: GaussNewton::solve() returned None")
-        tb.accumulate(poses[0], float(i))
+        i, k, target = pending.pop(0)
+        j, T = done[k].get()
+        assert j == i
         for lv in target:
             lv.free()
+        if isinstance(T, BaseException):
+            raise T
+        tb.accumulate(T, float(i))
 
     try:
         for i, cur in enumerate(frames):
             if last is not None:
-                k = i % in_flight
                 if len(pending) == in_flight:
                     collect()
-                if batches[k] is None:
-                    batches[k] = MultiscaleAlignBatch(ctxs[k], params, [last], [cur])
-                else:
-                    batches[k].rebind([last], [cur])
-                batches[k].enqueue()
-                pending.append((batches[k], i, last))
+                k = i % in_flight
+                jobs[k].put((i, last, cur))
+                pending.append((i, k, last))
             last = cur
         while pending:
             collect()
     finally:
         frames.close()
-        for b, _, target in pending:  # an exception on the way: wait for what is in flight, then free it
-            try:
-                b.results()
-            except Exception:
-                pass
+        for q in jobs:
+            q.put(None)
+        for w in workers:
+            w.join()
+        for i, k, target in pending:  # an exception on the way: the lanes have finished what was in flight
             for lv in target:
                 lv.free()
         if last is not None:
             for lv in last:
                 lv.free()
-        for b in batches:
-            if b is not None:
-                b.free()
     return tb
 
 

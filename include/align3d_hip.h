@@ -154,6 +154,11 @@ a3d_status a3d_context_create_with_priority(int32_t device_index, int32_t priori
  *     parallelism (a lone pair runs on 24 blocks instead of ~120).
  * Takes effect for batches created or re-bound and single alignments started after the call. */
 a3d_status a3d_context_set_tiling(a3d_context* ctx, uint32_t tiles_per_pair);
+/* The same, naming which of the context's four streams (created in order: consecutive hardware queues, i.e. compute pipes
+ * 0..3 when the process's streams are created by this library context by context) is its main stream; -1 = the default
+ * order of a3d_context_create_with_priority.  For a SECOND aligning context on one GPU (alignments in flight on separate
+ * streams, align3d_amd/odometry.py): main_slot 1 or 2 keeps its launch chain off the first context's pipe. */
+a3d_status a3d_context_create_on_pipe(int32_t device_index, int32_t priority, int32_t main_slot, a3d_context** out_ctx);
 /* An aligning context and the builder context (highest priority) that feeds it, created back to back.  Which compute
  * pipe of the GPU a HIP stream lands on follows the order in which the process creates its streams, and a pipe
  * dispatches one big grid at a time: created as a pair, the builder's kernel stream sits on the pipe of the aligner's
