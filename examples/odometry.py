@@ -21,6 +21,8 @@ ap.add_argument("dataset", help="dataset directory, or the seed for --format syn
 ap.add_argument("--max-frames", type=int, default=None)
 ap.add_argument("--batched", action="store_true", help="align windows of consecutive frames as one batch each")
 ap.add_argument("--window", type=int, default=64, help="pairs per batch with --batched")
+ap.add_argument("--in-flight", type=int, default=1,
+                help="frame-by-frame loop with this many alignments running at once (each on its own stream; same poses)")
 args = ap.parse_args()
 ctx = Context(0)
 if args.format == "synthetic":
@@ -29,5 +31,6 @@ else:
     ds = load_dataset(args.format, args.dataset)
     if args.max_frames is not None:  # odometry.rs:32-34
         ds = SubsetDataset.new(ds, range(min(args.max_frames, ds.len())))
-pred, metrics = run_odometry_batched(ctx, ds, window=args.window) if args.batched else run_odometry(ctx, ds)
+pred, metrics = (run_odometry_batched(ctx, ds, window=args.window) if args.batched
+                 else run_odometry(ctx, ds, in_flight=args.in_flight))
 print(f"Mean trajectory error: {metrics}")
