@@ -179,7 +179,8 @@ __global__ void dims_kernel(uint32_t* __restrict__ sc, uint32_t n_frames, uint32
   const uint32_t gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
   const uint32_t gd = (uint32_t)((double)(cmax - cmin) / sigma_color) + 1 + 4;
   sc[SC_GH] = gh, sc[SC_GW] = gw, sc[SC_GD] = gd;
-  sc[SC_TOO_BIG] = (unsigned long long)gh * gw * gd > capacity_cells ? 1u : 0u;
+  // (a grid beyond 32-bit cell offsets is refused like one beyond the capacity: the host reports it, frame.hip)
+  sc[SC_TOO_BIG] = ((unsigned long long)gh * gw * gd > capacity_cells || !grid_fits_idx32(gh, gw, gd)) ? 1u : 0u;
 }
 
 // Clears the cells of each frame's packed grid that its dimensions actually use (a batch's grids are `capacity`

@@ -37,6 +37,17 @@ __device__ __forceinline__ double normalized_cell(double value, double weight) {
 __device__ __forceinline__ double cell_value(const double* __restrict__ grid, GridDims g, uint32_t r, uint32_t c, uint32_t z) {
   return grid[((size_t)r * g.gw + c) * g.gd + z];
 }
+// Grids of the frame builder and of the one-enqueue filter are below 2^29 cells with gh x gw and gd below 2^24
+// (grid_fits_idx32; the device-side dims_kernel refuses anything else): a cell's byte offset is then 32-bit arithmetic on
+// the full-rate 24-bit multiplier off a uniform base pointer, instead of a 64-bit multiply-add (v_mad_u64_u32, quarter
+// rate) and a 64-bit shift-add per gathered cell — eight of each per pixel in a kernel that is VALU-issue bound.
+__host__ __device__ __forceinline__ bool grid_fits_idx32(unsigned long long gh, unsigned long long gw, unsigned long long gd) {
+  return gh * gw < (1ull << 24) && gd < (1ull << 24) && gh * gw * gd < (1ull << 29);
+}
+typedef const char __attribute__((address_space(1)))* a3d_gptr_c;
+__device__ __forceinline__ double cell_value32(const double* __restrict__ grid, uint32_t row_col_base, uint32_t z) {
+  return *(const double __attribute__((address_space(1)))*)((a3d_gptr_c)grid + (row_col_base + z) * 8u);
+}
 
 // One axis of the trilinear slice (grid.rs:132-146): the cell below, the cell above (both clamped) and the fraction.
 // The row and column parts depend on the pixel's row / column only: the frame builder computes them once per tile row and
@@ -57,20 +68,35 @@ __device__ __forceinline__ SliceAxis slice_axis_spatial(uint32_t pixel, double i
 
 // BilateralGrid::slice for one pixel (grid.rs:106-130, trilinear :132-162) from its row and column parts: every pixel,
 // zeros included.  Returns false when the value is not representable as u16 (num::cast::<f64,u16>().unwrap() would panic).
+template <bool IDX32 = false>
 __device__ __forceinline__ bool slice_pixel_axes(uint32_t color, const SliceAxis& ry, const SliceAxis& cx, double inv_sc,
                                                  uint32_t color_min, GridDims g, const double* __restrict__ grid,
                                                  uint16_t* out) {
   const SliceAxis cz = slice_axis((double)(color - color_min) * inv_sc + 2.0, g.gd);
   const uint32_t z = cz.lo, zz = cz.hi, y = ry.lo, yy = ry.hi, x = cx.lo, xx = cx.hi;
   const double za = cz.frac, ya = ry.frac, xa = cx.frac;
-  const double value = (1.0 - ya) * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, y, x, z) +
-                       (1.0 - ya) * xa * (1.0 - za) * cell_value(grid, g, y, xx, z) +
-                       ya * (1.0 - xa) * (1.0 - za) * cell_value(grid, g, yy, x, z) +
-                       ya * xa * (1.0 - za) * cell_value(grid, g, yy, xx, z) +
-                       (1.0 - ya) * (1.0 - xa) * za * cell_value(grid, g, y, x, zz) +
-                       (1.0 - ya) * xa * za * cell_value(grid, g, y, xx, zz) +
-                       ya * (1.0 - xa) * za * cell_value(grid, g, yy, x, zz) +
-                       ya * xa * za * cell_value(grid, g, yy, xx, zz);
+  double v000, v010, v100, v110, v001, v011, v101, v111;  // v[row][col][channel] of the cell's eight corners
+  if (IDX32) {
+    const uint32_t ry0 = __umul24(y, g.gw), ry1 = __umul24(yy, g.gw);
+    const uint32_t b00 = __umul24(ry0 + x, g.gd), b01 = __umul24(ry0 + xx, g.gd), b10 = __umul24(ry1 + x, g.gd),
+                   b11 = __umul24(ry1 + xx, g.gd);
+    v000 = cell_value32(grid, b00, z), v010 = cell_value32(grid, b01, z), v100 = cell_value32(grid, b10, z);
+    v110 = cell_value32(grid, b11, z), v001 = cell_value32(grid, b00, zz), v011 = cell_value32(grid, b01, zz);
+    v101 = cell_value32(grid, b10, zz), v111 = cell_value32(grid, b11, zz);
+  } else {
+    v000 = cell_value(grid, g, y, x, z), v010 = cell_value(grid, g, y, xx, z), v100 = cell_value(grid, g, yy, x, z);
+    v110 = cell_value(grid, g, yy, xx, z), v001 = cell_value(grid, g, y, x, zz), v011 = cell_value(grid, g, y, xx, zz);
+    v101 = cell_value(grid, g, yy, x, zz), v111 = cell_value(grid, g, yy, xx, zz);
+  }
+  // the 8-term sum in the order written at grid.rs:152-159
+  const double value = (1.0 - ya) * (1.0 - xa) * (1.0 - za) * v000 +
+                       (1.0 - ya) * xa * (1.0 - za) * v010 +
+                       ya * (1.0 - xa) * (1.0 - za) * v100 +
+                       ya * xa * (1.0 - za) * v110 +
+                       (1.0 - ya) * (1.0 - xa) * za * v001 +
+                       (1.0 - ya) * xa * za * v011 +
+                       ya * (1.0 - xa) * za * v101 +
+                       ya * xa * za * v111;
   if (value > -1.0 && value < 65536.0) {
     *out = (uint16_t)value;  // truncation toward zero
     return true;
@@ -78,11 +104,12 @@ __device__ __forceinline__ bool slice_pixel_axes(uint32_t color, const SliceAxis
   *out = 0;
   return false;
 }
+template <bool IDX32 = false>
 __device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t c, double inv_ss, double inv_sc,
                                             uint32_t color_min, GridDims g, const double* __restrict__ grid,
                                             uint16_t* out) {
-  return slice_pixel_axes(color, slice_axis_spatial(r, inv_ss, g.gh), slice_axis_spatial(c, inv_ss, g.gw), inv_sc, color_min,
-                          g, grid, out);
+  return slice_pixel_axes<IDX32>(color, slice_axis_spatial(r, inv_ss, g.gh), slice_axis_spatial(c, inv_ss, g.gw), inv_sc,
+                                 color_min, g, grid, out);
 }
 
 // Where the blurred grids of a batch of frames live (the context's grid scratch region):

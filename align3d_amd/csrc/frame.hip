@@ -63,7 +63,9 @@ __device__ __forceinline__ V3 pick_nearest_to_mean(const V3 (&cand)[4], const bo
       if (ok[q]) sum = sum + cand[q];
     // sum / n (resize.rs:22-25): n is 1, 2, 3 or 4 — a division by 1, 2 or 4 is a multiplication by an exact power of two,
     // only n == 3 needs a real (IEEE) quotient
-    const V3 mean = n == 3 ? sum / 3.0f : sum * (n == 1 ? 1.0f : (n == 2 ? 0.5f : 0.25f));
+    V3 mean = sum * (n == 1 ? 1.0f : (n == 2 ? 0.5f : 0.25f));
+    if (__builtin_amdgcn_ballot_w64(n == 3) != 0ull)  // (rare: three of the four valid — only at the edge of a hole)
+      if (n == 3) mean = sum / 3.0f;
     float min_dist = 3.402823466e+38f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -118,6 +120,8 @@ __global__ void __launch_bounds__(L0_THREADS)
     d[k] = in[k] ? depth[(size_t)f * w * h + (size_t)row[k] * w + col] : 0u;  // (both loads issued before either is used)
     px[k] = py[k] = pz[k] = 0.f;
   }
+  const DivBy dfx = div_prepare(fx), dfy = div_prepare(fy);
+  const bool focal_ok = div_den_ok(fx) & div_den_ok(fy);
 #pragma unroll
   for (int k = 0; k < L0_PPT; ++k) {
     if (in[k]) {
@@ -129,15 +133,22 @@ __global__ void __launch_bounds__(L0_THREADS)
           // (the column part of the slice is shared by the thread's two pixels: the compiler keeps one copy; moving the row
           // and column parts to per-tile LDS tables was measured in round 4: 75.3 against 73.4 us per 16 frames, dropped)
           uint16_t v;
-          if (!slice_pixel(d[k], (uint32_t)row[k], (uint32_t)col, inv_ss, inv_sc, cmin, g, grids + f * capacity, &v))
+          if (!slice_pixel<true>(d[k], (uint32_t)row[k], (uint32_t)col, inv_ss, inv_sc, cmin, g, grids + f * capacity, &v))
             atomicOr(&sc[SC_OVERFLOW], 1u);  // the reference's .unwrap() would panic
           d[k] = v;
         }
       }
-      if (d[k] > 0) {
+      if (d[k] > 0) {  // CameraIntrinsics::backproject (camera.rs:101-107): x = (u - cx) z / fx, y = (v - cy) z / fy
         pz[k] = (float)d[k] * scale;
-        px[k] = ((float)col - cx) * pz[k] / fx;
-        py[k] = ((float)row[k] - cy) * pz[k] / fy;
+        const float ax = ((float)col - cx) * pz[k], ay = ((float)row[k] - cy) * pz[k];
+        // the two IEEE quotients by the (uniform) focal lengths through their refined reciprocals (div_by: bit-identical
+        // to `/` inside its operand range, devmath.hpp); plain division for the wave when anything is outside it
+        const bool fast = focal_ok & div_num_ok(ax) & div_num_ok(ay);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0ull, 0)) {
+          px[k] = ax / fx, py[k] = ay / fy;
+        } else {
+          px[k] = ax == 0.0f ? ax : div_by(ax, dfx), py[k] = ay == 0.0f ? ay : div_by(ay, dfy);
+        }
       }
     }
     sp[0][ly[k]][lx] = px[k], sp[1][ly[k]][lx] = py[k], sp[2][ly[k]][lx] = pz[k];
@@ -752,6 +763,11 @@ a3d_status build_frames(a3d_context* ctx, const a3d_builder_params* prm, uint64_
     if (overflow) {
       set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
       return fail(A3D_CAST_OVERFLOW);
+    }
+    if (need >= (1ull << 29)) {  // (dims_kernel refuses such grids: the slice addresses cells with 32-bit byte offsets)
+      set_error("a3d_range_image_build_pyramids: a frame's bilateral grid would have %llu cells (the device builder handles "
+                "grids below 2^29 cells: raise sigma_color or sigma_space)", need);
+      return fail(A3D_INVALID_PARAMETER);
     }
     // a frame's bilateral grid outgrew the scratch region: grow it (25 % head room) and run those chunks again (their
     // inputs are still resident)
