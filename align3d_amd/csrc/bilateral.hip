@@ -247,7 +247,10 @@ __global__ void __launch_bounds__(256)
   // threads past the end get an empty footprint
   const uint32_t r_lo = row_starts[t_row], r_hi = active ? row_starts[t_row + 1] : r_lo;
   const uint32_t c_lo = col_starts[t_col], c_hi = col_starts[t_col + 1];
-  const size_t column = ((size_t)gr * g.gw + gc) * g.gd;
+  // (32-bit cell and pixel offsets off block-uniform base pointers: the grid is below 2^29 cells — grid_fits_idx32 — and
+  // the image below 2^24 pixels; 64-bit index arithmetic was a quarter of this kernel's instructions)
+  const uint32_t column = __umul24(__umul24(gr, g.gw) + gc, g.gd);
+  auto cell_at = [&](uint32_t ch) { return (CELL __attribute__((address_space(1)))*)((a3d_gptr)grid + (column + ch) * (uint32_t)sizeof(CELL)); };
   // Sums per channel are collected in four register slots (a footprint rarely spans more channels), branch-free per
   // pixel, and added to the grid at the end with all loads in flight together: anything done per channel CHANGE runs
   // for the whole wave at almost every pixel position, since some lane changes channel there.
@@ -265,11 +268,11 @@ __global__ void __launch_bounds__(256)
   auto flush = [&]() {  // this thread's cells: nobody else reads or writes them
     CELL old[SLOTS];
 #pragma unroll
-    for (int q = 0; q < SLOTS; ++q) old[q] = slot_ch[q] != EMPTY ? grid[column + slot_ch[q]] : (CELL)0;
+    for (int q = 0; q < SLOTS; ++q) old[q] = slot_ch[q] != EMPTY ? *cell_at(slot_ch[q]) : (CELL)0;
 #pragma unroll
     for (int q = 0; q < SLOTS; ++q) {
       if (slot_ch[q] != EMPTY) {
-        grid[column + slot_ch[q]] = old[q] + slot_sum[q];
+        *cell_at(slot_ch[q]) = old[q] + slot_sum[q];
         if (tile_flags) {
           const uint32_t tc = slot_ch[q] / BT, lc = slot_ch[q] % BT;
           const uint32_t z0 = (lc < 2 && tc > 0) ? tc - 1 : tc, z1 = (lc >= BT - 2 && tc + 1 < tz) ? tc + 1 : tc;
@@ -301,7 +304,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (uint32_t k = 0; k < UC; ++k) {
           const bool in = r0 + i < r_hi && c0 + k < c_hi;
-          const uint16_t v = img[in ? (size_t)(r0 + i) * w + (c0 + k) : (size_t)r_lo * w + c_lo];  // (unconditional load)
+          const uint32_t px = in ? __umul24(r0 + i, w) + (c0 + k) : __umul24(r_lo, w) + c_lo;  // (unconditional load)
+          const uint16_t v = *(const uint16_t __attribute__((address_space(1)))*)((a3d_gptr_c)img + px * 2u);
           s_px[i * UC + k][threadIdx.x] = in ? v : (uint16_t)0;
         }
 #pragma unroll 1
@@ -416,11 +420,16 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     EW vw[BR];
     const int gc = c0 + hi, gz = z0 + lo;
     const bool line_in = gc >= 0 && gc < gw && gz >= 0 && gz < gd;
+    // cell (gr, gc, gz) = first + i * row_stride: 32-bit arithmetic off the frame's (block-uniform) grid pointer — the
+    // fused kernels only see grids below 2^29 cells (grid_fits_idx32) — instead of a 64-bit multiply-add per load
+    const int row_stride = gw * gd * (int)sizeof(CELL);
+    int at_row = ((r0 * gw + gc) * gd + gz) * (int)sizeof(CELL);  // byte offset of (r0 + i, gc, gz), advanced by additions
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
+    for (int i = 0; i < BR; ++i, at_row += row_stride) {
       const int gr = r0 + i;
       CELL u = 0;
-      if (line_in && gr >= 0 && gr < gh) u = packed[((size_t)gr * gw + gc) * gd + gz];
+      if (line_in && gr >= 0 && gr < gh)
+        u = *(const CELL __attribute__((address_space(1)))*)((a3d_gptr_c)packed + (uint32_t)at_row);
       vx[i] = (EV)(u >> Pack<CELL>::SHIFT), vw[i] = (EW)(u & (((CELL)1 << Pack<CELL>::SHIFT) - 1));
     }
     // Empty windows: a depth image occupies ~1 % of its grid's cells and 20-30 % of its tiles.  A tile whose whole
@@ -474,12 +483,16 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     else blur_line_twice<true>(vx, vw, [&](int i) { return line_ok && col_ok(c0 + i); });
     // (a wave stores 4 rows x 12 channels = four 192-byte runs per column)
     if (hi >= 2 && hi < BR - 2 && lo >= 2 && lo < BR - 2 && gr < gh && gz < gd) {
+      const int col_stride = gd * 8;
+      int at_col = ((gr * gw + c0 + 2) * gd + gz) * 8;  // byte offset of cell (gr, c0 + i, gz) in the f64 grid
 #pragma unroll
-      for (int i = 2; i < BR - 2; ++i) {
+      for (int i = 2; i < BR - 2; ++i, at_col += col_stride) {
         const int gc = c0 + i;
         // normalised (grid.rs:90-104): value / weight — the common factor 4^6 cancels exactly — or, where the weight
         // is zero, the value itself (x 4^-6: the six divisions by four)
-        if (gc < gw) out[((size_t)gr * gw + gc) * gd + gz] = vw[i] > (W)0 ? vx[i] / (double)vw[i] : vx[i] * 0x1p-12;
+        if (gc < gw)
+          *(double __attribute__((address_space(1)))*)((a3d_gptr)out + (uint32_t)at_col) =
+              vw[i] > (W)0 ? vx[i] / (double)vw[i] : vx[i] * 0x1p-12;
       }
     }
   }
@@ -618,7 +631,8 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
     const size_t grid_bytes = ((cells * sizeof(double2) + 255) / 256) * 256;
     // images below 2^24 pixels: packed integer splat + all six blur passes in one LDS-tiled kernel
     const char* mode = A3D_DIAG_ENV("A3D_BILATERAL");  // diagnostics build: force the pass-per-launch path
-    const bool fused = n < (1u << PACK_SHIFT) && !(mode && !strcmp(mode, "unfused"));
+    // (and grids whose cells 32-bit offsets can address: the fused kernels index them so)
+    const bool fused = n < (1u << PACK_SHIFT) && grid_fits_idx32(g.gh, g.gw, g.gd) && !(mode && !strcmp(mode, "unfused"));
     // (growing the region synchronises; the stream is idle here anyway after the min/max read-back)
     if (ctx_scratch(ctx, 1, 256 + 2 * grid_bytes, &scratch) != A3D_OK) {
       st = A3D_HIP_ERROR;

@@ -45,6 +45,7 @@ __host__ __device__ __forceinline__ bool grid_fits_idx32(unsigned long long gh, 
   return gh * gw < (1ull << 24) && gd < (1ull << 24) && gh * gw * gd < (1ull << 29);
 }
 typedef const char __attribute__((address_space(1)))* a3d_gptr_c;
+typedef char __attribute__((address_space(1)))* a3d_gptr;
 __device__ __forceinline__ double cell_value32(const double* __restrict__ grid, uint32_t row_col_base, uint32_t z) {
   return *(const double __attribute__((address_space(1)))*)((a3d_gptr_c)grid + (row_col_base + z) * 8u);
 }

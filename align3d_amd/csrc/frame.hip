@@ -32,6 +32,14 @@ struct FrameBases {
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef f32x3 __attribute__((aligned(4))) f32x3_u;
 __device__ __forceinline__ void st_v3(float* base, size_t idx, V3 v) { *(f32x3_u*)(base + 3 * idx) = f32x3{v.x, v.y, v.z}; }
+// The same off a block-uniform base pointer with a 32-bit pixel index (images are below 2^28 pixels: idx * 12 fits):
+// `global_store … v_off, s[base]` — no 64-bit address arithmetic in the VALU (v_mad_u64_u32 runs at a quarter rate).
+__device__ __forceinline__ void st_v3u(void* base, uint32_t idx, V3 v) {
+  *(f32x3_u __attribute__((address_space(1)))*)((a3d_gptr)base + idx * 12u) = f32x3{v.x, v.y, v.z};
+}
+__device__ __forceinline__ void st_u8u(void* base, uint32_t idx, uint8_t v) {
+  *(uint8_t __attribute__((address_space(1)))*)((a3d_gptr)base + idx) = v;
+}
 __device__ __forceinline__ V3 ld_v3g(const float* base, size_t idx) {
   const f32x3 v = *(const f32x3_u*)(base + 3 * idx);
   return V3{v.x, v.y, v.z};
@@ -117,7 +125,10 @@ __global__ void __launch_bounds__(L0_THREADS)
     ly[k] = ly0 + k * (ST_H / L0_PPT);
     row[k] = (int)blockIdx.y * OWN_H + ly[k] - 1;
     in[k] = col >= 0 && col < (int)w && row[k] >= 0 && row[k] < (int)h;
-    d[k] = in[k] ? depth[(size_t)f * w * h + (size_t)row[k] * w + col] : 0u;  // (both loads issued before either is used)
+    // (both loads issued before either is used; the frame's image off a uniform base, the pixel by a 24-bit multiply-add)
+    d[k] = in[k] ? *(const uint16_t __attribute__((address_space(1)))*)((a3d_gptr_c)(depth + (size_t)f * w * h) +
+                                                                        (__umul24((uint32_t)row[k], w) + (uint32_t)col) * 2u)
+                 : 0u;
     px[k] = py[k] = pz[k] = 0.f;
   }
   const DivBy dfx = div_prepare(fx), dfy = div_prepare(fy);
@@ -175,10 +186,10 @@ __global__ void __launch_bounds__(L0_THREADS)
 #pragma unroll
   for (int k = 0; k < L0_PPT; ++k)
     if (owned[k] && ((A3D_L0_PROBE != 1 && A3D_L0_PROBE != 4) || px[k] == 12345.678f)) {
-      const size_t idx = (size_t)row[k] * w + col;
-      st_v3((float*)(base + off_points), idx, V3{px[k], py[k], pz[k]});
-      ((uint8_t*)(base + off_mask))[idx] = d[k] > 0 ? 1 : 0;
-      if (with_normals) st_v3((float*)(base + off_normals), idx, nrm[k]);
+      const uint32_t idx = __umul24((uint32_t)row[k], w) + (uint32_t)col;
+      st_v3u(base + off_points, idx, V3{px[k], py[k], pz[k]});
+      st_u8u(base + off_mask, idx, d[k] > 0 ? 1 : 0);
+      if (with_normals) st_v3u(base + off_normals, idx, nrm[k]);
     }
   if (!emit_l1 || A3D_L0_PROBE == 3 || A3D_L0_PROBE == 4) return;
   // ---- level 1 of the pyramid from the staged level-0 patch (pyr_scale_down: resize_range_points / _normals,
@@ -207,9 +218,9 @@ __global__ void __launch_bounds__(L0_THREADS)
     }
   int n_valid;
   const V3 pk = pick_nearest_to_mean(cand, ok, &n_valid);
-  const size_t i1 = (size_t)(r0 >> 1) * L1.w + (size_t)(c0 >> 1);
-  st_v3((float*)(base + (normals_task ? L1.normals : L1.points)), i1, pk);
-  if (!normals_task) ((uint8_t*)(base + L1.mask))[i1] = n_valid > 0 ? 1 : 0;
+  const uint32_t i1 = __umul24(r0 >> 1, L1.w) + (c0 >> 1);
+  st_v3u(base + (normals_task ? L1.normals : L1.points), i1, pk);  // (a per-lane choice of array: two bases, one select)
+  if (!normals_task) st_u8u(base + L1.mask, i1, n_valid > 0 ? 1 : 0);
 }
 
 // Colours that arrived as ONE upload for the whole chunk ([F][h][w][3] in the staging region) to each frame's arena.
@@ -396,7 +407,7 @@ __global__ void __launch_bounds__(256)
     for (int k = 0; k < MAX_TAPS; ++k)
       if (k < th.count) acc += s_v[r * BLUR_SPAN + h0 + 3u * (uint32_t)k] * th.w[k];
     acc = fminf(fmaxf(acc, 0.0f), 255.0f);
-    out[((size_t)(dy0 + r) * dw + dx) * 3 + ch] = (uint8_t)roundf(acc);
+    *(uint8_t __attribute__((address_space(1)))*)((a3d_gptr)out + (((dy0 + r) * dw + dx) * 3u + ch)) = (uint8_t)roundf(acc);
   }
 }
 
@@ -422,10 +433,12 @@ __global__ void __launch_bounds__(256)
   // ---- staging: thread = (row slot t / 128, word t % 128); a tile's row has at most 108 words ----
   {
     const uint32_t k = threadIdx.x & 127u, jj = threadIdx.x >> 7;
-    const size_t row_bytes = (size_t)w * 3;
-    const uint8_t* p = rgb + (((size_t)vtop * w + (size_t)cmin) * 3 & ~(size_t)3) + 4 * (size_t)k;
+    // (32-bit byte offsets off the frame's uniform colour pointer: an image is below 2^28 pixels)
+    const uint32_t row_bytes = w * 3u;
+    const uint32_t first = (((uint32_t)vtop * w + (uint32_t)cmin) * 3u & ~3u) + 4u * k;
     if (k < words)
-      for (uint32_t j = jj; j < nraw; j += 2) s_raw[j * PITCH_W + k] = *(const uint32_t*)(p + (size_t)j * row_bytes);
+      for (uint32_t j = jj; j < nraw; j += 2)
+        s_raw[j * PITCH_W + k] = *(const uint32_t __attribute__((address_space(1)))*)((a3d_gptr_c)rgb + (first + j * row_bytes));
   }
   __syncthreads();
   // ---- vertical pass, word-wise: item = (output row r, word q) ----
@@ -457,7 +470,7 @@ __global__ void __launch_bounds__(256)
     for (int k = 0; k < MAX_TAPS; ++k)
       if (k < th.count) acc += s_v[r * PITCH_W * 4 + h0 + 3u * (uint32_t)k] * th.w[k];
     acc = fminf(fmaxf(acc, 0.0f), 255.0f);
-    out[((size_t)(dy0 + r) * dw + dx) * 3 + ch] = (uint8_t)roundf(acc);
+    *(uint8_t __attribute__((address_space(1)))*)((a3d_gptr)out + (((dy0 + r) * dw + dx) * 3u + ch)) = (uint8_t)roundf(acc);
   }
 }
 
