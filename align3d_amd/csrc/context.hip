@@ -312,7 +312,13 @@ a3d_status a3d_context_create_on_pipe(int32_t device_index, int32_t priority, in
     //  * a further aligning context on the same GPU (a3d_context_create_on_pipe: run_odometry with alignments in flight)
     //    names the slot of its main stream, so that two lone-pair launch chains do not take turns on one pipe: with both
     //    main streams on pipe 0, two concurrent alignments took 1.84 ms each instead of 0.64.
-    const int m = main_slot >= 0 && main_slot < 4 ? main_slot : (priority < 0 ? 3 : 0), c = m == 3 ? 0 : 3;
+    //  * by default the k-th ALIGNING context a process creates on a device takes slot k % 3 (0, 1, 2, 0, ...): a host
+    //    that gives each of its threads a context of its own (the reference's objects are re-entrant, here a thread that
+    //    wants a concurrent `align` creates its own context) then does not stack their launch chains on pipe 0.
+    static std::atomic<int> aligners_created[64];
+    int m = main_slot >= 0 && main_slot < 4 ? main_slot : (priority < 0 ? 3 : 0);
+    if (!(main_slot >= 0 && main_slot < 4) && priority >= 0) m = aligners_created[device_index & 63]++ % 3;
+    const int c = m == 3 ? 0 : 3;
     ctx->stream = four[m], ctx->copy_stream = four[c];
     for (int k = 0; k < 4; ++k)
       if (k != m && k != c) ctx->side_streams.push_back(four[k]);

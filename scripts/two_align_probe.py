@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import numpy as np
 from align3d_amd import BilateralFilter, Context, MsIcpParams, MultiscaleAlign, MultiscaleAlignBatch, RangeImageBuilder, synth
 ctx = Context(0)
-c2 = Context(0, pair=False, main_slot=int(os.environ.get("SLOT", "1")))
+c2 = Context(0, pair=False, main_slot=int(os.environ.get("SLOT", "-1")))
 frames, _ = synth.frame_stream(7, 4, 640, 480)
 cam = synth.camera(640, 480)
 bm = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
