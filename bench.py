@@ -1170,7 +1170,13 @@ def main():
             extra["frame_build_page_locked"] = frame_build_bench(ctx, P + 1, W, H)
             extra["frame_build"] = {"roofline": frame_build_roofline(ctx, W, H)}
             extra["pairs_per_s_including_one_frame_build_per_pair"] = 1e3 / (build_ms + ms_per_step / P)
-            extra["streaming_from_host_frames"] = streaming_bench(ctx, params, P, W, H)
+            # the pipelined loop is sensitive to how its two host threads and the two launch chains interleave (10-15 k
+            # pairs/s between otherwise identical runs): five repetitions, the median reported, all of them kept
+            runs = [streaming_bench(ctx, params, P, W, H) for _ in range(5)]
+            runs.sort(key=lambda r: r["pairs_per_s"])
+            extra["streaming_from_host_frames"] = dict(runs[len(runs) // 2],
+                                                       pairs_per_s_stats=stats([r["pairs_per_s"] for r in runs]),
+                                                       failed_pairs=int(sum(r["failed_pairs"] for r in runs)))
         cpu = None
         if world == 1 and args.cpu_pairs > 0:
             O, flags = load_cpu_oracle()
