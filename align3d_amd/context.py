@@ -103,9 +103,6 @@ class Context:
         return ms.value
 
     def close(self):
-        for c in getattr(self, "_extra_aligners", None) or []:  # run_odometry(in_flight > 1)
-            c.close()
-        self._extra_aligners = None
         if self._sibling is not None:
             self._sibling.close()
             self._sibling = None

@@ -115,12 +115,9 @@ def _run_pipelined(ctx, frames, params, tb, in_flight):
     the lanes round robin and collected in frame order."""
     from .context import Context
 
-    aligners = getattr(ctx, "_extra_aligners", None)
-    if aligners is None or len(aligners) < in_flight - 1:
-        have = len(aligners or [])  # (each further aligner's main stream on a pipe of its own: 1, 2, 1, ...)
-        aligners = (aligners or []) + [Context(ctx.device_index, pair=False, library=ctx._library, main_slot=1 + (have + k) % 2)
-                                       for k in range(in_flight - 1 - have)]
-        ctx._extra_aligners = aligners  # kept with the context (closed with it)
+    # one more aligning context per further lane (each creates its main stream on a compute pipe of its own:
+    # a3d_context_create_on_pipe); they live for this run only, so that no idle streams stay behind in the process
+    aligners = [Context(ctx.device_index, pair=False, library=ctx._library, main_slot=1 + k % 2) for k in range(in_flight - 1)]
     ctxs = [ctx] + aligners[:in_flight - 1]
     jobs = [queue.Queue() for _ in ctxs]
     done = [queue.Queue() for _ in ctxs]
@@ -178,6 +175,8 @@ def _run_pipelined(ctx, frames, params, tb, in_flight):
         if last is not None:
             for lv in last:
                 lv.free()
+        for c in aligners:
+            c.close()
     return tb
 
 
