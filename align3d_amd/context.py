@@ -102,7 +102,14 @@ class Context:
         _abi.check(self.lib.a3d_context_last_build_kernel_ms(self.handle, C.byref(ms)))
         return ms.value
 
+    def release_lanes(self):
+        """Closes the further aligning contexts run_odometry(in_flight > 1) keeps with this one."""
+        for c in getattr(self, "_lanes", None) or []:
+            c.close()
+        self._lanes = []
+
     def close(self):
+        self.release_lanes()
         if self._sibling is not None:
             self._sibling.close()
             self._sibling = None

@@ -116,8 +116,12 @@ def _run_pipelined(ctx, frames, params, tb, in_flight):
     from .context import Context
 
     # one more aligning context per further lane (each creates its main stream on a compute pipe of its own:
-    # a3d_context_create_on_pipe); they live for this run only, so that no idle streams stay behind in the process
-    aligners = [Context(ctx.device_index, pair=False, library=ctx._library, main_slot=1 + k % 2) for k in range(in_flight - 1)]
+    # a3d_context_create_on_pipe).  Creating one costs milliseconds (streams, page-locked block, its single-pair engine):
+    # they are kept with the main context and closed with it (Context.close / release_lanes).
+    aligners = getattr(ctx, "_lanes", None) or []
+    for k in range(len(aligners), in_flight - 1):
+        aligners.append(Context(ctx.device_index, pair=False, library=ctx._library, main_slot=1 + k % 2))
+    ctx._lanes = aligners
     ctxs = [ctx] + aligners[:in_flight - 1]
     jobs = [queue.Queue() for _ in ctxs]
     done = [queue.Queue() for _ in ctxs]
@@ -175,8 +179,6 @@ def _run_pipelined(ctx, frames, params, tb, in_flight):
         if last is not None:
             for lv in last:
                 lv.free()
-        for c in aligners:
-            c.close()
     return tb
 
 

@@ -1161,6 +1161,7 @@ def main():
             extra["kdtree"]["x_vs_published_cpu_101.75ms"] = 101.75 / extra["kdtree"]["ms_per_500k_queries"]
             extra["pcl_icp"], clouds = pcl_icp_bench(ctx)
             extra["odometry"] = odometry_bench(ctx)
+            ctx.release_lanes()  # (the lanes' contexts of the in-flight runs: no idle streams beside what follows)
             level0_host = targets[0][0].download()
             depth0 = synth.frame_stream(1000, 1, W, H)[0][0][0]
             extra["frame_prep"] = frame_prep_bench(ctx, level0_host, depth0)
