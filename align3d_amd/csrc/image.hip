@@ -27,16 +27,29 @@ struct NormalsBatch {
 typedef float nf32x3 __attribute__((ext_vector_type(3)));
 typedef nf32x3 __attribute__((aligned(4))) nf32x3_u;
 
+// XCD-aware tile order (1-D grid): workgroups are dealt to the eight XCDs round robin (block b: group b % 8) and every XCD
+// has its own L2, so with the plain order the four neighbours of a tile run on four other XCDs and every halo line —
+// a 128-byte line for one 12-byte point — is fetched from the fabric again by each of them: 421 MB of reads per 64-frame
+// launch against 256 MB of points and masks (`profiles/round4_normals_traffic.json`), at 6.4 TB/s of fabric traffic.
+// Here group g takes the g-th CONTIGUOUS eighth of the tiles (whole frames at 64 frames per launch), so a tile's
+// neighbours hit in the L2 that already holds their lines.  The remap is bijective for any tile count (CDNA guide, T1).
+__device__ __forceinline__ uint32_t xcd_contiguous_tile(uint32_t b, uint32_t n) {
+  const uint32_t g = b & 7u, k = b >> 3, q = n >> 3, r = n & 7u;
+  return (g < r ? g * (q + 1u) : r * (q + 1u) + (g - r) * q) + k;
+}
 template <int NT_W, int NT_H, int NT_PPT>
 __global__ void __launch_bounds__(256)
-    compute_normals_kernel(NormalsBatch batch, int w, int h) {
+    compute_normals_kernel(NormalsBatch batch, int w, int h, uint32_t tiles_x, uint32_t tiles_y) {
   static_assert(NT_W * NT_H / NT_PPT == 256, "256 threads per block");
   __shared__ float tile[3][NT_H + 2][NT_W + 3];  // SoA planes; +3 keeps rows off the same banks
-  const float* __restrict__ points = batch.points[blockIdx.z];
-  const uint8_t* __restrict__ mask = batch.mask[blockIdx.z];
-  float* __restrict__ normals = batch.normals[blockIdx.z];
+  const uint32_t t = xcd_contiguous_tile(blockIdx.x, gridDim.x), per_frame = tiles_x * tiles_y;
+  const uint32_t frame = t / per_frame, in_frame = t - frame * per_frame, tile_y = in_frame / tiles_x,
+                 tile_x = in_frame - tile_y * tiles_x;
+  const float* __restrict__ points = batch.points[frame];
+  const uint8_t* __restrict__ mask = batch.mask[frame];
+  float* __restrict__ normals = batch.normals[frame];
   const int tx = threadIdx.x % NT_W, ty = threadIdx.x / NT_W;  // ty in 0..3
-  const int col0 = blockIdx.x * NT_W, row0 = blockIdx.y * NT_H;
+  const int col0 = (int)tile_x * NT_W, row0 = (int)tile_y * NT_H;
   const int col = col0 + tx;
   // ---- the thread's own four pixels: raw centre kept in registers, masked copy into the tile ----
   V3 center[NT_PPT];
@@ -85,21 +98,15 @@ __global__ void __launch_bounds__(256)
 a3d_status launch_compute_normals_batch(a3d_context* ctx, const NormalsBatch& batch, uint32_t frames, uint32_t w, uint32_t h) {
   int shape = (uint64_t)frames * w * h >= 4ull * 640 * 480 ? 1 : 0;
   if (const char* env = A3D_DIAG_ENV("A3D_NORMALS_SHAPE")) shape = atoi(env);  // diagnostics build: tile shape sweep
-  if (shape == 2)
-    hipLaunchKernelGGL((compute_normals_kernel<64, 32, 8>), dim3((w + 63) / 64, (h + 31) / 32, frames), dim3(256), 0, ctx->stream,
-                       batch, (int)w, (int)h);
-  else if (shape == 3)
-    hipLaunchKernelGGL((compute_normals_kernel<128, 8, 4>), dim3((w + 127) / 128, (h + 7) / 8, frames), dim3(256), 0, ctx->stream,
-                       batch, (int)w, (int)h);
-  else if (shape == 4)
-    hipLaunchKernelGGL((compute_normals_kernel<64, 8, 2>), dim3((w + 63) / 64, (h + 7) / 8, frames), dim3(256), 0, ctx->stream,
-                       batch, (int)w, (int)h);
-  else if (shape == 1)
-    hipLaunchKernelGGL((compute_normals_kernel<64, 16, 4>), dim3((w + 63) / 64, (h + 15) / 16, frames), dim3(256), 0, ctx->stream,
-                       batch, (int)w, (int)h);
-  else
-    hipLaunchKernelGGL((compute_normals_kernel<32, 8, 1>), dim3((w + 31) / 32, (h + 7) / 8, frames), dim3(256), 0, ctx->stream,
-                       batch, (int)w, (int)h);
+  auto launch = [&](auto kernel, uint32_t tw, uint32_t th) {
+    const uint32_t tiles_x = (w + tw - 1) / tw, tiles_y = (h + th - 1) / th;
+    hipLaunchKernelGGL(kernel, dim3(tiles_x * tiles_y * frames), dim3(256), 0, ctx->stream, batch, (int)w, (int)h, tiles_x, tiles_y);
+  };
+  if (shape == 2) launch(compute_normals_kernel<64, 32, 8>, 64, 32);
+  else if (shape == 3) launch(compute_normals_kernel<128, 8, 4>, 128, 8);
+  else if (shape == 4) launch(compute_normals_kernel<64, 8, 2>, 64, 8);
+  else if (shape == 1) launch(compute_normals_kernel<64, 16, 4>, 64, 16);
+  else launch(compute_normals_kernel<32, 8, 1>, 32, 8);
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
 }

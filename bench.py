@@ -240,7 +240,8 @@ def frame_prep_bench(ctx, host_pyramid_level0, depth_u16):
         "compute_normals_ms": n_ms, "compute_normals_ms_stats": stats(per),
         "compute_normals_roofline": roofline(25 * n_px, n_ms, kernel="compute_normals_kernel (one frame per launch)"),
         "compute_normals_batch_of_64_ms": nb_ms, "compute_normals_batch_of_64_ms_stats": stats(bper),
-        "compute_normals_batch_roofline": roofline(64 * 25 * n_px, nb_ms, kernel="compute_normals_kernel (64 frames per launch)"),
+        "compute_normals_batch_roofline": roofline(64 * 25 * n_px, nb_ms, *measured_traffic("normals", frames=64, pixels=int(n_px)),
+                                                   kernel="compute_normals_kernel (64 frames per launch)"),
         "bilateral_filter_ms_host_to_host": b_ms, "bilateral_filter_ms_stats": stats(b),
         "bilateral_grid_dims": list(f.last_grid_dims),
         "bilateral_note": "host-in / host-out call: the time includes two PCIe copies of the 0.6 MB image, so no roofline "
