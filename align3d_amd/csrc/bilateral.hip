@@ -16,9 +16,9 @@ namespace {
 
 // min / max over ALL pixels, zeros included (src/bilateral/grid.rs:41-49)
 __global__ void __launch_bounds__(256)
-    minmax_u16_kernel(const uint16_t* __restrict__ img, uint32_t n, uint32_t* __restrict__ out_minmax, bool min_inverted) {
-  img += (size_t)blockIdx.y * n;  // blockIdx.y = frame of a batch ([frames][n] pixels, SC_STRIDE words of scalars each)
-  out_minmax += blockIdx.y * SC_STRIDE;
+    minmax_u16_kernel(const uint16_t* __restrict__ img, uint32_t n, uint32_t* __restrict__ out_minmax,
+                      uint32_t* __restrict__ partials) {
+  img += (size_t)blockIdx.y * n;  // blockIdx.y = frame of a batch ([frames][n] pixels)
   uint32_t mi = 0xFFFFu, ma = 0u;
   // eight pixels per 16-byte load when the image is 16-byte aligned (it is when it comes from the library's own
   // allocations), the remainder and unaligned images one by one
@@ -47,13 +47,16 @@ __global__ void __launch_bounds__(256)
   __shared__ uint32_t s_mi[4], s_ma[4];
   if ((threadIdx.x & 63) == 0) s_mi[threadIdx.x >> 6] = mi, s_ma[threadIdx.x >> 6] = ma;
   __syncthreads();
-  if (threadIdx.x == 0) {  // one atomic pair per block: 64 blocks, not thousands of waves, meet on the two words
+  if (threadIdx.x == 0) {
     const uint32_t bmin = min(min(s_mi[0], s_mi[1]), min(s_mi[2], s_mi[3]));
-    // batches clear their scalar blocks with one memset to zero: the minimum is then kept as 0xFFFF - min (dims_kernel
-    // turns it back), so that zero is the neutral start for both words
-    if (min_inverted) atomicMax(&out_minmax[0], 0xFFFFu - bmin);
-    else atomicMin(&out_minmax[0], bmin);
-    atomicMax(&out_minmax[1], max(max(s_ma[0], s_ma[1]), max(s_ma[2], s_ma[3])));
+    const uint32_t bmax = max(max(s_ma[0], s_ma[1]), max(s_ma[2], s_ma[3]));
+    if (partials) {  // batches: one (min, max) per block, reduced by dims_table_kernel — nothing to initialise, no atomics
+      partials[(blockIdx.y * gridDim.x + blockIdx.x) * 2 + 0] = bmin;
+      partials[(blockIdx.y * gridDim.x + blockIdx.x) * 2 + 1] = bmax;
+    } else {         // one atomic pair per block: 64 blocks, not thousands of waves, meet on the two words
+      atomicMin(&out_minmax[0], bmin);
+      atomicMax(&out_minmax[1], bmax);
+    }
   }
 }
 
@@ -167,55 +170,97 @@ __device__ __forceinline__ T row_neighbour(T x, bool from_lower_lane) {
 }
 constexpr int BT = 12, BR = BT + 4;  // blur tiles: 16^3 cells per tile, 12^3 of them final
 
-// grid.rs:37-56 on the device (same f64 arithmetic as the host path), plus the capacity check
-__global__ void dims_kernel(uint32_t* __restrict__ sc, uint32_t n_frames, uint32_t w, uint32_t h, double sigma_space,
-                            double sigma_color, unsigned long long capacity_cells) {
-  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n_frames) return;
-  sc += f * SC_STRIDE;
-  const uint32_t cmin = 0xFFFFu - sc[SC_MIN], cmax = sc[SC_MAX];  // (see minmax_u16_kernel: kept inverted until here)
-  sc[SC_MIN] = cmin;
+// grid.rs:37-56 on the device (same f64 arithmetic as the host path), plus the capacity check, for a batch:
+// grid = (blocks, frames).  Every block reduces its frame's (min, max) partials and sizes the grid; block 0 writes the
+// frame's scalar block (all of it: nothing is cleared beforehand); all blocks fill the frame's colour -> channel table
+// (grid.rs:74: floor((v - min) / sigma_color + 0.5) + 2 for each of the 65 536 values of v, in the splat's own f64
+// arithmetic): the splat then looks a channel up instead of converting u16 -> f64 -> usize per pixel (conversions run at
+// a quarter of the f64 rate).
+__global__ void __launch_bounds__(256)
+    dims_table_kernel(const uint32_t* __restrict__ partials, uint32_t n_partials, uint32_t* __restrict__ scal, uint32_t w,
+                      uint32_t h, double sigma_space, double sigma_color, unsigned long long capacity_cells,
+                      uint32_t* __restrict__ channel_of, double inv_sc) {
+  __shared__ uint32_t s_mm[2];
+  uint32_t* sc = scal + blockIdx.y * SC_STRIDE;
+  if (threadIdx.x < 64) {  // n_partials <= 64
+    uint32_t mi = 0xFFFFu, ma = 0u;
+    if (threadIdx.x < n_partials)
+      mi = partials[(blockIdx.y * n_partials + threadIdx.x) * 2], ma = partials[(blockIdx.y * n_partials + threadIdx.x) * 2 + 1];
+    for (int off = 32; off >= 1; off >>= 1) {
+      mi = min(mi, (uint32_t)__shfl_xor((int)mi, off, 64));
+      ma = max(ma, (uint32_t)__shfl_xor((int)ma, off, 64));
+    }
+    if (threadIdx.x == 0) s_mm[0] = mi, s_mm[1] = ma;
+  }
+  __syncthreads();
+  const uint32_t cmin = s_mm[0], cmax = s_mm[1];
   const uint32_t gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4;
   const uint32_t gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
   const uint32_t gd = (uint32_t)((double)(cmax - cmin) / sigma_color) + 1 + 4;
-  sc[SC_GH] = gh, sc[SC_GW] = gw, sc[SC_GD] = gd;
   // (a grid beyond 32-bit cell offsets is refused like one beyond the capacity: the host reports it, frame.hip)
-  sc[SC_TOO_BIG] = ((unsigned long long)gh * gw * gd > capacity_cells || !grid_fits_idx32(gh, gw, gd)) ? 1u : 0u;
+  const bool too_big = (unsigned long long)gh * gw * gd > capacity_cells || !grid_fits_idx32(gh, gw, gd);
+  if (blockIdx.x == 0 && threadIdx.x < SC_STRIDE) {
+    uint32_t v = 0;  // SC_OVERFLOW, SC_NLIST, SC_NZERO and the unused words start at zero
+    switch (threadIdx.x) {
+      case SC_MIN: v = cmin; break;
+      case SC_MAX: v = cmax; break;
+      case SC_GH: v = gh; break;
+      case SC_GW: v = gw; break;
+      case SC_GD: v = gd; break;
+      case SC_TOO_BIG: v = too_big ? 1u : 0u; break;
+      default: break;
+    }
+    sc[threadIdx.x] = v;
+  }
+  if (too_big) return;
+  for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < 65536u; v += gridDim.x * 256u)
+    channel_of[blockIdx.y * 65536u + v] = v >= cmin ? f64_as_usize((double)(v - cmin) * inv_sc + 0.5) + 2 : 0u;
 }
 
-// Clears the cells of each frame's packed grid that its dimensions actually use (a batch's grids are `capacity`
-// cells apart; clearing whole capacities would move several times the bytes).
-// Also fills the frame's colour -> channel table (grid.rs:74: floor((v - min) / sigma_color + 0.5) + 2 for each of the
-// 65 536 values of v, in the splat's own f64 arithmetic): the splat then looks a channel up instead of converting
-// u16 -> f64 -> usize per pixel (conversions run at a quarter of the f64 rate).  The launch has 65 536 threads per frame.
+// The last kernel of a filter enqueue: puts back the zeros.  The splat left, per (row, column) of the grid, the range of
+// channels it added into; those cells and the frame's tile flags are the only non-zero bytes of the packed grid and the
+// flag array, so zeroing them restores "everything is zero" for the next enqueue — 60 KB of extents read and ~100 KB
+// written per frame instead of clearing 9.6 MB of cells of which 1 % are used.  Thread = the splat's (row, column).
+template <typename CELL>
 __global__ void __launch_bounds__(256)
-    clear_packed_kernel(char* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
-                        uint32_t cell_bytes, uint32_t* __restrict__ channel_of, double inv_sc) {
+    unsplat_kernel(CELL* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
+                   const uint2* __restrict__ extent, uint32_t columns, uint32_t* __restrict__ tile_flags, uint32_t flags_stride) {
   dyn += blockIdx.y * SC_STRIDE;
-  grid += blockIdx.y * capacity * cell_bytes;  // (capacity is a multiple of four cells: 16-byte aligned either way)
+  grid += blockIdx.y * capacity;
   GridDims g;
-  uint32_t color_min = 0;
-  if (!dyn_dims(dyn, &g, &color_min)) return;
-  for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < 65536u; v += gridDim.x * 256u)
-    channel_of[blockIdx.y * 65536u + v] = v >= color_min ? f64_as_usize((double)(v - color_min) * inv_sc + 0.5) + 2 : 0u;
-  const unsigned long long bytes = (unsigned long long)g.gh * g.gw * g.gd * cell_bytes;
-  ulonglong2* g2 = (ulonglong2*)grid;
-  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < (bytes + 15) / 16; i += gridDim.x * 256ull)
-    g2[i] = make_ulonglong2(0ull, 0ull);
+  if (!dyn_dims(dyn, &g, nullptr)) return;  // (its splat returned as well: nothing to put back)
+  const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+  for (uint32_t k = id; k < flags_stride / 4; k += gridDim.x * 256u) tile_flags[blockIdx.y * (flags_stride / 4) + k] = 0u;
+  const uint32_t cols = g.gw - 3, total = (g.gh - 3) * cols;
+  if (id >= total) return;
+  const uint2 e = extent[(size_t)blockIdx.y * columns + id];
+  const uint32_t column = __umul24(__umul24(id / cols + 2, g.gw) + id % cols + 2, g.gd);
+  for (uint32_t ch = e.x; ch <= e.y; ++ch)  // (an untouched column has e.x > e.y)
+    *(CELL __attribute__((address_space(1)))*)((a3d_gptr)grid + (column + ch) * (uint32_t)sizeof(CELL)) = (CELL)0;
 }
 
 // The splat as a GATHER: a thread owns one (row, column) of the grid — all its channels — and visits the pixels that
 // splat into it: the 4-5 image rows r with floor(r / sigma + 0.5) + 2 == its grid row (grid.rs:60-78) times the 4-5
-// columns likewise, found with the splat's own f64 expression.  Nobody else touches its cells, so the sums are plain
-// read-modify-writes on the cleared grid (no atomics, no same-address chains at the L2), consecutive pixels of one
-// channel are merged in registers first, and neighbouring threads read neighbouring pixels (coalesced).  Integer adds:
-// any grouping is exact.  Also marks the blur tiles whose window holds a cell it wrote.
+// columns likewise, found with the splat's own f64 expression.  Nobody else touches its cells, so the sums need no
+// global atomics (no same-address chains at the L2), and neighbouring threads read neighbouring pixels (coalesced).
+// Integer adds: any grouping is exact.  Also marks the blur tiles whose window holds a cell it wrote, and leaves the
+// range of channels it wrote for unsplat_kernel.
+//
+// Per patch of UR x UC pixels: every pixel load is issued before the first is used, then every colour -> channel lookup
+// (a dependent L2 round trip each: one at a time they were most of this kernel), then the sums are collected in the
+// thread's own SLOTS LDS words — slot = channel - lowest channel of the patch, one ds_add per pixel, conflict-free
+// (word q * 256 + thread) — and written out once.  A patch whose channels span more than SLOTS (a depth edge) takes
+// another round from the lowest channel not yet written; rounds are wave-uniform loops.  The earlier form kept four
+// (channel, sum) pairs in registers and flushed them to the grid whenever a fifth channel appeared: a global
+// read-modify-write round trip in the middle of the pixel loop for the whole wave, several times per wave on real
+// frames — 35 us per 16 frames against ~10 for this one.
 template <typename CELL>
 __global__ void __launch_bounds__(256)
     splat_packed_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, const uint32_t* __restrict__ row_starts,
                         const uint32_t* __restrict__ col_starts, double inv_sc, uint32_t color_min, GridDims g,
                         CELL* __restrict__ grid, const uint32_t* __restrict__ dyn, unsigned long long capacity,
-                        uint8_t* __restrict__ tile_flags, uint32_t flags_stride, const uint32_t* __restrict__ channel_of) {
+                        uint8_t* __restrict__ tile_flags, uint32_t flags_stride, const uint32_t* __restrict__ channel_of,
+                        uint2* __restrict__ extent, uint32_t columns) {
   if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
   img += (size_t)blockIdx.y * w * h;
   grid += blockIdx.y * capacity;
@@ -233,6 +278,8 @@ __global__ void __launch_bounds__(256)
   // range of the flag array; each set entry is stored once per block.  (Windows beyond MARKS entries: direct stores.)
   constexpr uint32_t MARKS = 8192;
   __shared__ uint8_t s_marks[MARKS];
+  constexpr uint32_t SLOTS = 8;
+  __shared__ CELL s_slot[SLOTS][256];
   const uint32_t last_id = min(first_id + 255u, total - 1u);
   const uint32_t ra = (first_id / cols + 2) / BT, rb = (last_id / cols + 2) / BT;
   const uint32_t ia = ra > 0 ? ra - 1 : 0u, ib = min(rb + 1, tx - 1), entries = (ib - ia + 1) * ty * tz;
@@ -241,6 +288,8 @@ __global__ void __launch_bounds__(256)
     for (uint32_t e = threadIdx.x; e < entries; e += 256) s_marks[e] = 0;
     __syncthreads();
   }
+#pragma unroll
+  for (uint32_t q = 0; q < SLOTS; ++q) s_slot[q][threadIdx.x] = 0;  // (a thread's own words: no barrier)
   const bool active = id < total;
   const uint32_t t_row = active ? id / cols : 0u, t_col = active ? id % cols : 0u, gr = t_row + 2, gc = t_col + 2;
   // the image rows / columns that splat into this grid row / column: [starts[t], starts[t + 1]) (splat_starts, host);
@@ -251,84 +300,84 @@ __global__ void __launch_bounds__(256)
   // the image below 2^24 pixels; 64-bit index arithmetic was a quarter of this kernel's instructions)
   const uint32_t column = __umul24(__umul24(gr, g.gw) + gc, g.gd);
   auto cell_at = [&](uint32_t ch) { return (CELL __attribute__((address_space(1)))*)((a3d_gptr)grid + (column + ch) * (uint32_t)sizeof(CELL)); };
-  // Sums per channel are collected in four register slots (a footprint rarely spans more channels), branch-free per
-  // pixel, and added to the grid at the end with all loads in flight together: anything done per channel CHANGE runs
-  // for the whole wave at almost every pixel position, since some lane changes channel there.
-  constexpr int SLOTS = 4;
-  constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-  uint32_t slot_ch[SLOTS], used = 0;
-  CELL slot_sum[SLOTS];
-#pragma unroll
-  for (int q = 0; q < SLOTS; ++q) slot_ch[q] = EMPTY, slot_sum[q] = 0;
+  constexpr uint32_t NONE = 0xFFFFFFFFu;
+  uint32_t ch_lo = NONE, ch_hi = 0u;  // the channels this (row, column) adds into: what unsplat_kernel zeroes again
   // the blur tiles whose 16^3 window (12^3 tile + 2 cells of halo) contains a cell of this column: rows and columns
   // of tiles are the thread's own, the channel tiles depend on the cell
   const uint32_t ta = gr / BT, tb = gc / BT, la = gr % BT, lb = gc % BT;
   const uint32_t a0 = (la < 2 && ta > 0) ? ta - 1 : ta, a1 = (la >= BT - 2 && ta + 1 < tx) ? ta + 1 : ta;
   const uint32_t b0 = (lb < 2 && tb > 0) ? tb - 1 : tb, b1 = (lb >= BT - 2 && tb + 1 < ty) ? tb + 1 : tb;
-  auto flush = [&]() {  // this thread's cells: nobody else reads or writes them
-    CELL old[SLOTS];
-#pragma unroll
-    for (int q = 0; q < SLOTS; ++q) old[q] = slot_ch[q] != EMPTY ? *cell_at(slot_ch[q]) : (CELL)0;
-#pragma unroll
-    for (int q = 0; q < SLOTS; ++q) {
-      if (slot_ch[q] != EMPTY) {
-        *cell_at(slot_ch[q]) = old[q] + slot_sum[q];
-        if (tile_flags) {
-          const uint32_t tc = slot_ch[q] / BT, lc = slot_ch[q] % BT;
-          const uint32_t z0 = (lc < 2 && tc > 0) ? tc - 1 : tc, z1 = (lc >= BT - 2 && tc + 1 < tz) ? tc + 1 : tc;
-          for (uint32_t i = a0; i <= a1; ++i)
-            for (uint32_t j = b0; j <= b1; ++j) {
-              if (marks_in_lds) {
-                s_marks[((i - ia) * ty + j) * tz + z0] = 1;
-                s_marks[((i - ia) * ty + j) * tz + z1] = 1;
-              } else {
-                tile_flags[(i * ty + j) * tz + z0] = 1;
-                tile_flags[(i * ty + j) * tz + z1] = 1;
-              }
-            }
-        }
-      }
-      slot_ch[q] = EMPTY, slot_sum[q] = 0;
-    }
-    used = 0;
-  };
-  // the footprint in patches of UR x UC pixels whose loads are all issued before the first is used (the default
-  // sigma's footprint, 4-5 x 4-5 pixels, is one patch)
-  constexpr uint32_t UR = 5, UC = 6;
-  __shared__ uint16_t s_px[UR * UC][256];  // a thread's patch, parked so that the loop over it stays rolled (the
-                                           // unrolled form is 14 000 instructions: it does not fit the instruction cache)
+  // (unconditional lookups — a conditional load is compiled into a branch with its own wait, one lookup at a time:
+  // without a table the loads read word 0 of the row table and the channel is computed instead)
+  const uint32_t* table = channel_of ? channel_of : row_starts;
+  const uint32_t table_mask = channel_of ? 0xFFFFu : 0u;
+  constexpr uint32_t UR = 5, UC = 6;  // the default sigma's footprint, 4-5 x 4-5 pixels, is one patch
+  bool wrote_before = false;          // an earlier patch of this thread may have written the same channels
   for (uint32_t r0 = r_lo; r0 < r_hi; r0 += UR)
     for (uint32_t c0 = c_lo; c0 < c_hi; c0 += UC) {
+      uint32_t v[UR * UC], chv[UR * UC];
 #pragma unroll
       for (uint32_t i = 0; i < UR; ++i)
 #pragma unroll
         for (uint32_t k = 0; k < UC; ++k) {
           const bool in = r0 + i < r_hi && c0 + k < c_hi;
           const uint32_t px = in ? __umul24(r0 + i, w) + (c0 + k) : __umul24(r_lo, w) + c_lo;  // (unconditional load)
-          const uint16_t v = *(const uint16_t __attribute__((address_space(1)))*)((a3d_gptr_c)img + px * 2u);
-          s_px[i * UC + k][threadIdx.x] = in ? v : (uint16_t)0;
+          const uint32_t got = *(const uint16_t __attribute__((address_space(1)))*)((a3d_gptr_c)img + px * 2u);
+          v[i * UC + k] = in ? got : 0u;  // `color <= I::min_value()` (:67) is skipped: pixels outside the footprint count as 0
         }
-#pragma unroll 1
+#pragma unroll
+      for (uint32_t j = 0; j < UR * UC; ++j)
+        chv[j] = *(const uint32_t __attribute__((address_space(1)))*)((a3d_gptr_c)table + (v[j] & table_mask) * 4u);
+      uint32_t base = NONE;
+#pragma unroll
       for (uint32_t j = 0; j < UR * UC; ++j) {
-        const uint32_t color = s_px[j][threadIdx.x];
-        const bool valid = color != 0;  // `color <= I::min_value()` (:67); pixels outside the footprint were parked as 0
-        const uint32_t ch = channel_of ? channel_of[color] : f64_as_usize((double)(color - color_min) * inv_sc + 0.5) + 2;
-        const CELL add = valid ? ((CELL)color << Pack<CELL>::SHIFT) + (CELL)1 : (CELL)0;
-        bool hit = false;
-#pragma unroll
-        for (int q = 0; q < SLOTS; ++q) hit |= slot_ch[q] == ch;
-        if (__builtin_expect(valid && !hit && used == SLOTS, 0)) flush();  // a fifth channel under this footprint: rare
-        const bool fresh = valid && !hit;  // takes the next free slot
-#pragma unroll
-        for (int q = 0; q < SLOTS; ++q) {
-          const bool take = fresh && used == (uint32_t)q;
-          if (take) slot_ch[q] = ch;
-          slot_sum[q] += (valid && slot_ch[q] == ch) ? add : (CELL)0;
-        }
-        used += fresh ? 1u : 0u;
+        if (!channel_of) chv[j] = f64_as_usize((double)(v[j] - color_min) * inv_sc + 0.5) + 2;  // (uniform branch)
+        base = v[j] != 0 ? min(base, chv[j]) : base;
+        ch_hi = v[j] != 0 ? max(ch_hi, chv[j]) : ch_hi;
       }
+      ch_lo = min(ch_lo, base);
+      while (__builtin_amdgcn_ballot_w64(base != NONE)) {  // rounds of SLOTS channels from `base` up
+        uint32_t next = NONE;
+#pragma unroll
+        for (uint32_t j = 0; j < UR * UC; ++j) {
+          const uint32_t q = chv[j] - base;
+          const bool valid = v[j] != 0 && base != NONE, mine = valid && q < SLOTS;  // (q wraps for channels below base: written)
+          const CELL add = mine ? ((CELL)v[j] << Pack<CELL>::SHIFT) + (CELL)1 : (CELL)0;
+          atomicAdd(&s_slot[mine ? q : 0u][threadIdx.x], add);  // ds_add without return; nobody else uses the word
+          next = (valid && chv[j] >= base + SLOTS && chv[j] - base < 0x80000000u) ? min(next, chv[j]) : next;
+        }
+        CELL sum[SLOTS], old[SLOTS];
+#pragma unroll
+        for (uint32_t q = 0; q < SLOTS; ++q) sum[q] = s_slot[q][threadIdx.x];
+#pragma unroll
+        for (uint32_t q = 0; q < SLOTS; ++q) old[q] = (wrote_before && sum[q] != 0) ? *cell_at(base + q) : (CELL)0;
+#pragma unroll
+        for (uint32_t q = 0; q < SLOTS; ++q) {
+          if (sum[q] != 0) {  // this thread's cell: nobody else reads or writes it (zero before the splat: a3d_context::grid_clean)
+            const uint32_t ch = base + q;
+            *cell_at(ch) = old[q] + sum[q];
+            s_slot[q][threadIdx.x] = 0;
+            if (tile_flags) {
+              const uint32_t tc = ch / BT, lc = ch % BT;
+              const uint32_t z0 = (lc < 2 && tc > 0) ? tc - 1 : tc, z1 = (lc >= BT - 2 && tc + 1 < tz) ? tc + 1 : tc;
+              for (uint32_t i = a0; i <= a1; ++i)
+                for (uint32_t j = b0; j <= b1; ++j) {
+                  if (marks_in_lds) {
+                    s_marks[((i - ia) * ty + j) * tz + z0] = 1;
+                    s_marks[((i - ia) * ty + j) * tz + z1] = 1;
+                  } else {
+                    tile_flags[(i * ty + j) * tz + z0] = 1;
+                    tile_flags[(i * ty + j) * tz + z1] = 1;
+                  }
+                }
+            }
+          }
+        }
+        base = next;
+      }
+      wrote_before = true;
     }
-  flush();
+  if (extent && active) extent[(size_t)blockIdx.y * columns + id] = ch_lo <= ch_hi ? make_uint2(ch_lo, ch_hi) : make_uint2(1u, 0u);
   if (marks_in_lds) {
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < entries; e += 256)
@@ -527,22 +576,72 @@ __global__ void __launch_bounds__(256)
   append(zero, &sc[SC_NZERO], work + flags_stride);
 }
 
-// grid = (blocks, frames).  With `lists`: every block walks its frame's lists with stride gridDim.x (the launch is
-// sized to the blocks the chip holds at once).  Without: one block per tile, blockIdx.x = tile.
+// grid = (blocks, frames).  With `lists` or `tile_flags`: every block walks its frame's lists with stride gridDim.x (the
+// launch is sized to the blocks the chip holds at once).  With neither: one block per tile, blockIdx.x = tile.
+// `tile_flags` (frames with at most BLUR_LIST_MAX tiles): every block compacts the frame's flags into the two lists
+// itself, in LDS — marked tiles in tile order from the front, unmarked first-channel tiles from the back; all blocks of a
+// frame derive the same lists (ordered scan, no atomics), so the strided walk covers every entry once.  That is a few
+// hundred instructions per block instead of a launch between splat and blur (tile_list_kernel: 4.8 us per 16 frames).
+constexpr uint32_t BLUR_LIST_MAX = 3072;
 template <typename CELL>
 __global__ void __launch_bounds__(256)
     blur_fused_kernel(const CELL* __restrict__ packed, GridDims g, double* __restrict__ out,
-                      const uint32_t* __restrict__ dyn, unsigned long long capacity,
-                      const uint32_t* __restrict__ lists, uint32_t flags_stride) {
+                      uint32_t* __restrict__ dyn, unsigned long long capacity,
+                      const uint32_t* __restrict__ lists, uint32_t flags_stride, const uint32_t* __restrict__ tile_flags) {
   __shared__ typename Pack<CELL>::EarlyValue tile_x[BCELLS];   // 16 KiB (narrow cells) / 32 KiB
   __shared__ typename Pack<CELL>::EarlyWeight tile_w[BCELLS];  // 16 KiB / 32 KiB
   if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
   packed += blockIdx.y * capacity;
   out += blockIdx.y * capacity;
   if (!dyn_dims(dyn, &g, nullptr)) return;
+  const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
+  if (tile_flags) {
+    __shared__ uint16_t s_list[BLUR_LIST_MAX];
+    __shared__ uint32_t s_wave[2][4];
+    tile_flags += blockIdx.y * (flags_stride / 4);
+    const uint32_t tiles = tx * ty * tz, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t n_work = 0, n_zero = 0;
+    for (uint32_t base = 0; base < tiles; base += 1024u) {  // 256 threads x one flag word (four tiles) per round
+      const uint32_t first = base + threadIdx.x * 4u;
+      const uint32_t word = first < tiles ? tile_flags[first / 4] : 0u;
+      uint32_t marked = 0, zero = 0;  // bit b: tile first + b
+#pragma unroll
+      for (uint32_t b = 0; b < 4; ++b) {
+        const uint32_t id = first + b;
+        const bool m = ((word >> (8 * b)) & 0xFFu) != 0;
+        marked |= (m ? 1u : 0u) << b;
+        zero |= ((id < tiles && !m && id % tz == 0) ? 1u : 0u) << b;
+      }
+      const uint32_t cm = __builtin_popcount(marked), cz = __builtin_popcount(zero);
+      uint32_t im = cm, iz = cz;  // inclusive scans over the wave
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = (uint32_t)__shfl_up((int)im, off, 64), c = (uint32_t)__shfl_up((int)iz, off, 64);
+        if (lane >= (uint32_t)off) im += a, iz += c;
+      }
+      if (lane == 63) s_wave[0][wave] = im, s_wave[1][wave] = iz;
+      __syncthreads();
+      uint32_t at_m = n_work + im - cm, at_z = n_zero + iz - cz;
+      for (uint32_t k = 0; k < wave; ++k) at_m += s_wave[0][k], at_z += s_wave[1][k];
+#pragma unroll
+      for (uint32_t b = 0; b < 4; ++b) {
+        if (marked >> b & 1u) s_list[at_m++] = (uint16_t)(first + b);
+        if (zero >> b & 1u) s_list[BLUR_LIST_MAX - 1u - at_z++] = (uint16_t)(first + b);
+      }
+      n_work += s_wave[0][0] + s_wave[0][1] + s_wave[0][2] + s_wave[0][3];
+      n_zero += s_wave[1][0] + s_wave[1][1] + s_wave[1][2] + s_wave[1][3];
+      __syncthreads();  // the wave totals are read before the next round replaces them; the lists before they are used
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) dyn[SC_NLIST] = n_work, dyn[SC_NZERO] = n_zero;  // (statistics for the host)
+    for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {
+      const bool work = j < n_work;
+      blur_tile<CELL>(tile_x, tile_w, work ? s_list[j] : s_list[BLUR_LIST_MAX - 1u - (j - n_work)], packed, g, out, true, !work);
+      __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
+    }
+    return;
+  }
   if (!lists) {
     // 1-D launch (the host may not know the dimensions): block -> tile (row, column, channel), channel fastest
-    const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
     if (blockIdx.x < tx * ty * tz) blur_tile<CELL>(tile_x, tile_w, blockIdx.x, packed, g, out, false, false);
     return;
   }
@@ -613,8 +712,9 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
   d_scal = (uint32_t*)scratch;
   if (hipMemcpyAsync(d_scal, h_scal, 12, hipMemcpyHostToDevice, s) != hipSuccess) fail("upload");
   if (st == A3D_OK) {
+    ctx->grid_clean = a3d_context::GridLayoutKey{};  // this path uses the grid scratch region its own way
     hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64)), dim3(256), 0, s, d_img, n,
-                       d_scal, false);
+                       d_scal, (uint32_t*)nullptr);
     if (hipMemcpyAsync(h_scal, d_scal, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
       fail("min/max");
@@ -657,11 +757,11 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
           return A3D_HIP_ERROR;
         hipLaunchKernelGGL(splat_packed_kernel<unsigned long long>, dim3(((g.gh - 3) * (g.gw - 3) + 255) / 256), dim3(256), 0, s, d_img, w, h,
                            row_starts, col_starts, inv_sc, cmin, g, (unsigned long long*)d_b, (const uint32_t*)nullptr, 0ull,
-                           (uint8_t*)nullptr, 0u, (const uint32_t*)nullptr);
+                           (uint8_t*)nullptr, 0u, (const uint32_t*)nullptr, (uint2*)nullptr, 0u);
         hipLaunchKernelGGL(blur_fused_kernel<unsigned long long>,
                            dim3(((g.gd + BT - 1) / BT) * ((g.gw + BT - 1) / BT) * ((g.gh + BT - 1) / BT)), dim3(256), 0, s,
-                           (const unsigned long long*)d_b, g, (double*)d_a, (const uint32_t*)nullptr, 0ull,
-                           (const uint32_t*)nullptr, 0u);
+                           (const unsigned long long*)d_b, g, (double*)d_a, (uint32_t*)nullptr, 0ull,
+                           (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
       } else {
         hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
                            (double*)d_a);
@@ -702,23 +802,55 @@ unsigned long long bilateral_grid_cells(uint32_t w, uint32_t h, double sigma_spa
 
 // The grids of a batch of frames enqueued WITHOUT a host round trip: min/max, the grid dimensions and the capacity
 // check stay on the device, the kernels read them from each frame's scalar block, launch sizes come from the capacity.
+// Five launches: minmax (per-block partials) -> dims_table -> splat -> blur (compacts its own tile lists) -> unsplat;
+// nothing is cleared per enqueue (a3d_context::grid_clean).
+template <typename CELL>
+static void enqueue_splat_blur(hipStream_t s, const uint16_t* d_depth, uint32_t n_frames, uint32_t w, uint32_t h,
+                               const uint32_t* row_starts, const uint32_t* col_starts, double inv_sc, dim3 splat_grid,
+                               dim3 blur_grid, dim3 list_grid, GridBatch* out, unsigned long long capacity, uint8_t* flags,
+                               uint32_t flags_stride, uint32_t* lists, bool lists_in_blur, const uint32_t* channel_of,
+                               uint2* extent, uint32_t columns) {
+  const GridDims none{0, 0, 0};
+  hipLaunchKernelGGL(splat_packed_kernel<CELL>, splat_grid, dim3(256), 0, s, d_depth, w, h, row_starts, col_starts, inv_sc, 0u,
+                     none, (CELL*)out->packed, (const uint32_t*)out->scal, capacity, flags, flags_stride, channel_of, extent, columns);
+  if (!lists_in_blur)
+    hipLaunchKernelGGL(tile_list_kernel, list_grid, dim3(256), 0, s, (const uint8_t*)flags, flags_stride, out->scal, lists);
+  hipLaunchKernelGGL(blur_fused_kernel<CELL>, blur_grid, dim3(256), 0, s, (const CELL*)out->packed, none, out->blurred, out->scal,
+                     capacity, lists_in_blur ? (const uint32_t*)nullptr : (const uint32_t*)lists, flags_stride,
+                     lists_in_blur ? (const uint32_t*)flags : (const uint32_t*)nullptr);
+  hipLaunchKernelGGL(unsplat_kernel<CELL>, splat_grid, dim3(256), 0, s, (CELL*)out->packed, (const uint32_t*)out->scal, capacity,
+                     (const uint2*)extent, columns, (uint32_t*)flags, flags_stride);
+  (void)n_frames;
+}
+
 a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, uint32_t n_frames, uint32_t w, uint32_t h,
                                    double sigma_space, double sigma_color, unsigned long long capacity, GridBatch* out) {
   const uint32_t n = w * h;
   A3D_REQUIRE(n < (1u << PACK_SHIFT), A3D_INVALID_PARAMETER,
               "the device frame builder's bilateral filter handles images below 2^24 pixels");
   hipStream_t s = ctx->stream;
+  // The region is laid out for the most frames any enqueue on this context has asked for, so that a short last chunk of
+  // a batch finds its arrays where the full chunks left them (and left them zeroed).
+  ctx->grid_layout_frames = std::max(ctx->grid_layout_frames, n_frames);
+  const uint32_t lf = ctx->grid_layout_frames;
   // any grid of `capacity` cells with this image's row / column extents has at most this many 12^3 tiles
   const uint32_t gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4, gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
   const unsigned long long plane_tiles = (unsigned long long)((gh + BT - 1) / BT) * ((gw + BT - 1) / BT);
   const unsigned long long max_gd = capacity / ((unsigned long long)gh * gw) + 1;
   const uint32_t tiles = (uint32_t)std::min<unsigned long long>(plane_tiles * ((max_gd + BT - 1) / BT), 1u << 30);
   const uint32_t flags_stride = ((tiles + 255) / 256) * 256;
-  // [scalars of every frame][tile flags of every frame]: cleared together
-  const size_t scal_only = (((size_t)n_frames * SC_STRIDE * 4 + 255) / 256) * 256;
-  const size_t flag_bytes = (size_t)n_frames * flags_stride;
-  const size_t list_bytes = (size_t)n_frames * 2 * flags_stride * 4;  // the two tile lists
-  const size_t scal_bytes = scal_only + flag_bytes + list_bytes + (size_t)n_frames * 65536 * 4;  // + colour -> channel
+  const uint32_t columns = (gh - 3) * (gw - 3);  // the (row, column)s of the grid pixels can splat into
+  constexpr uint32_t PARTIALS = 64;              // min / max blocks per frame
+  // [scalars][min / max partials][tile flags][tile lists][colour -> channel tables][splat extents][packed][blurred]
+  auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
+  const size_t scal_only = pad((size_t)lf * SC_STRIDE * 4);
+  const size_t partial_bytes = pad((size_t)lf * PARTIALS * 2 * 4);
+  const size_t flag_bytes = (size_t)lf * flags_stride;
+  const bool lists_in_blur = flags_stride <= BLUR_LIST_MAX;
+  const size_t list_bytes = lists_in_blur ? 0 : (size_t)lf * 2 * flags_stride * 4;  // the two tile lists
+  const size_t table_bytes = (size_t)lf * 65536 * 4;
+  const size_t extent_bytes = pad((size_t)lf * columns * sizeof(uint2));
+  const size_t head_bytes = scal_only + partial_bytes + flag_bytes + list_bytes + table_bytes + extent_bytes;
   capacity = (capacity + 3) & ~3ull;  // a multiple of four cells: every frame's packed grid starts 16-byte aligned
   // at most floor(sigma) + 1 image rows (columns) round to one grid row (column): 4-byte cells while a (row, column)
   // can not receive more than 255 pixels (A3D_BILATERAL_CELLS=wide: always 8-byte cells, a cross-check)
@@ -726,32 +858,41 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   const char* cells_mode = A3D_DIAG_ENV("A3D_BILATERAL_CELLS");
   const bool narrow = reach * reach <= 255 && !(cells_mode && !strcmp(cells_mode, "wide"));
   const uint32_t cell_bytes = narrow ? 4 : 8;
-  const size_t packed_bytes = (((size_t)n_frames * capacity * cell_bytes + 255) / 256) * 256;
+  const size_t packed_bytes = pad((size_t)lf * capacity * cell_bytes);
   void* region = nullptr;
-  A3D_TRY(ctx_scratch(ctx, 1, scal_bytes + packed_bytes + (size_t)n_frames * capacity * 8 + 256, &region));
+  A3D_TRY(ctx_scratch(ctx, 1, head_bytes + packed_bytes + (size_t)lf * capacity * 8 + 256, &region));
   out->scal = (uint32_t*)region;
-  uint8_t* flags = (uint8_t*)region + scal_only;
-  out->packed = (char*)region + scal_bytes;
-  out->blurred = (double*)((char*)out->packed + packed_bytes);
-  out->capacity = capacity;
+  uint32_t* partials = (uint32_t*)((char*)region + scal_only);
+  uint8_t* flags = (uint8_t*)partials + partial_bytes;
   uint32_t* lists = (uint32_t*)(flags + flag_bytes);
   uint32_t* channel_of = (uint32_t*)((char*)lists + list_bytes);
+  uint2* extent = (uint2*)((char*)channel_of + table_bytes);
+  out->packed = (char*)region + head_bytes;
+  out->blurred = (double*)((char*)out->packed + packed_bytes);
+  out->capacity = capacity;
   const uint32_t *row_starts = nullptr, *col_starts = nullptr;
   A3D_TRY(splat_starts(ctx, h, sigma_space, gh - 3, &row_starts));  // (before anything is enqueued: a first use synchronises)
   A3D_TRY(splat_starts(ctx, w, sigma_space, gw - 3, &col_starts));
-  A3D_HIP_TRY(hipMemsetAsync(region, 0, scal_only + flag_bytes, s));
-  hipLaunchKernelGGL(minmax_u16_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 64), n_frames), dim3(256), 0, s, d_depth, n,
-                     out->scal, true);
-  hipLaunchKernelGGL(dims_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s, out->scal, n_frames, w, h, sigma_space,
-                     sigma_color, capacity);
+  // the zero invariant of flags and packed cells: established once per layout, kept by unsplat_kernel
+  a3d_context::GridLayoutKey key;
+  key.region = region, key.capacity = capacity, key.cell_bytes = cell_bytes, key.flags_stride = flags_stride, key.frames = lf,
+  key.columns = columns;
+  const a3d_context::GridLayoutKey& have = ctx->grid_clean;
+  if (!(have.region == key.region && have.capacity == key.capacity && have.cell_bytes == key.cell_bytes &&
+        have.flags_stride == key.flags_stride && have.frames == key.frames && have.columns == key.columns)) {
+    A3D_HIP_TRY(hipMemsetAsync(flags, 0, flag_bytes, s));
+    A3D_HIP_TRY(hipMemsetAsync(out->packed, 0, packed_bytes, s));
+  }
+  ctx->grid_clean = a3d_context::GridLayoutKey{};  // unknown until the whole sequence is enqueued
+  const uint32_t mm_blocks = std::min<uint32_t>((n + 255) / 256, PARTIALS);
+  hipLaunchKernelGGL(minmax_u16_kernel, dim3(mm_blocks, n_frames), dim3(256), 0, s, d_depth, n, (uint32_t*)nullptr, partials);
   const double inv_sc = 1.0 / sigma_color;
-  hipLaunchKernelGGL(clear_packed_kernel, dim3(256, n_frames), dim3(256), 0, s, (char*)out->packed, (const uint32_t*)out->scal,
-                     capacity, cell_bytes, channel_of, inv_sc);
-  const GridDims none{0, 0, 0};
+  hipLaunchKernelGGL(dims_table_kernel, dim3(64, n_frames), dim3(256), 0, s, (const uint32_t*)partials, mm_blocks, out->scal, w, h,
+                     sigma_space, sigma_color, capacity, channel_of, inv_sc);
   // (gh and gw depend on the image size only: the launch covers every (row, column) pixels can splat into)
-  const dim3 splat_grid(((gh - 3) * (gw - 3) + 255) / 256, n_frames);
-  // one resident round of blur blocks, shared out over the frames: three blocks per CU with the narrow cells (48 KiB of
-  // LDS and 133 VGPRs each), two with the wide ones (64 KiB, 224 VGPRs)
+  const dim3 splat_grid((columns + 255) / 256, n_frames);
+  // one resident round of blur blocks, shared out over the frames: four blocks per CU with the narrow cells (39 KiB of
+  // LDS and 110 VGPRs each), two with the wide ones (70 KiB, 224 VGPRs)
   static const int blur_per_cu[2] = {[] {
                                        int n = 0;
                                        return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, blur_fused_kernel<unsigned long long>, 256, 0) == hipSuccess && n > 0 ? n : 2;
@@ -762,24 +903,16 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
                                      }()};
   const uint32_t resident = (uint32_t)blur_per_cu[narrow ? 1 : 0] * (uint32_t)std::max(1, ctx->num_cus);
   const uint32_t per_frame = std::max(8u, std::min(std::max(1u, tiles), (resident + n_frames - 1) / n_frames));
-  const dim3 list_grid((std::max(1u, tiles) + 255) / 256, n_frames);
-  if (narrow) {
-    hipLaunchKernelGGL(splat_packed_kernel<uint32_t>, splat_grid, dim3(256), 0, s, d_depth, w, h, row_starts, col_starts, inv_sc,
-                       0u, none, (uint32_t*)out->packed, (const uint32_t*)out->scal, capacity, flags, flags_stride,
-                       (const uint32_t*)channel_of);
-    hipLaunchKernelGGL(tile_list_kernel, list_grid, dim3(256), 0, s, (const uint8_t*)flags, flags_stride, out->scal, lists);
-    hipLaunchKernelGGL(blur_fused_kernel<uint32_t>, dim3(per_frame, n_frames), dim3(256), 0, s, (const uint32_t*)out->packed,
-                       none, out->blurred, (const uint32_t*)out->scal, capacity, (const uint32_t*)lists, flags_stride);
-  } else {
-    hipLaunchKernelGGL(splat_packed_kernel<unsigned long long>, splat_grid, dim3(256), 0, s, d_depth, w, h, row_starts,
-                       col_starts, inv_sc, 0u, none, (unsigned long long*)out->packed, (const uint32_t*)out->scal, capacity,
-                       flags, flags_stride, (const uint32_t*)channel_of);
-    hipLaunchKernelGGL(tile_list_kernel, list_grid, dim3(256), 0, s, (const uint8_t*)flags, flags_stride, out->scal, lists);
-    hipLaunchKernelGGL(blur_fused_kernel<unsigned long long>, dim3(per_frame, n_frames), dim3(256), 0, s,
-                       (const unsigned long long*)out->packed, none, out->blurred, (const uint32_t*)out->scal, capacity,
-                       (const uint32_t*)lists, flags_stride);
-  }
+  const dim3 list_grid((std::max(1u, tiles) + 255) / 256, n_frames), blur_grid(per_frame, n_frames);
+  if (narrow)
+    enqueue_splat_blur<uint32_t>(s, d_depth, n_frames, w, h, row_starts, col_starts, inv_sc, splat_grid, blur_grid, list_grid, out,
+                                 capacity, flags, flags_stride, lists, lists_in_blur, channel_of, extent, columns);
+  else
+    enqueue_splat_blur<unsigned long long>(s, d_depth, n_frames, w, h, row_starts, col_starts, inv_sc, splat_grid, blur_grid,
+                                           list_grid, out, capacity, flags, flags_stride, lists, lists_in_blur, channel_of, extent,
+                                           columns);
   A3D_HIP_TRY(hipGetLastError());
+  ctx->grid_clean = key;
   return A3D_OK;
 }
 

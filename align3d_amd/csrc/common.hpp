@@ -117,6 +117,15 @@ struct a3d_context {
   std::vector<hipEvent_t> copy_events;
   // Cells per frame the bilateral grids of the frame builder are given in the grid scratch region (grown on demand).
   unsigned long long grid_capacity = 0;
+  // The grid scratch region keeps an invariant between filter enqueues: every packed cell and every tile flag of the
+  // layout described here is ZERO (the enqueue's last kernel puts back the zeros its splat replaced), so no enqueue
+  // clears whole grids.  region == nullptr: unknown state, the next enqueue clears once.
+  struct GridLayoutKey {
+    const void* region = nullptr;
+    unsigned long long capacity = 0;
+    uint32_t cell_bytes = 0, flags_stride = 0, frames = 0, columns = 0;
+  } grid_clean;
+  uint32_t grid_layout_frames = 0;  // most frames one enqueue has asked for (the layout is sized for it)
   // How often each arena size has been asked for: a slab is only taken for a size that keeps coming back.
   std::vector<std::pair<size_t, uint32_t>> arena_requests;
   // Small read-only tables uploaded once and kept (the blur tap tables of the pyramid builder), keyed by four words.

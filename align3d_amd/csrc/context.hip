@@ -61,6 +61,7 @@ a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out) {
     if (ctx->scratch[which]) A3D_HIP_TRY(hipFree(ctx->scratch[which]));
     ctx->scratch[which] = nullptr;
     ctx->scratch_size[which] = 0;
+    if (which == 1) ctx->grid_clean = a3d_context::GridLayoutKey{};
     const size_t grown = bytes + bytes / 4;
     A3D_HIP_TRY(hipMalloc(&ctx->scratch[which], grown));
     ctx->scratch_size[which] = grown;

@@ -343,6 +343,16 @@ struct TapRow {
   int32_t left, count;
   float w[MAX_TAPS];
 };
+// First tap and tap count of output sample `o` (source coordinates) of image::imageops::blur's sampling filter: the same
+// f32 operations on host (make_taps) and device, so a kernel can place its loads without waiting for the table.
+__host__ __device__ __forceinline__ void tap_range(uint32_t o, float support, uint32_t size, int32_t* left, int32_t* count) {
+  const float in = (float)o + 0.5f;
+  int32_t l = (int32_t)floorf(in - support);
+  l = l < 0 ? 0 : (l > (int32_t)size - 1 ? (int32_t)size - 1 : l);
+  int32_t r = (int32_t)ceilf(in + support);
+  r = r < l + 1 ? l + 1 : (r > (int32_t)size ? (int32_t)size : r);
+  *left = l, *count = r - l < MAX_TAPS ? r - l : MAX_TAPS;
+}
 
 // imageops::blur + 2x subsample fused: the pyramid keeps only the even rows and columns of the blurred image,
 // so the vertical pass is evaluated at even rows only and never leaves the chip.  One block = BLUR_ROWS output rows x
@@ -416,43 +426,73 @@ __global__ void __launch_bounds__(256)
 // v_cvt_f32_ubyteN, four multiply / add pairs per word and tap instead of a byte-wide LDS read per output and tap — and
 // the staging loop has no integer division.  Same operations per output in the same order: same bits.
 __global__ void __launch_bounds__(256)
-    blur_halve_words_kernel(size_t off_src, uint32_t w, uint32_t dw, uint32_t dh, const TapRow* __restrict__ taps_v,
-                            const TapRow* __restrict__ taps_h, size_t off_dst, FrameBases bases) {
+    blur_halve_words_kernel(size_t off_src, uint32_t w, uint32_t h, uint32_t dw, uint32_t dh, float support,
+                            const TapRow* __restrict__ taps_v, const TapRow* __restrict__ taps_h, size_t off_dst,
+                            FrameBases bases) {
   constexpr uint32_t PITCH_W = RAW_PITCH / 4;                    // words per staged row
   __shared__ uint32_t s_raw[RAW_ROWS * PITCH_W];
   __shared__ __attribute__((aligned(16))) float s_v[BLUR_ROWS * PITCH_W * 4];  // vertical sums, indexed by RAW byte position
+  __shared__ uint32_t s_tv[BLUR_ROWS][16];                       // the tile's rows of the vertical tap table
+  static_assert(sizeof(TapRow) == 64, "a tap row is sixteen words");
   const uint8_t* __restrict__ rgb = (const uint8_t*)(bases.arena[blockIdx.z] + off_src);  // blockIdx.z = frame
   uint8_t* __restrict__ out = (uint8_t*)(bases.arena[blockIdx.z] + off_dst);
   const uint32_t dy0 = blockIdx.y * BLUR_ROWS, rows = min(BLUR_ROWS, dh - dy0);
   const uint32_t dx0 = blockIdx.x * BLUR_TILE, dx1 = min(dx0 + BLUR_TILE, dw) - 1;
-  const int32_t vtop = taps_v[dy0].left, vbot = taps_v[dy0 + rows - 1].left + taps_v[dy0 + rows - 1].count;
-  const int32_t cmin = taps_h[dx0].left, cmax = taps_h[dx1].left + taps_h[dx1].count;
+  // The source rows [vtop, vbot) and columns [cmin, cmax) under this tile, from tap_range (what the tables hold): a block
+  // then has ONE round of global loads — source words, its rows of the vertical table (to LDS) and each thread's row of
+  // the horizontal table (to registers) are all in flight together — instead of table -> addresses -> source -> table.
+  int32_t vtop, vbot, cmin, cmax, cnt;
+  tap_range(2 * dy0, support, h, &vtop, &cnt);
+  tap_range(2 * (dy0 + rows - 1), support, h, &vbot, &cnt), vbot += cnt;
+  tap_range(2 * dx0, support, w, &cmin, &cnt);
+  tap_range(2 * dx1, support, w, &cmax, &cnt), cmax += cnt;
   const uint32_t span = (uint32_t)(cmax - cmin) * 3u, nraw = (uint32_t)(vbot - vtop);
   const uint32_t sh = ((uint32_t)cmin * 3u) & 3u;               // the same for every row: w * 3 is a multiple of four
   const uint32_t words = (span + sh + 3) / 4;
+  const uint32_t o = threadIdx.x, dx = dx0 + o / 3, ch = o % 3;
+  const bool owns_output = o < BLUR_TILE * 3 && dx < dw;
+  uint4 th4[4] = {};  // taps_h[dx]
+  if (owns_output) {
+    const uint4* src = (const uint4*)(taps_h + dx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) th4[i] = src[i];
+  }
+  const bool stages_taps = threadIdx.x < rows * 16u;
+  const uint32_t tv_word = stages_taps ? ((const uint32_t*)(taps_v + dy0))[threadIdx.x] : 0u;  // (parked behind the source loads)
   // ---- staging: thread = (row slot t / 128, word t % 128); a tile's row has at most 108 words ----
   {
     const uint32_t k = threadIdx.x & 127u, jj = threadIdx.x >> 7;
     // (32-bit byte offsets off the frame's uniform colour pointer: an image is below 2^28 pixels)
     const uint32_t row_bytes = w * 3u;
     const uint32_t first = (((uint32_t)vtop * w + (uint32_t)cmin) * 3u & ~3u) + 4u * k;
-    if (k < words)
-      for (uint32_t j = jj; j < nraw; j += 2)
-        s_raw[j * PITCH_W + k] = *(const uint32_t __attribute__((address_space(1)))*)((a3d_gptr_c)rgb + (first + j * row_bytes));
+    // (every load of the thread issued before the first is parked in LDS: a loop over j with a run-time trip count is
+    // compiled into rounds of two loads, each round waiting for the previous one)
+    uint32_t got[RAW_ROWS / 2];
+#pragma unroll
+    for (uint32_t i = 0; i < RAW_ROWS / 2; ++i) {
+      const uint32_t j = jj + 2 * i;
+      got[i] = (k < words && j < nraw) ? *(const uint32_t __attribute__((address_space(1)))*)((a3d_gptr_c)rgb + (first + j * row_bytes)) : 0u;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < RAW_ROWS / 2; ++i) {
+      const uint32_t j = jj + 2 * i;
+      if (k < words && j < nraw) s_raw[j * PITCH_W + k] = got[i];
+    }
   }
+  if (stages_taps) s_tv[threadIdx.x >> 4][threadIdx.x & 15u] = tv_word;
   __syncthreads();
   // ---- vertical pass, word-wise: item = (output row r, word q) ----
   for (uint32_t e = threadIdx.x; e < rows * 128u; e += 256) {
     const uint32_t r = e >> 7, q = e & 127u;
     if (q >= words) continue;
-    const TapRow* tv = taps_v + dy0 + r;  // row 2 * (dy0 + r) of the source (table built with stride 2)
-    const int32_t j0 = tv->left - vtop, vcount = tv->count;
+    // row 2 * (dy0 + r) of the source (table built with stride 2)
+    const int32_t j0 = (int32_t)s_tv[r][0] - vtop, vcount = (int32_t)s_tv[r][1];
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
     for (int k = 0; k < MAX_TAPS; ++k)
       if (k < vcount) {
         const uint32_t word = s_raw[(uint32_t)(j0 + k) * PITCH_W + q];
-        const float wk = tv->w[k];
+        const float wk = __uint_as_float(s_tv[r][2 + k]);
         a0 += (float)(word & 255u) * wk, a1 += (float)((word >> 8) & 255u) * wk;
         a2 += (float)((word >> 16) & 255u) * wk, a3 += (float)(word >> 24) * wk;
       }
@@ -460,15 +500,16 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   // ---- horizontal pass: a thread owns one (column, channel) of the tile for all its rows: taps read once ------
-  const uint32_t o = threadIdx.x, dx = dx0 + o / 3, ch = o % 3;
-  if (o >= BLUR_TILE * 3 || dx >= dw) return;
-  const TapRow th = taps_h[dx];
-  const uint32_t h0 = (uint32_t)(th.left - cmin) * 3u + ch + sh;
+  if (!owns_output) return;
+  const uint32_t tw[16] = {th4[0].x, th4[0].y, th4[0].z, th4[0].w, th4[1].x, th4[1].y, th4[1].z, th4[1].w,
+                           th4[2].x, th4[2].y, th4[2].z, th4[2].w, th4[3].x, th4[3].y, th4[3].z, th4[3].w};
+  const int32_t hcount = (int32_t)tw[1];
+  const uint32_t h0 = (uint32_t)((int32_t)tw[0] - cmin) * 3u + ch + sh;
   for (uint32_t r = 0; r < rows; ++r) {
     float acc = 0.0f;
 #pragma unroll
     for (int k = 0; k < MAX_TAPS; ++k)
-      if (k < th.count) acc += s_v[r * PITCH_W * 4 + h0 + 3u * (uint32_t)k] * th.w[k];
+      if (k < hcount) acc += s_v[r * PITCH_W * 4 + h0 + 3u * (uint32_t)k] * __uint_as_float(tw[2 + k]);
     acc = fminf(fmaxf(acc, 0.0f), 255.0f);
     *(uint8_t __attribute__((address_space(1)))*)((a3d_gptr)out + (((dy0 + r) * dw + dx) * 3u + ch)) = (uint8_t)roundf(acc);
   }
@@ -482,14 +523,10 @@ std::vector<TapRow> make_taps(uint32_t size, float sigma, uint32_t stride, uint3
   for (uint32_t k = 0; k < count; ++k) {
     const uint32_t o = k * stride;
     const float in = (float)o + 0.5f;
-    int64_t left = (int64_t)std::floor(in - support);
-    left = std::min<int64_t>(std::max<int64_t>(left, 0), (int64_t)size - 1);
-    int64_t right = (int64_t)std::ceil(in + support);
-    right = std::min<int64_t>(std::max<int64_t>(right, left + 1), (int64_t)size);
     const float c = in - 0.5f;
     TapRow r{};
-    r.left = (int32_t)left;
-    r.count = (int32_t)std::min<int64_t>(right - left, MAX_TAPS);  // callers reject sigma > 3 (more taps)
+    tap_range(o, support, size, &r.left, &r.count);  // (callers reject sigma > 3: more than MAX_TAPS taps)
+    const int64_t left = r.left;
     float sum = 0.0f, wv[MAX_TAPS];
     for (int i = 0; i < r.count; ++i) {
       const float x = (float)(left + i) - c;
@@ -583,7 +620,8 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
     static const bool blur_words = !(A3D_DIAG_ENV("A3D_BUILDER_BLUR") && !strcmp(A3D_DIAG_ENV("A3D_BUILDER_BLUR"), "bytes"));  // cross-check knob
     const dim3 blur_grid((D.w + BLUR_TILE - 1) / BLUR_TILE, (D.h + BLUR_ROWS - 1) / BLUR_ROWS, F);
     if (blur_words && (S.w * 3) % 4 == 0 && (RAW_PITCH / 4) <= 128)
-      hipLaunchKernelGGL(blur_halve_words_kernel, blur_grid, dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
+      hipLaunchKernelGGL(blur_halve_words_kernel, blur_grid, dim3(256), 0, s, S.colors, S.w, S.h, D.w, D.h, 2.0f * sigma, d_tv,
+                         d_th, D.colors, bases);
     else
       hipLaunchKernelGGL(blur_halve_kernel, blur_grid, dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
   }
