@@ -25,14 +25,22 @@ __global__ void __launch_bounds__(256)
   const bool aligned = ((uintptr_t)img & 15u) == 0;
   const uint32_t n8 = aligned ? n / 8 : 0;
   const uint4* img8 = (const uint4*)img;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x) {
-    const uint4 q = img8[i];
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+  // (four loads of a thread in flight at a time: a 640x480 frame is 2.3 loads per thread of its 64 blocks, and one at a
+  // time the kernel ran at a seventh of the memory rate)
+  const uint32_t step = gridDim.x * blockDim.x;
+  for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n8; i0 += 4 * step) {
+    uint4 q[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
-      mi = min(mi, min(lo, hi));
-      ma = max(ma, max(lo, hi));
+    for (uint32_t u = 0; u < 4; ++u) q[u] = img8[min(i0 + u * step, n8 - 1)];  // (a clamped repeat changes neither result)
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
+        mi = min(mi, min(lo, hi));
+        ma = max(ma, max(lo, hi));
+      }
     }
   }
   for (uint32_t i = n8 * 8 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -168,7 +176,35 @@ __device__ __forceinline__ T row_neighbour(T x, bool from_lower_lane) {
     return r;
   }
 }
+// [1 2 1] along the 16 lanes of a DPP row.  Integers as (prev + c) + (next + c): each addition takes its shifted operand
+// straight through the DPP path of v_add_u32 (three instructions instead of two moves, a shift and an add3).
+// (The empty asm statements keep the two sums apart: left alone the compiler regroups them into prev + next + 2 c.)
+__device__ __forceinline__ uint32_t blur3_across_lanes(uint32_t c) {
+  uint32_t below = row_neighbour(c, true) + c, above = row_neighbour(c, false) + c;
+  asm("" : "+v"(below));
+  asm("" : "+v"(above));
+  return below + above;
+}
+__device__ __forceinline__ double blur3_across_lanes(double c) { return blur3(row_neighbour(c, true), c, row_neighbour(c, false)); }
+__device__ __forceinline__ float blur3_across_lanes(float c) { return blur3(row_neighbour(c, true), c, row_neighbour(c, false)); }
 constexpr int BT = 12, BR = BT + 4;  // blur tiles: 16^3 cells per tile, 12^3 of them final
+
+// value / weight of a blurred cell: both are integers times 4^6 — 0 <= value < 2^48, 1 <= weight < 2^32 — so neither the
+// operands nor the quotient come near the ends of the f64 range, and the compiler's correctly rounded division
+// (v_div_scale x 2, v_rcp, four fma, v_mul, fma, v_div_fmas, v_div_fixup: twelve instructions, a quarter of the blur's
+// last phase) reduces to its arithmetic core: the two Newton steps on the reciprocal, the quotient and its one fma
+// correction — the same operations on the same (unscaled, since the scale factors are 1 in this range) operands, eight
+// instructions, the same bits.  The selections the fix-up makes (zero, infinite or NaN operands) do not occur.
+__device__ __forceinline__ double quotient_of_counts(double value, double weight) {
+  const double r0 = __builtin_amdgcn_rcp(weight);
+  const double e0 = __builtin_fma(-weight, r0, 1.0);
+  const double r1 = __builtin_fma(r0, e0, r0);
+  const double e1 = __builtin_fma(-weight, r1, 1.0);
+  const double r2 = __builtin_fma(r1, e1, r1);
+  const double q = value * r2;
+  const double rem = __builtin_fma(-weight, q, value);
+  return __builtin_fma(rem, r2, q);
+}
 
 // grid.rs:37-56 on the device (same f64 arithmetic as the host path), plus the capacity check, for a batch:
 // grid = (blocks, frames).  Every block reduces its frame's (min, max) partials and sizes the grid; block 0 writes the
@@ -213,8 +249,10 @@ __global__ void __launch_bounds__(256)
     sc[threadIdx.x] = v;
   }
   if (too_big) return;
-  for (uint32_t v = blockIdx.x * 256u + threadIdx.x; v < 65536u; v += gridDim.x * 256u)
-    channel_of[blockIdx.y * 65536u + v] = v >= cmin ? f64_as_usize((double)(v - cmin) * inv_sc + 0.5) + 2 : 0u;
+  // (only the colours the frame holds, cmin .. cmax, and 0 — an invalid pixel, looked up but not used — are ever read)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && cmin > 0) channel_of[blockIdx.y * 65536u] = 0u;
+  for (uint32_t v = cmin + blockIdx.x * 256u + threadIdx.x; v <= cmax; v += gridDim.x * 256u)
+    channel_of[blockIdx.y * 65536u + v] = f64_as_usize((double)(v - cmin) * inv_sc + 0.5) + 2;
 }
 
 // The last kernel of a filter enqueue: puts back the zeros.  The splat left, per (row, column) of the grid, the range of
@@ -302,17 +340,28 @@ __global__ void __launch_bounds__(256)
   auto cell_at = [&](uint32_t ch) { return (CELL __attribute__((address_space(1)))*)((a3d_gptr)grid + (column + ch) * (uint32_t)sizeof(CELL)); };
   constexpr uint32_t NONE = 0xFFFFFFFFu;
   uint32_t ch_lo = NONE, ch_hi = 0u;  // the channels this (row, column) adds into: what unsplat_kernel zeroes again
-  // the blur tiles whose 16^3 window (12^3 tile + 2 cells of halo) contains a cell of this column: rows and columns
-  // of tiles are the thread's own, the channel tiles depend on the cell
+  // The blur tiles whose 16^3 window (12^3 tile + 2 cells of halo) contains a cell of this column: rows and columns of
+  // tiles are the thread's own (a0..a1 x b0..b1); the channel tiles depend on the cells and are collected as bits of
+  // `ztiles` (grids of up to 64 channel tiles, i.e. 768 channels; deeper grids mark as they write), marked once at the end.
   const uint32_t ta = gr / BT, tb = gc / BT, la = gr % BT, lb = gc % BT;
   const uint32_t a0 = (la < 2 && ta > 0) ? ta - 1 : ta, a1 = (la >= BT - 2 && ta + 1 < tx) ? ta + 1 : ta;
   const uint32_t b0 = (lb < 2 && tb > 0) ? tb - 1 : tb, b1 = (lb >= BT - 2 && tb + 1 < ty) ? tb + 1 : tb;
+  const bool ztiles_fit = tz <= 64;
+  unsigned long long ztiles = 0;
+  auto mark = [&](uint32_t z) {
+    for (uint32_t i = a0; i <= a1; ++i)
+      for (uint32_t j = b0; j <= b1; ++j) {
+        if (marks_in_lds) s_marks[((i - ia) * ty + j) * tz + z] = 1;
+        else tile_flags[(i * ty + j) * tz + z] = 1;
+      }
+  };
   // (unconditional lookups — a conditional load is compiled into a branch with its own wait, one lookup at a time:
   // without a table the loads read word 0 of the row table and the channel is computed instead)
   const uint32_t* table = channel_of ? channel_of : row_starts;
   const uint32_t table_mask = channel_of ? 0xFFFFu : 0u;
   constexpr uint32_t UR = 5, UC = 6;  // the default sigma's footprint, 4-5 x 4-5 pixels, is one patch
   bool wrote_before = false;          // an earlier patch of this thread may have written the same channels
+  const uint32_t own_word = threadIdx.x * (uint32_t)sizeof(CELL);
   for (uint32_t r0 = r_lo; r0 < r_hi; r0 += UR)
     for (uint32_t c0 = c_lo; c0 < c_hi; c0 += UC) {
       uint32_t v[UR * UC], chv[UR * UC];
@@ -332,19 +381,22 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (uint32_t j = 0; j < UR * UC; ++j) {
         if (!channel_of) chv[j] = f64_as_usize((double)(v[j] - color_min) * inv_sc + 0.5) + 2;  // (uniform branch)
-        base = v[j] != 0 ? min(base, chv[j]) : base;
+        chv[j] = v[j] != 0 ? chv[j] : NONE;  // a skipped pixel: in no round, never a candidate for the next one
+        base = min(base, chv[j]);
         ch_hi = v[j] != 0 ? max(ch_hi, chv[j]) : ch_hi;
       }
       ch_lo = min(ch_lo, base);
       while (__builtin_amdgcn_ballot_w64(base != NONE)) {  // rounds of SLOTS channels from `base` up
+        const uint32_t lim = base == NONE ? NONE : base + SLOTS;  // (a lane that is done takes part with nothing)
         uint32_t next = NONE;
 #pragma unroll
         for (uint32_t j = 0; j < UR * UC; ++j) {
           const uint32_t q = chv[j] - base;
-          const bool valid = v[j] != 0 && base != NONE, mine = valid && q < SLOTS;  // (q wraps for channels below base: written)
+          const bool mine = q < SLOTS && chv[j] != NONE && lim != NONE;  // (q wraps for channels below base: written in an earlier round)
           const CELL add = mine ? ((CELL)v[j] << Pack<CELL>::SHIFT) + (CELL)1 : (CELL)0;
-          atomicAdd(&s_slot[mine ? q : 0u][threadIdx.x], add);  // ds_add without return; nobody else uses the word
-          next = (valid && chv[j] >= base + SLOTS && chv[j] - base < 0x80000000u) ? min(next, chv[j]) : next;
+          // ds_add without return into the thread's own word of slot q; nobody else uses it
+          atomicAdd((CELL*)((char*)&s_slot[0][0] + ((mine ? q : 0u) * (256u * (uint32_t)sizeof(CELL)) + own_word)), add);
+          next = min(next, chv[j] >= lim ? chv[j] : NONE);
         }
         CELL sum[SLOTS], old[SLOTS];
 #pragma unroll
@@ -358,18 +410,10 @@ __global__ void __launch_bounds__(256)
             *cell_at(ch) = old[q] + sum[q];
             s_slot[q][threadIdx.x] = 0;
             if (tile_flags) {
-              const uint32_t tc = ch / BT, lc = ch % BT;
+              const uint32_t tc = ch / BT, lc = ch - tc * BT;
               const uint32_t z0 = (lc < 2 && tc > 0) ? tc - 1 : tc, z1 = (lc >= BT - 2 && tc + 1 < tz) ? tc + 1 : tc;
-              for (uint32_t i = a0; i <= a1; ++i)
-                for (uint32_t j = b0; j <= b1; ++j) {
-                  if (marks_in_lds) {
-                    s_marks[((i - ia) * ty + j) * tz + z0] = 1;
-                    s_marks[((i - ia) * ty + j) * tz + z1] = 1;
-                  } else {
-                    tile_flags[(i * ty + j) * tz + z0] = 1;
-                    tile_flags[(i * ty + j) * tz + z1] = 1;
-                  }
-                }
+              if (ztiles_fit) ztiles |= (1ull << z0) | (1ull << z1);
+              else mark(z0), mark(z1);
             }
           }
         }
@@ -377,6 +421,11 @@ __global__ void __launch_bounds__(256)
       }
       wrote_before = true;
     }
+  while (ztiles) {  // (a thread's cells lie in two or three channel tiles)
+    const uint32_t z = (uint32_t)__builtin_ctzll(ztiles);
+    ztiles &= ztiles - 1;
+    mark(z);
+  }
   if (extent && active) extent[(size_t)blockIdx.y * columns + id] = ch_lo <= ch_hi ? make_uint2(ch_lo, ch_hi) : make_uint2(1u, 0u);
   if (marks_in_lds) {
     __syncthreads();
@@ -430,12 +479,37 @@ __device__ __forceinline__ void blur_line_twice(V (&vx)[BR], W (&vw)[BR], OK ok)
   }
 }
 
+// The 16 cells a thread owns in a tile's first pass — the rows of (column hi, channel lo) of the 16^3 window — straight
+// from the packed grid (zero outside it).  Apart from blur_tile so that a block walking a list of tiles can have the
+// NEXT tile's sixteen loads in flight while it computes the current one: with four blocks of four waves per CU there is
+// one wave per SIMD and block to hide a tile's initial load latency behind, i.e. nothing.
+template <typename CELL>
+__device__ __forceinline__ void load_window(uint32_t tile_id, const CELL* __restrict__ packed, const GridDims g, CELL (&u)[BR]) {
+  const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT;
+  const int r0 = (int)(tile_id / (ty * tz)) * BT - 2, c0 = (int)((tile_id / tz) % ty) * BT - 2,
+            z0 = (int)(tile_id % tz) * BT - 2;
+  const int gh = (int)g.gh, gw = (int)g.gw, gd = (int)g.gd;
+  const int t = (int)threadIdx.x, hi = t >> 4, lo = t & 15;
+  const int gc = c0 + hi, gz = z0 + lo;
+  const bool line_in = gc >= 0 && gc < gw && gz >= 0 && gz < gd;
+  // cell (gr, gc, gz) = first + i * row_stride: 32-bit arithmetic off the frame's (block-uniform) grid pointer — the
+  // fused kernels only see grids below 2^29 cells (grid_fits_idx32) — instead of a 64-bit multiply-add per load
+  const int row_stride = gw * gd * (int)sizeof(CELL);
+  int at_row = ((r0 * gw + gc) * gd + gz) * (int)sizeof(CELL);  // byte offset of (r0 + i, gc, gz), advanced by additions
+#pragma unroll
+  for (int i = 0; i < BR; ++i, at_row += row_stride) {
+    const int gr = r0 + i;
+    u[i] = 0;
+    if (line_in && gr >= 0 && gr < gh)
+      u[i] = *(const CELL __attribute__((address_space(1)))*)((a3d_gptr_c)packed + (uint32_t)at_row);
+  }
+}
+
 // One tile.  `known_occupied`: the tile comes from the splat's list of marked windows; otherwise emptiness is decided
-// from the loaded window.  `zeros_only`: an unmarked first-channel tile, written as zeros (see below).
+// from the loaded window `u` (load_window).  `zeros_only`: an unmarked first-channel tile, written as zeros (see below).
 template <typename CELL>
 __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_x, typename Pack<CELL>::EarlyWeight* tile_w,
-                                          uint32_t tile_id,
-                                          const CELL* __restrict__ packed,
+                                          uint32_t tile_id, const CELL (&u)[BR],
                                           const GridDims g, double* __restrict__ out, bool known_occupied,
                                           bool zeros_only) {
   const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT;
@@ -468,19 +542,9 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     EV vx[BR];
     EW vw[BR];
     const int gc = c0 + hi, gz = z0 + lo;
-    const bool line_in = gc >= 0 && gc < gw && gz >= 0 && gz < gd;
-    // cell (gr, gc, gz) = first + i * row_stride: 32-bit arithmetic off the frame's (block-uniform) grid pointer — the
-    // fused kernels only see grids below 2^29 cells (grid_fits_idx32) — instead of a 64-bit multiply-add per load
-    const int row_stride = gw * gd * (int)sizeof(CELL);
-    int at_row = ((r0 * gw + gc) * gd + gz) * (int)sizeof(CELL);  // byte offset of (r0 + i, gc, gz), advanced by additions
 #pragma unroll
-    for (int i = 0; i < BR; ++i, at_row += row_stride) {
-      const int gr = r0 + i;
-      CELL u = 0;
-      if (line_in && gr >= 0 && gr < gh)
-        u = *(const CELL __attribute__((address_space(1)))*)((a3d_gptr_c)packed + (uint32_t)at_row);
-      vx[i] = (EV)(u >> Pack<CELL>::SHIFT), vw[i] = (EW)(u & (((CELL)1 << Pack<CELL>::SHIFT) - 1));
-    }
+    for (int i = 0; i < BR; ++i)
+      vx[i] = (EV)(u[i] >> Pack<CELL>::SHIFT), vw[i] = (EW)(u[i] & (((CELL)1 << Pack<CELL>::SHIFT) - 1));
     // Empty windows: a depth image occupies ~1 % of its grid's cells and 20-30 % of its tiles.  A tile whose whole
     // 16^3 window holds no splat blurs to zero, and the slice never reads it: a pixel's eight cells lie within one cell
     // of its own splat cell on every axis (grid.rs:60-78 vs :132-146: floor(t + 0.5) against floor(t), floor(t) + 1),
@@ -510,8 +574,8 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
         for (int rep = 0; rep < 2; ++rep) {
           const EV cx_ = vx[i];
           const EW cw_ = vw[i];
-          const EV ox = blur3(row_neighbour(cx_, true), cx_, row_neighbour(cx_, false));
-          const EW ow = blur3(row_neighbour(cw_, true), cw_, row_neighbour(cw_, false));
+          const EV ox = blur3_across_lanes(cx_);
+          const EW ow = blur3_across_lanes(cw_);
           vx[i] = ok ? ox : (EV)0, vw[i] = ok ? ow : (EW)0;
         }
       }
@@ -541,7 +605,7 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
         // is zero, the value itself (x 4^-6: the six divisions by four)
         if (gc < gw)
           *(double __attribute__((address_space(1)))*)((a3d_gptr)out + (uint32_t)at_col) =
-              vw[i] > (W)0 ? vx[i] / (double)vw[i] : vx[i] * 0x1p-12;
+              vw[i] > (W)0 ? quotient_of_counts(vx[i], (double)vw[i]) : vx[i] * 0x1p-12;
       }
     }
   }
@@ -584,7 +648,7 @@ __global__ void __launch_bounds__(256)
 // hundred instructions per block instead of a launch between splat and blur (tile_list_kernel: 4.8 us per 16 frames).
 constexpr uint32_t BLUR_LIST_MAX = 3072;
 template <typename CELL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, sizeof(CELL) == 4 ? 4 : 2)  // (waves per SIMD: 128 / 256 registers a thread)
     blur_fused_kernel(const CELL* __restrict__ packed, GridDims g, double* __restrict__ out,
                       uint32_t* __restrict__ dyn, unsigned long long capacity,
                       const uint32_t* __restrict__ lists, uint32_t flags_stride, const uint32_t* __restrict__ tile_flags) {
@@ -633,23 +697,43 @@ __global__ void __launch_bounds__(256)
       __syncthreads();  // the wave totals are read before the next round replaces them; the lists before they are used
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) dyn[SC_NLIST] = n_work, dyn[SC_NZERO] = n_zero;  // (statistics for the host)
+    auto entry = [&](uint32_t j) { return (uint32_t)(j < n_work ? s_list[j] : s_list[BLUR_LIST_MAX - 1u - (j - n_work)]); };
+    constexpr bool PREFETCH = sizeof(CELL) == 4;  // (the wide cells' kernel has no registers to spare for a second window)
+    CELL cur[BR] = {}, nxt[PREFETCH ? BR : 1] = {};
+    if (PREFETCH && blockIdx.x < n_work) load_window<CELL>(entry(blockIdx.x), packed, g, cur);
     for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {
       const bool work = j < n_work;
-      blur_tile<CELL>(tile_x, tile_w, work ? s_list[j] : s_list[BLUR_LIST_MAX - 1u - (j - n_work)], packed, g, out, true, !work);
+      if constexpr (PREFETCH) {
+        if (j + gridDim.x < n_work) load_window<CELL>(entry(j + gridDim.x), packed, g, nxt);  // in flight under this tile
+      } else {
+        if (work) load_window<CELL>(entry(j), packed, g, cur);
+      }
+      blur_tile<CELL>(tile_x, tile_w, entry(j), cur, g, out, true, !work);
+      if constexpr (PREFETCH) {
+#pragma unroll
+        for (int i = 0; i < BR; ++i) cur[i] = nxt[i];
+      }
       __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
     }
     return;
   }
   if (!lists) {
     // 1-D launch (the host may not know the dimensions): block -> tile (row, column, channel), channel fastest
-    if (blockIdx.x < tx * ty * tz) blur_tile<CELL>(tile_x, tile_w, blockIdx.x, packed, g, out, false, false);
+    if (blockIdx.x < tx * ty * tz) {
+      CELL u[BR];
+      load_window<CELL>(blockIdx.x, packed, g, u);
+      blur_tile<CELL>(tile_x, tile_w, blockIdx.x, u, g, out, false, false);
+    }
     return;
   }
   lists += (size_t)blockIdx.y * 2 * flags_stride;
   const uint32_t n_work = dyn[SC_NLIST], n_zero = dyn[SC_NZERO];
-  for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {
+  for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {  // (grids of more than BLUR_LIST_MAX tiles: no prefetch)
     const bool work = j < n_work;
-    blur_tile<CELL>(tile_x, tile_w, work ? lists[j] : lists[flags_stride + (j - n_work)], packed, g, out, true, !work);
+    const uint32_t tile = work ? lists[j] : lists[flags_stride + (j - n_work)];
+    CELL u[BR] = {};
+    if (work) load_window<CELL>(tile, packed, g, u);
+    blur_tile<CELL>(tile_x, tile_w, tile, u, g, out, true, !work);
     __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
   }
 }
@@ -887,7 +971,7 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   const uint32_t mm_blocks = std::min<uint32_t>((n + 255) / 256, PARTIALS);
   hipLaunchKernelGGL(minmax_u16_kernel, dim3(mm_blocks, n_frames), dim3(256), 0, s, d_depth, n, (uint32_t*)nullptr, partials);
   const double inv_sc = 1.0 / sigma_color;
-  hipLaunchKernelGGL(dims_table_kernel, dim3(64, n_frames), dim3(256), 0, s, (const uint32_t*)partials, mm_blocks, out->scal, w, h,
+  hipLaunchKernelGGL(dims_table_kernel, dim3(16, n_frames), dim3(256), 0, s, (const uint32_t*)partials, mm_blocks, out->scal, w, h,
                      sigma_space, sigma_color, capacity, channel_of, inv_sc);
   // (gh and gw depend on the image size only: the launch covers every (row, column) pixels can splat into)
   const dim3 splat_grid((columns + 255) / 256, n_frames);

@@ -22,7 +22,18 @@ using namespace a3d;
 
 namespace {
 
-constexpr uint32_t MAX_BATCH = 16;  // frames per launch sequence
+// Frames per launch sequence.  The dozen launches of a sequence have fixed costs (boundaries, ramps, the tail of the
+// slowest block) that more frames share: kernels per frame measured 14.9 us at 16 frames per sequence, 14.0 at 32, 13.7
+// at 64.  Against that, a sequence starts when ITS uploads have landed and the last one runs with nothing under it, so
+// a build from host memory wants several sequences: a call's frames are split into equal chunks of at most MAX_BATCH
+// (64 frames -> 2 x 32, 65 -> 33 + 32).
+#ifndef A3D_MAX_BATCH
+#define A3D_MAX_BATCH 48
+#endif
+#ifndef A3D_GRID_BUDGET_GB
+#define A3D_GRID_BUDGET_GB 4  // a chunk's bilateral grids (24 B per cell of capacity) stay below this
+#endif
+constexpr uint32_t MAX_BATCH = A3D_MAX_BATCH;
 struct FrameBases {
   char* arena[MAX_BATCH];
 };
@@ -582,10 +593,16 @@ a3d_status taps_for(a3d_context* ctx, uint32_t size, uint32_t count, float sigma
 
 // Everything after the uploads for up to MAX_BATCH frames whose depth images sit at d_depth ([F][h][w]) and whose
 // colours are already in their arenas.  Enqueue only; the caller synchronises and then reads `result`.
+// The work has two independent halves that meet in nobody's input: the DEPTH half (bilateral grid, level 0, picked
+// levels: `depth_part`) and the COLOUR half (blurred + halved colours, intensities and their maps: `color_part`); a
+// chunk whose grids outgrew the scratch region repeats the depth half only.  (Running the colour half on a second
+// stream under the depth half's VALU-bound kernels was measured in round 4: 15.3 against 15.4 us per frame — the blur
+// fills every CU's LDS, so the colour kernels only fit into the tails — and dropped.)
 a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32_t F, const uint16_t* d_depth, uint32_t w,
                          uint32_t h, float fx, float fy, float cx, float cy, float depth_scale, const ArenaPlan& plan,
-                         const FrameBases& bases, uint32_t* result) {
+                         const FrameBases& bases, uint32_t* result, bool depth_part, bool color_part) {
   hipStream_t s = ctx->stream;
+  hipStream_t color_stream = s;
   const PyramidLayout& P = plan.layout;
   const LevelLayout& L0 = P.lv[0];
   const dim3 grid0((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F);
@@ -593,7 +610,8 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   // resize's float index arithmetic is exactly 2 dv, 2 du); A3D_BUILDER_FUSE_L1=0 keeps the separate kernel (cross-check)
   static const bool fuse_allowed = !(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L1") && atoi(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L1")) == 0);
   const bool fuse_l1 = fuse_allowed && prm->pyramid_levels >= 2 && w % 2 == 0 && h % 2 == 0;
-  if (prm->use_bilateral) {  // builder.rs:75-77
+  if (!depth_part) {
+  } else if (prm->use_bilateral) {  // builder.rs:75-77
     GridBatch gb;
     A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb));
     hipLaunchKernelGGL(level0_kernel<true>, grid0, dim3(L0_THREADS), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
@@ -611,29 +629,30 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   if (sigma <= 0.0f) sigma = 1.0f;
   for (uint64_t l = 1; l < prm->pyramid_levels; ++l) {
     const LevelLayout &S = P.lv[l - 1], &D = P.lv[l];
-    if (!(l == 1 && fuse_l1))
+    if (depth_part && !(l == 1 && fuse_l1))
       hipLaunchKernelGGL(resize_pick_kernel, dim3((D.w * D.h + 255) / 256, prm->with_normals ? 2 : 1, F), dim3(256), 0, s, S,
                          D, bases);
+    if (!color_part) continue;
     TapRow *d_tv = nullptr, *d_th = nullptr;
     A3D_TRY(taps_for(ctx, S.h, D.h, sigma, &d_tv));
     A3D_TRY(taps_for(ctx, S.w, D.w, sigma, &d_th));
     static const bool blur_words = !(A3D_DIAG_ENV("A3D_BUILDER_BLUR") && !strcmp(A3D_DIAG_ENV("A3D_BUILDER_BLUR"), "bytes"));  // cross-check knob
     const dim3 blur_grid((D.w + BLUR_TILE - 1) / BLUR_TILE, (D.h + BLUR_ROWS - 1) / BLUR_ROWS, F);
     if (blur_words && (S.w * 3) % 4 == 0 && (RAW_PITCH / 4) <= 128)
-      hipLaunchKernelGGL(blur_halve_words_kernel, blur_grid, dim3(256), 0, s, S.colors, S.w, S.h, D.w, D.h, 2.0f * sigma, d_tv,
+      hipLaunchKernelGGL(blur_halve_words_kernel, blur_grid, dim3(256), 0, color_stream, S.colors, S.w, S.h, D.w, D.h, 2.0f * sigma, d_tv,
                          d_th, D.colors, bases);
     else
-      hipLaunchKernelGGL(blur_halve_kernel, blur_grid, dim3(256), 0, s, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
+      hipLaunchKernelGGL(blur_halve_kernel, blur_grid, dim3(256), 0, color_stream, S.colors, S.w, D.w, D.h, d_tv, d_th, D.colors, bases);
   }
-  if (prm->with_intensity) {
+  if (prm->with_intensity && color_part) {
     bool quads = true;  // every level's width a multiple of four (the colour, intensity and map rows then stay word-aligned)
     for (uint64_t l = 0; l < prm->pyramid_levels; ++l) quads = quads && P.lv[l].w % 4 == 0;
     if (quads)
       hipLaunchKernelGGL(luma_imap_kernel<true>, dim3((h * (w / 4) + 2 * (w + 2) + 2 * h + 255) / 256, (uint32_t)prm->pyramid_levels, F),
-                         dim3(256), 0, s, P, bases);
+                         dim3(256), 0, color_stream, P, bases);
     else
       hipLaunchKernelGGL(luma_imap_kernel<false>, dim3(((w + 2) * (h + 2) + 255) / 256, (uint32_t)prm->pyramid_levels, F),
-                         dim3(256), 0, s, P, bases);
+                         dim3(256), 0, color_stream, P, bases);
   }
   A3D_HIP_TRY(hipGetLastError());
   return A3D_OK;
@@ -786,8 +805,9 @@ a3d_status build_frames(a3d_context* ctx, const a3d_builder_params* prm, uint64_
       if (attempt == 0 && c.colors_staged)
         hipLaunchKernelGGL(scatter_colors_kernel, dim3((uint32_t)((n * 3 / 16 + 255) / 256), 1, c.F), dim3(256), 0, s,
                            (const uint4*)c.d_colors, n * 3, plan.layout.lv[0].colors, c.bases);
+      // (the colour half runs once: a repeated attempt only redoes the grids)
       const a3d_status st = enqueue_chunk(ctx, prm, c.F, c.d_depth, w, h, (float)fx, (float)fy, (float)cx, (float)cy,
-                                          (float)depth_scale, plan, c.bases, c.result);
+                                          (float)depth_scale, plan, c.bases, c.result, true, attempt == 0);
       if (st != A3D_OK) return fail(st);
       if (ctx->build_profiling) (void)hipEventRecord(ctx->build_events[2 * n_profiled++ + 1], s);
     }
@@ -886,13 +906,13 @@ a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_pa
               "the device frame builder's bilateral filter handles images below 2^24 pixels");
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   const uint64_t L = prm->pyramid_levels;
-  // frames per launch sequence: at most MAX_BATCH, and few enough that their bilateral grids fit ~2 GiB of scratch
+  // frames per launch sequence: at most MAX_BATCH, and few enough that their bilateral grids fit A3D_GRID_BUDGET_GB of scratch
   uint64_t chunk = MAX_BATCH;
   if (prm->use_bilateral) {
     const unsigned long long cap = ctx->grid_capacity ? ctx->grid_capacity
                                                       : bilateral_grid_cells((uint32_t)width, (uint32_t)height, prm->sigma_space,
                                                                              prm->sigma_color, 4096);
-    chunk = std::max<uint64_t>(1, std::min<uint64_t>(MAX_BATCH, (2ull << 30) / (cap * 24 + 1)));
+    chunk = std::max<uint64_t>(1, std::min<uint64_t>(MAX_BATCH, ((unsigned long long)A3D_GRID_BUDGET_GB << 30) / (cap * 24 + 1)));
   }
   for (uint64_t& v : ctx->build_stats) v = 0;
   ctx->last_build_kernel_ms = 0.f;
@@ -900,7 +920,8 @@ a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_pa
   const uint64_t pass = chunk * (a3d_context::PINNED_WORDS / (MAX_BATCH * SC_STRIDE));
   for (uint64_t f0 = 0; f0 < n_frames; f0 += pass) {
     const uint64_t F = std::min<uint64_t>(pass, n_frames - f0);
-    const a3d_status st = build_frames(ctx, prm, F, chunk, depth_frames + f0, rgb_frames + f0, (uint32_t)width, (uint32_t)height,
+    const uint64_t pieces = (F + chunk - 1) / chunk, balanced = (F + pieces - 1) / pieces;  // equal chunks, none tiny
+    const a3d_status st = build_frames(ctx, prm, F, balanced, depth_frames + f0, rgb_frames + f0, (uint32_t)width, (uint32_t)height,
                                        fx, fy, cx, cy, depth_scale, out_levels + f0 * L);
     if (st != A3D_OK) {  // the caller gets all the pyramids or none
       for (uint64_t k = 0; k < f0 * L; ++k) a3d_range_image_free(out_levels[k]);

@@ -429,10 +429,10 @@ def bench_icp_shape(ctx):
     return out, (tgt, src)
 
 
-def frame_build_kernel_us(frames_per_probe=160):
+def frame_build_kernel_us(frames_per_probe=320):
     """Kernel time per frame of the batched frame builder from the committed rocprofv3 summary of
-    scripts/build_trace_probe.py (10 builds of 16 frames): sum over the builder's kernels of TotalDurationNs / frames.
-    (Measured live the build is PCIe-bound: 16 frames of u16 depth + u8 RGB take longer to upload than to build.)"""
+    scripts/build_trace_probe.py (10 builds of 32 frames): sum over the builder's kernels of TotalDurationNs / frames.
+    (Measured live the build is PCIe-bound: a chunk of u16 depth + u8 RGB frames takes longer to upload than to build.)"""
     import csv
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_frame_build_kernel_stats.csv")), reverse=True)
@@ -456,13 +456,15 @@ def frame_build_kernel_us(frames_per_probe=160):
 def frame_build_roofline(ctx, W, H, levels=3):
     """Algorithmic bytes of ONE frame through the fused builder (DESIGN.md §4 "frame builder"): u16 depth + u8 RGB in;
     every array of every pyramid level written once (colours 3, points 12, mask 1, normals 12, intensities 1 B per
-    pixel + the (h+2)(w+2) f32 map); the packed grid cleared once (4 B per cell the grid uses); per blur tile the splat
-    marked: its 16^3-cell window read once (4 B per cell) and its 12^3 blurred cells written once and read once by the
-    slice (8 B each); first-channel zero tiles written once.  Kernel time from the committed profile."""
+    pixel + the (h+2)(w+2) f32 map); per blur tile the splat marked: its 16^3-cell window read once (4 B per cell) and its
+    12^3 blurred cells written once and read once by the slice (8 B each); first-channel zero tiles written once.
+    (Until round 4 the packed grid was also cleared per build, 4 B per cell of the grid = 9.6 of then 43.9 MB per frame:
+    the builder no longer does that — its last kernel puts back the zeros the splat replaced — so those bytes are no
+    longer counted: the same kernel time now gives a LOWER fraction.)  Kernel time: live, see below."""
     frames, _ = synth.frame_stream(4242, 64, W, H)
     builder = RangeImageBuilder(ctx).with_bilateral_filter(BilateralFilter.default())
     cam = synth.camera(W, H)
-    # LIVE kernel time: every 16-frame chunk of a build bracketed by hipEvents on the builder's stream behind the wait for
+    # LIVE kernel time: every chunk of a build (64 frames: two of 32) bracketed by hipEvents on the builder's stream behind the wait for
     # its upload (a3d_context_set_build_profiling): the builder's kernels without PCIe, measured in this very run
     ctx.set_build_profiling(True)
     live = []
@@ -478,15 +480,15 @@ def frame_build_roofline(ctx, W, H, levels=3):
     n = st["frames"] or 1
     px = sum((W >> l) * (H >> l) for l in range(levels))
     out_bytes = 29 * px + sum(4 * ((W >> l) + 2) * ((H >> l) + 2) for l in range(levels))
-    grid_bytes = (st["grid_cells"] * 4 + st["marked_tiles"] * (4096 * 4 + 1728 * 16) + st["zero_tiles"] * 1728 * 8) / n
+    grid_bytes = (st["marked_tiles"] * (4096 * 4 + 1728 * 16) + st["zero_tiles"] * 1728 * 8) / n
     alg = 5 * W * H + out_bytes + grid_bytes
     us = float(np.median(live))
     prof_us, per_kernel, src = frame_build_kernel_us()
-    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "the ~13 kernels of one batched build, per frame",
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "the 10 kernels of one batched build, per frame",
          "algorithmic_bytes_per_frame": alg, "input_bytes": 5 * W * H, "pyramid_bytes": out_bytes, "grid_bytes": grid_bytes,
          "grid_cells_per_frame": st["grid_cells"] / n, "marked_tiles_per_frame": st["marked_tiles"] / n,
          "kernel_us_per_frame": us, "kernel_us_per_frame_stats": stats(live),
-         "kernel_us_source": "live: hipEvent brackets around each 16-frame chunk's kernels (4 chunks per build, 5 builds)",
+         "kernel_us_source": "live: hipEvent brackets around each chunk's kernels (2 chunks of 32 frames per build, 5 builds)",
          "profile_kernel_us_per_frame": prof_us, "profile_kernel_us_by_kernel": per_kernel, "profile_source": src,
          "traffic": None, "achieved": alg / (us * 1e-6) / 1e9}
     r["frac"] = r["achieved"] / HBM_PEAK_GBS
@@ -550,7 +552,7 @@ def streaming_bench(ctx, params, P, W, H, rounds=32, builders=1, pinned=True, bu
 
     frames, _ = synth.frame_stream(4242, P + 1, W, H)  # the same host frames every round: they are rebuilt each time
     # the stream's frames lie back to back in ONE buffer per array (as a capture ring would hold them): the builder
-    # then uploads a 16-frame chunk with one copy per array; page-locked: a DMA at the PCIe rate
+    # then uploads a chunk (up to 48 frames) with one copy per array; page-locked: a DMA at the PCIe rate
     alloc = ctx.pinned_empty if pinned else (lambda shape, dtype: np.empty(shape, dtype))
     all_d, all_c = alloc((P + 1, H, W), np.uint16), alloc((P + 1, H, W, 3), np.uint8)
     for i, (d, rgb) in enumerate(frames):
@@ -564,7 +566,7 @@ def streaming_bench(ctx, params, P, W, H, rounds=32, builders=1, pinned=True, bu
             for k in range(builders)]
     bld = [RangeImageBuilder(c).with_bilateral_filter(BilateralFilter.default()) for c in ctxs]
 
-    def build_round(k=0):  # one batched build call: ~12 launches per 16 frames
+    def build_round(k=0):  # one batched build call: 10 launches per chunk of up to 48 frames
         return bld[k].build_many(cam, frames, synth.DEPTH_SCALE)
 
     def free_round(pyr):

@@ -2,7 +2,7 @@
 # WAIT_ANY (parked on s_waitcnt / barrier), WAIT_INST_ANY (issue stalls), ACTIVE_INST_ANY, plus instruction counts.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc_builder
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d gpurun_out/pmc_builder -- python3 scripts/build_trace_probe.py > gpurun_out/pmc_builder.out 2> gpurun_out/pmc_builder.err &&
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d gpurun_out/pmc_builder -- python3 scripts/build_trace_probe.py ${FRAMES:-32} ${PRIO:--1} > gpurun_out/pmc_builder.out 2> gpurun_out/pmc_builder.err &&
 python3 - <<'PY'
 import csv, glob, re, collections
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
