@@ -278,7 +278,7 @@ def test_device_builder_without_minmax_round_trip_and_scratch_regrow():
 
 
 def test_batched_builder_equals_oracle_and_single_builds(ctx):
-    """a3d_range_image_build_pyramids: 20 real frames in two launch sequences (16 + 4) — every level of every frame
+    """a3d_range_image_build_pyramids: 20 real frames in one launch sequence — every level of every frame
     equals the single-frame build bit for bit, and the oracle's pyramid on the frames checked against it; frames with
     very different depth ranges (= bilateral grids of different sizes, one of which outgrows the scratch region and
     forces the chunk to run again) share a batch."""
@@ -293,7 +293,7 @@ def test_batched_builder_equals_oracle_and_single_builds(ctx):
         b = RangeImageBuilder(own).with_bilateral_filter(BilateralFilter.default())
         many = b.build_many(cam, frames, s.depth_scale(0))
         assert len(many) == 20 and all(len(p) == 3 for p in many)
-        for i in (0, 1, 7, 15, 16, 19):  # both chunks, first and last slot of each
+        for i in (0, 1, 7, 15, 16, 19):
             for lv, r in zip(many[i], oracle_pyramid("sample1", i)):
                 _assert_same_level(lv, r)
         for i in (3, 12, 18):
@@ -395,3 +395,64 @@ def test_compute_normals_wide_dynamic_range_and_signed_zeros(ctx):
         ref = O.compute_normals(pts, mask)
         got = RangeImage(pts, mask, CameraIntrinsics(100, 100, w / 2, h / 2, w, h)).compute_normals(ctx).normals
         assert np.array_equal(_bits(got), _bits(ref)), (k, int(np.sum(_bits(got) != _bits(ref))))
+
+
+def test_builder_keeps_its_grid_scratch_clean_between_enqueues():
+    """The builder never clears its bilateral grids: the last kernel of an enqueue zeroes the cells its splat wrote and
+    the tile flags (a3d_context::grid_clean).  One context, a sequence chosen to break that if anything is left behind:
+    two launch sequences in one call (50 frames), frames whose grids are sparse, dense (full-range noise: every
+    footprint spans dozens of channels, i.e. several splat rounds), empty and 2000 channels deep (more channel tiles
+    than the splat's tile bits hold and more tiles than the blur lists in LDS: the general paths), the host filter on
+    another image size in between (same scratch region, another layout), then the first frames again.  Everything
+    equals the oracle bit for bit."""
+    from align3d_amd import CameraIntrinsics, Context, RangeImageBuilder
+
+    rng = np.random.default_rng(11)
+
+    def scene(w, h, kind):
+        base = 1500 + 500 * np.sin(np.linspace(0, 5, w))[None, :] + 300 * np.cos(np.linspace(0, 3, h))[:, None]
+        if kind == "smooth":
+            d = base + rng.integers(0, 20, size=(h, w))
+        elif kind == "steps":   # depth edges: foreground squares 1.2 m in front of the background
+            d = base + 6000.0
+            d[h // 4: h // 2, w // 4: w // 2] -= 6000.0
+            d[h // 2 + 3: h - 9, 5: w // 3] = 0
+        elif kind == "noise":   # every pixel anywhere in the u16 range
+            d = rng.integers(1, 65000, size=(h, w)).astype(np.float64)
+        else:
+            d = np.zeros((h, w))
+        return d.astype(np.uint16), rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+
+    def check(b, cam, frames, which=None):
+        many = b.build_many(cam, frames, 0.001)
+        for i in (range(len(frames)) if which is None else which):
+            d, rgb = frames[i]
+            ref = O.build_pyramid(d, rgb, cam.fx, cam.fy, cam.cx, cam.cy, 0.001, levels=3, use_bilateral=True)
+            for lv, r in zip(many[i], ref):
+                _assert_same_level(lv, r)
+        for lv in (lv for p in many for lv in p):
+            lv.free()
+
+    own = Context(0)
+    try:
+        b = RangeImageBuilder(own).with_bilateral_filter(BilateralFilter.default())
+        w, h = 320, 240
+        cam = CameraIntrinsics(300.0, 300.0, w / 2.0, h / 2.0, w, h)
+        big = [scene(w, h, k) for k in ("smooth", "steps", "noise", "zeros", "smooth")]
+        check(b, cam, big)
+        check(b, cam, [big[4], big[1]])
+        # the host filter on the same context and scratch region, another image size
+        fw, fh = 200, 120
+        fd, _ = scene(fw, fh, "steps")
+        f = BilateralFilter.default()
+        got = f.filter(own, fd)
+        assert np.array_equal(got, O.bilateral(fd, f.sigma_space, f.sigma_color)[1])
+        check(b, cam, [big[0], big[2], big[1]])
+        # 50 small frames: two launch sequences of 25
+        sw, sh = 96, 64
+        cam_s = CameraIntrinsics(90.0, 90.0, sw / 2.0, sh / 2.0, sw, sh)
+        small = [scene(sw, sh, ("smooth", "steps", "noise", "zeros")[i % 4]) for i in range(50)]
+        check(b, cam_s, small, which=(0, 1, 2, 3, 24, 25, 26, 49))
+        check(b, cam, [big[1]])
+    finally:
+        own.close()
