@@ -14,7 +14,7 @@ trace() {  # NAME program args...
 trace bench python3 bench.py --steps 5 --warmup 2 --no-extras --cpu-pairs 0 &&
 trace kdtree python3 scripts/kd_probe.py &&
 trace pcl_icp python3 scripts/pcl_probe.py &&
-trace frame_build python3 scripts/build_trace_probe.py &&
+trace frame_build python3 scripts/build_trace_probe.py 32 -1 &&
 ROUND=$ROUND bash scripts/traffic_pmc.sh bench image_icp_head_kernel "pairs_per_gpu=64 concurrent_launches=${CONC:-3} distinct_frames=1" python3 bench.py --steps 2 --warmup 1 --no-extras --cpu-pairs 0 > /dev/null &&
 mv gpurun_out/${ROUND}_bench_traffic.json gpurun_out/${ROUND}_bench_traffic_distinct.json &&
 ROUND=$ROUND bash scripts/traffic_pmc.sh bench image_icp_head_kernel "pairs_per_gpu=64 concurrent_launches=${CONC:-3} distinct_frames=0" python3 bench.py --shared-frames --steps 2 --warmup 1 --no-extras --cpu-pairs 0 > /dev/null &&
