@@ -1098,6 +1098,12 @@ def main():
             "per_launch_GBs": bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9,
             "launch_sequence_ms": rms, "launch_sequence_ms_stats": stats(region_ms),
             "kernel_share_of_step": rms / ms_per_step,
+            # The frames come from the device builder, whose images carry "mask == (z > 0)": the kernel derives both masks
+            # from z and never reads the two mask bytes per pixel that SURVEY §8(d)'s 39 B per pixel credit it with, so
+            # the rate it actually delivers from HBM is 37/39 of `achieved` (the PMC `traffic` above shows the same).
+            "delivered_GBs": achieved * (37 * W * H + 4 * (W + 2) * (H + 2)) / level_bytes(W, H),
+            "delivered_frac": achieved * (37 * W * H + 4 * (W + 2) * (H + 2)) / level_bytes(W, H) / HBM_PEAK_GBS,
+            "delivered_note": "masks derived from z (builder-made frames): 37 instead of 39 B per pixel are read",
         }
         # per pyramid level: `conc` launches of a level run at once (the pair groups move in step), so the level's share
         # of the sequence is its summed launch time / conc, and its bandwidth the level's bytes over that
