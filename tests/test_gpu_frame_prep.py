@@ -456,3 +456,43 @@ def test_builder_keeps_its_grid_scratch_clean_between_enqueues():
         check(b, cam, [big[1]])
     finally:
         own.close()
+
+
+def test_bilateral_wide_cells_for_a_large_sigma_space():
+    """sigma_space >= 15: more than 255 pixels can fall into one grid (row, column), so the packed cells are u64
+    (value sum << 24 | count) and the blur carries f64 throughout — the other instantiation of splat / blur / unsplat.
+    The host filter and the frame builder (two enqueues on one context: the grid scratch must come back clean) against
+    the oracle, bit for bit; footprints of 16-17 x 16-17 pixels also take several load patches per grid column."""
+    from align3d_amd import CameraIntrinsics, Context, RangeImageBuilder
+
+    rng = np.random.default_rng(21)
+    w, h = 200, 150
+    base = 1200 + 500 * np.sin(np.linspace(0, 5, w))[None, :] + 300 * np.cos(np.linspace(0, 3, h))[:, None]
+    d0 = (base + rng.integers(0, 25, size=(h, w))).astype(np.uint16)
+    d0[40:70, 30:90] = 0
+    d1 = base.copy()
+    d1[h // 3: 2 * h // 3, w // 3: 2 * w // 3] += 5000.0   # a depth step
+    d1 = d1.astype(np.uint16)
+    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    cam = CameraIntrinsics(180.0, 180.0, w / 2.0, h / 2.0, w, h)
+    own = Context(0)
+    try:
+        for ss, sc in ((16.0, 40.0), (23.5, 300.0)):
+            f = BilateralFilter.new(ss, sc)
+            for d in (d0, d1):
+                st, ref, dims = O.bilateral(d, ss, sc)
+                out = f.filter(own, d)
+                assert st == 0 and f.last_grid_dims == dims
+                assert np.array_equal(out, ref), (ss, sc)
+            b = RangeImageBuilder(own).with_bilateral_filter(f)
+            for rep in range(2):
+                many = b.build_many(cam, [(d0, rgb), (d1, rgb), (d0, rgb)], 0.001)
+                for (d, c), pyr in zip([(d0, rgb), (d1, rgb), (d0, rgb)], many):
+                    filtered = O.bilateral(d, ss, sc)[1]  # (the oracle's builder with this filter: filter, then build)
+                    ref = O.build_pyramid(filtered, c, cam.fx, cam.fy, cam.cx, cam.cy, 0.001, levels=3, use_bilateral=False)
+                    for lv, r in zip(pyr, ref):
+                        _assert_same_level(lv, r)
+                for lv in (lv for p in many for lv in p):
+                    lv.free()
+    finally:
+        own.close()
