@@ -227,7 +227,7 @@ a3d_status a3d_range_image_build_pyramid(a3d_context* ctx, const a3d_builder_par
                                          uint64_t height, double fx, double fy, double cx, double cy,
                                          double depth_scale, a3d_device_image** out_levels);
 /* The same for n_frames frames of one stream (same size, intrinsics and depth scale) in ONE launch sequence: every
- * kernel of the builder has a frame dimension, so 16 frames cost the ~12 launches one frame costs (a frame stream is
+ * kernel of the builder has a frame dimension, so up to 48 frames cost the 10 launches one frame costs (a frame stream is
  * launch-bound otherwise).  depth_frames / rgb_frames: n_frames host pointers (page-locked buffers from a3d_host_alloc
  * are copied by DMA).  out_levels: [n_frames][params->pyramid_levels] handles, frame-major.  All or nothing: on
  * failure no handle is returned.  The call returns when every pyramid is complete. */
@@ -239,7 +239,7 @@ a3d_status a3d_range_image_build_pyramids(a3d_context* ctx, const a3d_builder_pa
  * this context processed — out_stats = {frames, cells of their bilateral grids (GH x GW x GD, src/bilateral/grid.rs:37-56),
  * 12^3-cell blur tiles the splat marked, first-channel tiles written as zeros}. */
 a3d_status a3d_context_last_build_stats(a3d_context* ctx, uint64_t out_stats[4]);
-/* Instrumentation: when on, every chunk (up to 16 frames) of a3d_range_image_build_pyramids is bracketed by a hipEvent
+/* Instrumentation: when on, every chunk (up to 48 frames) of a3d_range_image_build_pyramids is bracketed by a hipEvent
  * pair on the context's stream, recorded behind the wait for the chunk's upload: a3d_context_last_build_kernel_ms is the
  * sum of those brackets for the most recent build — the device time of the builder's kernels without the PCIe copies
  * (a live figure for the builder's roofline; rocprofv3 --kernel-trace shows the same kernels one by one). */
