@@ -51,6 +51,21 @@ __device__ __forceinline__ void st_v3u(void* base, uint32_t idx, V3 v) {
 __device__ __forceinline__ void st_u8u(void* base, uint32_t idx, uint8_t v) {
   *(uint8_t __attribute__((address_space(1)))*)((a3d_gptr)base + idx) = v;
 }
+// Streaming forms for arrays nothing reads back soon (level 0's points, mask and normals; intensities and their maps).
+__device__ __forceinline__ void st_v3u_stream(void* base, uint32_t idx, V3 v) {
+#ifdef A3D_BUILDER_NO_NT
+  st_v3u(base, idx, v);
+#else
+  __builtin_nontemporal_store(f32x3{v.x, v.y, v.z}, (f32x3_u __attribute__((address_space(1)))*)((a3d_gptr)base + idx * 12u));
+#endif
+}
+__device__ __forceinline__ void st_u8u_stream(void* base, uint32_t idx, uint8_t v) {
+#ifdef A3D_BUILDER_NO_NT
+  st_u8u(base, idx, v);
+#else
+  __builtin_nontemporal_store(v, (uint8_t __attribute__((address_space(1)))*)((a3d_gptr)base + idx));
+#endif
+}
 __device__ __forceinline__ V3 ld_v3g(const float* base, size_t idx) {
   const f32x3 v = *(const f32x3_u*)(base + 3 * idx);
   return V3{v.x, v.y, v.z};
@@ -198,9 +213,9 @@ __global__ void __launch_bounds__(L0_THREADS)
   for (int k = 0; k < L0_PPT; ++k)
     if (owned[k] && ((A3D_L0_PROBE != 1 && A3D_L0_PROBE != 4) || px[k] == 12345.678f)) {
       const uint32_t idx = __umul24((uint32_t)row[k], w) + (uint32_t)col;
-      st_v3u(base + off_points, idx, V3{px[k], py[k], pz[k]});
-      st_u8u(base + off_mask, idx, d[k] > 0 ? 1 : 0);
-      if (with_normals) st_v3u(base + off_normals, idx, nrm[k]);
+      st_v3u_stream(base + off_points, idx, V3{px[k], py[k], pz[k]});
+      st_u8u_stream(base + off_mask, idx, d[k] > 0 ? 1 : 0);
+      if (with_normals) st_v3u_stream(base + off_normals, idx, nrm[k]);
     }
   if (!emit_l1 || A3D_L0_PROBE == 3 || A3D_L0_PROBE == 4) return;
   // ---- level 1 of the pyramid from the staged level-0 patch (pyr_scale_down: resize_range_points / _normals,
@@ -288,9 +303,16 @@ __global__ void __launch_bounds__(256) luma_imap_kernel(PyramidLayout layout, Fr
       const uint8_t l1 = luma_of(a >> 24, b & 255u, (b >> 8) & 255u);
       const uint8_t l2 = luma_of((b >> 16) & 255u, b >> 24, d & 255u);
       const uint8_t l3 = luma_of((d >> 8) & 255u, (d >> 16) & 255u, d >> 24);
-      *(uint32_t*)((uint8_t*)(base + L.intensities) + px) = (uint32_t)l0 | ((uint32_t)l1 << 8) | ((uint32_t)l2 << 16) | ((uint32_t)l3 << 24);
+      const uint32_t packed4 = (uint32_t)l0 | ((uint32_t)l1 << 8) | ((uint32_t)l2 << 16) | ((uint32_t)l3 << 24);
       float* o = imap + (size_t)r * mw + c;
+#ifdef A3D_BUILDER_NO_NT
+      *(uint32_t*)((uint8_t*)(base + L.intensities) + px) = packed4;
       o[0] = (float)l0 / 255.0f, o[1] = (float)l1 / 255.0f, o[2] = (float)l2 / 255.0f, o[3] = (float)l3 / 255.0f;
+#else  // streaming stores: the alignment reads these, much later
+      __builtin_nontemporal_store(packed4, (uint32_t*)((uint8_t*)(base + L.intensities) + px));
+      __builtin_nontemporal_store((float)l0 / 255.0f, o), __builtin_nontemporal_store((float)l1 / 255.0f, o + 1);
+      __builtin_nontemporal_store((float)l2 / 255.0f, o + 2), __builtin_nontemporal_store((float)l3 / 255.0f, o + 3);
+#endif
     } else if (i < n_quads + n_border) {
       const uint32_t j = i - n_quads;
       uint32_t r, c;
@@ -344,8 +366,8 @@ __global__ void __launch_bounds__(256) resize_pick_kernel(LevelLayout S, LevelLa
     }
   int n;
   const V3 nearest = pick_nearest_to_mean(cand, ok, &n);
-  st_v3(dst, i, nearest);
-  if (!normals) ((uint8_t*)(base + D.mask))[i] = n > 0 ? 1 : 0;
+  st_v3u_stream(dst, i, nearest);  // (the coarsest levels: read by the alignment, not by the builder)
+  if (!normals) st_u8u_stream(base + D.mask, i, n > 0 ? 1 : 0);
 }
 
 // One tap table entry per output row / column: first tap, tap count, normalised weights.

@@ -91,7 +91,9 @@ __global__ void __launch_bounds__(256)
     const int ly = ty + k * (NT_H / NT_PPT) + 1, lx = tx + 1;
     const V3 out = normal_from_neighbours_dev(center[k], at(ly, lx - 1), at(ly, lx + 1), at(ly - 1, lx), at(ly + 1, lx));
     const int row = row0 + ly - 1;
-    *(nf32x3_u*)(normals + 3 * ((size_t)row * w + col)) = nf32x3{out.x, out.y, out.z};
+    // (a streaming store — nothing reads the normals back soon: 102 -> 95 us per 64 frames, 0.60 -> 0.64 of 8 TB/s;
+    // streaming LOADS of the points gained nothing at 64 frames and lost at 16)
+    __builtin_nontemporal_store(nf32x3{out.x, out.y, out.z}, (nf32x3_u*)(normals + 3 * ((size_t)row * w + col)));
   }
 }
 

@@ -4,7 +4,7 @@ import copy, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench
 from align3d_amd import Context, compute_normals_batch, _abi
-ctx = Context(0, library=_abi.DIAG_LIB_PATH if os.environ.get("A3D_NORMALS_SHAPE") else None)
+ctx = Context(0, library=os.environ.get("A3D_LIBRARY") or (_abi.DIAG_LIB_PATH if os.environ.get("A3D_NORMALS_SHAPE") else None))
 pyr, _, _ = bench.build_stream_pyramids(ctx, 1000, 2, 640, 480)
 host = pyr[0][0].download()
 devs = []
