@@ -519,16 +519,26 @@ __global__ void __launch_bounds__(256)
     const uint32_t r = e >> 7, q = e & 127u;
     if (q >= words) continue;
     // row 2 * (dy0 + r) of the source (table built with stride 2)
-    const int32_t j0 = (int32_t)s_tv[r][0] - vtop, vcount = (int32_t)s_tv[r][1];
+    // (r is the same for the 64 lanes of a wave — 128 items per row — so the tap count is a scalar: up to SHORT_TAPS
+    // taps (sigma = 1 has five) run an unrolled body of that many predicated taps instead of fourteen)
+    const int32_t j0 = (int32_t)s_tv[r][0] - vtop, vcount = __builtin_amdgcn_readfirstlane((int32_t)s_tv[r][1]);
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    auto tap = [&](int k) {
+      const uint32_t word = s_raw[(uint32_t)(j0 + k) * PITCH_W + q];
+      const float wk = __uint_as_float(s_tv[r][2 + k]);
+      a0 += (float)(word & 255u) * wk, a1 += (float)((word >> 8) & 255u) * wk;
+      a2 += (float)((word >> 16) & 255u) * wk, a3 += (float)(word >> 24) * wk;
+    };
+    constexpr int SHORT_TAPS = 6;
+    if (vcount <= SHORT_TAPS) {
 #pragma unroll
-    for (int k = 0; k < MAX_TAPS; ++k)
-      if (k < vcount) {
-        const uint32_t word = s_raw[(uint32_t)(j0 + k) * PITCH_W + q];
-        const float wk = __uint_as_float(s_tv[r][2 + k]);
-        a0 += (float)(word & 255u) * wk, a1 += (float)((word >> 8) & 255u) * wk;
-        a2 += (float)((word >> 16) & 255u) * wk, a3 += (float)(word >> 24) * wk;
-      }
+      for (int k = 0; k < SHORT_TAPS; ++k)
+        if (k < vcount) tap(k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAX_TAPS; ++k)
+        if (k < vcount) tap(k);
+    }
     *(float4*)(s_v + (r * PITCH_W + q) * 4) = make_float4(a0, a1, a2, a3);
   }
   __syncthreads();
@@ -538,11 +548,19 @@ __global__ void __launch_bounds__(256)
                            th4[2].x, th4[2].y, th4[2].z, th4[2].w, th4[3].x, th4[3].y, th4[3].z, th4[3].w};
   const int32_t hcount = (int32_t)tw[1];
   const uint32_t h0 = (uint32_t)((int32_t)tw[0] - cmin) * 3u + ch + sh;
+  // (the same short body when no lane of the wave has more than SHORT_TAPS taps)
+  const bool short_taps = __builtin_amdgcn_ballot_w64(hcount > 6) == 0ull;
   for (uint32_t r = 0; r < rows; ++r) {
     float acc = 0.0f;
+    if (short_taps) {
 #pragma unroll
-    for (int k = 0; k < MAX_TAPS; ++k)
-      if (k < hcount) acc += s_v[r * PITCH_W * 4 + h0 + 3u * (uint32_t)k] * __uint_as_float(tw[2 + k]);
+      for (int k = 0; k < 6; ++k)
+        if (k < hcount) acc += s_v[r * PITCH_W * 4 + h0 + 3u * (uint32_t)k] * __uint_as_float(tw[2 + k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAX_TAPS; ++k)
+        if (k < hcount) acc += s_v[r * PITCH_W * 4 + h0 + 3u * (uint32_t)k] * __uint_as_float(tw[2 + k]);
+    }
     acc = fminf(fmaxf(acc, 0.0f), 255.0f);
     *(uint8_t __attribute__((address_space(1)))*)((a3d_gptr)out + (((dy0 + r) * dw + dx) * 3u + ch)) = (uint8_t)roundf(acc);
   }
