@@ -114,12 +114,12 @@ __global__ void __launch_bounds__(256)
 
 // ---- packed splat + fused blur (images below 2^24 pixels) ------------------------------------------------
 // Both sums of a cell are integers: the value sum is < pixels x 65535 < 2^40 and the count < 2^24, so a cell is
-// ONE u64 (value sum << 24 | count) and a pixel is ONE integer atomic instead of two f64 atomics; integer adds are
-// exact, so the cell holds exactly the reference's f64 sums.
+// ONE u64 (value sum << 24 | count) and a pixel is ONE integer add (in the gather-splat: an LDS add into the owning
+// thread's slot) instead of two f64 atomics; integer adds are exact, so the cell holds exactly the reference's f64 sums.
 constexpr int PACK_SHIFT = 24;
 // When at most 255 pixels can splat into one (row, column) of the grid — sigma_space below ~14 — the count of a cell
 // is < 2^8 and its value sum < 255 x 65535 < 2^24: the cell is ONE u32 (value sum << 8 | count), half the bytes to
-// clear, to add into and to load in the blur.
+// write and to load in the blur.
 template <typename CELL>
 struct Pack;
 // Weight: the type the blur carries a cell's COUNT in.  Six unnormalised [1 2 1] passes multiply a count by at most
@@ -611,6 +611,7 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
   }
 }
 
+// (Grids of more than BLUR_LIST_MAX tiles only: otherwise the blur's blocks compact the flags themselves.)
 // Turns the tile flags the splat wrote into two lists per frame: the marked windows (the blur's work) and the
 // unmarked first-channel tiles (written as zeros).  A depth image marks 20-30 % of its tiles; launching one block
 // per TILE made the blur a block-dispatch benchmark (each block holds 68 KiB of LDS, two fit a CU, and an empty one

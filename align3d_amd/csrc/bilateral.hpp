@@ -38,7 +38,7 @@ __device__ __forceinline__ double cell_value(const double* __restrict__ grid, Gr
   return grid[((size_t)r * g.gw + c) * g.gd + z];
 }
 // Grids of the frame builder and of the one-enqueue filter are below 2^29 cells with gh x gw and gd below 2^24
-// (grid_fits_idx32; the device-side dims_kernel refuses anything else): a cell's byte offset is then 32-bit arithmetic on
+// (grid_fits_idx32; the device-side dims_table_kernel refuses anything else): a cell's byte offset is then 32-bit arithmetic on
 // the full-rate 24-bit multiplier off a uniform base pointer, instead of a 64-bit multiply-add (v_mad_u64_u32, quarter
 // rate) and a 64-bit shift-add per gathered cell — eight of each per pixel in a kernel that is VALU-issue bound.
 __host__ __device__ __forceinline__ bool grid_fits_idx32(unsigned long long gh, unsigned long long gw, unsigned long long gd) {

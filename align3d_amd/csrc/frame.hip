@@ -8,7 +8,7 @@
 //   compute_intensity / _map         src/range_image/structure.rs:266-297, src/image/luma.rs:81-83,
 //                                    src/intensity_map.rs:37-92
 // Every kernel has a frame dimension (blockIdx.z, or .y where noted), so up to MAX_BATCH frames cost the same
-// ~12 launches as one frame; the per-frame arenas are laid out identically, so a kernel needs one base pointer per
+// 10 launches as one frame; the per-frame arenas are laid out identically, so a kernel needs one base pointer per
 // frame (FrameBases, passed by value) plus array offsets that are the same for all frames.
 // The RGB blur of the pyramid (image 0.24.7 imageops::blur) is restated from its published algorithm
 // like the oracle's: PARITY UNPINNED (no reference test pins its values).
@@ -22,7 +22,7 @@ using namespace a3d;
 
 namespace {
 
-// Frames per launch sequence.  The dozen launches of a sequence have fixed costs (boundaries, ramps, the tail of the
+// Frames per launch sequence.  The ten launches of a sequence have fixed costs (boundaries, ramps, the tail of the
 // slowest block) that more frames share: kernels per frame measured 14.9 us at 16 frames per sequence, 14.0 at 32, 13.7
 // at 64.  Against that, a sequence starts when ITS uploads have landed and the last one runs with nothing under it, so
 // a build from host memory wants several sequences: a call's frames are split into equal chunks of at most MAX_BATCH
@@ -875,7 +875,7 @@ a3d_status build_frames(a3d_context* ctx, const a3d_builder_params* prm, uint64_
       set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
       return fail(A3D_CAST_OVERFLOW);
     }
-    if (need >= (1ull << 29)) {  // (dims_kernel refuses such grids: the slice addresses cells with 32-bit byte offsets)
+    if (need >= (1ull << 29)) {  // (dims_table_kernel refuses such grids: the slice addresses cells with 32-bit byte offsets)
       set_error("a3d_range_image_build_pyramids: a frame's bilateral grid would have %llu cells (the device builder handles "
                 "grids below 2^29 cells: raise sigma_color or sigma_space)", need);
       return fail(A3D_INVALID_PARAMETER);
