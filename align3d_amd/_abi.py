@@ -3,6 +3,7 @@ libalign3d_hip.so.  The product path has no CPU fallback: if the HIP library is 
 fails, an exception is raised (never a silent detour)."""
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -258,20 +259,38 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
+        if restype is _ST:
+            _note_failures(lib, fn)
     for name, (restype, argtypes) in DIAG_SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.restype = restype
             fn.argtypes = argtypes
+            if restype is _ST:
+                _note_failures(lib, fn)
     if lib.a3d_abi_version() != 1:
         raise RuntimeError("libalign3d_hip.so ABI version mismatch")
     _libs[path] = lib
     return lib
 
 
-def check(status, what=""):
+_failed = threading.local()  # .lib: the library whose call most recently returned a failure status on this thread
+
+
+def _note_failures(lib, fn):
+    """ctypes errcheck hook for a status-returning entry point: remembers on which LIBRARY a call failed, so that check()
+    reads a3d_last_error from that one (the product and the diagnostics build can both be loaded; the text is the
+    library's most recent failure and is not cleared on success, so the other library's would be stale)."""
+    def errcheck(result, func, args):
+        if result != A3D_OK:
+            _failed.lib = lib
+        return result
+    fn.errcheck = errcheck
+
+
+def check(status, what="", lib=None):
+    """Raises A3dError for a failed call, with the a3d_last_error text of the library the failing call ran on."""
     if status != A3D_OK:
-        msg = ""
-        for lib in list(_libs.values()) or [load_library()]:  # the failing call's library holds the text
-            msg = msg or lib.a3d_last_error().decode("utf-8", "replace")
+        lib = lib or getattr(_failed, "lib", None) or load_library()
+        msg = lib.a3d_last_error().decode("utf-8", "replace")
         raise A3dError(status, f"{what}: {msg}" if what else msg)

@@ -334,7 +334,9 @@ a3d_status a3d_context_create_on_pipe(int32_t device_index, int32_t priority, in
 a3d_status a3d_context_create_pair(int32_t device_index, a3d_context** out_aligner, a3d_context** out_builder) {
   A3D_REQUIRE(out_aligner && out_builder, A3D_INVALID_PARAMETER, "null argument");
   // created back to back on purpose: see the stream order in a3d_context_create_with_priority
-  A3D_TRY(a3d_context_create_with_priority(device_index, 0, out_aligner));
+  // The aligner of a pair always has its main stream in slot 0 (not the process-wide rotation of unpaired aligners): the
+  // builder's main stream (slot 3) is placed against THAT, so every pair a process creates has the same pipe relation.
+  A3D_TRY(a3d_context_create_on_pipe(device_index, 0, 0, out_aligner));
   const a3d_status st = a3d_context_create_with_priority(device_index, -1, out_builder);
   if (st != A3D_OK) {
     a3d_context_destroy(*out_aligner);

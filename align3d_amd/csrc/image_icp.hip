@@ -1,7 +1,9 @@
 // ImageIcp::align (src/icp/image_icp.rs:43-164) and MultiscaleAlign (src/icp/multiscale.rs:26-67)
 // for P independent frame pairs at once: per iteration ONE kernel per stream group of pairs (grid = tiles x
-// pairs) whose last block per pair also runs the Gauss-Newton solve and the pose update (icp_engine.hpp); the
-// whole coarse-to-fine sequence is enqueued without a host round trip.
+// pairs).  Every block stores its partial sums plainly; every block of the NEXT launch first finishes the previous
+// iteration at its head (sums its pair's partials in a fixed order and runs the Gauss-Newton solve and the pose
+// update redundantly: icp_engine.hpp, head_advance) — no atomics, no last block.  The whole coarse-to-fine
+// sequence is enqueued without a host round trip.
 #include <cstdlib>
 #include <memory>
 
@@ -1170,15 +1172,20 @@ void plan_tiling(a3d_multiscale_batch* b) {
       }
     }
 #endif
-    b->tiles[l] = tiles, b->ppt[l] = ppt;
     for (uint32_t p = 0; p < P; ++p) {
       LevelDesc& d = b->h_descs[(size_t)l * P + p];
       d.ppt = ppt;
-      if (pinned) {  // from the pair's own size (a smaller pair's surplus blocks store zero partials)
+      if (pinned) {
+        // From the pair's own size; the grid is the LARGEST own cut of the batch, not the cut of the largest pair:
+        // tiling_for is not monotonic in n (pixels per thread are rounded up to even, so 512x384 at level 2 is cut into
+        // 24 blocks where 640x480 takes 19), and a grid sized from max_n alone left a smaller pair's last blocks
+        // unlaunched.  A pair with fewer own blocks than the grid stores zero partials from the surplus ones.
         uint32_t t_own = 0;
         tiling_for(d.src_n, pinned, 1, &t_own, &d.ppt);
+        tiles = p == 0 ? t_own : std::max(tiles, t_own);
       }
     }
+    b->tiles[l] = tiles, b->ppt[l] = ppt;
     // a pinned grid that does not fit the chip at once runs as per-iteration launches (same bits)
     if (((mask >> l) & 1u) && (uint64_t)tiles * P > b->persist_resident_blocks) mask &= ~(1u << l);
   }

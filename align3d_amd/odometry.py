@@ -77,7 +77,10 @@ def run_odometry(ctx, dataset, params=None, builder=None, max_frames=None, prefe
     n = dataset.len() if max_frames is None else min(max_frames, dataset.len())
     tb = TrajectoryBuilder.with_start(Transform.eye(), 0.0)
     last = None
-    side = ctx.sibling() if (prefetch and n >= 3) else None
+    # With alignments in flight lane 0 aligns on `ctx` from a worker thread, so the frames must never be built on `ctx`
+    # by this thread at the same time (calls that take one context may not run concurrently: shared stream, scratch,
+    # cached engine — include/align3d_hip.h): they are then always built on the sibling context, prefetch or not.
+    side = ctx.sibling() if ((prefetch and n >= 3) or in_flight > 1) else None
     frames = _pyramids(dataset, builder, n, side)
     if in_flight > 1:
         return _finish(_run_pipelined(ctx, frames, params, tb, int(in_flight)), dataset, n)

@@ -166,8 +166,9 @@ a3d_status a3d_context_create_on_pipe(int32_t device_index, int32_t priority, in
  * unrelated moments, it lands wherever the process's stream count happens to point (measured: 11 k instead of 14 k
  * frame pairs/s in the streaming loop).  Destroy both with a3d_context_destroy. */
 a3d_status a3d_context_create_pair(int32_t device_index, a3d_context** out_aligner, a3d_context** out_builder);
-/* Releases the context's stream, scratch regions and every pyramid arena, including those of images that are still
- * alive: images (and the objects that borrow them) must not be used after their context has been destroyed. */
+/* Waits for the context's work and releases its streams and scratch regions.  Every other handle created on the context
+ * must have been freed.  Images may still be alive ("Lifetime of contexts" above): the context then only refuses new
+ * work, and its pyramid arenas and streams go when the last of those images is freed. */
 a3d_status a3d_context_destroy(a3d_context* ctx);
 a3d_status a3d_context_synchronize(a3d_context* ctx);
 /* The context's hipStream_t, for callers that want to order their own work after ours. */
@@ -407,7 +408,9 @@ a3d_status a3d_multiscale_multi_batch_free(a3d_multiscale_multi_batch* batch);
 
 /* ---- R3dTree (src/kdtree.rs:19-106) ------------------------------------------------------- */
 
-/* R3dTree::new(&points): host build (stable sort, leaf <= 16, mid = len/2), uploaded to HBM. */
+/* R3dTree::new(&points): `points` [n][3] f32 in host memory are uploaded and the tree is built ON THE DEVICE
+ * (kdtree_build.hip: per level one stable sort of every range along the level's axis, leaf <= 16, mid = len / 2 —
+ * the same tree, bit for bit, as the reference's recursive host build). */
 a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d_kdtree** out);
 /* R3dTree::nearest for m queries (leaf-only search, no backtracking).  Host pointers.
  * out_indices are indices into the `points` given to a3d_kdtree_new. */

@@ -44,7 +44,6 @@ impl Context {
         (Context(a), Context(b))
     }
 
-    /// This thread's context on device `ALIGN3D_HIP_DEVICE` (default 0).
     /// `a3d_context_set_tiling`: 0 = throughput tiling; n > 0 = every (pair, level) is cut into n blocks whatever the
     /// batch, so that a pair's pose is bit-identical alone and in any batch (no counterpart in the reference, whose own
     /// sums depend on the order rayon delivers its chunks in: src/icp/image_icp.rs:96,143-148).
@@ -52,6 +51,7 @@ impl Context {
         check(unsafe { sys::a3d_context_set_tiling(self.0, tiles_per_pair) }, "a3d_context_set_tiling");
     }
 
+    /// This thread's context on device `ALIGN3D_HIP_DEVICE` (default 0).
     pub fn current() -> *mut sys::a3d_context {
         thread_local! { static CTX: RefCell<Option<Context>> = RefCell::new(None); }
         CTX.with(|c| {

@@ -805,11 +805,24 @@ def test_pinned_tiling_makes_a_pair_independent_of_its_batch(ctx):
     cam = synth.camera(320, 240)
     small = [[to_range_image(f) for f in O.build_pyramid(d, rgb, cam.fx, cam.fy, cam.cx, cam.cy, synth.DEPTH_SCALE)]
              for d, rgb in frames]
+    # ... and 512x384: tiles = 24 cuts its level 1 / level 2 into 24 / 24 blocks where 640x480 takes 22 / 19 (pixels per
+    # thread are rounded up to even), so the grid must follow the largest OWN cut, not the largest image (advisor r4)
+    frames, _ = synth.frame_stream(6, 2, 512, 384)
+    cam = synth.camera(512, 384)
+    mid = [[to_range_image(f) for f in O.build_pyramid(d, rgb, cam.fx, cam.fy, cam.cx, cam.cy, synth.DEPTH_SCALE)]
+           for d, rgb in frames]
     for tiles in (8, 24):
         ctx.set_tiling(tiles)
         try:
             alone = [MultiscaleAlign.new(ctx, prm, tps[k]).align(sps[k]) for k in range(len(base))]
             alone_small = MultiscaleAlign.new(ctx, prm, small[0]).align(small[1])
+            alone_mid = MultiscaleAlign.new(ctx, prm, mid[0]).align(mid[1])
+            for t3, s3, at in (([tps[0], mid[0], small[0]], [sps[0], mid[1], small[1]], 1),
+                               ([mid[0], tps[1]], [mid[1], sps[1]], 0)):
+                got3, st = MultiscaleAlignBatch(ctx, prm, t3, s3).align()
+                assert not st.any()
+                assert np.array_equal(_pose_bits(got3)[at], _pose_bits([alone_mid])[0]), (tiles, "512x384 pair in a mixed batch")
+                assert np.array_equal(_pose_bits(got3)[1 - at], _pose_bits([alone[1 - at]])[0])
             ref = _pose_bits(alone)
             b5, st = MultiscaleAlignBatch(ctx, prm, tps, sps).align()
             assert not st.any() and np.array_equal(_pose_bits(b5), ref)
