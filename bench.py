@@ -326,6 +326,7 @@ def pinned_tiling_bench(ctx, params, targets, sources, lone_ms_default, step_ms_
     a = np.concatenate([alone.t, alone.q]).view(np.uint32)
     b = np.concatenate([poses[5 % P].t, poses[5 % P].q]).view(np.uint32)
     step = float(np.median(reps))
+    pinned_tiling_bench.poses = poses  # for the parity leg (cpu_baseline_main: the same 64 pairs under pinned tiling)
     return {"tiles_per_pair": tiles, "ms_per_step": step, "ms_per_step_stats": stats(reps), "pairs_per_s": P / step * 1e3,
             "cost_vs_throughput_tiling": step / step_ms_default - 1.0,
             "lone_pair_latency_ms": float(np.median(lat)), "lone_pair_latency_ms_throughput_tiling": lone_ms_default,
@@ -737,7 +738,8 @@ def load_cpu_oracle():
     return O, ("-O3 -march=native" if os.path.exists(native) else "-O2 (portable)")
 
 
-def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_poses, cores, orders=13, budget_s=25.0):
+def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_poses, cores, orders=13, budget_s=25.0,
+                      gpu_poses_pinned=None):
     """ms3x15 on the batch's pairs, threaded like the reference (4096-pixel chunks over the host's cores).
     TIMED: the chunk-order run of every pair (until `budget_s` of CPU work is spent) -> `value`.
     UNTIMED (parity of the headline): every pair also under `orders` - 1 seeded chunk-merge orders
@@ -747,7 +749,7 @@ def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_p
     import headline_parity as HP
 
     parr = params.to_c_array()
-    per, entries = [], []
+    per, entries, entries_pinned = [], [], []
     keep = {}
     for p in range(n_pairs):
         fa, fb = pair_frames[p]
@@ -768,9 +770,14 @@ def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_p
                     runs.append(T2)
         finally:
             O.set_chunk_merge_order(0)
-        e = HP.envelope(gpu_poses[p], runs)
+        table = HP.oracle_distance_table(runs)
+        e = HP.envelope_from_distances(gpu_poses[p], runs, table)
         e["pair"] = p
         entries.append(e)
+        if gpu_poses_pinned is not None:  # the same pair under a3d_context_set_tiling(24), against the same oracle runs
+            e2 = HP.envelope_from_distances(gpu_poses_pinned[p], runs, table)
+            e2["pair"] = p
+            entries_pinned.append(e2)
         keep[p] = (ta, tb)
         if len(keep) > 4:  # host copies of the most sensitive pairs only
             best = sorted(keep, key=lambda q: -next(x for x in entries if x["pair"] == q)["gpu_vs_cpu_translation_m"])[:2]
@@ -792,6 +799,12 @@ def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_p
         # ms3x15 = IcpParams::default() per level, which is not contractive on every pair: where the GPU
         # differs from the oracle by more than 1e-4 the oracle differs from ITSELF as much under another chunk-merge order
         out["per_pair_parity"] = entries
+        if entries_pinned:
+            sp = HP.summarize(entries_pinned)
+            out["pinned_tiling_parity"] = dict(sp, per_pair_parity=entries_pinned)
+            out["pinned_tiling_pairs_over_1e-4"] = sp["pairs_over_1e-4"]
+            out["pinned_tiling_pairs_over_1e-4_and_outside_the_cpu_envelope"] = sp["pairs_over_1e-4_and_outside_the_cpu_envelope"]
+            out["pinned_tiling_max_gpu_vs_cpu_translation_m"] = sp["max_gpu_vs_cpu_translation_m"]
         worst = sorted(keep, key=lambda q: -next(x for x in entries if x["pair"] == q)["gpu_vs_cpu_translation_m"])[:2]
         tfs = []
         for p in worst:
@@ -955,7 +968,8 @@ _ROOFLINE_KEYS = ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffi
                   "level1_avg_launch_us", "level2_avg_launch_us", "failed_pairs"]
 _CPU_KEYS = ["value", "unit", "cores", "kind", "sample", "cpu_model", "compiler_flags", "single_thread_ms_per_pair",
              "pairs_compared", "merge_orders_per_pair", "pairs_over_1e-4", "pairs_over_1e-4_and_outside_the_cpu_envelope",
-             "pairs_over_1e-4_and_beyond_the_median_cpu_order", "max_gpu_vs_cpu_angle_rad", "max_gpu_vs_cpu_translation_m",
+             "pairs_over_1e-4_and_beyond_the_median_cpu_order", "pairs_over_1e-4_and_farther_than_every_cpu_order",
+             "ranks_of_pairs_over_1e-4", "pinned_tiling_pairs_over_1e-4", "max_gpu_vs_cpu_angle_rad", "max_gpu_vs_cpu_translation_m",
              "median_gpu_vs_cpu_translation_m", "max_cpu_spread_translation_m", "pairs_whose_cpu_spread_exceeds_1e-4",
              "teacher_forced_count_mismatches", "teacher_forced_max_rel_err_sums", "teacher_forced_max_one_step_translation_m",
              "pinned_tiling_pairs_over_1e-4_and_outside_the_cpu_envelope", "pinned_tiling_max_gpu_vs_cpu_translation_m"]
@@ -1333,7 +1347,8 @@ def main():
             O, flags = load_cpu_oracle()
             model, cores = cpu_info()
             cpu = cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, min(args.cpu_pairs, P), poses, cores,
-                                    orders=max(1, args.cpu_orders))
+                                    orders=max(1, args.cpu_orders),
+                                    gpu_poses_pinned=getattr(pinned_tiling_bench, "poses", None))
             cpu["cpu_model"], cpu["compiler_flags"] = model, flags
             if level0_host is not None:
                 def oframe(dev_level):

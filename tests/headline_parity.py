@@ -42,12 +42,17 @@ def oracle_runs(params, target, source, threads, orders):
     return runs
 
 
+def oracle_distance_table(runs):
+    return np.array([[[abs(x[0]), x[1]] for x in (O.transform_metrics(a, b) for b in runs)] for a in runs])
+
+
 def envelope(gpu_pose, runs):
     """GPU against the oracle's runs.  `rank`: how many of the other merge orders lie farther from the chunk-order run
     than the GPU does (orders - 1 = the GPU is closer to it than every alternative order; 0 = farther than all)."""
-    g = gpu_pose.to_c()
-    to_runs = np.array([[abs(a), t] for a, t in (O.transform_metrics(g, r) for r in runs)])
-    among = np.array([[[abs(x[0]), x[1]] for x in (O.transform_metrics(a, b) for b in runs)] for a in runs])
+    return envelope_from_distances(gpu_pose, runs, oracle_distance_table(runs))
+
+
+def _envelope(to_runs, among, n_runs):
     from_first = among[0, 1:]
     return {
         "gpu_vs_cpu_angle_rad": float(to_runs[0, 0]), "gpu_vs_cpu_translation_m": float(to_runs[0, 1]),
@@ -57,7 +62,11 @@ def envelope(gpu_pose, runs):
         "cpu_other_orders_vs_chunk_order_angle_rad": float(from_first[:, 0].max()) if len(from_first) else 0.0,
         "cpu_other_orders_vs_chunk_order_translation_m": float(from_first[:, 1].max()) if len(from_first) else 0.0,
         "gpu_rank_inside_cpu_spread": int(np.sum(from_first[:, 1] > to_runs[0, 1])) if len(from_first) else 0,
-        "merge_orders": len(runs),
+        # the tighter pairing: the GPU's distance to the chunk-order run against the MEDIAN distance
+        # of the other merge orders to that same run (same reference point on both sides, not nearest-vs-max)
+        "cpu_median_other_order_vs_chunk_order_angle_rad": float(np.median(from_first[:, 0])) if len(from_first) else 0.0,
+        "cpu_median_other_order_vs_chunk_order_translation_m": float(np.median(from_first[:, 1])) if len(from_first) else 0.0,
+        "merge_orders": n_runs,
     }
 
 
@@ -69,6 +78,19 @@ def inside_envelope(e):
     """No farther from the nearest oracle run than the oracle's runs are from each other."""
     return (e["gpu_to_nearest_cpu_run_angle_rad"] <= e["cpu_spread_angle_rad"]
             and e["gpu_to_nearest_cpu_run_translation_m"] <= e["cpu_spread_translation_m"])
+
+
+def within_median_order(e):
+    """The GPU is no farther from the oracle's chunk-order run than the median alternative merge order is."""
+    return (e["gpu_vs_cpu_angle_rad"] <= e["cpu_median_other_order_vs_chunk_order_angle_rad"]
+            and e["gpu_vs_cpu_translation_m"] <= e["cpu_median_other_order_vs_chunk_order_translation_m"])
+
+
+def envelope_from_distances(gpu_pose, runs, among):
+    """envelope() with the oracle-to-oracle distance table precomputed (a second GPU result against the same runs)."""
+    g = gpu_pose.to_c()
+    to_runs = np.array([[abs(a), t] for a, t in (O.transform_metrics(g, r) for r in runs)])
+    return _envelope(to_runs, among, len(runs))
 
 
 def _pose_dist(a, b):
@@ -147,6 +169,9 @@ def summarize(entries):
         "merge_orders_per_pair": entries[0]["merge_orders"] if entries else 0,
         "pairs_over_1e-4": len(over),
         "pairs_over_1e-4_and_outside_the_cpu_envelope": sum(1 for e in over if not inside_envelope(e)),
+        "pairs_over_1e-4_and_beyond_the_median_cpu_order": sum(1 for e in over if not within_median_order(e)),
+        "pairs_over_1e-4_and_farther_than_every_cpu_order": sum(1 for e in over if e["gpu_rank_inside_cpu_spread"] == 0),
+        "ranks_of_pairs_over_1e-4": [e["gpu_rank_inside_cpu_spread"] for e in over],
         "max_gpu_vs_cpu_angle_rad": max((e["gpu_vs_cpu_angle_rad"] for e in entries), default=0.0),
         "max_gpu_vs_cpu_translation_m": max((e["gpu_vs_cpu_translation_m"] for e in entries), default=0.0),
         "median_gpu_vs_cpu_translation_m": float(np.median([e["gpu_vs_cpu_translation_m"] for e in entries])) if entries else 0.0,

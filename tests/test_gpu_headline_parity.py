@@ -19,60 +19,87 @@ from align3d_amd import IcpParams, MsIcpParams, MultiscaleAlignBatch
 pytestmark = pytest.mark.gpu
 
 ORDERS = 13
+P = 64
 
 
-def test_all_64_headline_pairs_against_the_oracle_and_its_own_envelope(ctx):
+@pytest.fixture(scope="module")
+def headline(ctx):
+    """The 128 resident frames of the headline batch and, per pair, the oracle's 13 runs (832 oracle alignments, once for
+    both tilings) with their pairwise distance table."""
     import bench
 
-    P = 64
     pyr, _, _ = bench.build_stream_pyramids(ctx, 1000, 2 * P, 640, 480)
     prm = MsIcpParams.repeat(3, IcpParams.default())
     pairs = [(2 * p, 2 * p + 1) for p in range(P)]
-    batch = MultiscaleAlignBatch(ctx, prm, [pyr[a] for a, _ in pairs], [pyr[b] for _, b in pairs])
-    poses, status = batch.align()
-    batch.free()
-    assert not np.any(status)
     _, cores = bench.cpu_info()
-    entries, hosts = [], {}
-    for p, (a, b) in enumerate(pairs):
+    runs, tables = [], []
+    for a, b in pairs:
         ta, tb = [HP.host_frame(lv) for lv in pyr[a]], [HP.host_frame(lv) for lv in pyr[b]]
-        runs = HP.oracle_runs(prm, ta, tb, cores, ORDERS)
-        e = HP.envelope(poses[p], runs)
+        r = HP.oracle_runs(prm, ta, tb, cores, ORDERS)
+        runs.append(r)
+        tables.append(HP.oracle_distance_table(r))
+    yield {"pyr": pyr, "prm": prm, "pairs": pairs, "cores": cores, "runs": runs, "tables": tables}
+    for lv in (lv for q in pyr for lv in q):
+        lv.free()
+
+
+@pytest.mark.parametrize("tiles", [0, 24], ids=["throughput_tiling", "pinned_tiling_24"])
+def test_all_64_headline_pairs_against_the_oracle_and_its_own_envelope(ctx, headline, tiles):
+    """`tiles` = 24: the same under a3d_context_set_tiling(24), the mode a caller who wants reproducible poses uses (every
+    pair cut into 24 blocks per level whatever the batch: a different association of the f32 sums than the default)."""
+    pyr, prm, pairs, cores = headline["pyr"], headline["prm"], headline["pairs"], headline["cores"]
+    ctx.set_tiling(tiles)
+    try:
+        batch = MultiscaleAlignBatch(ctx, prm, [pyr[a] for a, _ in pairs], [pyr[b] for _, b in pairs])
+        poses, status = batch.align()
+        batch.free()
+    finally:
+        ctx.set_tiling(0)
+    assert not np.any(status)
+    entries = []
+    for p in range(P):
+        e = HP.envelope_from_distances(poses[p], headline["runs"][p], headline["tables"][p])
         e["pair"] = p
         entries.append(e)
-        hosts[p] = (ta, tb)
         if not HP.within_tolerance(e):
-            print(f"[headline pair {p}] GPU vs oracle {e['gpu_vs_cpu_angle_rad']:.2e} rad {e['gpu_vs_cpu_translation_m']:.2e} m; "
+            print(f"[headline pair {p}, tiles {tiles}] GPU vs oracle {e['gpu_vs_cpu_angle_rad']:.2e} rad {e['gpu_vs_cpu_translation_m']:.2e} m; "
                   f"nearest of {ORDERS} oracle runs {e['gpu_to_nearest_cpu_run_translation_m']:.2e} m; oracle spread "
-                  f"{e['cpu_spread_angle_rad']:.2e} rad {e['cpu_spread_translation_m']:.2e} m; rank {e['gpu_rank_inside_cpu_spread']}")
-        if len(hosts) > 6:  # keep the host copies of the most sensitive pairs only (12 MB per frame)
-            keep = sorted(hosts, key=lambda q: -entries[q]["gpu_vs_cpu_translation_m"])[:3]
-            hosts = {q: hosts[q] for q in keep}
+                  f"{e['cpu_spread_angle_rad']:.2e} rad {e['cpu_spread_translation_m']:.2e} m; other orders vs chunk order: median "
+                  f"{e['cpu_median_other_order_vs_chunk_order_translation_m']:.2e} m, max "
+                  f"{e['cpu_other_orders_vs_chunk_order_translation_m']:.2e} m; rank {e['gpu_rank_inside_cpu_spread']} of {ORDERS - 1}")
     s = HP.summarize(entries)
-    print("[headline parity]", s)
+    print(f"[headline parity, tiles {tiles}]", s)
     # (a) or (b) for every pair
     for e in entries:
         assert HP.within_tolerance(e) or HP.inside_envelope(e), e
-    # wherever the GPU is beyond 1e-4, the reference's own spread is beyond 1e-4 as well
     for e in entries:
         if not HP.within_tolerance(e):
+            # wherever the GPU is beyond 1e-4, the reference's own spread is beyond 1e-4 as well ...
             assert e["cpu_spread_translation_m"] > 1e-4 or e["cpu_spread_angle_rad"] > 1e-4, e
+            # ... and, measured from the SAME reference point (the chunk-order run), the GPU is not the outlier: at least
+            # one of the 12 alternative merge orders of the reference itself lies farther from it (rank 0 fails); whether it
+            # is also within the median order is reported (`pairs_over_1e-4_and_beyond_the_median_cpu_order`)
+            assert e["gpu_rank_inside_cpu_spread"] >= 1, e
     assert s["pairs_over_1e-4"] <= P // 8  # the sensitive pairs are the exception
+    assert s["pairs_over_1e-4_and_farther_than_every_cpu_order"] == 0
     # the two most sensitive pairs, at all 45 iterations
     worst = sorted(range(P), key=lambda q: -entries[q]["gpu_vs_cpu_translation_m"])[:2]
-    for p in worst:
-        a, b = pairs[p]
-        ta, tb = hosts[p]
-        tf = HP.teacher_forced(ctx, prm, ta, tb, pyr[a], pyr[b], threads=cores)
-        print(f"[headline pair {p}, teacher-forced at {tf['iterations']} iterations] count mismatches {tf['count_mismatches']}, "
-              f"sums <= {tf['max_rel_err_sums']:.1e}, one step <= {tf['max_one_step_angle_rad']:.1e} rad "
-              f"{tf['max_one_step_translation_m']:.1e} m; free-running growth per iteration median "
-              f"{tf['median_growth_per_iteration']}, max {tf['max_growth_per_iteration']}")
-        for r in tf["rows"]:
-            print(f"    level {r['level']} it {r['iteration']:2d}: one step {r['one_step_translation_m']:.1e} m, free-running "
-                  f"{r['free_running_angle_rad']:.1e} rad {r['free_running_translation_m']:.1e} m, sums {r['rel_err_sums']:.1e}")
-        assert tf["iterations"] == 45 and tf["count_mismatches"] == 0
-        assert tf["max_rel_err_sums"] <= 1e-6
-        assert tf["max_one_step_angle_rad"] <= 5e-6 and tf["max_one_step_translation_m"] <= 5e-6
-    for lv in (lv for q in pyr for lv in q):
-        lv.free()
+    ctx.set_tiling(tiles)
+    try:
+        for p in worst:
+            a, b = pairs[p]
+            ta, tb = [HP.host_frame(lv) for lv in pyr[a]], [HP.host_frame(lv) for lv in pyr[b]]
+            tf = HP.teacher_forced(ctx, prm, ta, tb, pyr[a], pyr[b], threads=cores)
+            print(f"[headline pair {p}, tiles {tiles}, teacher-forced at {tf['iterations']} iterations] count mismatches "
+                  f"{tf['count_mismatches']}, sums <= {tf['max_rel_err_sums']:.1e}, one step <= {tf['max_one_step_angle_rad']:.1e} rad "
+                  f"{tf['max_one_step_translation_m']:.1e} m; free-running growth per iteration median "
+                  f"{tf['median_growth_per_iteration']}, max {tf['max_growth_per_iteration']}")
+            if tiles == 0:
+                for r in tf["rows"]:
+                    print(f"    level {r['level']} it {r['iteration']:2d}: one step {r['one_step_translation_m']:.1e} m, free-running "
+                          f"{r['free_running_angle_rad']:.1e} rad {r['free_running_translation_m']:.1e} m, sums {r['rel_err_sums']:.1e}")
+            assert tf["iterations"] == 45 and tf["count_mismatches"] == 0
+            assert tf["max_rel_err_sums"] <= 1e-6
+            assert tf["max_one_step_angle_rad"] <= 5e-6 and tf["max_one_step_translation_m"] <= 5e-6
+    finally:
+        ctx.set_tiling(0)
