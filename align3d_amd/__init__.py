@@ -28,7 +28,7 @@ if "GPU_MAX_HW_QUEUES" not in _os.environ:
 from ._abi import A3dError, InvalidParameter, load_library  # noqa: F401
 from .bilateral import BilateralFilter  # noqa: F401
 from .context import Context  # noqa: F401
-from .icp import Icp, ImageIcp, MultiscaleAlign, MultiscaleAlignBatch, PointCloud  # noqa: F401
+from .icp import DevicePointCloud, Icp, ImageIcp, MultiscaleAlign, MultiscaleAlignBatch, PointCloud  # noqa: F401
 from .icp_params import IcpParams, MsIcpParams  # noqa: F401
 from .kdtree import R3dTree  # noqa: F401
 from .multi import MultiContext, MultiscaleAlignMultiBatch  # noqa: F401

@@ -207,11 +207,15 @@ SIGNATURES = {
     "a3d_kdtree_stats": (_ST, [_P, C.POINTER(C.c_uint64)]),
     "a3d_kdtree_download": (_ST, [_P, _P, _P, C.POINTER(C.c_uint64)]),
     "a3d_kdtree_new": (_ST, [_P, _P, C.c_uint64, _PP]),
+    "a3d_kdtree_new_device": (_ST, [_P, _P, C.c_uint64, _PP]),
+    "a3d_kdtree_build_path": (_ST, [_P, C.POINTER(C.c_int32)]),
     "a3d_kdtree_nearest": (_ST, [_P, _P, C.c_uint64, _P, _P]),
     "a3d_kdtree_nearest_device": (_ST, [_P, _P, C.c_uint64, _P, _P]),
     "a3d_kdtree_free": (_ST, [_P]),
     "a3d_pcl_icp_new": (_ST, [_P, C.POINTER(IcpParamsC), C.POINTER(PointCloudViewC), _PP]),
     "a3d_pcl_icp_align": (_ST, [_P, C.POINTER(PointCloudViewC), C.POINTER(PoseC)]),
+    "a3d_pcl_icp_new_device": (_ST, [_P, C.POINTER(IcpParamsC), C.POINTER(PointCloudViewC), _PP]),
+    "a3d_pcl_icp_align_device": (_ST, [_P, C.POINTER(PointCloudViewC), C.POINTER(PoseC)]),
     "a3d_pcl_icp_accumulate": (_ST, [_P, C.POINTER(PointCloudViewC), C.POINTER(PoseC), C.POINTER(GnStateC)]),
     "a3d_pcl_icp_last_device_ms": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_pcl_icp_free": (_ST, [_P]),

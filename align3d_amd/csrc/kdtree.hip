@@ -297,7 +297,7 @@ struct a3d_pcl_icp {
 
 extern "C" {
 
-a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d_kdtree** out) {
+static a3d_status kdtree_new_impl(a3d_context* ctx, const float* points, uint64_t n, bool on_device, a3d_kdtree** out) {
   A3D_REQUIRE(ctx && out && points, A3D_INVALID_PARAMETER, "null argument");
   A3D_REQUIRE(n > 0 && n < (1ull << 31), A3D_INVALID_PARAMETER,
               "kd-tree needs 1 <= n < 2^31 points (the reference indexes an empty leaf and panics)");
@@ -306,7 +306,14 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
   t->n = (uint32_t)n;
   A3D_HIP_TRY(hipSetDevice(ctx->device));
   const char* mode = A3D_DIAG_ENV("A3D_KDTREE_BUILD");  // diagnostics build: "host" = std::stable_sort build (cross-check)
-  if (!(mode && !strcmp(mode, "host"))) {  // device build: upload the points, sort level by level on the GPU
+  std::vector<float> host_copy;
+  if (mode && !strcmp(mode, "host") && on_device) {  // (cross-check of the device-pointer form: through host memory)
+    host_copy.resize((size_t)n * 3);
+    A3D_HIP_TRY(hipMemcpy(host_copy.data(), points, (size_t)n * 12, hipMemcpyDeviceToHost));
+    points = host_copy.data();
+    on_device = false;
+  }
+  if (!(mode && !strcmp(mode, "host"))) {  // device build: upload the points (unless resident), build on the GPU
     kdtree_shape(t->n, &t->max_depth, &t->n_leaves, &t->n_internal);
     A3D_REQUIRE(t->max_depth <= 23, A3D_INVALID_PARAMETER, "point cloud too large for the implicit kd-tree layout (leaf byte offsets are 32-bit)");
     t->n_split = (uint32_t)((1ull << t->max_depth) - 1);
@@ -315,9 +322,9 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
     // this context: no hipMalloc / hipFree — each a device-wide synchronisation — for temporaries)
     void* region = nullptr;
     A3D_TRY(ctx_scratch(ctx, 2, kdtree_build_scratch_bytes(t->n, t->max_depth, ctx->stream), &region));
-    float* d_points = (float*)region;
+    const float* d_points = on_device ? points : (const float*)region;
     a3d_status st = A3D_OK;
-    if (hipMemcpyAsync(d_points, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+    if (!on_device && hipMemcpyAsync(region, points, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
       set_error("a3d_kdtree_new: upload failed: %s", hipGetErrorString(hipGetLastError()));
       st = A3D_HIP_ERROR;
     }
@@ -344,6 +351,20 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
                              ctx->stream));
   A3D_HIP_TRY(hipStreamSynchronize(ctx->stream));
   *out = t.release();
+  return A3D_OK;
+}
+
+a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d_kdtree** out) {
+  return kdtree_new_impl(ctx, points, n, /*on_device=*/false, out);
+}
+
+a3d_status a3d_kdtree_new_device(a3d_context* ctx, const void* d_points, uint64_t n, a3d_kdtree** out) {
+  return kdtree_new_impl(ctx, (const float*)d_points, n, /*on_device=*/true, out);
+}
+
+a3d_status a3d_kdtree_build_path(a3d_kdtree* t, int32_t* out_path) {
+  A3D_REQUIRE(t && out_path, A3D_INVALID_PARAMETER, "null argument");
+  *out_path = t->built_by;
   return A3D_OK;
 }
 
@@ -429,29 +450,35 @@ a3d_status a3d_kdtree_free(a3d_kdtree* t) {
   return A3D_OK;
 }
 
-a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const a3d_point_cloud_view* target,
-                           a3d_pcl_icp** out) {
+static a3d_status pcl_icp_new_impl(a3d_context* ctx, const a3d_icp_params* params, const a3d_point_cloud_view* target,
+                                   bool on_device, a3d_pcl_icp** out) {
   A3D_REQUIRE(ctx && params && target && out && target->points, A3D_INVALID_PARAMETER, "null argument");
   auto icp = std::make_unique<a3d_pcl_icp>();
   icp->ctx = ctx;
   icp->params = *params;
-  A3D_TRY(a3d_kdtree_new(ctx, target->points, target->len, &icp->tree));
+  A3D_TRY(kdtree_new_impl(ctx, target->points, target->len, on_device, &icp->tree));
   a3d_kdtree* t = icp->tree;
   a3d_status st = A3D_OK;
-  if (target->normals && t->d_slot_of_point) {  // device build: scatter on the device
+  std::vector<float> host_normals;
+  const float* normals = target->normals;
+  if (normals && on_device && !t->d_slot_of_point) {  // (diagnostics: host build of a resident cloud)
+    host_normals.resize((size_t)t->n * 3);
+    if (hipMemcpy(host_normals.data(), normals, (size_t)t->n * 12, hipMemcpyDeviceToHost) != hipSuccess) st = A3D_HIP_ERROR;
+    normals = host_normals.data();
+  }
+  if (normals && t->d_slot_of_point) {  // device build: scatter on the device
     // staged where the build staged the points (dead by now): the head of the context's kd-tree scratch region
-    float* d_n = (float*)ctx->scratch[2];
-    if (!d_n || ctx->scratch_size[2] < (size_t)t->n * 12 ||
-        hipMemcpyAsync(d_n, target->normals, (size_t)t->n * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    const float* d_n = on_device ? normals : (const float*)ctx->scratch[2];
+    if (!on_device && (!d_n || ctx->scratch_size[2] < (size_t)t->n * 12 ||
+                       hipMemcpyAsync(ctx->scratch[2], normals, (size_t)t->n * 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess))
       st = A3D_HIP_ERROR;
     if (st == A3D_OK) st = kdtree_scatter_normals_device(t, d_n);
     hipStreamSynchronize(ctx->stream);
     icp->target_has_normals = true;
-  } else if (target->normals) {  // scatter the target normals into the leaf slots of their points
+  } else if (normals) {  // scatter the target normals into the leaf slots of their points
     std::vector<float4> ln(t->n_leaf_slots, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < t->n; ++i)
-      ln[t->h_slot_of_point[i]] =
-          make_float4(target->normals[3 * i], target->normals[3 * i + 1], target->normals[3 * i + 2], 0.f);
+      ln[t->h_slot_of_point[i]] = make_float4(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 0.f);
     if (hipMalloc((void**)&t->d_leaf_normals, ln.size() * sizeof(float4)) != hipSuccess ||
         hipMemcpy(t->d_leaf_normals, ln.data(), ln.size() * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess)
       st = A3D_HIP_ERROR;
@@ -478,7 +505,17 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const
   return A3D_OK;
 }
 
-static a3d_status pcl_upload_source(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, float** d_pts,
+a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params, const a3d_point_cloud_view* target,
+                           a3d_pcl_icp** out) {
+  return pcl_icp_new_impl(ctx, params, target, /*on_device=*/false, out);
+}
+
+a3d_status a3d_pcl_icp_new_device(a3d_context* ctx, const a3d_icp_params* params, const a3d_point_cloud_view* d_target,
+                                  a3d_pcl_icp** out) {
+  return pcl_icp_new_impl(ctx, params, d_target, /*on_device=*/true, out);
+}
+
+static a3d_status pcl_upload_source(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, bool on_device, float** d_pts,
                                     float** d_nrm) {
   A3D_HIP_TRY(hipSetDevice(icp->ctx->device));
   // the reference `expect`s both normal sets at align time (pcl_icp.rs:50-58)
@@ -488,6 +525,11 @@ static a3d_status pcl_upload_source(a3d_pcl_icp* icp, const a3d_point_cloud_view
               "bad source cloud");
   // staged in the context's grow-only kd-tree scratch region (idle between tree builds; calls on one context are
   // serialised and this one is host-synchronous): no hipMalloc / hipFree pair — two device-wide synchronisations — per align
+  if (on_device) {  // resident source: nothing to stage
+    *d_pts = const_cast<float*>(source->points);
+    *d_nrm = const_cast<float*>(source->normals);
+    return A3D_OK;
+  }
   const size_t bytes = source->len * 12, stride = ((bytes + 255) / 256) * 256;
   void* region = nullptr;
   A3D_TRY(ctx_scratch(icp->ctx, 2, 2 * stride, &region));
@@ -546,10 +588,10 @@ static a3d_status pcl_launch_head_pass(a3d_pcl_icp* icp, const float* d_pts, con
   return A3D_OK;
 }
 
-a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, a3d_pose* out_pose) {
+static a3d_status pcl_icp_align_impl(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, bool on_device, a3d_pose* out_pose) {
   A3D_REQUIRE(icp && source && out_pose, A3D_INVALID_PARAMETER, "null argument");
   float *d_pts = nullptr, *d_nrm = nullptr;
-  a3d_status st = pcl_upload_source(icp, source, &d_pts, &d_nrm);
+  a3d_status st = pcl_upload_source(icp, source, on_device, &d_pts, &d_nrm);
   hipStream_t s = icp->ctx->stream;
   const uint32_t m = (uint32_t)source->len;
   // Icp::align starts from Transform::eye(): initial_transform is ignored (pcl_icp.rs:59)
@@ -607,11 +649,19 @@ a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* sourc
   return (a3d_status)h_status;
 }
 
+a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, a3d_pose* out_pose) {
+  return pcl_icp_align_impl(icp, source, /*on_device=*/false, out_pose);
+}
+
+a3d_status a3d_pcl_icp_align_device(a3d_pcl_icp* icp, const a3d_point_cloud_view* d_source, a3d_pose* out_pose) {
+  return pcl_icp_align_impl(icp, d_source, /*on_device=*/true, out_pose);
+}
+
 a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* source, const a3d_pose* pose,
                                   a3d_gn_state* out_state) {
   A3D_REQUIRE(icp && source && out_state, A3D_INVALID_PARAMETER, "null argument");
   float *d_pts = nullptr, *d_nrm = nullptr;
-  a3d_status st = pcl_upload_source(icp, source, &d_pts, &d_nrm);
+  a3d_status st = pcl_upload_source(icp, source, /*on_device=*/false, &d_pts, &d_nrm);
   hipStream_t s = icp->ctx->stream;
   Pose h_pose = pose ? pose_from_c(pose) : pose_eye();
   Pose* d_pose = nullptr;

@@ -23,6 +23,7 @@ struct a3d_kdtree {
   std::vector<float> h_split;
   std::vector<uint32_t> h_slot_of_point;  // [n] leaf slot of each original point index
   uint64_t n_leaves = 0, n_internal = 0;
+  int built_by = 0;  // instrumentation: 0 host build, 1 selection build (kdtree_select.hip), 2 sorting build (diagnostics)
 };
 
 namespace a3d {
@@ -36,9 +37,13 @@ a3d_status kdtree_build_host(const float* points, uint32_t n, std::vector<float>
 // Shape of the tree for n points (data independent): depth of the deepest leaf, leaf and internal node counts.
 void kdtree_shape(uint32_t n, uint32_t* max_depth, uint64_t* n_leaves, uint64_t* n_internal);
 
-// Device build (kdtree_build.hip): one segmented stable radix sort per level; bit-identical to the host build.
-// Expects t->n, max_depth, n_split, n_leaf_slots set; fills d_split, d_leaves, d_slot_of_point.
+// Device build: the selection build (kdtree_select.hip); diagnostics build: also the sorting build (kdtree_build.hip: one
+// segmented stable sort per level, A3D_KDTREE_BUILD=sorted); both bit-identical to the host build.
+// Expects t->n, max_depth, n_split, n_leaf_slots set; allocates and fills d_split, d_leaves, d_slot_of_point.
 a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points);
+// The selection build: `scratch` holds kdtree_select_scratch_bytes(n) bytes.
+size_t kdtree_select_scratch_bytes(uint32_t n);
+a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void* scratch);
 // Size of the context scratch region [2] a device build of n points needs: the staged points + the temporaries.
 size_t kdtree_build_scratch_bytes(uint32_t n, uint32_t max_depth, hipStream_t s);
 // leaf_normals[slot_of_point[i]] = normals[i] (device build)

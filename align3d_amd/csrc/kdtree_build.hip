@@ -1,20 +1,18 @@
-// R3dTree::new (src/kdtree.rs:28-58) on the device.
+// R3dTree::new (src/kdtree.rs:28-58) on the device: dispatch + the SORTING build.
 //
+// The product's build is the selection build (kdtree_select.hip, round 5).  This file keeps the round-2..4 build — one
+// segmented stable sort per level — in the DIAGNOSTICS build only (A3D_KDTREE_BUILD=sorted), as the cross-check:
 // The reference sorts the index list of every node by one coordinate (stable sort, depth % 3), splits it at
 // len / 2 and recurses until len <= 16.  The shape of that recursion depends on N only, so level d of the
-// tree is a set of disjoint index ranges that is known without looking at the data; the device build runs
+// tree is a set of disjoint index ranges that is known without looking at the data; the sorting build runs
 // one SEGMENTED STABLE sort per level over all ranges of that level at once:
 //   keys   = coordinate (d % 3) of the point each index refers to, with -0.0 canonicalised to +0.0 so that
 //            the radix order equals `partial_cmp` (which calls the two zeros equal) and stability then keeps
 //            the parent's order among equal keys, exactly like `slice::sort_by`;
 //   values = the indices.
-// One workgroup per range (or per handful of short ranges) is right for the thousands of short ranges of the
-// deep levels but would leave the chip idle on the few long ranges at the top; those levels use ONE
-// device-wide stable radix sort instead, on 64-bit keys (range number << 32 | order-preserving key bits).
-// The sorts are hand-written (kdtree_sort.hip).  Key gather, NaN detection, range tables, split extraction and leaf
-// packing are written here.  The result is bit-identical to the host build (kdtree.hip, std::stable_sort) — the
-// diagnostics build (-DA3D_DIAGNOSTICS) keeps that build (A3D_KDTREE_BUILD=host) and the same device build on
-// rocPRIM's stable radix sorts (A3D_KDTREE_SORT=rocprim) as cross-checks; the product library contains neither.
+// Short ranges: LDS bitonic sort per range; long ranges: ONE device-wide stable radix sort on 64-bit keys (range
+// number << 32 | order-preserving key bits) (kdtree_sort.hip), or rocPRIM's sorts (A3D_KDTREE_SORT=rocprim).
+// Bit-identical to the host build (kdtree.hip, std::stable_sort; A3D_KDTREE_BUILD=host) and to the selection build.
 #ifdef A3D_DIAGNOSTICS
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
@@ -22,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "kdtree.hpp"
 
@@ -29,6 +28,7 @@ using namespace a3d;
 
 namespace {
 
+#ifdef A3D_DIAGNOSTICS  // kernels of the sorting build
 // Range of node `j` (0-based within its level) at `level`: follow the bits of j from the root.
 __device__ __forceinline__ void node_range(uint32_t n, uint32_t level, uint32_t j, uint32_t* start, uint32_t* len,
                                            bool* exists) {
@@ -148,6 +148,8 @@ __global__ void iota_kernel(uint32_t* __restrict__ idx, uint32_t n) {
   if (i < n) idx[i] = i;
 }
 
+#endif  // A3D_DIAGNOSTICS (kernels of the sorting build)
+
 __global__ void scatter_normals_kernel(const float* __restrict__ normals, const uint32_t* __restrict__ slot_of_point,
                                        uint32_t n, float4* __restrict__ leaf_normals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,10 +167,10 @@ namespace a3d {
 // Bytes of temporaries kdtree_build_device needs for n points (behind the staged points, see a3d_kdtree_new).
 size_t kdtree_build_scratch_bytes(uint32_t n, uint32_t max_depth, hipStream_t s) {
   auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
+  size_t sorted = 0;
+#ifdef A3D_DIAGNOSTICS  // the sorting build's temporaries share the region with the selection build's: the larger of the two
   const size_t max_nodes = max_depth ? (1ull << (max_depth - 1)) : 1;
-  size_t sort_bytes = 0;
-#ifdef A3D_DIAGNOSTICS
-  size_t wide_bytes = 0;
+  size_t sort_bytes = 0, wide_bytes = 0;
   if (max_depth > 0) {
     (void)rocprim::segmented_radix_sort_pairs(nullptr, sort_bytes, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr,
                                               (uint32_t*)nullptr, n, (unsigned)max_nodes, (uint32_t*)nullptr,
@@ -177,28 +179,57 @@ size_t kdtree_build_scratch_bytes(uint32_t n, uint32_t max_depth, hipStream_t s)
                                     (uint32_t*)nullptr, n, 0, 64, s);
     sort_bytes = std::max(sort_bytes, wide_bytes);
   }
+  sorted = 2 * pad((size_t)n * 4) + 2 * pad((size_t)n * 8) + 2 * pad(max_nodes * 4) + 256 + pad(sort_bytes) +
+           pad(kdtree_sort_scratch_bytes(n));
 #else
-  (void)s;
+  (void)max_depth, (void)s;
 #endif
-  return 2 * pad((size_t)n * 4) + 2 * pad((size_t)n * 8) + 2 * pad(max_nodes * 4) + 256 + pad(sort_bytes) +
-         pad(kdtree_sort_scratch_bytes(n)) + pad((size_t)n * 12);
+  return std::max(sorted, pad(kdtree_select_scratch_bytes(n))) + pad((size_t)n * 12);
 }
 
+// The tree's three arrays in ONE allocation (hipMalloc synchronises the device): leaves first (16-byte records).
+static a3d_status kdtree_alloc_arrays(a3d_kdtree* t) {
+  const uint64_t n_slots = (1ull << t->max_depth) * 16;
+  auto pad256 = [](size_t b) { return ((b + 255) / 256) * 256; };
+  const size_t leaves_b = pad256(n_slots * sizeof(float4)), split_b = pad256(std::max<size_t>(1, (size_t)t->n_split) * 4);
+  char* block = nullptr;
+  A3D_HIP_TRY(hipMalloc((void**)&block, leaves_b + split_b + (size_t)t->n * sizeof(uint32_t)));
+  t->d_block = block;
+  t->d_leaves = (float4*)block;
+  t->d_split = (float*)(block + leaves_b);
+  t->d_slot_of_point = (uint32_t*)(block + leaves_b + split_b);
+  return A3D_OK;
+}
+
+#ifdef A3D_DIAGNOSTICS
+static a3d_status kdtree_build_device_sorted(a3d_kdtree* t, const float* d_points);
+#endif
+
+// The selection build (kdtree_select.hip).  Diagnostics build: A3D_KDTREE_BUILD=sorted runs the sorting build below
+// instead (the cross-check of the selection build, as the host build and rocPRIM are of the sorting build).
 a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
+  A3D_TRY(kdtree_alloc_arrays(t));
+#ifdef A3D_DIAGNOSTICS
+  const char* mode = getenv("A3D_KDTREE_BUILD");
+  if (mode && !strcmp(mode, "sorted")) {
+    t->built_by = 2;
+    return kdtree_build_device_sorted(t, d_points);
+  }
+#endif
+  t->built_by = 1;
+  auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
+  char* scratch = (char*)t->ctx->scratch[2] + pad((size_t)t->n * 12);  // behind the points the caller may have staged there
+  A3D_REQUIRE(t->ctx->scratch[2] && t->ctx->scratch_size[2] >= pad((size_t)t->n * 12) + kdtree_select_scratch_bytes(t->n),
+              A3D_INVALID_PARAMETER, "internal: kd-tree scratch region too small");
+  return kdtree_build_device_select(t, d_points, scratch);
+}
+
+#ifdef A3D_DIAGNOSTICS
+static a3d_status kdtree_build_device_sorted(a3d_kdtree* t, const float* d_points) {
   a3d_context* ctx = t->ctx;
   hipStream_t s = ctx->stream;
   const uint32_t n = t->n, D = t->max_depth;
   const uint64_t n_slots = (1ull << D) * 16;
-  {  // the tree's three arrays in ONE allocation (hipMalloc synchronises the device): leaves first (16-byte records)
-    auto pad256 = [](size_t b) { return ((b + 255) / 256) * 256; };
-    const size_t leaves_b = pad256(n_slots * sizeof(float4)), split_b = pad256(std::max<size_t>(1, (size_t)t->n_split) * 4);
-    char* block = nullptr;
-    A3D_HIP_TRY(hipMalloc((void**)&block, leaves_b + split_b + (size_t)n * sizeof(uint32_t)));
-    t->d_block = block;
-    t->d_leaves = (float4*)block;
-    t->d_split = (float*)(block + leaves_b);
-    t->d_slot_of_point = (uint32_t*)(block + leaves_b + split_b);
-  }
   A3D_HIP_TRY(hipMemsetAsync(t->d_split, 0, std::max<size_t>(1, (size_t)t->n_split) * sizeof(float), s));
   hipLaunchKernelGGL(fill_leaves_kernel, grid_for(n_slots), dim3(256), 0, s, t->d_leaves, n_slots);
 
@@ -303,6 +334,8 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
               "NaN coordinate in kd-tree input (the reference panics in partial_cmp().unwrap())");
   return A3D_OK;
 }
+
+#endif  // A3D_DIAGNOSTICS (the sorting build)
 
 a3d_status kdtree_scatter_normals_device(a3d_kdtree* t, const float* d_normals) {
   hipStream_t s = t->ctx->stream;

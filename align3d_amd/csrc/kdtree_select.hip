@@ -1,0 +1,763 @@
+// R3dTree::new (src/kdtree.rs:28-58) on the device by SELECTION instead of by sorting (round 5).
+//
+// The reference sorts every node's index list by one coordinate (stable, axis = depth % 3), splits it at len / 2 and
+// recurses until len <= 16.  Two facts make a much cheaper device build give the same tree, bit for bit:
+//   (1) The shape (every node's [start, len)) depends on n only.
+//   (2) A stable sort keeps the previous order among equal keys, and the previous order is the parent's sorted order,
+//       so by induction the order of a node at depth d after its sort is the LEXICOGRAPHIC order
+//           L_d = (x[d % 3], x[(d - 1) % 3], x[(d - 2) % 3], original index)
+//       (keys of negative depths dropped; -0.0 == +0.0 as partial_cmp has it; three distinct axes exhaust the
+//       coordinates, so older keys can no longer decide anything and the original index breaks what is left).  L_d does
+//       not depend on how the node's points were arranged before: WHICH points go left (the len / 2 smallest under
+//       L_d), the split value (coordinate of the point of rank len / 2) and the order inside a leaf (L of its parent's
+//       depth) are all functions of the point set alone.
+// So a level needs no sort: it needs, per node, the point of rank len / 2 under L_d and a partition around it, in any
+// order — and only the last few levels, where the leaves' order is fixed, need real sorts.
+//
+//   wide levels (ranges longer than 2048 points), TWO launches per level, nothing sorted:
+//     sel_split_kernel    every point's key falls into one of <= 2048 buckets, linear over the node's bounding box
+//                         along the axis (a monotone map: equal keys share a bucket).  The bucket that holds rank
+//                         len / 2 is known from the node's histogram (the `plan`); points below it go to the left end
+//                         of the range, points above it to the right end (block-wise reservations, any order), the
+//                         few in it to a side buffer.  The points routed left / right are at once counted into their
+//                         CHILD's histogram along the next axis (the child's box along that axis is the parent's).
+//     sel_resolve_kernel  one block per node: among the side buffer's points (a bucket: len / buckets points) the one
+//                         of rank len / 2 under L_d is found exactly — rounds of finer buckets over the set's actual
+//                         [min, max], component of L_d by component, then brute-force counting among the last <= 64 —
+//                         and all of them placed; the block writes the split value, the children's boxes, adds its
+//                         points to the children's histograms and derives the children's plans.
+//   ranges of <= 2048 points: sel_narrow_kernel, ONE launch, one block per range, everything in LDS: a bitonic network
+//     on 128-bit words (L_d itself, + the position as payload) puts the range into L_d order; each further level is the
+//     network on 64-bit words `key bits << 32 | position in the range` (the position carries L_{d-1}); split values,
+//     leaf slots (+inf padding included) and slot_of_point are written from there.  Two network stages (partner
+//     distances j and j / 2) share one LDS round trip.
+//
+// 500 k points: 21 launches instead of ~110.  Exact for every input: a degenerate cloud (one coordinate
+// constant over a node, thousands of equal points) only costs the resolve block more narrowing rounds.  The sorting
+// build (kdtree_build.hip, diagnostics build) is the cross-check: same tree, bit for bit (tests/test_gpu_kdtree.py).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "kdtree.hpp"
+
+using namespace a3d;
+
+namespace {
+
+constexpr uint32_t NARROW = 2048;      // ranges up to this many points are finished inside one block
+constexpr uint32_t MIDDLE_CAP = 4096;  // candidates the resolve block holds in LDS (64 KiB); larger sets are narrowed from global memory first
+constexpr uint32_t NB_MAX = 2048;      // buckets per node and level (fewer on deep levels: ~32 points per bucket)
+constexpr uint32_t NSUB = 1024;        // finer buckets inside the median bucket
+constexpr uint32_t K1_THREADS = 512, K1_ROUNDS = 4, K1_TILE = K1_THREADS * K1_ROUNDS;
+constexpr uint32_t K2_THREADS = 1024;
+constexpr uint32_t PACK_THREADS = 256, PACK_ROUNDS = 4, PACK_TILE = PACK_THREADS * PACK_ROUNDS;
+constexpr uint32_t NW_THREADS = 512;   // narrow kernel: four words per thread
+
+enum : uint32_t { FLAG_NAN = 0 };
+
+struct SelPlan {   // of one node: which bucket holds rank len / 2
+  uint32_t bucket, below, count, pad;
+};
+struct SelBox {    // bounds of the node's points (canonical values), per axis
+  float lo[3], hi[3], pad[2];
+};
+
+__device__ __forceinline__ float canon(float v) { return v + 0.0f; }  // -0.0 -> +0.0 (partial_cmp: equal)
+__device__ __forceinline__ uint32_t ord_bits(float v) {                // monotone f32 -> u32 of the canonical value
+  const uint32_t u = __float_as_uint(v + 0.0f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float comp(const float4& r, uint32_t a) { return a == 0 ? r.x : (a == 1 ? r.y : r.z); }
+
+// Monotone in v for fixed (lo, hi, nb): rounded subtraction, multiplication by a non-negative constant, clamp and
+// truncation all keep order, so v1 <= v2 => bucket(v1) <= bucket(v2) and equal keys share a bucket.  A degenerate or
+// non-finite box gives scale 0 (everything in bucket 0); NaN falls into bucket 0 (and is flagged by the caller).
+__device__ __forceinline__ float bucket_pos(float v, float lo, float hi, uint32_t nb) {
+  const float scale = (hi > lo) ? (float)nb / (hi - lo) : 0.0f;
+  const float g = (v - lo) * scale;
+  return fminf(fmaxf(g, 0.0f), (float)(nb - 1));
+}
+__device__ __forceinline__ uint32_t bucket_of(float v, float lo, float hi, uint32_t nb) {
+  return (uint32_t)bucket_pos(v, lo, hi, nb);
+}
+__device__ __forceinline__ uint32_t subbucket_of(float v, float lo, float hi, uint32_t nb, uint32_t b) {
+  const float u = (bucket_pos(v, lo, hi, nb) - (float)b) * (float)NSUB;
+  return (uint32_t)fminf(fmaxf(u, 0.0f), (float)(NSUB - 1));
+}
+
+// [start, len) of node `j` of `level` (kdtree.rs:46-52: mid = len / 2).  `exists` is false below a leaf.
+__device__ __forceinline__ void sel_node_range(uint32_t n, uint32_t level, uint32_t j, uint32_t* start, uint32_t* len,
+                                               bool* exists) {
+  uint32_t s = 0, l = n;
+  bool ok = true;
+  for (uint32_t t = 0; t < level; ++t) {
+    if (l <= 16) {
+      ok = false;
+      break;
+    }
+    const uint32_t mid = l >> 1;
+    if ((j >> (level - 1 - t)) & 1u) {
+      s += mid;
+      l -= mid;
+    } else {
+      l = mid;
+    }
+  }
+  *start = s, *len = l, *exists = ok;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Exclusive scan of one value per thread over a block of THREADS threads (THREADS / 64 <= 16 waves); `tmp` >= 16 words.
+template <uint32_t THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* tmp) {
+  const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= (uint32_t)off) incl += up;
+  }
+  __syncthreads();  // tmp may still be read from a previous call
+  if (lane == 63) tmp[w] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t ww = 0; ww < w; ++ww) before += tmp[ww];
+  return before + incl - v;
+}
+
+// Which of the `nb` <= 2 * THREADS buckets of `h` (LDS) holds rank `rank`: bucket b with  below(b) <= rank < below(b) + h[b].
+// Every thread of the block calls it; the one that owns the bucket writes *out.
+template <uint32_t THREADS>
+__device__ __forceinline__ void plan_from_hist(const uint32_t* h, uint32_t nb, uint32_t rank, SelPlan* out, uint32_t* tmp) {
+  const uint32_t b0 = 2 * threadIdx.x;
+  const uint32_t v0 = b0 < nb ? h[b0] : 0u, v1 = b0 + 1 < nb ? h[b0 + 1] : 0u;
+  const uint32_t ex = block_exclusive_scan<THREADS>(v0 + v1, tmp);
+  if (ex <= rank && rank < ex + v0) *out = SelPlan{b0, ex, v0, 0u};
+  else if (ex + v0 <= rank && rank < ex + v0 + v1) *out = SelPlan{b0 + 1, ex + v0, v1, 0u};
+}
+
+// ---- records {x, y, z, index bits} + per-block bounds -------------------------------------------------------------
+typedef float sel_f32x3 __attribute__((ext_vector_type(3)));
+typedef sel_f32x3 __attribute__((aligned(4))) sel_f32x3_u;
+
+__global__ void __launch_bounds__(PACK_THREADS)
+    sel_pack_kernel(const float* __restrict__ points, uint32_t n, float4* __restrict__ recs, float* __restrict__ partials) {
+  __shared__ float red[PACK_THREADS / 64][6];
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+  for (uint32_t k = 0; k < PACK_ROUNDS; ++k) {
+    const uint32_t i = blockIdx.x * PACK_TILE + k * PACK_THREADS + threadIdx.x;
+    if (i < n) {
+      const sel_f32x3 p = *(const sel_f32x3_u*)(points + 3 * (size_t)i);
+      recs[i] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
+      const float c[3] = {canon(p.x), canon(p.y), canon(p.z)};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) lo[a] = fminf(lo[a], c[a]), hi[a] = fmaxf(hi[a], c[a]);  // (NaN is skipped)
+    }
+  }
+#pragma unroll
+  for (int off = 32; off; off >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+  const uint32_t w = threadIdx.x >> 6;
+  if (lane_id() == 0)
+    for (int a = 0; a < 3; ++a) red[w][a] = lo[a], red[w][3 + a] = hi[a];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = red[0][threadIdx.x];
+    for (uint32_t ww = 1; ww < PACK_THREADS / 64; ++ww)
+      v = threadIdx.x < 3 ? fminf(v, red[ww][threadIdx.x]) : fmaxf(v, red[ww][threadIdx.x]);
+    partials[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+// The root's box (every block reduces the pack kernel's partials itself) and the root's histogram along x.
+__global__ void __launch_bounds__(K1_THREADS)
+    sel_hist0_kernel(const float4* __restrict__ recs, uint32_t n, const float* __restrict__ partials, uint32_t n_partials,
+                     uint32_t nb, SelBox* __restrict__ boxes, uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t h[];
+  __shared__ float red[K1_THREADS / 64][6];
+  __shared__ float box[6];
+  for (uint32_t q = threadIdx.x; q < nb; q += K1_THREADS) h[q] = 0u;
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (uint32_t b = threadIdx.x; b < n_partials; b += K1_THREADS)
+    for (int a = 0; a < 3; ++a) lo[a] = fminf(lo[a], partials[(size_t)b * 6 + a]), hi[a] = fmaxf(hi[a], partials[(size_t)b * 6 + 3 + a]);
+#pragma unroll
+  for (int off = 32; off; off >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+  if (lane_id() == 0)
+    for (int a = 0; a < 3; ++a) red[threadIdx.x >> 6][a] = lo[a], red[threadIdx.x >> 6][3 + a] = hi[a];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = red[0][threadIdx.x];
+    for (uint32_t ww = 1; ww < K1_THREADS / 64; ++ww)
+      v = threadIdx.x < 3 ? fminf(v, red[ww][threadIdx.x]) : fmaxf(v, red[ww][threadIdx.x]);
+    box[threadIdx.x] = v;
+    if (blockIdx.x == 0) (threadIdx.x < 3 ? boxes[0].lo[threadIdx.x] : boxes[0].hi[threadIdx.x - 3]) = v;
+  }
+  __syncthreads();
+  const float blo = box[0], bhi = box[3];
+#pragma unroll
+  for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+    const uint32_t i = blockIdx.x * K1_TILE + k * K1_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[bucket_of(canon(recs[i].x), blo, bhi, nb)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < nb; q += K1_THREADS) {
+    const uint32_t v = h[q];
+    if (v) atomicAdd(&hist[q], v);
+  }
+}
+
+__global__ void __launch_bounds__(K2_THREADS)
+    sel_plan0_kernel(uint32_t n, uint32_t nb, uint32_t* __restrict__ hist, SelPlan* __restrict__ plans) {
+  __shared__ uint32_t h[NB_MAX];
+  __shared__ uint32_t tmp[16];
+  for (uint32_t q = threadIdx.x; q < nb; q += K2_THREADS) h[q] = hist[q], hist[q] = 0u;
+  __syncthreads();
+  plan_from_hist<K2_THREADS>(h, nb, n >> 1, &plans[0], tmp);
+}
+
+// ---- wide levels: route every point of a node below / into / above the bucket of its median -----------------------
+__global__ void __launch_bounds__(K1_THREADS)
+    sel_split_kernel(const float4* __restrict__ rin, float4* __restrict__ rout, float4* __restrict__ midbuf, uint32_t n,
+                     uint32_t level, uint32_t blocks_per_node, uint32_t nb, uint32_t nb_next,
+                     const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes, uint32_t* __restrict__ cursors,
+                     uint32_t* __restrict__ hist_next, uint32_t* __restrict__ flags) {
+  extern __shared__ uint32_t h[];  // [2][nb_next]: the two children's histograms along the next axis
+  __shared__ uint32_t wcnt[3][K1_ROUNDS * (K1_THREADS / 64)];  // per class: (round, wave) counts, then exclusive prefixes
+  __shared__ uint32_t base[3];
+  const uint32_t node = blockIdx.x / blocks_per_node, part = blockIdx.x % blocks_per_node;
+  uint32_t s, l;
+  bool exists;
+  sel_node_range(n, level, node, &s, &l, &exists);
+  const uint32_t tile_lo = part * K1_TILE;
+  if (tile_lo >= l) return;
+  const SelPlan plan = plans[node];
+  const SelBox box = boxes[node];
+  const uint32_t a = level % 3, a2 = (level + 1) % 3;
+  const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K1_THREADS) h[q] = 0u;
+  float4 r[K1_ROUNDS];
+  uint32_t cls[K1_ROUNDS], rank[K1_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+    const uint32_t i = tile_lo + k * K1_THREADS + threadIdx.x;
+    const bool valid = i < l;
+    r[k] = valid ? rin[s + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float key = canon(comp(r[k], a));
+    if (valid && key != key) atomicOr(&flags[FLAG_NAN], 1u);  // partial_cmp().unwrap() would panic (kdtree.rs:43)
+    const uint32_t b = bucket_of(key, box.lo[a], box.hi[a], nb);
+    cls[k] = !valid ? 3u : (b < plan.bucket ? 0u : (b > plan.bucket ? 2u : 1u));
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls[k] == 0u), m1 = __builtin_amdgcn_ballot_w64(cls[k] == 1u),
+                             m2 = __builtin_amdgcn_ballot_w64(cls[k] == 2u);
+    const unsigned long long mine = cls[k] == 0u ? m0 : (cls[k] == 1u ? m1 : m2);
+    rank[k] = (uint32_t)__builtin_popcountll(mine & lower);
+    if (lane == 0) {
+      const uint32_t e = k * (K1_THREADS / 64) + w;
+      wcnt[0][e] = (uint32_t)__builtin_popcountll(m0), wcnt[1][e] = (uint32_t)__builtin_popcountll(m1),
+      wcnt[2][e] = (uint32_t)__builtin_popcountll(m2);
+    }
+  }
+  __syncthreads();
+  // waves 0..2: exclusive prefix of class w over the 32 (round, wave) entries; the class total reserves the block's
+  // places in the node's left end / side buffer / right end
+  constexpr uint32_t ENTRIES = K1_ROUNDS * (K1_THREADS / 64);
+  static_assert(ENTRIES <= 64, "one wave scans the (round, wave) counts");
+  if (w < 3) {
+    const uint32_t v = lane < ENTRIES ? wcnt[w][lane] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= (uint32_t)off) incl += up;
+    }
+    if (lane < ENTRIES) wcnt[w][lane] = incl - v;
+    if (lane == 63) base[w] = incl ? atomicAdd(&cursors[node * 4 + w], incl) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+    if (cls[k] == 3u) continue;
+    const uint32_t off = base[cls[k]] + wcnt[cls[k]][k * (K1_THREADS / 64) + w] + rank[k];
+    if (cls[k] == 0u) rout[s + off] = r[k];
+    else if (cls[k] == 2u) rout[s + l - 1u - off] = r[k];
+    else midbuf[s + off] = r[k];
+    if (nb_next && cls[k] != 1u)
+      atomicAdd(&h[(cls[k] >> 1) * nb_next + bucket_of(canon(comp(r[k], a2)), box.lo[a2], box.hi[a2], nb_next)], 1u);
+  }
+  if (!nb_next) return;
+  __syncthreads();
+  uint32_t* g = hist_next + (size_t)(2 * node) * nb_next;  // children 2 node, 2 node + 1: adjacent tables
+  for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K1_THREADS) {
+    const uint32_t v = h[q];
+    if (v) atomicAdd(&g[q], v);  // (executes at the memory side: contiguous lanes, contiguous words)
+  }
+}
+
+// L_d as a tuple of u32: (key, previous axis' key, the one before, original index)
+struct LKey {
+  uint32_t k0, k1, k2, idx;
+};
+__device__ __forceinline__ LKey lkey_of(const float4& r, uint32_t level) {
+  const uint32_t a = level % 3;
+  return LKey{ord_bits(comp(r, a)), level >= 1 ? ord_bits(comp(r, (a + 2) % 3)) : 0u,
+              level >= 2 ? ord_bits(comp(r, (a + 1) % 3)) : 0u, __float_as_uint(r.w)};
+}
+__device__ __forceinline__ bool lkey_less(const LKey& p, const LKey& q) {
+  return p.k0 != q.k0 ? p.k0 < q.k0 : (p.k1 != q.k1 ? p.k1 < q.k1 : (p.k2 != q.k2 ? p.k2 < q.k2 : p.idx < q.idx));
+}
+
+constexpr uint32_t RANK_SMALL = 64;  // a tied set this small is ranked by brute force (count the smaller ones)
+constexpr size_t K2_LDS_BYTES = MIDDLE_CAP * sizeof(float4) + 2 * MIDDLE_CAP * sizeof(uint16_t) + (NSUB + 2 * NB_MAX) * sizeof(uint32_t);
+
+__device__ __forceinline__ uint32_t lkey_comp(const float4& r, uint32_t level, uint32_t c) {
+  const LKey k = lkey_of(r, level);
+  return c == 0 ? k.k0 : (c == 1 ? k.k1 : (c == 2 ? k.k2 : k.idx));
+}
+// Monotone map of [mn, mx] onto < NSUB buckets by a shift; mn and mx land in different buckets whenever mn < mx.
+__device__ __forceinline__ uint32_t shift_for(uint32_t mn, uint32_t mx) {
+  const uint32_t span = mx - mn, bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
+  return bits > 10u ? bits - 10u : 0u;  // (NSUB = 2^10)
+}
+static_assert(NSUB == 1024, "shift_for assumes 2^10 finer buckets");
+
+// One block per node: finds the point of rank `t` under L_d among the node's median-bucket points and places them all.
+// The set is narrowed round by round — buckets over the actual [min, max] of one component of L_d at a time (a set
+// whose points all agree in a component moves on to the next one; the original index, unique, ends it) — first from
+// global memory while it is larger than the block's LDS (a degenerate cloud: thousands of equal or nearly equal
+// coordinates), then in LDS; the last <= 64 candidates are ranked by brute force.  Exact for every input.
+__global__ void __launch_bounds__(K2_THREADS)
+    sel_resolve_kernel(float4* __restrict__ midbuf, float4* __restrict__ spare, float4* __restrict__ rout, uint32_t n,
+                       uint32_t level, uint32_t nb_next, const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes,
+                       SelPlan* __restrict__ plans_next, SelBox* __restrict__ boxes_next, uint32_t* __restrict__ hist_next,
+                       float* __restrict__ split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* rec = (float4*)smem;                         // [MIDDLE_CAP] the candidates once they fit
+  uint16_t* list_a = (uint16_t*)(rec + MIDDLE_CAP);    // [MIDDLE_CAP] the current candidate set (indices into rec) ...
+  uint16_t* list_b = list_a + MIDDLE_CAP;              // ... and the next
+  uint32_t* hsub = (uint32_t*)(list_b + MIDDLE_CAP);   // [NSUB] histogram of a round
+  uint32_t* hchild = hsub + NSUB;                      // [2][nb_next] the children's histograms along the next axis
+  __shared__ uint32_t tmp[16];
+  __shared__ SelPlan sub_plan;
+  __shared__ uint32_t n_left, n_right, n_keep, s_mn, s_mx;
+  __shared__ float split_raw;
+  const uint32_t node = blockIdx.x;
+  uint32_t s, l;
+  bool exists;
+  sel_node_range(n, level, node, &s, &l, &exists);
+  const uint32_t mid = l >> 1;
+  const SelPlan plan = plans[node];
+  const SelBox box = boxes[node];
+  const uint32_t a = level % 3, a2 = (level + 1) % 3;
+  uint32_t* g = hist_next + (size_t)(2 * node) * nb_next;
+  for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K2_THREADS) hchild[q] = g[q], g[q] = 0u;  // (zeroed for level + 2)
+  if (threadIdx.x == 0) n_left = 0u, n_right = 0u;
+  __syncthreads();
+  float4* left_out = rout + s + plan.below;  // behind the points the split kernel put at the left end
+  float4* right_out = rout + s + mid;        // in front of the points it put at the right end
+  auto emit = [&](const float4& r, bool right) {
+    (right ? right_out : left_out)[atomicAdd(right ? &n_right : &n_left, 1u)] = r;
+    if (nb_next)
+      atomicAdd(&hchild[(right ? nb_next : 0u) + bucket_of(canon(comp(r, a2)), box.lo[a2], box.hi[a2], nb_next)], 1u);
+  };
+  // min / max of component `cmp` over the set: one LDS atomic per wave
+  auto min_max = [&](auto fetch, uint32_t cnt, uint32_t cmp) {
+    if (threadIdx.x == 0) s_mn = ~0u, s_mx = 0u;
+    __syncthreads();
+    uint32_t mn = ~0u, mx = 0u;
+    for (uint32_t i = threadIdx.x; i < cnt; i += K2_THREADS) {
+      const uint32_t k = lkey_comp(fetch(i), level, cmp);
+      mn = min(mn, k), mx = max(mx, k);
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+      mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    }
+    if (lane_id() == 0) atomicMin(&s_mn, mn), atomicMax(&s_mx, mx);
+    __syncthreads();
+  };
+  // one narrowing round: histogram over [mn, mx], the bucket of rank t, everything else placed; returns through
+  // sub_plan / n_keep.  `keep(r, i)` stores a candidate of the next round.
+  auto round = [&](auto fetch, auto keep, uint32_t cnt, uint32_t cmp, uint32_t t) {
+    const uint32_t mn = s_mn, sh = shift_for(s_mn, s_mx);
+    for (uint32_t q = threadIdx.x; q < NSUB; q += K2_THREADS) hsub[q] = 0u;
+    if (threadIdx.x == 0) n_keep = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += K2_THREADS) atomicAdd(&hsub[(lkey_comp(fetch(i), level, cmp) - mn) >> sh], 1u);
+    __syncthreads();
+    plan_from_hist<K2_THREADS>(hsub, NSUB, t, &sub_plan, tmp);
+    __syncthreads();
+    const uint32_t star = sub_plan.bucket;
+    for (uint32_t i = threadIdx.x; i < cnt; i += K2_THREADS) {
+      const float4 r = fetch(i);
+      const uint32_t b = (lkey_comp(r, level, cmp) - mn) >> sh;
+      if (b == star) keep(r, i, atomicAdd(&n_keep, 1u));
+      else emit(r, b > star);
+    }
+    __syncthreads();
+  };
+  uint32_t c = plan.count, t = mid - plan.below, cmp = 0;  // the set's rank-t point is the node's median
+  // ---- while the set does not fit: rounds from global memory, the survivors ping-pong between the side buffer and
+  // this node's range of the previous level's input (dead since the split kernel read it)
+  float4* src = midbuf + s;
+  float4* dst = spare + s;
+  while (c > MIDDLE_CAP) {
+    auto fetch = [&](uint32_t i) { return src[i]; };
+    min_max(fetch, c, cmp);
+    if (s_mn == s_mx) {  // all agree in this component of L_d: the next one decides
+      ++cmp;
+      continue;
+    }
+    round(fetch, [&](const float4& r, uint32_t, uint32_t at) { dst[at] = r; }, c, cmp, t);
+    t -= sub_plan.below, c = sub_plan.count;
+    float4* sw = src;
+    src = dst, dst = sw;
+  }
+  // ---- in LDS
+  for (uint32_t i = threadIdx.x; i < c; i += K2_THREADS) rec[i] = src[i], list_a[i] = (uint16_t)i;
+  __syncthreads();
+  uint16_t *cur = list_a, *nxt = list_b;
+  while (c > RANK_SMALL) {
+    auto fetch = [&](uint32_t i) { return rec[cur[i]]; };
+    min_max(fetch, c, cmp);
+    if (s_mn == s_mx) {
+      ++cmp;
+      continue;
+    }
+    round(fetch, [&](const float4&, uint32_t i, uint32_t at) { nxt[at] = cur[i]; }, c, cmp, t);
+    t -= sub_plan.below, c = sub_plan.count;
+    uint16_t* sw = cur;
+    cur = nxt, nxt = sw;
+  }
+  // exact rank under L_d among the last candidates: count the smaller ones
+  for (uint32_t e = threadIdx.x; e < c; e += K2_THREADS) {
+    const float4 r = rec[cur[e]];
+    const LKey ke = lkey_of(r, level);
+    uint32_t rnk = 0;
+    for (uint32_t f = 0; f < c; ++f) rnk += lkey_less(lkey_of(rec[cur[f]], level), ke) ? 1u : 0u;
+    emit(r, rnk >= t);
+    if (rnk == t) split_raw = comp(r, a);  // the point of rank len / 2: `points[mid][k]` (kdtree.rs:47-49)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) split[((1u << level) - 1u) + node] = split_raw;
+  if (!nb_next) return;  // the children are finished by the narrow kernel: no boxes or plans needed
+  if (threadIdx.x < 2) {  // the children's boxes: the parent's, cut at the split value along the split axis
+    SelBox cb = box;
+    if (threadIdx.x == 0) cb.hi[a] = canon(split_raw);
+    else cb.lo[a] = canon(split_raw);
+    boxes_next[2 * node + threadIdx.x] = cb;
+  }
+  plan_from_hist<K2_THREADS>(hchild, nb_next, mid >> 1, &plans_next[2 * node], tmp);
+  plan_from_hist<K2_THREADS>(hchild + nb_next, nb_next, (l - mid) >> 1, &plans_next[2 * node + 1], tmp);
+}
+
+// ---- ranges of <= NARROW points: all remaining levels in LDS -----------------------------------------------------------
+__device__ __forceinline__ bool lt128(const uint4& p, const uint4& q) {
+  return p.x != q.x ? p.x < q.x : (p.y != q.y ? p.y < q.y : (p.z != q.z ? p.z < q.z : p.w < q.w));
+}
+
+// Bitonic network over `total` words in cells of `cap` (powers of two, cap <= total <= 4 * NW_THREADS).  Two stages
+// (partner distances j and j / 2) share one LDS round trip: a thread owns the four words base + {0, j/2, j, 3j/2}.
+template <typename W, typename P, typename Less>
+__device__ __forceinline__ void bitonic_cells(W* w, P* pay, uint32_t total, uint32_t cap, Less less) {
+  constexpr bool HAS_PAYLOAD = !std::is_same<P, void>::value;
+  auto ce = [&](W& x, W& y, uint32_t& px, uint32_t& py, bool up) {
+    if (less(y, x) == up) {  // (words are unique: x > y  <=>  y < x)
+      const W tw = x;
+      x = y, y = tw;
+      const uint32_t tp = px;
+      px = py, py = tp;
+    }
+  };
+  for (uint32_t kk = 2; kk <= cap; kk <<= 1) {
+    uint32_t j = kk >> 1;
+    while (j >= 2) {
+      const uint32_t hh = j >> 1, lh = 31u - (uint32_t)__builtin_clz(hh);
+      for (uint32_t q = threadIdx.x; q < (total >> 2); q += NW_THREADS) {
+        const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
+        const bool up = ((base & (cap - 1u)) & kk) == 0u;
+        W x0 = w[base], x1 = w[base + hh], x2 = w[base + j], x3 = w[base + j + hh];
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        if constexpr (HAS_PAYLOAD) p0 = pay[base], p1 = pay[base + hh], p2 = pay[base + j], p3 = pay[base + j + hh];
+        ce(x0, x2, p0, p2, up), ce(x1, x3, p1, p3, up);
+        ce(x0, x1, p0, p1, up), ce(x2, x3, p2, p3, up);
+        w[base] = x0, w[base + hh] = x1, w[base + j] = x2, w[base + j + hh] = x3;
+        if constexpr (HAS_PAYLOAD) pay[base] = p0, pay[base + hh] = p1, pay[base + j] = p2, pay[base + j + hh] = p3;
+      }
+      __syncthreads();
+      j >>= 2;
+    }
+    if (j == 1) {
+      for (uint32_t q = threadIdx.x; q < (total >> 1); q += NW_THREADS) {
+        const uint32_t i = 2 * q;
+        const bool up = ((i & (cap - 1u)) & kk) == 0u;
+        W x0 = w[i], x1 = w[i + 1];
+        uint32_t p0 = 0, p1 = 0;
+        if constexpr (HAS_PAYLOAD) p0 = pay[i], p1 = pay[i + 1];
+        ce(x0, x1, p0, p1, up);
+        w[i] = x0, w[i + 1] = x1;
+        if constexpr (HAS_PAYLOAD) pay[i] = p0, pay[i + 1] = p1;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+constexpr size_t NW_LDS_BYTES = NARROW * (sizeof(float4) + sizeof(uint4) + sizeof(uint32_t));
+
+__global__ void __launch_bounds__(NW_THREADS)
+    sel_narrow_kernel(const float4* __restrict__ recs, uint32_t n, uint32_t d0, uint32_t D, float* __restrict__ split,
+                      float4* __restrict__ leaves, uint32_t* __restrict__ slot_of_point, uint32_t* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* rec = (float4*)smem;                       // [NARROW]
+  uint4* w128 = (uint4*)(rec + NARROW);              // [NARROW] level d0: L_d0 as one word ...
+  unsigned long long* w64 = (unsigned long long*)w128;  // ... deeper levels: key bits << 32 | position in the range
+  uint32_t* pay = (uint32_t*)(w128 + NARROW);        // [NARROW] level d0: where the word's point was
+  constexpr uint32_t OWN = NARROW / NW_THREADS;      // positions per thread: p = threadIdx.x + k * NW_THREADS
+  const uint32_t node0 = blockIdx.x;
+  uint32_t s0, l0;
+  bool exists0;
+  sel_node_range(n, d0, node0, &s0, &l0, &exists0);
+  uint32_t cap0 = 32;
+  while (cap0 < l0) cap0 <<= 1;
+  // per owned position: the node it is in (relative start, length, path) and that node's depth
+  uint32_t rs[OWN], rl[OWN], path[OWN], depth[OWN];
+#pragma unroll
+  for (uint32_t k = 0; k < OWN; ++k) {
+    const uint32_t p = threadIdx.x + k * NW_THREADS;
+    rs[k] = 0, rl[k] = l0, path[k] = node0, depth[k] = d0;
+    if (p < l0) rec[p] = recs[s0 + p];
+  }
+  __syncthreads();
+  if (l0 <= 16 && d0 >= 1) {
+    // A range that already is a leaf (only with a lowered wide / narrow border: at the default one every range that
+    // arrives here is longer than 16): its points must stand in the order its parent's sort left them in, L_{d0 - 1}.
+    for (uint32_t q = threadIdx.x; q < cap0; q += NW_THREADS) {
+      uint4 word = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (q < l0) {
+        const LKey lk = lkey_of(rec[q], d0 - 1);
+        word = make_uint4(lk.k0, lk.k1, lk.k2, lk.idx);
+      }
+      w128[q] = word, pay[q] = q;
+    }
+    __syncthreads();
+    bitonic_cells<uint4, uint32_t>(w128, pay, cap0, cap0, [](const uint4& x, const uint4& y) { return lt128(x, y); });
+    float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < l0) moved = rec[pay[threadIdx.x]];
+    __syncthreads();
+    if (threadIdx.x < l0) rec[threadIdx.x] = moved;
+    __syncthreads();
+  }
+  for (uint32_t d = d0; d < D; ++d) {
+    const uint32_t a = d % 3, rel = d - d0;
+    const uint32_t cap = cap0 >> rel;  // >= 32 wherever a range of this level is longer than 16 (ranges halve with cap)
+    if (cap < 32) break;               // everything below is a leaf
+    // words of the ranges that are sorted at this level (len > 16); everything else is padding that sorts last
+    if (d == d0) {
+      for (uint32_t q = threadIdx.x; q < cap0; q += NW_THREADS) w128[q] = make_uint4(~0u, ~0u, ~0u, ~0u), pay[q] = 0u;
+    } else {
+      for (uint32_t q = threadIdx.x; q < cap0; q += NW_THREADS) w64[q] = ~0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < OWN; ++k) {
+      const uint32_t p = threadIdx.x + k * NW_THREADS;
+      if (p >= l0 || depth[k] != d || rl[k] <= 16) continue;
+      const float4 r = rec[p];
+      const float v = comp(r, a);
+      if (v != v) atomicOr(&flags[FLAG_NAN], 1u);  // partial_cmp().unwrap() would panic (kdtree.rs:43)
+      const uint32_t cell = path[k] - (node0 << rel), pos = p - rs[k];
+      if (d == d0) {
+        const LKey lk = lkey_of(r, d);
+        w128[pos] = make_uint4(lk.k0, lk.k1, lk.k2, lk.idx), pay[pos] = p;  // (one cell: cell == 0, rs == 0)
+      } else {
+        w64[cell * cap + pos] = ((unsigned long long)ord_bits(v) << 32) | pos;
+      }
+    }
+    __syncthreads();
+    if (d == d0) bitonic_cells<uint4, uint32_t>(w128, pay, cap0, cap0, [](const uint4& x, const uint4& y) { return lt128(x, y); });
+    else bitonic_cells<unsigned long long, void>(w64, (void*)nullptr, cap0, cap, [](unsigned long long x, unsigned long long y) { return x < y; });
+    // the new arrangement: position p of a sorted range takes the point its word names
+    float4 moved[OWN];
+#pragma unroll
+    for (uint32_t k = 0; k < OWN; ++k) {
+      const uint32_t p = threadIdx.x + k * NW_THREADS;
+      if (p >= l0 || depth[k] != d || rl[k] <= 16) continue;
+      const uint32_t cell = path[k] - (node0 << rel), pos = p - rs[k];
+      const uint32_t src = d == d0 ? pay[pos] : rs[k] + (uint32_t)w64[cell * cap + pos];
+      moved[k] = rec[src];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < OWN; ++k) {
+      const uint32_t p = threadIdx.x + k * NW_THREADS;
+      if (p >= l0 || depth[k] != d || rl[k] <= 16) continue;
+      rec[p] = moved[k];
+      const uint32_t mid = rl[k] >> 1, pos = p - rs[k];
+      if (pos == mid) split[((1u << d) - 1u) + path[k]] = comp(moved[k], a);  // points[mid][k] (kdtree.rs:47-49)
+      if (pos < mid) rl[k] = mid, path[k] = 2 * path[k];
+      else rs[k] += mid, rl[k] -= mid, path[k] = 2 * path[k] + 1;
+      depth[k] = d + 1;
+    }
+    __syncthreads();
+  }
+  // leaves: slot r of the leaf reached by `path` at depth `depth` lives at (path << (D - depth)) * 16 + r (kdtree.hpp)
+#pragma unroll
+  for (uint32_t k = 0; k < OWN; ++k) {
+    const uint32_t p = threadIdx.x + k * NW_THREADS;
+    if (p >= l0) continue;
+    const uint32_t slot = (path[k] << (D - depth[k])) * 16u + (p - rs[k]);
+    const float4 r = rec[p];
+    leaves[slot] = r;
+    slot_of_point[__float_as_uint(r.w)] = slot;
+  }
+  // +inf in the slots no point took, 0 in the split entries of this subtree's nodes that are leaves at depth D - 1
+  const uint32_t sub = D - d0, first_leaf = node0 << sub;
+  for (uint32_t q = threadIdx.x; q < (16u << sub); q += NW_THREADS) {
+    const uint32_t P = first_leaf + (q >> 4), r = q & 15u;
+    bool used;
+    if (D == 0) {
+      used = r < n;
+    } else {
+      uint32_t ps, pl;
+      bool pe;
+      sel_node_range(n, D - 1, P >> 1, &ps, &pl, &pe);  // (every node of depth D - 1 exists: leaves sit at D - 1 or D)
+      if (pl <= 16) used = (P & 1u) == 0u && r < pl;      // a leaf at depth D - 1 fills the even child's slots
+      else used = r < ((P & 1u) ? pl - (pl >> 1) : (pl >> 1));
+    }
+    if (!used) leaves[(size_t)first_leaf * 16u + q] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f);
+  }
+  if (D >= 1 && D - 1 >= d0) {
+    const uint32_t subm = D - 1 - d0;
+    for (uint32_t q = threadIdx.x; q < (1u << subm); q += NW_THREADS) {
+      const uint32_t pth = (node0 << subm) + q;
+      uint32_t ps, pl;
+      bool pe;
+      sel_node_range(n, D - 1, pth, &ps, &pl, &pe);
+      if (!(pe && pl > 16)) split[((1u << (D - 1)) - 1u) + pth] = 0.0f;
+    }
+  }
+}
+
+struct SelLayout {
+  uint32_t wide_levels = 0;            // levels 0 .. wide_levels - 1 run the split / resolve kernels
+  uint32_t narrow_len = NARROW;
+  uint32_t nb[32] = {};                // buckets per node on each wide level
+  size_t recs_a = 0, recs_b = 0, mid = 0, hist = 0, hist_words = 0, boxes = 0, plans = 0, cursors = 0, partials = 0,
+         flags = 0, zero_begin = 0, zero_bytes = 0, total = 0;
+  uint32_t pack_blocks = 0;
+};
+
+uint32_t max_len_at(uint32_t n, uint32_t level) { return (uint32_t)(((uint64_t)n + (1ull << level) - 1) >> level); }
+
+SelLayout sel_layout(uint32_t n, uint32_t narrow_len) {
+  SelLayout L;
+  L.narrow_len = narrow_len;
+  while (max_len_at(n, L.wide_levels) > narrow_len) ++L.wide_levels;
+  size_t hist_words = 1;
+  for (uint32_t d = 0; d < L.wide_levels; ++d) {
+    uint32_t nb = 64;
+    while (nb < NB_MAX && nb * 32u < max_len_at(n, d)) nb <<= 1;
+    L.nb[d] = nb;
+    hist_words = std::max(hist_words, ((size_t)1 << d) * nb);
+  }
+  auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
+  const size_t nodes = (size_t)1 << L.wide_levels;  // heap-indexed tables over all wide levels: 2^levels - 1 entries
+  L.pack_blocks = (n + PACK_TILE - 1) / PACK_TILE;
+  size_t off = 0;
+  L.recs_a = off, off += pad((size_t)n * 16);
+  L.recs_b = off, off += pad((size_t)n * 16);
+  L.mid = off, off += pad((size_t)n * 16);
+  L.boxes = off, off += pad(nodes * sizeof(SelBox));
+  L.plans = off, off += pad(nodes * sizeof(SelPlan));
+  L.partials = off, off += pad((size_t)L.pack_blocks * 6 * sizeof(float));
+  L.zero_begin = off;
+  L.flags = off, off += 256;
+  L.cursors = off, off += pad(nodes * 4 * sizeof(uint32_t));
+  L.hist_words = hist_words;
+  L.hist = off, off += pad(2 * hist_words * sizeof(uint32_t));
+  L.zero_bytes = off - L.zero_begin;
+  L.total = off;
+  return L;
+}
+
+uint32_t narrow_len_setting() {
+  uint32_t v = NARROW;
+  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_NARROW_LEN"))  // diagnostics build: wide levels at test sizes
+    if (*env) v = std::min(NARROW, std::max(32u, (uint32_t)atoi(env)));
+  return v;
+}
+
+}  // namespace
+
+namespace a3d {
+
+size_t kdtree_select_scratch_bytes(uint32_t n) { return sel_layout(n, narrow_len_setting()).total; }
+
+// d_points: [n][3] f32 on the device; `scratch`: kdtree_select_scratch_bytes(n) bytes.  Fills t->d_split, t->d_leaves,
+// t->d_slot_of_point (allocated by the caller) and synchronises.
+a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void* scratch) {
+  hipStream_t s = t->ctx->stream;
+  const uint32_t n = t->n, D = t->max_depth;
+  const SelLayout L = sel_layout(n, narrow_len_setting());
+  char* base = (char*)scratch;
+  float4* recs[2] = {(float4*)(base + L.recs_a), (float4*)(base + L.recs_b)};
+  float4* mid = (float4*)(base + L.mid);
+  SelBox* boxes = (SelBox*)(base + L.boxes);
+  SelPlan* plans = (SelPlan*)(base + L.plans);
+  float* partials = (float*)(base + L.partials);
+  uint32_t* flags = (uint32_t*)(base + L.flags);
+  uint32_t* cursors = (uint32_t*)(base + L.cursors);
+  uint32_t* hist[2] = {(uint32_t*)(base + L.hist), (uint32_t*)(base + L.hist) + L.hist_words};
+  static bool lds_allowed = false;  // more than 64 KiB of dynamic LDS has to be requested once per kernel
+  if (!lds_allowed) {
+    A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS_BYTES));
+    A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NW_LDS_BYTES));
+    lds_allowed = true;
+  }
+  A3D_HIP_TRY(hipMemsetAsync(base + L.zero_begin, 0, L.zero_bytes, s));  // flags, cursors, both histogram tables
+  hipLaunchKernelGGL(sel_pack_kernel, dim3(L.pack_blocks), dim3(PACK_THREADS), 0, s, d_points, n, recs[0], partials);
+  const uint32_t W = L.wide_levels;
+  if (W > 0) {
+    hipLaunchKernelGGL(sel_hist0_kernel, dim3((n + K1_TILE - 1) / K1_TILE), dim3(K1_THREADS), L.nb[0] * sizeof(uint32_t), s,
+                       recs[0], n, partials, L.pack_blocks, L.nb[0], boxes, hist[0]);
+    hipLaunchKernelGGL(sel_plan0_kernel, dim3(1), dim3(K2_THREADS), 0, s, n, L.nb[0], hist[0], plans);
+  }
+  for (uint32_t d = 0; d < W; ++d) {
+    const uint32_t nodes = 1u << d, off = nodes - 1u;  // heap offset of the level in the per-node tables
+    const uint32_t bpn = (max_len_at(n, d) + K1_TILE - 1) / K1_TILE;
+    const uint32_t nb_next = d + 1 < W ? L.nb[d + 1] : 0u;
+    hipLaunchKernelGGL(sel_split_kernel, dim3(nodes * bpn), dim3(K1_THREADS), 2 * nb_next * sizeof(uint32_t), s,
+                       recs[d & 1], recs[(d + 1) & 1], mid, n, d, bpn, L.nb[d], nb_next, plans + off, boxes + off,
+                       cursors + 4 * (size_t)off, hist[(d + 1) & 1], flags);
+    hipLaunchKernelGGL(sel_resolve_kernel, dim3(nodes), dim3(K2_THREADS), K2_LDS_BYTES, s, mid, recs[d & 1],
+                       recs[(d + 1) & 1], n, d, nb_next, plans + off, boxes + off, plans + (2 * nodes - 1u),
+                       boxes + (2 * nodes - 1u), hist[(d + 1) & 1], t->d_split);
+  }
+  hipLaunchKernelGGL(sel_narrow_kernel, dim3(1u << W), dim3(NW_THREADS), NW_LDS_BYTES, s, recs[W & 1], n, W, D, t->d_split,
+                     t->d_leaves, t->d_slot_of_point, flags);
+  A3D_HIP_TRY(hipGetLastError());
+  uint32_t h_flags[1] = {0};
+  A3D_HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+  A3D_HIP_TRY(hipStreamSynchronize(s));
+  A3D_REQUIRE(!h_flags[FLAG_NAN], A3D_NAN_IN_INPUT,
+              "NaN coordinate in kd-tree input (the reference panics in partial_cmp().unwrap())");
+  return A3D_OK;
+}
+
+}  // namespace a3d

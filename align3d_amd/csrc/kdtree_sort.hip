@@ -1,4 +1,5 @@
-// The two stable sorts of the device kd-tree build (kdtree_build.hip), hand-written for gfx950.
+// The two stable sorts of the SORTING kd-tree build (kdtree_build.hip; diagnostics build only since round 5: the
+// product builds by selection, kdtree_select.hip), hand-written for gfx950.
 //
 //   wide levels   (ranges longer than 4096 points; at most ~n / 4096 of them): ONE device-wide stable LSD radix
 //                 sort per level on 64-bit keys `range number << 32 | order-preserving key bits`, 8 bits per pass:
@@ -16,6 +17,8 @@
 #include <cstring>
 
 #include "kdtree.hpp"
+
+#ifdef A3D_DIAGNOSTICS
 
 using namespace a3d;
 
@@ -297,3 +300,5 @@ a3d_status kdtree_sort_ranges(hipStream_t s, const float* points, const uint32_t
 }
 
 }  // namespace a3d
+
+#endif  // A3D_DIAGNOSTICS

@@ -273,8 +273,36 @@ class PointCloud:
         return v
 
 
+class DevicePointCloud:
+    """A PointCloud (src/pointcloud.rs:8-12) resident in HBM: points / normals [len][3] f32 on the context's GPU, for
+    the device-pointer forms a3d_pcl_icp_new_device / a3d_pcl_icp_align_device (no PCIe traffic per call)."""
+
+    def __init__(self, ctx, cloud):
+        self.ctx = ctx
+        self.n = cloud.len()
+        self.d_points = ctx.to_device(cloud.points)
+        self.d_normals = None if cloud.normals is None else ctx.to_device(cloud.normals)
+
+    def len(self):
+        return self.n
+
+    def view(self):
+        v = _abi.PointCloudViewC()
+        v.points = self.d_points
+        v.normals = self.d_normals
+        v.len = self.n
+        return v
+
+    def free(self):
+        for p in (self.d_points, self.d_normals):
+            if p is not None and self.ctx.handle:
+                self.ctx.free(p)
+        self.d_points = self.d_normals = None
+
+
 class Icp:
-    """Icp (src/icp/pcl_icp.rs:15-108): point-to-plane ICP with kd-tree correspondences."""
+    """Icp (src/icp/pcl_icp.rs:15-108): point-to-plane ICP with kd-tree correspondences.  `target` / `source` may be
+    PointCloud (host arrays, as in the reference) or DevicePointCloud (already resident)."""
 
     def __init__(self, ctx, params, target):
         self.ctx = ctx
@@ -284,7 +312,8 @@ class Icp:
         self.handle = C.c_void_p()
         p = params.to_c()
         v = target.view()
-        _abi.check(ctx.lib.a3d_pcl_icp_new(ctx.handle, C.byref(p), C.byref(v), C.byref(self.handle)), "Icp::new")
+        fn = ctx.lib.a3d_pcl_icp_new_device if isinstance(target, DevicePointCloud) else ctx.lib.a3d_pcl_icp_new
+        _abi.check(fn(ctx.handle, C.byref(p), C.byref(v), C.byref(self.handle)), "Icp::new")
 
     @staticmethod
     def new(ctx, params, target):
@@ -293,7 +322,8 @@ class Icp:
     def align(self, source):
         v = source.view()
         out = _abi.PoseC()
-        _abi.check(self.ctx.lib.a3d_pcl_icp_align(self.handle, C.byref(v), C.byref(out)), "Icp::align")
+        fn = self.ctx.lib.a3d_pcl_icp_align_device if isinstance(source, DevicePointCloud) else self.ctx.lib.a3d_pcl_icp_align
+        _abi.check(fn(self.handle, C.byref(v), C.byref(out)), "Icp::align")
         return Transform.from_c(out)
 
     def last_device_ms(self):

@@ -7,17 +7,33 @@ from . import _abi
 
 
 class R3dTree:
-    def __init__(self, ctx, points):
-        """R3dTree::new(&points)"""
+    def __init__(self, ctx, points, device_points=None, n=None):
+        """R3dTree::new(&points); `device_points` (a device pointer to [n][3] f32): a3d_kdtree_new_device."""
         self.ctx = ctx
-        self.points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         self.handle = C.c_void_p()
+        if device_points is not None:
+            self.points = None
+            _abi.check(ctx.lib.a3d_kdtree_new_device(ctx.handle, device_points, int(n), C.byref(self.handle)),
+                       "a3d_kdtree_new_device")
+            return
+        self.points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         _abi.check(ctx.lib.a3d_kdtree_new(ctx.handle, _abi.ptr(self.points), len(self.points), C.byref(self.handle)),
                    "a3d_kdtree_new")
 
     @staticmethod
     def new(ctx, points):
         return R3dTree(ctx, points)
+
+    @staticmethod
+    def new_device(ctx, d_points, n):
+        """The tree over points already resident in HBM (d_points: device pointer, [n][3] f32)."""
+        return R3dTree(ctx, None, device_points=d_points, n=n)
+
+    def build_path(self):
+        """1 = the selection build, 2 = the sorting build (its fallback), 0 = host build (diagnostics)."""
+        v = C.c_int32()
+        _abi.check(self.ctx.lib.a3d_kdtree_build_path(self.handle, C.byref(v)))
+        return v.value
 
     def nearest(self, queries):
         """R3dTree::nearest for a batch: (indices u64, squared distances f32)."""

@@ -324,6 +324,13 @@ class MultiscaleAlign {
 class R3dTree {
  public:
   R3dTree(const Context& ctx, const float* points_n3, uint64_t n) { check(a3d_kdtree_new(ctx.raw(), points_n3, n, &t_)); }
+  /// Over points already resident in HBM (device pointer, [n][3] f32): a3d_kdtree_new_device.
+  static R3dTree from_device(const Context& ctx, const void* d_points_n3, uint64_t n) {
+    R3dTree t;
+    check(a3d_kdtree_new_device(ctx.raw(), d_points_n3, n, &t.t_));
+    return t;
+  }
+  R3dTree(R3dTree&& o) noexcept : t_(o.t_) { o.t_ = nullptr; }
   ~R3dTree() { a3d_kdtree_free(t_); }
   R3dTree(const R3dTree&) = delete;
   R3dTree& operator=(const R3dTree&) = delete;
@@ -338,6 +345,7 @@ class R3dTree {
   }
 
  private:
+  R3dTree() = default;
   a3d_kdtree* t_ = nullptr;
 };
 
@@ -355,8 +363,21 @@ class Icp {
     check(a3d_pcl_icp_align(icp_, &source, &out));
     return Transform::from_c(out);
   }
+  /// Clouds already resident in HBM: the views hold DEVICE pointers (a3d_pcl_icp_new_device / _align_device).
+  static Icp from_device(const Context& ctx, const IcpParams& params, const a3d_point_cloud_view& d_target) {
+    Icp icp;
+    check(a3d_pcl_icp_new_device(ctx.raw(), &params, &d_target, &icp.icp_));
+    return icp;
+  }
+  Icp(Icp&& o) noexcept : icp_(o.icp_) { o.icp_ = nullptr; }
+  Transform align_device(const a3d_point_cloud_view& d_source) const {
+    a3d_pose out;
+    check(a3d_pcl_icp_align_device(icp_, &d_source, &out));
+    return Transform::from_c(out);
+  }
 
  private:
+  Icp() = default;
   a3d_pcl_icp* icp_ = nullptr;
 };
 

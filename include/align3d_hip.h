@@ -409,9 +409,16 @@ a3d_status a3d_multiscale_multi_batch_free(a3d_multiscale_multi_batch* batch);
 /* ---- R3dTree (src/kdtree.rs:19-106) ------------------------------------------------------- */
 
 /* R3dTree::new(&points): `points` [n][3] f32 in host memory are uploaded and the tree is built ON THE DEVICE
- * (kdtree_build.hip: per level one stable sort of every range along the level's axis, leaf <= 16, mid = len / 2 —
- * the same tree, bit for bit, as the reference's recursive host build). */
+ * (kdtree_select.hip: per level the point of rank len / 2 in the reference's own order and a partition around it, the
+ * last levels sorted in LDS; leaf <= 16, mid = len / 2 — the same tree, bit for bit, as the reference's recursive build
+ * with a stable sort per node). */
 a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d_kdtree** out);
+/* The same over points that are already resident: d_points [n][3] f32 in device memory of the context's GPU (the
+ * layout of PointCloud::points, src/pointcloud.rs:8-12).  Read during the call only; the same tree, bit for bit. */
+a3d_status a3d_kdtree_new_device(a3d_context* ctx, const void* d_points, uint64_t n, a3d_kdtree** out);
+/* Instrumentation: which build made the tree: 1 selection build (kdtree_select.hip: the product's); diagnostics build
+ * only: 0 host build, 2 sorting build (the cross-checks). */
+a3d_status a3d_kdtree_build_path(a3d_kdtree* tree, int32_t* out_path);
 /* R3dTree::nearest for m queries (leaf-only search, no backtracking).  Host pointers.
  * out_indices are indices into the `points` given to a3d_kdtree_new. */
 a3d_status a3d_kdtree_nearest(a3d_kdtree* tree, const float* queries, uint64_t m,
@@ -436,6 +443,15 @@ a3d_status a3d_pcl_icp_new(a3d_context* ctx, const a3d_icp_params* params,
 /* Icp::align(&source): starts from Transform::eye() (initial_transform is ignored, pcl_icp.rs:59). */
 a3d_status a3d_pcl_icp_align(a3d_pcl_icp* icp, const a3d_point_cloud_view* source,
                              a3d_pose* out_pose);
+/* Icp::new / Icp::align over clouds that are already resident: the view's `points` / `normals` are DEVICE pointers
+ * (same layout: [len][3] f32, src/pointcloud.rs:8-12) on the context's GPU.  The target's arrays are read during
+ * a3d_pcl_icp_new_device only (tree and leaf normals are copies); the source's during a3d_pcl_icp_align_device, which
+ * is host-synchronous like a3d_pcl_icp_align.  Same tree, same pose bits as the host-pointer forms; no PCIe traffic
+ * except the 32-byte result (benches/bench_icp.rs:9-39 without the copies). */
+a3d_status a3d_pcl_icp_new_device(a3d_context* ctx, const a3d_icp_params* params,
+                                  const a3d_point_cloud_view* d_target, a3d_pcl_icp** out);
+a3d_status a3d_pcl_icp_align_device(a3d_pcl_icp* icp, const a3d_point_cloud_view* d_source,
+                                    a3d_pose* out_pose);
 /* One pass of the per-point body (pcl_icp.rs:68-92) from `pose`: test hook. */
 a3d_status a3d_pcl_icp_accumulate(a3d_pcl_icp* icp, const a3d_point_cloud_view* source,
                                   const a3d_pose* pose, a3d_gn_state* out_state);

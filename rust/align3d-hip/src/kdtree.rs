@@ -26,6 +26,17 @@ impl R3dTree {
         Self { handle }
     }
 
+    /// The same tree over points that are already resident in HBM (`d_points`: device pointer to `[n][3]` f32 on this
+    /// thread's context's GPU; read during the call only): `a3d_kdtree_new_device`.
+    ///
+    /// # Safety
+    /// `d_points` must be a valid device allocation of at least `12 * n` bytes.
+    pub unsafe fn new_device(d_points: *const std::ffi::c_void, n: usize) -> Self {
+        let mut handle = std::ptr::null_mut();
+        device::check(sys::a3d_kdtree_new_device(device::Context::current(), d_points, n as u64, &mut handle), "R3dTree::new_device");
+        Self { handle }
+    }
+
     /// src/kdtree.rs:69-105: (index of the nearest neighbour in its leaf, squared distance).
     pub fn nearest(&self, point: &Vector3<f32>) -> (usize, f32) {
         let (idx, dist) = self.nearest_batch(std::slice::from_ref(point));

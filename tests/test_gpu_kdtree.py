@@ -93,17 +93,40 @@ def test_kdtree_full_size_500k_bit_exact(ctx):
     assert np.array_equal(g2, gidx) and np.array_equal(d2, gd)
 
 
-def _build(ctx, db, mode, monkeypatch, wide_len=None, sort=None):
-    monkeypatch.setenv("A3D_KDTREE_BUILD", mode)
-    if sort is not None:
-        monkeypatch.setenv("A3D_KDTREE_SORT", sort)
-    else:
-        monkeypatch.delenv("A3D_KDTREE_SORT", raising=False)
-    if wide_len is not None:
-        monkeypatch.setenv("A3D_KDTREE_WIDE_LEN", str(wide_len))
-    else:
-        monkeypatch.delenv("A3D_KDTREE_WIDE_LEN", raising=False)
-    return R3dTree.new(ctx, db)
+_KD_KNOBS = ("A3D_KDTREE_BUILD", "A3D_KDTREE_SORT", "A3D_KDTREE_WIDE_LEN", "A3D_KDTREE_NARROW_LEN", "A3D_KDTREE_SCAN")
+
+# The device builds (diagnostics build: knobs).  "select" is what the product library runs: the selection build
+# (kdtree_select.hip); NARROW_LEN makes its wide-level kernels run at test sizes; "sorted" is the sorting build (the
+# cross-check, diagnostics build only: hand-written radix + bitonic sorts, or rocPRIM's), WIDE_LEN moves its wide / narrow border.
+_KD_BUILDS = {
+    "select": {},
+    "select_narrow32": {"A3D_KDTREE_NARROW_LEN": "32"},
+    "select_narrow64": {"A3D_KDTREE_NARROW_LEN": "64"},
+    "select_narrow512": {"A3D_KDTREE_NARROW_LEN": "512"},
+    "sorted": {"A3D_KDTREE_BUILD": "sorted"},
+    "sorted_wide64": {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_WIDE_LEN": "64"},
+    "sorted_all_wide": {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_WIDE_LEN": str(1 << 30)},
+    "sorted_rocprim": {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_SORT": "rocprim"},
+    "sorted_rocprim_wide64": {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_SORT": "rocprim", "A3D_KDTREE_WIDE_LEN": "64"},
+}
+
+
+def _build(ctx, db, env, monkeypatch, device_pointer=False):
+    for k in _KD_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    try:
+        if device_pointer:
+            d = ctx.to_device(np.ascontiguousarray(db, np.float32))
+            try:
+                return R3dTree.new_device(ctx, d, len(db))
+            finally:
+                ctx.free(d)  # (read during the call only)
+        return R3dTree.new(ctx, db)
+    finally:
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
 
 
 def _kd_cases():
@@ -113,58 +136,117 @@ def _kd_cases():
     dup[::5, 1] = 0.0
     neg = (uniform01(3, 3 * 70001).reshape(-1, 3) - 0.5) * np.float32(1e3)
     neg[::11] *= np.float32(1e-30)  # subnormal-range magnitudes keep their order too
+    # clustered: a few tight blobs + far outliers (buckets over the bounding box are very unevenly filled)
+    blobs = np.concatenate([rng.normal(c, 0.01, size=(15000, 3)) for c in ((0, 0, 0), (1, 0.2, -3), (1.001, 0.2, -3), (50, 50, 50))]
+                           + [rng.uniform(-1e4, 1e4, size=(37, 3))]).astype(np.float32)
+    rng.shuffle(blobs)
+    # exactly equal points in bulk (every key of L_d ties: the original index decides) beside distinct ones
+    twins = np.repeat(uniform01(8, 3 * 3000).reshape(-1, 3), 5, axis=0)
+    rng.shuffle(twins)
     return {"n1": uniform01(1, 3).reshape(1, 3), "n16": uniform01(2, 48).reshape(16, 3),
             "n17": uniform01(2, 51).reshape(17, 3), "n33": uniform01(4, 99).reshape(33, 3),
-            "n1000": uniform01(5, 3000).reshape(1000, 3), "dup": dup, "neg": neg.astype(np.float32),
-            "n270213": uniform01(6, 3 * 270213).reshape(-1, 3)}
+            "n1000": uniform01(5, 3000).reshape(1000, 3), "n2049": uniform01(7, 3 * 2049).reshape(-1, 3),
+            "n4099": uniform01(9, 3 * 4099).reshape(-1, 3), "dup": dup, "neg": neg.astype(np.float32),
+            "blobs": blobs, "twins": twins, "n270213": uniform01(6, 3 * 270213).reshape(-1, 3)}
 
 
-@pytest.mark.parametrize("case", ["n1", "n16", "n17", "n33", "n1000", "dup", "neg", "n270213"])
-@pytest.mark.parametrize("wide_len", [None, 64, 1 << 30])
-@pytest.mark.parametrize("sort", [None, "rocprim"])
-def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monkeypatch, case, wide_len, sort):
-    """The device build (hand-written device-wide radix sort for the long ranges + LDS bitonic sort on
-    (key, position) words for the short ones; rocPRIM's stable sorts as the cross-check) lays out exactly the tree
-    of the host build (std::stable_sort per node = R3dTree::new, src/kdtree.rs:28-58): split table and every leaf
-    slot."""
+@pytest.mark.parametrize("case", ["n1", "n16", "n17", "n33", "n1000", "n2049", "n4099", "dup", "neg", "blobs", "twins", "n270213"])
+@pytest.mark.parametrize("build", list(_KD_BUILDS))
+def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monkeypatch, case, build):
+    """Every device build lays out exactly the tree of the host build (std::stable_sort per node = R3dTree::new,
+    src/kdtree.rs:28-58): split table and every leaf slot.  The selection build (per level a bucket selection of the
+    median under the closed-form order L_d + an unordered partition; the last levels sorted in LDS) against the sorting
+    build (one stable sort per level) against rocPRIM's sorts against the host."""
     db = _kd_cases()[case]
-    host = _build(diag_ctx, db, "host", monkeypatch)  # (the host build and the knobs exist in the diagnostics build only)
-    dev = _build(diag_ctx, db, "device", monkeypatch, wide_len, sort)
+    if case == "n270213" and build not in ("select", "select_narrow512", "sorted", "sorted_rocprim"):
+        pytest.skip("the large case runs on the default borders only")
+    host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
+    dev = _build(diag_ctx, db, _KD_BUILDS[build], monkeypatch)
+    assert host.build_path() == 0
+    if build.startswith("sorted"):
+        assert dev.build_path() == 2
     assert dev.stats() == host.stats()
     hs, hl = host.download()
     ds, dl = dev.download()
     assert np.array_equal(ds, hs)
     assert np.array_equal(dl, hl)
-    if wide_len is None and sort is None:  # and the PRODUCT library's build (no knobs) is that tree too
-        prod = R3dTree.new(ctx, db)
-        ps, pl = prod.download()
-        assert prod.stats() == host.stats() and np.array_equal(ps, hs) and np.array_equal(pl, hl)
+    if build == "select":  # and the PRODUCT library's build (no knobs) is that tree too, from host and from device memory
+        for dp in (False, True):
+            prod = _build(ctx, db, {}, monkeypatch, device_pointer=dp)
+            ps, pl = prod.download()
+            assert prod.stats() == host.stats() and np.array_equal(ps, hs) and np.array_equal(pl, hl)
+            assert prod.build_path() == dev.build_path() == 1
+
+
+def test_kdtree_selection_build_finishes_degenerate_clouds(ctx, diag_ctx, monkeypatch):
+    """Clouds whose median bucket is (nearly) the whole node — one coordinate constant, a handful of distinct values,
+    every point the same, tens of thousands of values within 1e-27 of zero — cost the resolve block more narrowing rounds
+    (from global memory while the candidates exceed its LDS, component of L_d by component), nothing else: same tree."""
+    rng = np.random.default_rng(23)
+    plane = rng.uniform(-1, 1, size=(60000, 3)).astype(np.float32)
+    plane[:, 1] = 0.25  # y constant: level 1 cannot be bucketed at all
+    ties = rng.integers(0, 3, size=(50000, 3)).astype(np.float32)  # ~16 k equal keys per node at the top
+    same = np.tile(np.array([[1.5, -2.0, 0.0]], np.float32), (30000, 1))  # only the original index tells points apart
+    tiny = (uniform01(3, 3 * 70001).reshape(-1, 3) - 0.5) * np.float32(1e3)
+    tiny[::3] *= np.float32(1e-30)  # a third of the cloud within 5e-28 of the origin, all distinct
+    for db in (plane, ties, same, tiny.astype(np.float32)):
+        host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
+        hs, hl = host.download()
+        for c, env in ((ctx, {}), (diag_ctx, {"A3D_KDTREE_NARROW_LEN": "64"})):
+            t = _build(c, db, env, monkeypatch)
+            assert t.build_path() == 1
+            s_, l_ = t.download()
+            assert t.stats() == host.stats() and np.array_equal(s_, hs) and np.array_equal(l_, hl)
 
 
 @pytest.mark.parametrize("case", ["n1000", "dup", "n270213"])
 def test_kdtree_device_build_with_the_separate_scan_kernel(diag_ctx, monkeypatch, case):
     ctx = diag_ctx
-    """Above 4M keys the radix passes keep their digit-major table and one-block scan kernel instead of deriving the
-    offsets inside the scatter blocks; A3D_KDTREE_SCAN=unfused forces that form at test sizes.  Same tree."""
+    """Above 4M keys the sorting build's radix passes keep their digit-major table and one-block scan kernel instead of
+    deriving the offsets inside the scatter blocks; A3D_KDTREE_SCAN=unfused forces that form at test sizes.  Same tree."""
     db = _kd_cases()[case]
-    host = _build(ctx, db, "host", monkeypatch)
-    monkeypatch.setenv("A3D_KDTREE_SCAN", "unfused")
-    dev = _build(ctx, db, "device", monkeypatch, 64)
-    monkeypatch.delenv("A3D_KDTREE_SCAN")
+    host = _build(ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
+    dev = _build(ctx, db, {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_WIDE_LEN": "64", "A3D_KDTREE_SCAN": "unfused"}, monkeypatch)
     hs, hl = host.download()
     ds, dl = dev.download()
     assert dev.stats() == host.stats() and np.array_equal(ds, hs) and np.array_equal(dl, hl)
 
 
-def test_kdtree_device_build_nan_rules(ctx, monkeypatch):
+def test_kdtree_device_build_nan_rules(ctx, diag_ctx, monkeypatch):
     """NaN in a coordinate that gets compared is the reference's panic; one that never is compared is not."""
-    for mode in ("host", "device"):
+    for c, env in ((diag_ctx, {"A3D_KDTREE_BUILD": "host"}), (ctx, {}), (diag_ctx, {"A3D_KDTREE_BUILD": "sorted"}),
+                   (diag_ctx, {"A3D_KDTREE_NARROW_LEN": "32"})):
         db = uniform01(1, 300).reshape(100, 3)
         db[50, 2] = np.nan  # 100 points: depth 0 sorts x (100), depth 1 y (50), depth 2 z (25) -> compared
         with pytest.raises(A3dError) as e:
-            _build(ctx, db, mode, monkeypatch)
+            _build(c, db, env, monkeypatch)
         assert e.value.status == 5
         db = uniform01(1, 90).reshape(30, 3)
         db[3, 2] = np.nan  # 30 points: x at depth 0, leaves of 15 afterwards: z never compared
-        t = _build(ctx, db, mode, monkeypatch)
+        t = _build(c, db, env, monkeypatch)
         assert t.stats() == (2, 1, 1)
+        big = uniform01(2, 3 * 9000).reshape(-1, 3)
+        big[4321, 1] = np.nan  # wide levels of the selection build: y is compared at depth 1
+        with pytest.raises(A3dError) as e:
+            _build(c, big, env, monkeypatch)
+        assert e.value.status == 5
+
+
+def test_icp_from_resident_clouds_gives_the_same_bits(ctx):
+    """a3d_pcl_icp_new_device / a3d_pcl_icp_align_device (clouds already in HBM: PointCloud's layout, src/pointcloud.rs:8-12)
+    against the host-pointer forms: the same pose bits."""
+    from align3d_amd import DevicePointCloud, Icp, IcpParams, PointCloud
+    from gpu_util import to_range_image
+
+    tc = PointCloud.from_range_image(to_range_image(oracle_frame("sample1", 0, True)))
+    sc = PointCloud.from_range_image(to_range_image(oracle_frame("sample1", 1, True)))
+    prm = IcpParams(max_iterations=5)
+    ref = Icp.new(ctx, prm, tc).align(sc)
+    dt, ds = DevicePointCloud(ctx, tc), DevicePointCloud(ctx, sc)
+    icp = Icp.new(ctx, prm, dt)
+    dt.free()  # the target's arrays are read during Icp::new only
+    got = icp.align(ds)
+    again = icp.align(sc)  # a host-pointer source on an Icp made from a resident target
+    for T in (got, again):
+        assert np.array_equal(np.concatenate([T.t, T.q]).view(np.uint32), np.concatenate([ref.t, ref.q]).view(np.uint32))
+    ds.free()
