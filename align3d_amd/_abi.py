@@ -209,6 +209,7 @@ SIGNATURES = {
     "a3d_kdtree_new": (_ST, [_P, _P, C.c_uint64, _PP]),
     "a3d_kdtree_new_device": (_ST, [_P, _P, C.c_uint64, _PP]),
     "a3d_kdtree_build_path": (_ST, [_P, C.POINTER(C.c_int32)]),
+    "a3d_kdtree_build_ms": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_kdtree_nearest": (_ST, [_P, _P, C.c_uint64, _P, _P]),
     "a3d_kdtree_nearest_device": (_ST, [_P, _P, C.c_uint64, _P, _P]),
     "a3d_kdtree_free": (_ST, [_P]),

@@ -368,6 +368,12 @@ a3d_status a3d_kdtree_build_path(a3d_kdtree* t, int32_t* out_path) {
   return A3D_OK;
 }
 
+a3d_status a3d_kdtree_build_ms(a3d_kdtree* t, float* out_ms) {
+  A3D_REQUIRE(t && out_ms, A3D_INVALID_PARAMETER, "null argument");
+  *out_ms = t->build_ms;
+  return A3D_OK;
+}
+
 a3d_status a3d_kdtree_nearest_device(a3d_kdtree* t, const void* d_queries, uint64_t m, void* d_indices,
                                      void* d_sqr) {
   A3D_REQUIRE(t && (m == 0 || (d_queries && d_indices && d_sqr)), A3D_INVALID_PARAMETER, "null argument");

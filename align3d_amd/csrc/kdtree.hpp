@@ -23,6 +23,7 @@ struct a3d_kdtree {
   std::vector<float> h_split;
   std::vector<uint32_t> h_slot_of_point;  // [n] leaf slot of each original point index
   uint64_t n_leaves = 0, n_internal = 0;
+  float build_ms = 0.f;  // instrumentation: device time of the build's launches (selection build)
   int built_by = 0;  // instrumentation: 0 host build, 1 selection build (kdtree_select.hip), 2 sorting build (diagnostics)
 };
 
@@ -43,7 +44,7 @@ void kdtree_shape(uint32_t n, uint32_t* max_depth, uint64_t* n_leaves, uint64_t*
 a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points);
 // The selection build: `scratch` holds kdtree_select_scratch_bytes(n) bytes.
 size_t kdtree_select_scratch_bytes(uint32_t n);
-a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void* scratch);
+a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void* scratch, hipEvent_t done);
 // Size of the context scratch region [2] a device build of n points needs: the staged points + the temporaries.
 size_t kdtree_build_scratch_bytes(uint32_t n, uint32_t max_depth, hipStream_t s);
 // leaf_normals[slot_of_point[i]] = normals[i] (device build)

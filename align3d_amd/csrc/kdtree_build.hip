@@ -221,7 +221,15 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
   char* scratch = (char*)t->ctx->scratch[2] + pad((size_t)t->n * 12);  // behind the points the caller may have staged there
   A3D_REQUIRE(t->ctx->scratch[2] && t->ctx->scratch_size[2] >= pad((size_t)t->n * 12) + kdtree_select_scratch_bytes(t->n),
               A3D_INVALID_PARAMETER, "internal: kd-tree scratch region too small");
-  return kdtree_build_device_select(t, d_points, scratch);
+  // instrumentation (a3d_kdtree_build_ms): the build's launches between two events on the stream
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool timed = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  if (timed) hipEventRecord(e0, t->ctx->stream);
+  const a3d_status st = kdtree_build_device_select(t, d_points, scratch, timed ? e1 : nullptr);
+  if (timed && st == A3D_OK) hipEventElapsedTime(&t->build_ms, e0, e1);
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  return st;
 }
 
 #ifdef A3D_DIAGNOSTICS

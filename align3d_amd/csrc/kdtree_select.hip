@@ -26,11 +26,11 @@
 //                         [min, max], component of L_d by component, then brute-force counting among the last <= 64 —
 //                         and all of them placed; the block writes the split value, the children's boxes, adds its
 //                         points to the children's histograms and derives the children's plans.
-//   ranges of <= 2048 points: sel_narrow_kernel, ONE launch, one block per range, everything in LDS: a bitonic network
-//     on 128-bit words (L_d itself, + the position as payload) puts the range into L_d order; each further level is the
-//     network on 64-bit words `key bits << 32 | position in the range` (the position carries L_{d-1}); split values,
-//     leaf slots (+inf padding included) and slot_of_point are written from there.  Two network stages (partner
-//     distances j and j / 2) share one LDS round trip.
+//   ranges of <= 2048 points: sel_narrow_kernel, ONE launch, one block per range: a bitonic network on 128-bit words
+//     (L_d itself, + the point's position as payload) puts the range into L_d order; each further level is the network
+//     on 64-bit words `key bits << 32 | position in the range` (the position carries L_{d-1}); split values, leaf slots
+//     (+inf padding included) and slot_of_point are written from there.  A thread holds four consecutive words in
+//     registers: partner distances 1, 2 stay in the thread, 4 .. 128 are lane exchanges, only 256+ go through LDS.
 //
 // 500 k points: 21 launches instead of ~110.  Exact for every input: a degenerate cloud (one coordinate
 // constant over a node, thousands of equal points) only costs the resolve block more narrowing rounds.  The sorting
@@ -48,12 +48,12 @@ namespace {
 
 constexpr uint32_t NARROW = 2048;      // ranges up to this many points are finished inside one block
 constexpr uint32_t MIDDLE_CAP = 4096;  // candidates the resolve block holds in LDS (64 KiB); larger sets are narrowed from global memory first
-constexpr uint32_t NB_MAX = 2048;      // buckets per node and level (fewer on deep levels: ~32 points per bucket)
+constexpr uint32_t NB_MAX = 2048;      // most buckets per node and level the kernels' LDS tables hold
+constexpr uint32_t NB_DEFAULT = 2048;  // buckets per node and level (fewer on deep levels: ~32 points per bucket)
 constexpr uint32_t NSUB = 1024;        // finer buckets inside the median bucket
 constexpr uint32_t K1_THREADS = 512, K1_ROUNDS = 4, K1_TILE = K1_THREADS * K1_ROUNDS;
 constexpr uint32_t K2_THREADS = 1024;
 constexpr uint32_t PACK_THREADS = 256, PACK_ROUNDS = 4, PACK_TILE = PACK_THREADS * PACK_ROUNDS;
-constexpr uint32_t NW_THREADS = 512;   // narrow kernel: four words per thread
 
 enum : uint32_t { FLAG_NAN = 0 };
 
@@ -70,6 +70,8 @@ __device__ __forceinline__ uint32_t ord_bits(float v) {                // monoto
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float comp(const float4& r, uint32_t a) { return a == 0 ? r.x : (a == 1 ? r.y : r.z); }
+// (selects, not indexing: a dynamically indexed array of a struct held in registers goes to scratch memory)
+__device__ __forceinline__ float pick3(const float* v, uint32_t a) { return a == 0 ? v[0] : (a == 1 ? v[1] : v[2]); }
 
 // Monotone in v for fixed (lo, hi, nb): rounded subtraction, multiplication by a non-negative constant, clamp and
 // truncation all keep order, so v1 <= v2 => bucket(v1) <= bucket(v2) and equal keys share a bucket.  A degenerate or
@@ -248,6 +250,7 @@ __global__ void __launch_bounds__(K1_THREADS)
   const SelPlan plan = plans[node];
   const SelBox box = boxes[node];
   const uint32_t a = level % 3, a2 = (level + 1) % 3;
+  const float lo_a = pick3(box.lo, a), hi_a = pick3(box.hi, a), lo_a2 = pick3(box.lo, a2), hi_a2 = pick3(box.hi, a2);
   const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
   const unsigned long long lower = (1ull << lane) - 1ull;
   for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K1_THREADS) h[q] = 0u;
@@ -258,9 +261,13 @@ __global__ void __launch_bounds__(K1_THREADS)
     const uint32_t i = tile_lo + k * K1_THREADS + threadIdx.x;
     const bool valid = i < l;
     r[k] = valid ? rin[s + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+    const bool valid = tile_lo + k * K1_THREADS + threadIdx.x < l;
     const float key = canon(comp(r[k], a));
     if (valid && key != key) atomicOr(&flags[FLAG_NAN], 1u);  // partial_cmp().unwrap() would panic (kdtree.rs:43)
-    const uint32_t b = bucket_of(key, box.lo[a], box.hi[a], nb);
+    const uint32_t b = bucket_of(key, lo_a, hi_a, nb);
     cls[k] = !valid ? 3u : (b < plan.bucket ? 0u : (b > plan.bucket ? 2u : 1u));
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls[k] == 0u), m1 = __builtin_amdgcn_ballot_w64(cls[k] == 1u),
                              m2 = __builtin_amdgcn_ballot_w64(cls[k] == 2u);
@@ -274,9 +281,11 @@ __global__ void __launch_bounds__(K1_THREADS)
   }
   __syncthreads();
   // waves 0..2: exclusive prefix of class w over the 32 (round, wave) entries; the class total reserves the block's
-  // places in the node's left end / side buffer / right end
+  // places in the node's left end / side buffer / right end (one atomic with return per class: its round trip to the
+  // memory side runs under the histogram work below)
   constexpr uint32_t ENTRIES = K1_ROUNDS * (K1_THREADS / 64);
   static_assert(ENTRIES <= 64, "one wave scans the (round, wave) counts");
+  uint32_t reserved = 0;
   if (w < 3) {
     const uint32_t v = lane < ENTRIES ? wcnt[w][lane] : 0u;
     uint32_t incl = v;
@@ -286,8 +295,21 @@ __global__ void __launch_bounds__(K1_THREADS)
       if (lane >= (uint32_t)off) incl += up;
     }
     if (lane < ENTRIES) wcnt[w][lane] = incl - v;
-    if (lane == 63) base[w] = incl ? atomicAdd(&cursors[node * 4 + w], incl) : 0u;
+    if (lane == 63 && incl) reserved = atomicAdd(&cursors[node * 4 + w], incl);
   }
+  if (nb_next) {  // the points routed left / right, counted into their child's histogram along the next axis
+#pragma unroll
+    for (uint32_t k = 0; k < K1_ROUNDS; ++k)
+      if (cls[k] == 0u || cls[k] == 2u)
+        atomicAdd(&h[(cls[k] >> 1) * nb_next + bucket_of(canon(comp(r[k], a2)), lo_a2, hi_a2, nb_next)], 1u);
+    __syncthreads();
+    uint32_t* g = hist_next + (size_t)(2 * node) * nb_next;  // children 2 node, 2 node + 1: adjacent tables
+    for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K1_THREADS) {
+      const uint32_t v = h[q];
+      if (v) atomicAdd(&g[q], v);  // (executes at the memory side: contiguous lanes, contiguous words)
+    }
+  }
+  if (w < 3 && lane == 63) base[w] = reserved;
   __syncthreads();
 #pragma unroll
   for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
@@ -296,15 +318,6 @@ __global__ void __launch_bounds__(K1_THREADS)
     if (cls[k] == 0u) rout[s + off] = r[k];
     else if (cls[k] == 2u) rout[s + l - 1u - off] = r[k];
     else midbuf[s + off] = r[k];
-    if (nb_next && cls[k] != 1u)
-      atomicAdd(&h[(cls[k] >> 1) * nb_next + bucket_of(canon(comp(r[k], a2)), box.lo[a2], box.hi[a2], nb_next)], 1u);
-  }
-  if (!nb_next) return;
-  __syncthreads();
-  uint32_t* g = hist_next + (size_t)(2 * node) * nb_next;  // children 2 node, 2 node + 1: adjacent tables
-  for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K1_THREADS) {
-    const uint32_t v = h[q];
-    if (v) atomicAdd(&g[q], v);  // (executes at the memory side: contiguous lanes, contiguous words)
   }
 }
 
@@ -317,8 +330,10 @@ __device__ __forceinline__ LKey lkey_of(const float4& r, uint32_t level) {
   return LKey{ord_bits(comp(r, a)), level >= 1 ? ord_bits(comp(r, (a + 2) % 3)) : 0u,
               level >= 2 ? ord_bits(comp(r, (a + 1) % 3)) : 0u, __float_as_uint(r.w)};
 }
-__device__ __forceinline__ bool lkey_less(const LKey& p, const LKey& q) {
-  return p.k0 != q.k0 ? p.k0 < q.k0 : (p.k1 != q.k1 ? p.k1 < q.k1 : (p.k2 != q.k2 ? p.k2 < q.k2 : p.idx < q.idx));
+__device__ __forceinline__ bool lkey_less(const LKey& p, const LKey& q) {  // (branch-free: see lt128)
+  const unsigned long long ph = ((unsigned long long)p.k0 << 32) | p.k1, pl = ((unsigned long long)p.k2 << 32) | p.idx;
+  const unsigned long long qh = ((unsigned long long)q.k0 << 32) | q.k1, ql = ((unsigned long long)q.k2 << 32) | q.idx;
+  return (ph < qh) | ((ph == qh) & (pl < ql));
 }
 
 constexpr uint32_t RANK_SMALL = 64;  // a tied set this small is ranked by brute force (count the smaller ones)
@@ -363,6 +378,7 @@ __global__ void __launch_bounds__(K2_THREADS)
   const SelPlan plan = plans[node];
   const SelBox box = boxes[node];
   const uint32_t a = level % 3, a2 = (level + 1) % 3;
+  const float lo_a2 = pick3(box.lo, a2), hi_a2 = pick3(box.hi, a2);
   uint32_t* g = hist_next + (size_t)(2 * node) * nb_next;
   for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K2_THREADS) hchild[q] = g[q], g[q] = 0u;  // (zeroed for level + 2)
   if (threadIdx.x == 0) n_left = 0u, n_right = 0u;
@@ -372,7 +388,7 @@ __global__ void __launch_bounds__(K2_THREADS)
   auto emit = [&](const float4& r, bool right) {
     (right ? right_out : left_out)[atomicAdd(right ? &n_right : &n_left, 1u)] = r;
     if (nb_next)
-      atomicAdd(&hchild[(right ? nb_next : 0u) + bucket_of(canon(comp(r, a2)), box.lo[a2], box.hi[a2], nb_next)], 1u);
+      atomicAdd(&hchild[(right ? nb_next : 0u) + bucket_of(canon(comp(r, a2)), lo_a2, hi_a2, nb_next)], 1u);
   };
   // min / max of component `cmp` over the set: one LDS atomic per wave
   auto min_max = [&](auto fetch, uint32_t cnt, uint32_t cmp) {
@@ -444,191 +460,269 @@ __global__ void __launch_bounds__(K2_THREADS)
     uint16_t* sw = cur;
     cur = nxt, nxt = sw;
   }
-  // exact rank under L_d among the last candidates: count the smaller ones
-  for (uint32_t e = threadIdx.x; e < c; e += K2_THREADS) {
-    const float4 r = rec[cur[e]];
+  // exact rank under L_d among the last <= 64 candidates: one wave, a candidate per lane, every other candidate's key
+  // by v_readlane (no LDS round trip per comparison)
+  if (threadIdx.x < 64) {
+    const uint32_t e = threadIdx.x;
+    const float4 r = e < c ? rec[cur[e]] : make_float4(0.f, 0.f, 0.f, 0.f);
     const LKey ke = lkey_of(r, level);
     uint32_t rnk = 0;
-    for (uint32_t f = 0; f < c; ++f) rnk += lkey_less(lkey_of(rec[cur[f]], level), ke) ? 1u : 0u;
-    emit(r, rnk >= t);
-    if (rnk == t) split_raw = comp(r, a);  // the point of rank len / 2: `points[mid][k]` (kdtree.rs:47-49)
+    for (uint32_t f = 0; f < c; ++f) {  // (c is block-uniform)
+      const LKey kf{(uint32_t)__builtin_amdgcn_readlane((int)ke.k0, (int)f), (uint32_t)__builtin_amdgcn_readlane((int)ke.k1, (int)f),
+                    (uint32_t)__builtin_amdgcn_readlane((int)ke.k2, (int)f), (uint32_t)__builtin_amdgcn_readlane((int)ke.idx, (int)f)};
+      rnk += lkey_less(kf, ke) ? 1u : 0u;
+    }
+    if (e < c) {
+      emit(r, rnk >= t);
+      if (rnk == t) split_raw = comp(r, a);  // the point of rank len / 2: `points[mid][k]` (kdtree.rs:47-49)
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) split[((1u << level) - 1u) + node] = split_raw;
   if (!nb_next) return;  // the children are finished by the narrow kernel: no boxes or plans needed
   if (threadIdx.x < 2) {  // the children's boxes: the parent's, cut at the split value along the split axis
     SelBox cb = box;
-    if (threadIdx.x == 0) cb.hi[a] = canon(split_raw);
-    else cb.lo[a] = canon(split_raw);
+    const float m = canon(split_raw);
+#pragma unroll
+    for (uint32_t ax = 0; ax < 3; ++ax) {
+      if (ax == a && threadIdx.x == 0) cb.hi[ax] = m;
+      if (ax == a && threadIdx.x == 1) cb.lo[ax] = m;
+    }
     boxes_next[2 * node + threadIdx.x] = cb;
   }
   plan_from_hist<K2_THREADS>(hchild, nb_next, mid >> 1, &plans_next[2 * node], tmp);
   plan_from_hist<K2_THREADS>(hchild + nb_next, nb_next, (l - mid) >> 1, &plans_next[2 * node + 1], tmp);
 }
 
-// ---- ranges of <= NARROW points: all remaining levels in LDS -----------------------------------------------------------
-__device__ __forceinline__ bool lt128(const uint4& p, const uint4& q) {
-  return p.x != q.x ? p.x < q.x : (p.y != q.y ? p.y < q.y : (p.z != q.z ? p.z < q.z : p.w < q.w));
-}
+// ---- ranges of <= NARROW points: all remaining levels in one block ---------------------------------------------------
+// A sort word: `key bits << 32 | position` — the position makes every word unique and carries the previous order, so
+// the (unstable) network yields exactly the stable order.  Padding sorts last.
+typedef unsigned long long Word;
+constexpr Word WORD_PADDING = ~0ull;
 
-// Bitonic network over `total` words in cells of `cap` (powers of two, cap <= total <= 4 * NW_THREADS).  Two stages
-// (partner distances j and j / 2) share one LDS round trip: a thread owns the four words base + {0, j/2, j, 3j/2}.
-template <typename W, typename P, typename Less>
-__device__ __forceinline__ void bitonic_cells(W* w, P* pay, uint32_t total, uint32_t cap, Less less) {
-  constexpr bool HAS_PAYLOAD = !std::is_same<P, void>::value;
-  auto ce = [&](W& x, W& y, uint32_t& px, uint32_t& py, bool up) {
-    if (less(y, x) == up) {  // (words are unique: x > y  <=>  y < x)
-      const W tw = x;
-      x = y, y = tw;
-      const uint32_t tp = px;
-      px = py, py = tp;
+// Bitonic network over SLOTS words in cells of `cap` (a power of two, 32 <= cap <= SLOTS), four CONSECUTIVE words per
+// thread (word i = 4 * threadIdx.x + e) in registers on entry and exit.
+//   REGS: partner distances 1 and 2 stay inside the thread, 4 .. 128 are lane exchanges inside the wave (no barrier),
+//         256 and more go through LDS (two barriers each).
+//   else: the words live in LDS; two network stages (distances j and j / 2) share one LDS round trip: a thread owns the
+//         four words base + {0, j/2, j, 3j/2}.
+template <uint32_t SLOTS, bool REGS>
+__device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* lds) {
+  constexpr uint32_t THREADS = SLOTS / 4;
+  const uint32_t i0 = 4u * threadIdx.x;
+  auto inside = [&](Word& lo, Word& hi, bool up) {  // compare-exchange of two words one thread holds
+    if ((hi < lo) == up) {
+      const Word t = lo;
+      lo = hi, hi = t;
     }
   };
-  for (uint32_t kk = 2; kk <= cap; kk <<= 1) {
+  if (REGS) {
+    auto keep = [&](Word& own, Word other, bool want_min) {
+      if ((other < own) == want_min) own = other;  // (equal words — padding — : either way the same word stays)
+    };
+    for (uint32_t kk = 2; kk <= cap; kk <<= 1) {
+      for (uint32_t j = kk >> 1; j >= 1; j >>= 1) {
+        if (j == 1) {
+          inside(x[0], x[1], ((i0 & (cap - 1u)) & kk) == 0u);
+          inside(x[2], x[3], (((i0 + 2u) & (cap - 1u)) & kk) == 0u);
+        } else if (j == 2) {
+          const bool up = ((i0 & (cap - 1u)) & kk) == 0u;  // (kk >= 4: one direction for the thread's four words)
+          inside(x[0], x[2], up), inside(x[1], x[3], up);
+        } else {
+          const bool up = ((i0 & (cap - 1u)) & kk) == 0u;
+          const bool lower = (i0 & j) == 0u;  // this thread holds the lower index of each pair
+          if (j <= 128u) {
+            const int m = (int)(j >> 2);
+            Word y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (Word)__shfl_xor((long long)x[e], m, 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) keep(x[e], y[e], lower == up);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds[i0 + e] = x[e];
+            __syncthreads();
+            Word y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = lds[(i0 ^ j) + e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) keep(x[e], y[e], lower == up);
+          }
+        }
+      }
+    }
+    return;
+  }
+  // the first phases (kk = 2, 4: distances 1 | 2, 1) stay inside the thread, then everything through LDS
+  inside(x[0], x[1], ((i0 & (cap - 1u)) & 2u) == 0u), inside(x[2], x[3], (((i0 + 2u) & (cap - 1u)) & 2u) == 0u);
+  {
+    const bool up = ((i0 & (cap - 1u)) & 4u) == 0u;
+    inside(x[0], x[2], up), inside(x[1], x[3], up), inside(x[0], x[1], up), inside(x[2], x[3], up);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lds[i0 + e] = x[e];
+  __syncthreads();
+  for (uint32_t kk = 8; kk <= cap; kk <<= 1) {
     uint32_t j = kk >> 1;
     while (j >= 2) {
       const uint32_t hh = j >> 1, lh = 31u - (uint32_t)__builtin_clz(hh);
-      for (uint32_t q = threadIdx.x; q < (total >> 2); q += NW_THREADS) {
-        const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
-        const bool up = ((base & (cap - 1u)) & kk) == 0u;
-        W x0 = w[base], x1 = w[base + hh], x2 = w[base + j], x3 = w[base + j + hh];
-        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-        if constexpr (HAS_PAYLOAD) p0 = pay[base], p1 = pay[base + hh], p2 = pay[base + j], p3 = pay[base + j + hh];
-        ce(x0, x2, p0, p2, up), ce(x1, x3, p1, p3, up);
-        ce(x0, x1, p0, p1, up), ce(x2, x3, p2, p3, up);
-        w[base] = x0, w[base + hh] = x1, w[base + j] = x2, w[base + j + hh] = x3;
-        if constexpr (HAS_PAYLOAD) pay[base] = p0, pay[base + hh] = p1, pay[base + j] = p2, pay[base + j + hh] = p3;
-      }
+      const uint32_t q = threadIdx.x;  // SLOTS / 4 quads, one per thread
+      const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
+      const bool up = ((base & (cap - 1u)) & kk) == 0u;
+      Word a0 = lds[base], a1 = lds[base + hh], a2 = lds[base + j], a3 = lds[base + j + hh];
+      inside(a0, a2, up), inside(a1, a3, up);
+      inside(a0, a1, up), inside(a2, a3, up);
+      lds[base] = a0, lds[base + hh] = a1, lds[base + j] = a2, lds[base + j + hh] = a3;
       __syncthreads();
       j >>= 2;
     }
     if (j == 1) {
-      for (uint32_t q = threadIdx.x; q < (total >> 1); q += NW_THREADS) {
+      for (uint32_t q = threadIdx.x; q < SLOTS / 2; q += THREADS) {
         const uint32_t i = 2 * q;
-        const bool up = ((i & (cap - 1u)) & kk) == 0u;
-        W x0 = w[i], x1 = w[i + 1];
-        uint32_t p0 = 0, p1 = 0;
-        if constexpr (HAS_PAYLOAD) p0 = pay[i], p1 = pay[i + 1];
-        ce(x0, x1, p0, p1, up);
-        w[i] = x0, w[i + 1] = x1;
-        if constexpr (HAS_PAYLOAD) pay[i] = p0, pay[i + 1] = p1;
+        Word a0 = lds[i], a1 = lds[i + 1];
+        inside(a0, a1, ((i & (cap - 1u)) & kk) == 0u);
+        lds[i] = a0, lds[i + 1] = a1;
       }
       __syncthreads();
     }
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x[e] = lds[i0 + e];
+  __syncthreads();
 }
 
-constexpr size_t NW_LDS_BYTES = NARROW * (sizeof(float4) + sizeof(uint4) + sizeof(uint32_t));
+template <uint32_t SLOTS>
+constexpr size_t nw_lds_bytes() { return SLOTS * (sizeof(float4) + sizeof(Word)); }
 
-__global__ void __launch_bounds__(NW_THREADS)
+template <uint32_t SLOTS, bool REGS>
+__global__ void __launch_bounds__(SLOTS / 4)
     sel_narrow_kernel(const float4* __restrict__ recs, uint32_t n, uint32_t d0, uint32_t D, float* __restrict__ split,
                       float4* __restrict__ leaves, uint32_t* __restrict__ slot_of_point, uint32_t* __restrict__ flags) {
+  constexpr uint32_t THREADS = SLOTS / 4;  // four words per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float4* rec = (float4*)smem;                       // [NARROW]
-  uint4* w128 = (uint4*)(rec + NARROW);              // [NARROW] level d0: L_d0 as one word ...
-  unsigned long long* w64 = (unsigned long long*)w128;  // ... deeper levels: key bits << 32 | position in the range
-  uint32_t* pay = (uint32_t*)(w128 + NARROW);        // [NARROW] level d0: where the word's point was
-  constexpr uint32_t OWN = NARROW / NW_THREADS;      // positions per thread: p = threadIdx.x + k * NW_THREADS
+  float4* rec = (float4*)smem;           // [SLOTS] the range's points in their current arrangement
+  Word* xw = (Word*)(rec + SLOTS);       // [SLOTS] the network's words (or its exchange buffer)
+  // A coordinate of a point in LDS by ADDRESS (axis = dword offset in the record), never by a select on the axis:
+  // hipcc (ROCm 7.2) turns `axis == 0 ? r.x : axis == 1 ? r.y : r.z` with a wave-uniform axis inside a divergent
+  // while-loop into a ladder of scalar branches around a strength-reduced pointer, and the axis-0 arm of that pointer is
+  // left one record behind when the loop exits (observed: runs of equal x keys ranked over [lo - 1, hi - 1)).
+  const float* recf = (const float*)rec;
+  auto coord = [&](uint32_t pos, uint32_t axis) { return recf[4u * pos + axis]; };
+  auto lkey_at = [&](uint32_t pos, uint32_t level) {
+    const uint32_t ax = level % 3;
+    return LKey{ord_bits(coord(pos, ax)), level >= 1 ? ord_bits(coord(pos, (ax + 2) % 3)) : 0u,
+                level >= 2 ? ord_bits(coord(pos, (ax + 1) % 3)) : 0u, __float_as_uint(coord(pos, 3))};
+  };
   const uint32_t node0 = blockIdx.x;
   uint32_t s0, l0;
   bool exists0;
   sel_node_range(n, d0, node0, &s0, &l0, &exists0);
   uint32_t cap0 = 32;
   while (cap0 < l0) cap0 <<= 1;
-  // per owned position: the node it is in (relative start, length, path) and that node's depth
-  uint32_t rs[OWN], rl[OWN], path[OWN], depth[OWN];
-#pragma unroll
-  for (uint32_t k = 0; k < OWN; ++k) {
-    const uint32_t p = threadIdx.x + k * NW_THREADS;
-    rs[k] = 0, rl[k] = l0, path[k] = node0, depth[k] = d0;
-    if (p < l0) rec[p] = recs[s0 + p];
-  }
+  for (uint32_t p = threadIdx.x; p < l0; p += THREADS) rec[p] = recs[s0 + p];
   __syncthreads();
-  if (l0 <= 16 && d0 >= 1) {
-    // A range that already is a leaf (only with a lowered wide / narrow border: at the default one every range that
-    // arrives here is longer than 16): its points must stand in the order its parent's sort left them in, L_{d0 - 1}.
-    for (uint32_t q = threadIdx.x; q < cap0; q += NW_THREADS) {
-      uint4 word = make_uint4(~0u, ~0u, ~0u, ~0u);
-      if (q < l0) {
-        const LKey lk = lkey_of(rec[q], d0 - 1);
-        word = make_uint4(lk.k0, lk.k1, lk.k2, lk.idx);
-      }
-      w128[q] = word, pay[q] = q;
-    }
-    __syncthreads();
-    bitonic_cells<uint4, uint32_t>(w128, pay, cap0, cap0, [](const uint4& x, const uint4& y) { return lt128(x, y); });
-    float4 moved = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (threadIdx.x < l0) moved = rec[pay[threadIdx.x]];
-    __syncthreads();
-    if (threadIdx.x < l0) rec[threadIdx.x] = moved;
-    __syncthreads();
-  }
-  for (uint32_t d = d0; d < D; ++d) {
-    const uint32_t a = d % 3, rel = d - d0;
-    const uint32_t cap = cap0 >> rel;  // >= 32 wherever a range of this level is longer than 16 (ranges halve with cap)
-    if (cap < 32) break;               // everything below is a leaf
-    // words of the ranges that are sorted at this level (len > 16); everything else is padding that sorts last
-    if (d == d0) {
-      for (uint32_t q = threadIdx.x; q < cap0; q += NW_THREADS) w128[q] = make_uint4(~0u, ~0u, ~0u, ~0u), pay[q] = 0u;
-    } else {
-      for (uint32_t q = threadIdx.x; q < cap0; q += NW_THREADS) w64[q] = ~0ull;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < OWN; ++k) {
-      const uint32_t p = threadIdx.x + k * NW_THREADS;
-      if (p >= l0 || depth[k] != d || rl[k] <= 16) continue;
-      const float4 r = rec[p];
-      const float v = comp(r, a);
-      if (v != v) atomicOr(&flags[FLAG_NAN], 1u);  // partial_cmp().unwrap() would panic (kdtree.rs:43)
-      const uint32_t cell = path[k] - (node0 << rel), pos = p - rs[k];
-      if (d == d0) {
-        const LKey lk = lkey_of(r, d);
-        w128[pos] = make_uint4(lk.k0, lk.k1, lk.k2, lk.idx), pay[pos] = p;  // (one cell: cell == 0, rs == 0)
+  const uint32_t i0 = 4u * threadIdx.x;
+  // The level a range enters at finds its points in arbitrary order and has to establish L_d itself: the network on
+  // `key << 32 | current position` orders the keys, then every run of EQUAL keys (none, on ordinary data) is put into the
+  // order of the rest of L_d by counting.  (Level d0 - 1 first if the range already is a leaf — possible with a lowered
+  // wide / narrow border only: its points must stand in the order its parent's sort left them in.)  Every deeper level
+  // finds L_{d-1} in the positions and needs the network only.
+  const uint32_t first = (l0 <= 16 && d0 >= 1) ? d0 - 1 : d0;
+  for (uint32_t d = first; d < D || d == first; ++d) {
+    const bool entry = d <= d0;
+    const uint32_t a = d % 3, rel = entry ? 0u : d - d0;
+    const uint32_t cap = cap0 >> rel;
+    if (cap < 32) break;  // everything below is a leaf
+    const uint32_t cell = i0 / cap, pos0 = i0 & (cap - 1u);
+    uint32_t rs = 0, lc = 0;
+    bool sorted = false;
+    if (cell < (1u << rel)) {
+      if (entry) {
+        rs = 0, lc = l0;
+        sorted = d < d0 ? true : l0 > 16;  // (d < d0: the leaf's own order, no split below)
       } else {
-        w64[cell * cap + pos] = ((unsigned long long)ord_bits(v) << 32) | pos;
+        uint32_t sc;
+        bool ok;
+        sel_node_range(n, d, (node0 << rel) + cell, &sc, &lc, &ok);
+        rs = sc - s0;
+        sorted = ok && lc > 16;
       }
     }
-    __syncthreads();
-    if (d == d0) bitonic_cells<uint4, uint32_t>(w128, pay, cap0, cap0, [](const uint4& x, const uint4& y) { return lt128(x, y); });
-    else bitonic_cells<unsigned long long, void>(w64, (void*)nullptr, cap0, cap, [](unsigned long long x, unsigned long long y) { return x < y; });
-    // the new arrangement: position p of a sorted range takes the point its word names
-    float4 moved[OWN];
+    float4 moved[4];
+    bool mine[4];
+    Word x[4];
 #pragma unroll
-    for (uint32_t k = 0; k < OWN; ++k) {
-      const uint32_t p = threadIdx.x + k * NW_THREADS;
-      if (p >= l0 || depth[k] != d || rl[k] <= 16) continue;
-      const uint32_t cell = path[k] - (node0 << rel), pos = p - rs[k];
-      const uint32_t src = d == d0 ? pay[pos] : rs[k] + (uint32_t)w64[cell * cap + pos];
-      moved[k] = rec[src];
+    for (uint32_t e = 0; e < 4; ++e) {
+      mine[e] = sorted && pos0 + e < lc;
+      x[e] = WORD_PADDING;
+      if (mine[e]) {
+        const float v = coord(rs + pos0 + e, a);
+        if (d >= d0 && v != v) atomicOr(&flags[FLAG_NAN], 1u);  // partial_cmp().unwrap() would panic (kdtree.rs:43)
+        x[e] = ((Word)ord_bits(v) << 32) | (pos0 + e);
+      }
     }
+    bitonic_sort<SLOTS, REGS>(x, cap, xw);
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e)
+      if (mine[e]) moved[e] = rec[rs + (uint32_t)x[e]];
     __syncthreads();
 #pragma unroll
-    for (uint32_t k = 0; k < OWN; ++k) {
-      const uint32_t p = threadIdx.x + k * NW_THREADS;
-      if (p >= l0 || depth[k] != d || rl[k] <= 16) continue;
-      rec[p] = moved[k];
-      const uint32_t mid = rl[k] >> 1, pos = p - rs[k];
-      if (pos == mid) split[((1u << d) - 1u) + path[k]] = comp(moved[k], a);  // points[mid][k] (kdtree.rs:47-49)
-      if (pos < mid) rl[k] = mid, path[k] = 2 * path[k];
-      else rs[k] += mid, rl[k] -= mid, path[k] = 2 * path[k] + 1;
-      depth[k] = d + 1;
-    }
+    for (uint32_t e = 0; e < 4; ++e)
+      if (mine[e]) rec[rs + pos0 + e] = moved[e];
     __syncthreads();
+    if (entry) {  // runs of equal keys into the order of (previous axis' key, the one before, original index)
+      uint32_t* dest = (uint32_t*)xw;  // (the network's buffer is free between sorts)
+      for (uint32_t p = threadIdx.x; p < l0; p += THREADS) {
+        const uint32_t k = ord_bits(coord(p, a));
+        uint32_t lo = p, hi = p + 1;
+        while (lo > 0 && ord_bits(coord(lo - 1, a)) == k) --lo;
+        while (hi < l0 && ord_bits(coord(hi, a)) == k) ++hi;
+        uint32_t rnk = p - lo;
+        if (hi - lo > 1) {
+          const LKey me = lkey_at(p, d);
+          rnk = 0;
+          for (uint32_t q = lo; q < hi; ++q) rnk += lkey_less(lkey_at(q, d), me) ? 1u : 0u;
+        }
+        dest[p] = lo + rnk;
+      }
+      __syncthreads();
+      float4 mv[4];
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e) {
+        const uint32_t p = threadIdx.x + e * THREADS;
+        if (p < l0) mv[e] = rec[p];
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e) {
+        const uint32_t p = threadIdx.x + e * THREADS;
+        if (p < l0) rec[dest[p]] = mv[e];
+      }
+      __syncthreads();
+    }
+    if (d >= d0 && sorted) {
+      const uint32_t mid = lc >> 1;
+      if (mid >= pos0 && mid < pos0 + 4) split[((1u << d) - 1u) + (node0 << rel) + cell] = coord(rs + mid, a);  // points[mid][k] (kdtree.rs:47-49)
+    }
   }
   // leaves: slot r of the leaf reached by `path` at depth `depth` lives at (path << (D - depth)) * 16 + r (kdtree.hpp)
-#pragma unroll
-  for (uint32_t k = 0; k < OWN; ++k) {
-    const uint32_t p = threadIdx.x + k * NW_THREADS;
-    if (p >= l0) continue;
-    const uint32_t slot = (path[k] << (D - depth[k])) * 16u + (p - rs[k]);
+  for (uint32_t p = threadIdx.x; p < l0; p += THREADS) {
+    uint32_t rs = 0, rl = l0, path = node0, depth = d0;
+    while (depth < D && rl > 16) {
+      const uint32_t mid = rl >> 1;
+      if (p - rs < mid) rl = mid, path = 2 * path;
+      else rs += mid, rl -= mid, path = 2 * path + 1;
+      ++depth;
+    }
+    const uint32_t slot = (path << (D - depth)) * 16u + (p - rs);
     const float4 r = rec[p];
     leaves[slot] = r;
     slot_of_point[__float_as_uint(r.w)] = slot;
   }
   // +inf in the slots no point took, 0 in the split entries of this subtree's nodes that are leaves at depth D - 1
   const uint32_t sub = D - d0, first_leaf = node0 << sub;
-  for (uint32_t q = threadIdx.x; q < (16u << sub); q += NW_THREADS) {
+  for (uint32_t q = threadIdx.x; q < (16u << sub); q += THREADS) {
     const uint32_t P = first_leaf + (q >> 4), r = q & 15u;
     bool used;
     if (D == 0) {
@@ -644,7 +738,7 @@ __global__ void __launch_bounds__(NW_THREADS)
   }
   if (D >= 1 && D - 1 >= d0) {
     const uint32_t subm = D - 1 - d0;
-    for (uint32_t q = threadIdx.x; q < (1u << subm); q += NW_THREADS) {
+    for (uint32_t q = threadIdx.x; q < (1u << subm); q += THREADS) {
       const uint32_t pth = (node0 << subm) + q;
       uint32_t ps, pl;
       bool pe;
@@ -665,14 +759,24 @@ struct SelLayout {
 
 uint32_t max_len_at(uint32_t n, uint32_t level) { return (uint32_t)(((uint64_t)n + (1ull << level) - 1) >> level); }
 
+uint32_t buckets_setting() {
+  uint32_t v = NB_DEFAULT;
+  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_BUCKETS"))  // diagnostics build: tuning / tests
+    if (*env) v = std::min(NB_MAX, std::max(64u, (uint32_t)atoi(env)));
+  uint32_t p = 64;
+  while (p < v) p <<= 1;
+  return p;
+}
+
 SelLayout sel_layout(uint32_t n, uint32_t narrow_len) {
   SelLayout L;
   L.narrow_len = narrow_len;
   while (max_len_at(n, L.wide_levels) > narrow_len) ++L.wide_levels;
   size_t hist_words = 1;
+  const uint32_t nb_cap = buckets_setting();
   for (uint32_t d = 0; d < L.wide_levels; ++d) {
     uint32_t nb = 64;
-    while (nb < NB_MAX && nb * 32u < max_len_at(n, d)) nb <<= 1;
+    while (nb < nb_cap && nb * 32u < max_len_at(n, d)) nb <<= 1;
     L.nb[d] = nb;
     hist_words = std::max(hist_words, ((size_t)1 << d) * nb);
   }
@@ -711,7 +815,7 @@ size_t kdtree_select_scratch_bytes(uint32_t n) { return sel_layout(n, narrow_len
 
 // d_points: [n][3] f32 on the device; `scratch`: kdtree_select_scratch_bytes(n) bytes.  Fills t->d_split, t->d_leaves,
 // t->d_slot_of_point (allocated by the caller) and synchronises.
-a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void* scratch) {
+a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void* scratch, hipEvent_t done) {
   hipStream_t s = t->ctx->stream;
   const uint32_t n = t->n, D = t->max_depth;
   const SelLayout L = sel_layout(n, narrow_len_setting());
@@ -727,7 +831,6 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   static bool lds_allowed = false;  // more than 64 KiB of dynamic LDS has to be requested once per kernel
   if (!lds_allowed) {
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS_BYTES));
-    A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NW_LDS_BYTES));
     lds_allowed = true;
   }
   A3D_HIP_TRY(hipMemsetAsync(base + L.zero_begin, 0, L.zero_bytes, s));  // flags, cursors, both histogram tables
@@ -749,9 +852,21 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
                        recs[(d + 1) & 1], n, d, nb_next, plans + off, boxes + off, plans + (2 * nodes - 1u),
                        boxes + (2 * nodes - 1u), hist[(d + 1) & 1], t->d_split);
   }
-  hipLaunchKernelGGL(sel_narrow_kernel, dim3(1u << W), dim3(NW_THREADS), NW_LDS_BYTES, s, recs[W & 1], n, W, D, t->d_split,
-                     t->d_leaves, t->d_slot_of_point, flags);
+  bool regs = false;  // the network's words in LDS (measured faster: DESIGN.md); diagnostics build: A3D_KDTREE_SORTNET=regs
+  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_SORTNET")) regs = !strcmp(env, "regs");
+#define A3D_NARROW_LAUNCH(SLOTS, REGS)                                                                                  \
+  hipLaunchKernelGGL((sel_narrow_kernel<SLOTS, REGS>), dim3(1u << W), dim3(SLOTS / 4), nw_lds_bytes<SLOTS>(), s, recs[W & 1], n, \
+                     W, D, t->d_split, t->d_leaves, t->d_slot_of_point, flags)
+  if (L.narrow_len <= 1024) {
+    if (regs) A3D_NARROW_LAUNCH(1024, true);
+    else A3D_NARROW_LAUNCH(1024, false);
+  } else {
+    if (regs) A3D_NARROW_LAUNCH(2048, true);
+    else A3D_NARROW_LAUNCH(2048, false);
+  }
+#undef A3D_NARROW_LAUNCH
   A3D_HIP_TRY(hipGetLastError());
+  if (done) A3D_HIP_TRY(hipEventRecord(done, s));
   uint32_t h_flags[1] = {0};
   A3D_HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
   A3D_HIP_TRY(hipStreamSynchronize(s));

@@ -35,6 +35,12 @@ class R3dTree:
         _abi.check(self.ctx.lib.a3d_kdtree_build_path(self.handle, C.byref(v)))
         return v.value
 
+    def build_ms(self):
+        """Device time (ms) of the build's launches (a3d_kdtree_build_ms)."""
+        v = C.c_float()
+        _abi.check(self.ctx.lib.a3d_kdtree_build_ms(self.handle, C.byref(v)))
+        return v.value
+
     def nearest(self, queries):
         """R3dTree::nearest for a batch: (indices u64, squared distances f32)."""
         q = np.ascontiguousarray(queries, np.float32).reshape(-1, 3)

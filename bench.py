@@ -110,6 +110,18 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         tree = R3dTree.new(ctx, db)
         builds.append((time.perf_counter() - t0) * 1e3)
         tree.free()
+    # R3dTree::new over points that are already resident (a3d_kdtree_new_device): wall time of the call (allocation of the
+    # tree's arrays + 21 launches + the flag read-back) and the device time of its launches (events on the stream)
+    d_db = ctx.to_device(db)
+    R3dTree.new_device(ctx, d_db, n).free()
+    dev_wall, dev_kernels = [], []
+    for _ in range(9):
+        t0 = time.perf_counter()
+        tree = R3dTree.new_device(ctx, d_db, n)
+        dev_wall.append((time.perf_counter() - t0) * 1e3)
+        dev_kernels.append(tree.build_ms())
+        tree.free()
+    ctx.free(d_db)
     tree = R3dTree.new(ctx, db)
     d_q = ctx.to_device(q)
     d_i, d_d = ctx.malloc(4 * n), ctx.malloc(4 * n)
@@ -132,7 +144,14 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         "metric": "kdtree 500k queries/s (500k database, uniform [0,1)^3)",
         "value": n / (ms * 1e-3), "unit": "queries/s", "ms_per_500k_queries": ms,
         "ms_per_500k_queries_stats": stats(per),
-        "build_ms_incl_pcie": float(np.median(builds)),  # R3dTree::new from host points: upload + device sort levels
+        "build_ms_incl_pcie": float(np.median(builds)),  # R3dTree::new from host points: upload + device build
+        # benches/bench_kdtree.rs:25-27 "R3dTree creation".  Algorithmic bytes: 20 B per point and level (12 B of
+        # coordinates read, a 4-byte index read and written: what a level-by-level build moves at least) x `depth` levels
+        "build": {"device_ms": float(np.median(dev_wall)), "device_ms_stats": stats(dev_wall),
+                  "kernel_ms": float(np.median(dev_kernels)), "kernel_ms_stats": stats(dev_kernels),
+                  "launches": 5 + 2 * max(0, int(np.ceil(np.log2(max(1, n / 2048))))),
+                  "roofline": roofline(20 * n * depth, float(np.median(dev_kernels)), kernel="the selection build's launches (kdtree_select.hip), first to last",
+                                       levels=int(depth))},
         "roofline": roofline(alg_bytes, ms, traffic, src, kernel="kdtree_nearest_kernel",
                              binding_resource="L2 / Infinity Cache gather rate and latency (HBM-nominal fraction: the 8 MB leaf "
                                               "table and the 6 MB query array stay cache-resident between launches)"),
@@ -177,6 +196,21 @@ def pcl_icp_bench(ctx, n=500_000):
     ms = float(np.median(times))
     iters = 15
     alg = 252 * src.len()  # 252 B per source point per iteration
+    # the same with both clouds resident (a3d_pcl_icp_new_device / _align_device): Icp::new + align end to end, no PCIe
+    from align3d_amd import DevicePointCloud
+    dt, dsrc = DevicePointCloud(ctx, tgt), DevicePointCloud(ctx, src)
+    Icp.new(ctx, IcpParams.default(), dt).free()
+    d_new, d_align, d_both = [], [], []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        icp_d = Icp.new(ctx, IcpParams.default(), dt)
+        t1 = time.perf_counter()
+        Td = icp_d.align(dsrc)
+        t2 = time.perf_counter()
+        d_new.append((t1 - t0) * 1e3), d_align.append((t2 - t1) * 1e3), d_both.append((t2 - t0) * 1e3)
+        icp_d.free()
+    same_bits = bool(np.array_equal(np.concatenate([Td.t, Td.q]).view(np.uint32), np.concatenate([T.t, T.q]).view(np.uint32)))
+    dt.free(), dsrc.free()
     gt = synth.relative_pose(poses[0], poses[1])
     dm = np.linalg.inv(gt) @ T.matrix().astype(np.float64)
     icp.free()
@@ -185,6 +219,9 @@ def pcl_icp_bench(ctx, n=500_000):
         "workload": f"Icp::align, {tgt.len()} target x {src.len()} source points, 15 iterations (configs[2])",
         "device_ms_per_align": ms, "device_ms_per_align_stats": stats(times), "aligns_per_s": 1e3 / ms,
         "us_per_iteration": ms * 1e3 / iters, "icp_new_ms_incl_pcie": build_ms,
+        "icp_new_device_ms": float(np.median(d_new)), "align_device_wall_ms": float(np.median(d_align)),
+        "new_plus_align_device_ms": float(np.median(d_both)), "new_plus_align_device_ms_stats": stats(d_both),
+        "device_forms_give_the_same_pose_bits": same_bits,
         "align_wall_ms_incl_pcie": float(np.median(walls)),  # Icp::align from host clouds: 12 MB upload + 15 iterations
         "error_vs_synthetic_gt": {"angle_rad": float(np.arccos(np.clip((np.trace(dm[:3, :3]) - 1) / 2, -1, 1))),
                                   "translation_m": float(np.linalg.norm(dm[:3, 3]))},
@@ -427,11 +464,27 @@ def bench_icp_shape(ctx):
         wall.append((time.perf_counter() - t0) * 1e3)
         dev.append(icp.last_device_ms())
     icp.free()
+    from align3d_amd import DevicePointCloud
+    dt, dsrc = DevicePointCloud(ctx, tgt), DevicePointCloud(ctx, src)
+    Icp.new(ctx, prm, dt).free()
+    d_new, d_both = [], []
+    for _ in range(9):
+        t0 = time.perf_counter()
+        icp_d = Icp.new(ctx, prm, dt)
+        t1 = time.perf_counter()
+        Td = icp_d.align(dsrc)
+        d_new.append((t1 - t0) * 1e3), d_both.append((time.perf_counter() - t0) * 1e3)
+        icp_d.free()
+    dt.free(), dsrc.free()
+    same_bits = bool(np.array_equal(np.concatenate([Td.t, Td.q]).view(np.uint32), np.concatenate([T.t, T.q]).view(np.uint32)))
     out = {"workload": f"benches/bench_icp.rs: sample1 0 <- 5 as clouds ({tgt.len()} target x {src.len()} source points), "
                        "IcpParams{max_iterations: 10}",
            "device_ms_per_align": float(np.median(dev)), "device_ms_per_align_stats": stats(dev),
            "align_wall_ms_incl_pcie": float(np.median(wall)), "align_wall_ms_stats": stats(wall),
-           "icp_new_ms_incl_pcie": float(np.median(news)), "gpu_pose": [float(x) for x in T.matrix().reshape(-1)]}
+           "icp_new_ms_incl_pcie": float(np.median(news)), "gpu_pose": [float(x) for x in T.matrix().reshape(-1)],
+           # clouds already resident (a3d_pcl_icp_new_device / _align_device): the bench's body without the copies
+           "icp_new_device_ms": float(np.median(d_new)), "new_plus_align_device_ms": float(np.median(d_both)),
+           "new_plus_align_device_ms_stats": stats(d_both), "device_forms_give_the_same_pose_bits": same_bits}
     return out, (tgt, src)
 
 
@@ -926,8 +979,8 @@ _EXTRA_SCALARS = [
     ("msdefault_pairs_per_s", "extra.named_shapes.msdefault.pairs_per_s_batch_of_64"),
     ("msdefault_frac", "extra.named_shapes.msdefault.frac_of_8TBs_batched"),
     ("bench_icp_align_ms", "extra.named_shapes.bench_icp.device_ms_per_align"),
-    ("bench_icp_new_ms", "extra.named_shapes.bench_icp.icp_new_device_ms"),
-    ("bench_icp_new_plus_align_ms", "extra.named_shapes.bench_icp.new_plus_align_device_ms"),
+    ("bench_icp_new_device_ms", "extra.named_shapes.bench_icp.icp_new_device_ms"),
+    ("bench_icp_new_plus_align_device_ms", "extra.named_shapes.bench_icp.new_plus_align_device_ms"),
     ("kdtree_queries_per_s", "extra.kdtree.value"),
     ("kdtree_ms_per_500k_queries", "extra.kdtree.ms_per_500k_queries"),
     ("kdtree_nearest_frac", "extra.kdtree.roofline.frac"),
@@ -938,7 +991,8 @@ _EXTRA_SCALARS = [
     ("kdtree_build_ms_incl_pcie", "extra.kdtree.build_ms_incl_pcie"),
     ("pcl_icp_us_per_iteration", "extra.pcl_icp.us_per_iteration"),
     ("pcl_icp_frac", "extra.pcl_icp.roofline.frac"),
-    ("pcl_icp_new_plus_align_ms", "extra.pcl_icp.new_plus_align_device_ms"),
+    ("pcl_icp_new_device_ms", "extra.pcl_icp.icp_new_device_ms"),
+    ("pcl_icp_new_plus_align_device_ms", "extra.pcl_icp.new_plus_align_device_ms"),
     ("odometry_frames_per_s", "extra.odometry.frames_per_s"),
     ("odometry_frames_per_s_two_in_flight", "extra.odometry.two_alignments_in_flight.frames_per_s"),
     ("odometry_frames_per_s_recorded_batched", "extra.odometry.recorded_sequence_batched.frames_per_s"),

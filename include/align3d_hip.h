@@ -419,6 +419,9 @@ a3d_status a3d_kdtree_new_device(a3d_context* ctx, const void* d_points, uint64_
 /* Instrumentation: which build made the tree: 1 selection build (kdtree_select.hip: the product's); diagnostics build
  * only: 0 host build, 2 sorting build (the cross-checks). */
 a3d_status a3d_kdtree_build_path(a3d_kdtree* tree, int32_t* out_path);
+/* Instrumentation: device time (ms) of the build's launches (first kernel to last, hipEvents on the context's stream;
+ * without the upload of host points and without the allocation of the tree's arrays). */
+a3d_status a3d_kdtree_build_ms(a3d_kdtree* tree, float* out_ms);
 /* R3dTree::nearest for m queries (leaf-only search, no backtracking).  Host pointers.
  * out_indices are indices into the `points` given to a3d_kdtree_new. */
 a3d_status a3d_kdtree_nearest(a3d_kdtree* tree, const float* queries, uint64_t m,

@@ -93,7 +93,8 @@ def test_kdtree_full_size_500k_bit_exact(ctx):
     assert np.array_equal(g2, gidx) and np.array_equal(d2, gd)
 
 
-_KD_KNOBS = ("A3D_KDTREE_BUILD", "A3D_KDTREE_SORT", "A3D_KDTREE_WIDE_LEN", "A3D_KDTREE_NARROW_LEN", "A3D_KDTREE_SCAN")
+_KD_KNOBS = ("A3D_KDTREE_BUILD", "A3D_KDTREE_SORT", "A3D_KDTREE_WIDE_LEN", "A3D_KDTREE_NARROW_LEN", "A3D_KDTREE_SCAN",
+             "A3D_KDTREE_SORTNET", "A3D_KDTREE_BUCKETS")
 
 # The device builds (diagnostics build: knobs).  "select" is what the product library runs: the selection build
 # (kdtree_select.hip); NARROW_LEN makes its wide-level kernels run at test sizes; "sorted" is the sorting build (the
@@ -103,6 +104,7 @@ _KD_BUILDS = {
     "select_narrow32": {"A3D_KDTREE_NARROW_LEN": "32"},
     "select_narrow64": {"A3D_KDTREE_NARROW_LEN": "64"},
     "select_narrow512": {"A3D_KDTREE_NARROW_LEN": "512"},
+    "select_regs": {"A3D_KDTREE_SORTNET": "regs"},  # the in-block network with its words in registers / lane exchanges
     "sorted": {"A3D_KDTREE_BUILD": "sorted"},
     "sorted_wide64": {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_WIDE_LEN": "64"},
     "sorted_all_wide": {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_WIDE_LEN": str(1 << 30)},
@@ -158,7 +160,7 @@ def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monke
     median under the closed-form order L_d + an unordered partition; the last levels sorted in LDS) against the sorting
     build (one stable sort per level) against rocPRIM's sorts against the host."""
     db = _kd_cases()[case]
-    if case == "n270213" and build not in ("select", "select_narrow512", "sorted", "sorted_rocprim"):
+    if case == "n270213" and build not in ("select", "select_narrow512", "select_regs", "sorted", "sorted_rocprim"):
         pytest.skip("the large case runs on the default borders only")
     host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
     dev = _build(diag_ctx, db, _KD_BUILDS[build], monkeypatch)
@@ -176,6 +178,27 @@ def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monke
             ps, pl = prod.download()
             assert prod.stats() == host.stats() and np.array_equal(ps, hs) and np.array_equal(pl, hl)
             assert prod.build_path() == dev.build_path() == 1
+
+
+@pytest.mark.parametrize("n", [16384, 20000, 40000, 100000])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_kdtree_pairs_of_equal_coordinates_at_every_entry_axis(ctx, diag_ctx, monkeypatch, n, axis):
+    """Otherwise distinct coordinates with 400 planted pairs equal along ONE axis.  The in-block kernel takes over at
+    depth 3 / 4 / 5 / 6 for these sizes (entry axis x / y / z / x), 6 / 7 / 7 / 8 with the border at 512: every
+    combination of tie axis and entry axis, where a run of equal keys has to be put into the order of the older keys.
+    (Round 5: the x-entry case was broken by a miscompiled coordinate select and no test had equal x keys at such a
+    depth: found by the full-size run.)"""
+    rng = np.random.default_rng(5 + n + axis)
+    db = np.stack([rng.permutation(n * 4)[:n] for _ in range(3)], axis=1).astype(np.float32) / np.float32(n * 4)
+    for i in range(400):
+        db[2 * i + 1, axis] = db[2 * i, axis]
+    host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
+    hs, hl = host.download()
+    for c, env in ((ctx, {}), (diag_ctx, _KD_BUILDS["select_regs"]), (diag_ctx, _KD_BUILDS["select_narrow512"]),
+                   (diag_ctx, {"A3D_KDTREE_NARROW_LEN": "1024", "A3D_KDTREE_BUCKETS": "256"})):
+        t = _build(c, db, env, monkeypatch)
+        s_, l_ = t.download()
+        assert t.stats() == host.stats() and np.array_equal(s_, hs) and np.array_equal(l_, hl), env
 
 
 def test_kdtree_selection_build_finishes_degenerate_clouds(ctx, diag_ctx, monkeypatch):
