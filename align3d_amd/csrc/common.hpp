@@ -93,6 +93,14 @@ struct a3d_context {
   // so successive calls may reuse them): [0] frame builder temporaries, [1] bilateral grids, [2] kd-tree build.
   void* scratch[3] = {nullptr, nullptr, nullptr};
   size_t scratch_size[3] = {0, 0, 0};
+  // Device blocks handed back by freed kd-trees / Icp objects (ctx_block_release), kept for the next one of about the
+  // same size (ctx_block_alloc): Icp::new per frame then costs no hipMalloc / hipFree (each a device-wide
+  // synchronisation, ~0.1 ms).  Reuse is stream-ordered: everything on a context runs on its one stream.
+  struct SpareBlock {
+    void* p;
+    size_t bytes;
+  };
+  std::vector<SpareBlock> spare_blocks;
   // Pyramid arenas handed back by a3d_range_image_free, kept for the next frame of the same size: a frame
   // stream then costs no hipMalloc / hipFree (each of which synchronises the whole device) per frame.
   // Guarded by a mutex because an image may be freed from another thread than the one building frames.
@@ -163,6 +171,11 @@ namespace a3d {
 a3d_status ctx_side_stream(a3d_context* ctx, uint32_t index, hipStream_t* out);
 // Returns a scratch region of at least `bytes` (256-byte aligned); growing one synchronises the stream first.
 a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out);
+// A device block of at least `bytes` that outlives the call (a kd-tree's arrays, an Icp's state): a spare one of
+// bytes <= size <= 2 * bytes if the context holds one, else hipMalloc.  *out_bytes = the block's real size (pass it to
+// ctx_block_release).  Released blocks are kept (at most 8, 512 MiB) for later calls on the same context / stream.
+a3d_status ctx_block_alloc(a3d_context* ctx, size_t bytes, void** out, size_t* out_bytes);
+void ctx_block_release(a3d_context* ctx, void* p, size_t bytes);
 
 // One hipMalloc shared by the arrays of several device images (a pyramid); freed with its last user.
 struct DeviceArena {

@@ -285,6 +285,8 @@ struct a3d_pcl_icp {
   bool target_has_normals = false;
   uint32_t blocks = 0;  // block partials (= grid size of the iteration kernel)
   KdLaunch launch{};
+  void* d_block = nullptr;         // one device block (ctx_block_alloc) behind the five pointers below
+  size_t block_bytes = 0;
   JobState* d_state = nullptr;     // two buffers: the head-solve form alternates between them
   float* d_partials = nullptr;    // [2][blocks][GN_PARTIAL]
   Pose* d_out_pose = nullptr;     // what job_finish_head leaves for the host (one allocation with d_out_status)
@@ -443,15 +445,16 @@ a3d_status a3d_kdtree_download(a3d_kdtree* t, float* out_split, float* out_leave
 
 a3d_status a3d_kdtree_free(a3d_kdtree* t) {
   if (!t) return A3D_OK;
-  hipStreamSynchronize(t->ctx->stream);
-  if (t->d_block) {  // device build: one allocation
-    hipFree(t->d_block);
+  if (t->d_block) {  // device build: blocks of the context's (stream-ordered reuse: no synchronisation needed)
+    ctx_block_release(t->ctx, t->d_block, t->block_bytes);
+    ctx_block_release(t->ctx, t->d_normals_block, t->normals_block_bytes);
   } else {
+    hipStreamSynchronize(t->ctx->stream);
     hipFree(t->d_split);
     hipFree(t->d_leaves);
     hipFree(t->d_slot_of_point);
+    hipFree(t->d_leaf_normals);
   }
-  hipFree(t->d_leaf_normals);
   delete t;
   return A3D_OK;
 }
@@ -494,14 +497,22 @@ static a3d_status pcl_icp_new_impl(a3d_context* ctx, const a3d_icp_params* param
   // is fixed per Icp object (sized for a source cloud as large as the target) so the partials buffer is too
   icp->launch = kd_launch_config(t, 1ull << 31, "A3D_PCL", 1024, 15, 1);
   icp->blocks = icp->launch.blocks;
-  if (st == A3D_OK &&
-      (hipMalloc((void**)&icp->d_state, 2 * sizeof(JobState)) != hipSuccess ||
-       hipMalloc((void**)&icp->d_partials, 2 * (size_t)icp->blocks * GN_PARTIAL * sizeof(float)) != hipSuccess ||
-       hipMalloc((void**)&icp->d_out_pose, 256) != hipSuccess ||
-       hipMalloc((void**)&icp->d_readback, GN_PARTIAL * sizeof(double)) != hipSuccess ||
-       hipMalloc((void**)&icp->d_counter, sizeof(unsigned)) != hipSuccess ||
-       hipMemset(icp->d_counter, 0, sizeof(unsigned)) != hipSuccess))
-    st = A3D_HIP_ERROR;
+  if (st == A3D_OK) {  // the object's device state: one block of the context's (no hipMalloc once a previous Icp was freed)
+    auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
+    const size_t state_b = pad(2 * sizeof(JobState)), part_b = pad(2 * (size_t)icp->blocks * GN_PARTIAL * sizeof(float)),
+                 pose_b = 256, read_b = pad(GN_PARTIAL * sizeof(double)), count_b = 256;
+    char* blk = nullptr;
+    st = ctx_block_alloc(ctx, state_b + part_b + pose_b + read_b + count_b, (void**)&blk, &icp->block_bytes);
+    if (st == A3D_OK) {
+      icp->d_block = blk;
+      icp->d_state = (JobState*)blk;
+      icp->d_partials = (float*)(blk + state_b);
+      icp->d_out_pose = (Pose*)(blk + state_b + part_b);
+      icp->d_readback = (double*)(blk + state_b + part_b + pose_b);
+      icp->d_counter = (unsigned*)(blk + state_b + part_b + pose_b + read_b);
+      if (hipMemsetAsync(icp->d_counter, 0, sizeof(unsigned), ctx->stream) != hipSuccess) st = A3D_HIP_ERROR;
+    }
+  }
   if (st != A3D_OK) {
     set_error("a3d_pcl_icp_new: HIP failure: %s", hipGetErrorString(hipGetLastError()));
     a3d_pcl_icp_free(icp.release());
@@ -702,11 +713,7 @@ a3d_status a3d_pcl_icp_free(a3d_pcl_icp* icp) {
   if (!icp) return A3D_OK;
   hipStreamSynchronize(icp->ctx->stream);
   a3d_kdtree_free(icp->tree);
-  hipFree(icp->d_state);
-  hipFree(icp->d_partials);
-  hipFree(icp->d_out_pose);
-  hipFree(icp->d_counter);
-  hipFree(icp->d_readback);
+  ctx_block_release(icp->ctx, icp->d_block, icp->block_bytes);
   if (icp->ev0) hipEventDestroy(icp->ev0);
   if (icp->ev1) hipEventDestroy(icp->ev1);
   delete icp;

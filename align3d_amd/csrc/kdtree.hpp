@@ -14,7 +14,10 @@ struct a3d_kdtree {
   uint32_t max_depth = 0;      // depth of the deepest leaf
   uint32_t n_split = 0;        // heap entries: 2^max_depth - 1
   uint64_t n_leaf_slots = 0;   // 2^max_depth leaves * 16
-  void* d_block = nullptr;     // device build: ONE allocation behind d_leaves, d_split, d_slot_of_point
+  void* d_block = nullptr;     // device build: ONE block (ctx_block_alloc) behind d_leaves, d_split, d_slot_of_point
+  size_t block_bytes = 0;
+  void* d_normals_block = nullptr;  // d_leaf_normals of a device-built tree (ctx_block_alloc)
+  size_t normals_block_bytes = 0;
   float* d_split = nullptr;    // [n_split] split values, heap order (root = 0, children 2i+1, 2i+2)
   float4* d_leaves = nullptr;  // [n_leaf_slots]
   float4* d_leaf_normals = nullptr;  // same slots: {nx, ny, nz, 0} (only for Icp targets)

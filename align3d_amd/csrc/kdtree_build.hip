@@ -193,7 +193,7 @@ static a3d_status kdtree_alloc_arrays(a3d_kdtree* t) {
   auto pad256 = [](size_t b) { return ((b + 255) / 256) * 256; };
   const size_t leaves_b = pad256(n_slots * sizeof(float4)), split_b = pad256(std::max<size_t>(1, (size_t)t->n_split) * 4);
   char* block = nullptr;
-  A3D_HIP_TRY(hipMalloc((void**)&block, leaves_b + split_b + (size_t)t->n * sizeof(uint32_t)));
+  A3D_TRY(ctx_block_alloc(t->ctx, leaves_b + split_b + (size_t)t->n * sizeof(uint32_t), (void**)&block, &t->block_bytes));
   t->d_block = block;
   t->d_leaves = (float4*)block;
   t->d_split = (float*)(block + leaves_b);
@@ -347,7 +347,8 @@ static a3d_status kdtree_build_device_sorted(a3d_kdtree* t, const float* d_point
 
 a3d_status kdtree_scatter_normals_device(a3d_kdtree* t, const float* d_normals) {
   hipStream_t s = t->ctx->stream;
-  A3D_HIP_TRY(hipMalloc((void**)&t->d_leaf_normals, t->n_leaf_slots * sizeof(float4)));
+  A3D_TRY(ctx_block_alloc(t->ctx, t->n_leaf_slots * sizeof(float4), &t->d_normals_block, &t->normals_block_bytes));
+  t->d_leaf_normals = (float4*)t->d_normals_block;
   A3D_HIP_TRY(hipMemsetAsync(t->d_leaf_normals, 0, t->n_leaf_slots * sizeof(float4), s));
   hipLaunchKernelGGL(scatter_normals_kernel, grid_for(t->n), dim3(256), 0, s, d_normals, t->d_slot_of_point, t->n,
                      t->d_leaf_normals);

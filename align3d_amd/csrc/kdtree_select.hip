@@ -554,14 +554,17 @@ __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* l
     }
     return;
   }
-  // the first phases (kk = 2, 4: distances 1 | 2, 1) stay inside the thread, then everything through LDS
+  // the first phases (kk = 2, 4: distances 1 | 2, 1) stay inside the thread, then everything through LDS.  Word i lives
+  // at i + (i >> 5): one padding word per 32 keeps the quads of the short distances (8 .. 64 bytes apart in a plain
+  // layout: four-way bank conflicts on 64-bit accesses) on different banks.
+  auto at = [&](uint32_t i) -> Word& { return lds[i + (i >> 5)]; };
   inside(x[0], x[1], ((i0 & (cap - 1u)) & 2u) == 0u), inside(x[2], x[3], (((i0 + 2u) & (cap - 1u)) & 2u) == 0u);
   {
     const bool up = ((i0 & (cap - 1u)) & 4u) == 0u;
     inside(x[0], x[2], up), inside(x[1], x[3], up), inside(x[0], x[1], up), inside(x[2], x[3], up);
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) lds[i0 + e] = x[e];
+  for (int e = 0; e < 4; ++e) at(i0 + e) = x[e];
   __syncthreads();
   for (uint32_t kk = 8; kk <= cap; kk <<= 1) {
     uint32_t j = kk >> 1;
@@ -570,30 +573,30 @@ __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* l
       const uint32_t q = threadIdx.x;  // SLOTS / 4 quads, one per thread
       const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
       const bool up = ((base & (cap - 1u)) & kk) == 0u;
-      Word a0 = lds[base], a1 = lds[base + hh], a2 = lds[base + j], a3 = lds[base + j + hh];
+      Word a0 = at(base), a1 = at(base + hh), a2 = at(base + j), a3 = at(base + j + hh);
       inside(a0, a2, up), inside(a1, a3, up);
       inside(a0, a1, up), inside(a2, a3, up);
-      lds[base] = a0, lds[base + hh] = a1, lds[base + j] = a2, lds[base + j + hh] = a3;
+      at(base) = a0, at(base + hh) = a1, at(base + j) = a2, at(base + j + hh) = a3;
       __syncthreads();
       j >>= 2;
     }
     if (j == 1) {
       for (uint32_t q = threadIdx.x; q < SLOTS / 2; q += THREADS) {
         const uint32_t i = 2 * q;
-        Word a0 = lds[i], a1 = lds[i + 1];
+        Word a0 = at(i), a1 = at(i + 1);
         inside(a0, a1, ((i & (cap - 1u)) & kk) == 0u);
-        lds[i] = a0, lds[i + 1] = a1;
+        at(i) = a0, at(i + 1) = a1;
       }
       __syncthreads();
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) x[e] = lds[i0 + e];
+  for (int e = 0; e < 4; ++e) x[e] = at(i0 + e);
   __syncthreads();
 }
 
 template <uint32_t SLOTS>
-constexpr size_t nw_lds_bytes() { return SLOTS * (sizeof(float4) + sizeof(Word)); }
+constexpr size_t nw_lds_bytes() { return SLOTS * sizeof(float4) + (SLOTS + SLOTS / 32) * sizeof(Word); }
 
 template <uint32_t SLOTS, bool REGS>
 __global__ void __launch_bounds__(SLOTS / 4)
