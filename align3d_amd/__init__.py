@@ -31,7 +31,7 @@ from .context import Context  # noqa: F401
 from .icp import DevicePointCloud, Icp, ImageIcp, MultiscaleAlign, MultiscaleAlignBatch, PointCloud  # noqa: F401
 from .icp_params import IcpParams, MsIcpParams  # noqa: F401
 from .kdtree import R3dTree  # noqa: F401
-from .multi import MultiContext, MultiscaleAlignMultiBatch  # noqa: F401
+from .multi import MultiContext, MultiscaleAlignMultiBatch, device_count  # noqa: F401
 from .range_image import (CameraIntrinsics, DeviceRangeImage, RangeImage, RangeImageBuilder,  # noqa: F401
                           compute_normals_batch)
 from .transform import Transform  # noqa: F401

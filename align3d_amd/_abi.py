@@ -123,6 +123,7 @@ SIGNATURES = {
     "a3d_abi_version": (C.c_uint32, []),
     "a3d_last_error": (C.c_char_p, []),
     "a3d_status_string": (C.c_char_p, [C.c_int]),
+    "a3d_device_count": (_ST, [C.POINTER(C.c_int32)]),
     "a3d_context_create": (_ST, [C.c_int32, _PP]),
     "a3d_context_create_with_priority": (_ST, [C.c_int32, C.c_int32, _PP]),
     "a3d_context_create_pair": (_ST, [C.c_int32, _PP, _PP]),

@@ -1058,6 +1058,13 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
       continue;
     }
     if (out_grid_dims) out_grid_dims[0] = r[SC_GH], out_grid_dims[1] = r[SC_GW], out_grid_dims[2] = r[SC_GD];
+    // A3D_CAST_OVERFLOW mirrors `num::cast::cast(trilinear).unwrap()` (src/bilateral/grid.rs:129): None iff the value is
+    // NaN, <= -1 or >= 65536.  With the sigmas this entry point accepts (positive, finite or +inf) it cannot happen:
+    // every normalised cell is 0 or a weighted mean of u16 inputs (grid.rs:97-102), so it lies in [0, 65535]; the slice
+    // position of a pixel is inside the padded grid (two cells of padding on every side, edge_aware_filter.rs:64-74), so
+    // the three interpolation weights lie in [0, 1) and the trilinear value is a convex combination of such cells, off by
+    // rounding of a few ulp of 65535 (1e-11) — nowhere near 65536 or -1.  The flag is kept (the kernel computes it for
+    // free) as a guard on that argument; tests/test_gpu_frame_prep.py pins the extreme input (0 / 65535 checkerboards).
     if (r[SC_OVERFLOW]) {
       set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
       return A3D_CAST_OVERFLOW;

@@ -197,20 +197,41 @@ struct UseFence {
   std::mutex m;
   hipEvent_t ev = nullptr;
   bool recorded = false;
-  void record(hipStream_t s) {
-    std::lock_guard<std::mutex> lock(m);
+  hipStream_t deferred = nullptr;  // record_later(): the stream the event is recorded on when somebody first waits
+  void record_locked(hipStream_t s) {
     if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
       ev = nullptr;
       return;
     }
     recorded = hipEventRecord(ev, s) == hipSuccess;
   }
+  void record(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(m);
+    record_locked(s);
+  }
+  // "Whatever is on `s` by the time somebody waits": no event record on the enqueue path (a single-frame
+  // compute_normals is a 1.3 us kernel: the record cost as much as the launch); the first waiter records it, which
+  // covers this work and whatever the stream was given since — the right trade where the caller synchronises anyway.
+  void record_later(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(m);
+    deferred = s;
+  }
+  void settle_locked() {
+    if (deferred && !recorded) record_locked(deferred);
+    deferred = nullptr;
+  }
   void wait() {  // host wait: the arena is about to be handed to another stream's build
     std::lock_guard<std::mutex> lock(m);
+    settle_locked();
     if (ev && recorded) hipEventSynchronize(ev);
   }
   bool wait_on(hipStream_t s) {  // device-side wait: `s` continues after everything recorded so far
     std::lock_guard<std::mutex> lock(m);
+    if (deferred == s && !recorded) {  // the waiting stream is the one the work is on: stream order is the fence
+      deferred = nullptr;
+      return true;
+    }
+    settle_locked();
     return !(ev && recorded) || hipStreamWaitEvent(s, ev, 0) == hipSuccess;
   }
   void retire() {  // the consumer is gone (it synchronised its streams first)

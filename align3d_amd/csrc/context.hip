@@ -282,6 +282,17 @@ const char* a3d_status_string(a3d_status s) {
   return "A3D_UNKNOWN";
 }
 
+a3d_status a3d_device_count(int32_t* out_count) {
+  A3D_REQUIRE(out_count, A3D_INVALID_PARAMETER, "null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *out_count = n;
+  return A3D_OK;
+}
+
 a3d_status a3d_context_create(int32_t device_index, a3d_context** out_ctx) {
   return a3d_context_create_with_priority(device_index, 0, out_ctx);
 }

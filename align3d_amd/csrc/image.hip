@@ -113,7 +113,7 @@ a3d_status launch_compute_normals_batch(a3d_context* ctx, const NormalsBatch& ba
   return A3D_OK;
 }
 
-// Enqueue-only work of a context on images that live in arenas: ONE fence (one event record) per call, shared by the
+// Enqueue-only work of a context on images that live in arenas: ONE (lazily recorded) fence per call, shared by the
 // arenas of all the images the call touched; it replaces the fence an earlier call left on an arena (a later event on
 // the same stream covers the earlier work), so repeated calls do not pile fences up.
 void fence_self_work(a3d_context* ctx, a3d_device_image* const* images, uint64_t n) {
@@ -123,7 +123,7 @@ void fence_self_work(a3d_context* ctx, a3d_device_image* const* images, uint64_t
     if (!a) continue;
     if (!fence) {
       fence = std::make_shared<UseFence>();
-      fence->record(ctx->stream);
+      fence->record_later(ctx->stream);  // (no event on the enqueue path: UseFence::record_later)
     }
     std::lock_guard<std::mutex> lock(a->fence_mutex);
     bool replaced = false;
@@ -276,9 +276,8 @@ a3d_status a3d_range_image_compute_normals(a3d_device_image* im) {
     im->own_normals = true;
   }
   A3D_TRY(launch_compute_normals(im->ctx, im->points, im->mask, im->normals, im->width, im->height));
-  // enqueue-only: the arena must outlive the launch.  A fence is recorded right behind the launch (one event record),
-  // so that freeing the image later waits for THIS launch only — not for whatever else (the next frames' builds) has
-  // been enqueued on the context's stream by then.
+  // enqueue-only: the arena must outlive the launch.  The arena gets a fence that is recorded when somebody first waits
+  // for it (freeing the image, recycling the arena for another stream's build): nothing but the launch on this path.
   fence_self_work(im->ctx, &im, 1);
   im->has_normals = true;
   return A3D_OK;

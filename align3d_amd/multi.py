@@ -19,6 +19,13 @@ def shard_range(n_items, n_devices, device):
     return int(lo.value), int(hi.value)
 
 
+def device_count():
+    """a3d_device_count: HIP devices visible to the process (0 without a GPU)."""
+    n = C.c_int32()
+    _abi.check(_abi.load_library().a3d_device_count(C.byref(n)), "a3d_device_count")
+    return int(n.value)
+
+
 class MultiContext:
     """One Context per entry of `device_ids` (an id may repeat: several contexts on one GPU)."""
 

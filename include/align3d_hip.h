@@ -131,6 +131,8 @@ typedef struct a3d_pcl_icp a3d_pcl_icp;                 /* Icp */
  * such image is freed; a3d_range_image_free on them stays valid. */
 
 uint32_t a3d_abi_version(void);
+/* HIP devices visible to the process (0 without a GPU): the device list a3d_multi_context_create is given. */
+a3d_status a3d_device_count(int32_t* out_count);
 /* Text of the most recent failure on the calling thread ("" if none). */
 const char* a3d_last_error(void);
 const char* a3d_status_string(a3d_status s);

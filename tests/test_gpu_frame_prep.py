@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from align3d_amd import BilateralFilter
+from align3d_amd import A3dError, BilateralFilter
 from data_util import SlamTbSample, uniform01
 from gpu_util import oracle_frame, to_range_image
 
@@ -110,6 +110,30 @@ def test_bilateral_bit_exact_synthetic_and_edges(ctx):
         out = f.filter(ctx, img)
         assert st == 0 and f.last_grid_dims == dims
         assert np.array_equal(out, ref)
+
+
+def test_bilateral_cast_never_overflows_on_the_extreme_u16_inputs(ctx):
+    """`num::cast::cast(trilinear).unwrap()` (src/bilateral/grid.rs:129) panics on a value outside u16 -> A3D_CAST_OVERFLOW.
+    With positive sigmas the trilinear value is a convex combination of weighted means of u16 inputs, so the status is
+    unreachable (the argument is written out at its check in bilateral.hip); the inputs that come closest — 0 / 65535
+    checkerboards and stripes, all-65535, colour sigmas from far below one grey level to far above the range — stay
+    A3D_OK and bit-identical to the oracle, whose own cast check is the same.  Non-positive sigmas (where the reference
+    divides by them and then casts garbage) are rejected up front."""
+    yy, xx = np.mgrid[0:70, 0:90]
+    board = (((yy + xx) & 1) * 65535).astype(np.uint16)
+    stripes = ((xx // 7 & 1) * 65535).astype(np.uint16)
+    full = np.full((40, 50), 65535, np.uint16)
+    for img in (board, stripes, full):
+        for ss, sc in ((4.5, 30.0), (1.0, 0.25), (2.0, 1e6), (9.0, 65535.0)):
+            if sc < 1.0 and img.max() > 2000:
+                continue  # (a 65535 / 0.25 = 262 k-channel grid: the reference allocates 70 x 90 x 262 k cells; not a case)
+            st, ref, dims = O.bilateral(img, ss, sc)
+            out = BilateralFilter.new(ss, sc).filter(ctx, img)
+            assert st == 0 and np.array_equal(out, ref), (ss, sc)
+    for ss, sc in ((0.0, 30.0), (4.5, 0.0), (-4.5, 30.0), (4.5, -30.0), (float("nan"), 30.0), (4.5, float("nan"))):
+        with pytest.raises(A3dError) as e:
+            BilateralFilter.new(ss, sc).filter(ctx, board)
+        assert e.value.status == 1
 
 
 def test_bilateral_bit_exact_on_the_reference_known_answer_image(ctx):

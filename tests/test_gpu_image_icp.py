@@ -538,12 +538,28 @@ def test_images_may_be_freed_right_after_an_enqueue_only_align():
 def test_multi_device_batch_equals_the_single_device_batch():
     """a3d_multiscale_batch_new_multi on the one-GPU box: the device list [0] gives bit for bit the poses of
     a3d_multiscale_batch_new; the lists [0, 0] and [0, 0, 0] (several contexts = streams on the same GPU) exercise
-    the block partition, the per-device host threads and the peer-copy gather with more than one block; a parameter
-    list of the wrong length is rejected like MultiscaleAlign::new."""
+    the block partition and the per-device host threads (the gather between contexts of ONE device is not the
+    cross-device copy: that is the next test); a parameter list of the wrong length is rejected like MultiscaleAlign::new."""
+    _multi_device_batch_check([[0], [0, 0], [0, 0, 0]], P=10)
+
+
+def test_multi_device_batch_over_every_visible_device():
+    """The same over the device list the box REPORTS (a3d_device_count): contexts on different GPUs, every device's block
+    built and aligned on its own GPU, the 4x4 poses gathered onto device 0 by hipMemcpyPeerAsync — the copy that a
+    list of zeros never makes.  Skipped, not faked, where only one device is visible (this build's pool: one GPU)."""
+    from align3d_amd import device_count
+
+    n = device_count()
+    if n < 2:
+        pytest.skip(f"{n} device visible: the cross-device gather cannot run here")
+    ids = list(range(min(n, 8)))
+    _multi_device_batch_check([ids, ids[::-1]], P=2 * len(ids) + 1)
+
+
+def _multi_device_batch_check(id_lists, P):
     from align3d_amd import BilateralFilter, Context, MultiContext, MultiscaleAlignMultiBatch, RangeImageBuilder, synth
     from align3d_amd.multi import shard_range
 
-    P = 10
     frames, _ = synth.frame_stream(77, P + 1, 320, 240)
     cam = synth.camera(320, 240)
     # contractive parameters (SURVEY §10): differences of f32 association between batch shapes are not amplified
@@ -556,7 +572,7 @@ def test_multi_device_batch_equals_the_single_device_batch():
         want, want_status = batch.align()
         batch.free()
         want_bits = np.array([np.concatenate([t.t, t.q]) for t in want], np.float32).view(np.uint32)
-        for ids in ([0], [0, 0], [0, 0, 0]):
+        for ids in id_lists:
             mc = MultiContext(ids)
             assert len(mc) == len(ids)
             tp, sp = [], []

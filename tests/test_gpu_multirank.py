@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def run_bench(args, env_extra=None, timeout=900):
@@ -134,6 +135,14 @@ def test_four_fresh_ranks_keep_global_pair_order(ctx, tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
+    # the line the driver's SCALE record is made of: inside the budget, every contract key present, value = all ranks' pairs
+    import bench as bench_module
+    assert len(lines[0]) < bench_module.LINE_BUDGET_BYTES
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["scaling"] == "weak" and out["unit"] == "frame-pairs/s" and out["cpu_baseline"] is None
+    assert abs(out["value"] - N * P * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"])) <= 1e-3 * out["value"]
     assert out["n_gpus"] == N and out["config"]["ranks_in_collective"] == N and out["config"]["gathered_pairs"] == N * P
     assert out["config"]["gather_matches_local_poses"] is True and out["roofline"]["failed_pairs"] == 0
     gathered = np.load(dump)
