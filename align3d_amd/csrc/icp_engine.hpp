@@ -136,7 +136,7 @@ __device__ __forceinline__ void block_reduce_store(const float (&acc)[N], float*
 }
 
 #if defined(A3D_DIAGNOSTICS) && defined(A3D_TAIL_STAMPS)
-__device__ unsigned long long g_tail_stamps[16];
+__device__ unsigned long long g_tail_stamps[64];  // [0, 16): last-block tail; [16 + 8 * (launch parity), +8): head kernel
 #define A3D_STAMP(k)                                                                       \
   do {                                                                                     \
     if (threadIdx.x == 0 && job == 0) g_tail_stamps[k] = __builtin_amdgcn_s_memrealtime(); \

@@ -478,18 +478,33 @@ __global__ void __launch_bounds__(256, 1)
   float acc[GN_PARTIAL];
 #pragma unroll
   for (int k = 0; k < GN_PARTIAL; ++k) acc[k] = 0.0f;
+#if defined(A3D_DIAGNOSTICS) && defined(A3D_TAIL_STAMPS)
+  // s_memrealtime stamps (100 MHz) of the pair-0 block that owns the LAST tile (scripts/head_stamps.py): where one
+  // iteration's launch spends its time.  Slot base alternates with the launch so that two consecutive launches survive.
+  const bool stamping = threadIdx.x == 0 && pair == 0 && tile + 1 == gridDim.x;
+  unsigned long long* stamp = g_tail_stamps + 16 + 8 * ((states_out > states_in) ? 1 : 0);
+#define A3D_HEAD_STAMP(k) do { if (stamping) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define A3D_HEAD_STAMP(k) do { } while (0)
+#endif
+  A3D_HEAD_STAMP(0);  // kernel entry
   const LevelDesc d = descs[pair];
   const int ppt = (int)d.ppt;
   const uint32_t base = tile * (256u * (uint32_t)ppt) + threadIdx.x;
   const SrcPx s0 = pixel_source_at<ZMASK>(d, base, ppt, 0), s1 = pixel_source_at<ZMASK>(d, base, ppt, 1);
+  A3D_HEAD_STAMP(1);  // descriptor loaded, first source pixels requested
   head_advance(states_in + pair, tile == 0 ? states_out + pair : nullptr, partials_in + (size_t)pair * job_stride, head,
                pair, s_state, tile == 0);
+  A3D_HEAD_STAMP(2);  // previous iteration finished: partials summed, solve, pose update
   if ((int)s_state[15] == A3D_OK) {  // a failed job stays frozen: its blocks contribute nothing
     auto uni = [&](int k) { return __uint_as_float(__builtin_amdgcn_readfirstlane(s_state[k])); };
     const Pose T{{uni(0), uni(1), uni(2)}, {uni(3), uni(4), uni(5), uni(6)}};
     pixel_pass<ZMASK>(d, gt, T, base, ppt, s0, s1, acc);
   }
+  A3D_HEAD_STAMP(3);  // pixel pass done
   block_reduce_store<GN_PARTIAL, false>(acc, partials_out + (size_t)pair * job_stride + (size_t)tile * GN_PARTIAL);
+  A3D_HEAD_STAMP(4);  // block partial stored
+#undef A3D_HEAD_STAMP
 }
 
 #ifdef A3D_DIAGNOSTICS
@@ -2060,6 +2075,9 @@ a3d_status a3d_selftest_transform(a3d_context* ctx, const float* updates6, const
 #if defined(A3D_DIAGNOSTICS) && defined(A3D_TAIL_STAMPS)
 extern "C" int a3d_debug_tail_stamps(unsigned long long out[16]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int a3d_debug_head_stamps(unsigned long long out[16]) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 16 * sizeof(unsigned long long), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif
 

@@ -549,7 +549,10 @@ def frame_build_roofline(ctx, W, H, levels=3):
          "kernel_us_per_frame": us, "kernel_us_per_frame_stats": stats(live),
          "kernel_us_source": "live: hipEvent brackets around each chunk's kernels (2 chunks of 32 frames per build, 5 builds)",
          "profile_kernel_us_per_frame": prof_us, "profile_kernel_us_by_kernel": per_kernel, "profile_source": src,
-         "traffic": None, "achieved": alg / (us * 1e-6) / 1e9}
+         "achieved": alg / (us * 1e-6) / 1e9}
+    # fabric bytes per frame of the builder's kernels together, from the committed PMC passes (scripts/profile_round.sh)
+    r["traffic"], r["traffic_source"] = measured_traffic("frame_build", frames_per_build=32, width=W, height=H)
+    r["traffic_unit"] = "bytes/frame"
     r["frac"] = r["achieved"] / HBM_PEAK_GBS
     return r
 

@@ -22,6 +22,12 @@ __global__ void __launch_bounds__(256) k_lds(unsigned* p) {
   __syncthreads();
   if (s[(threadIdx.x + 1) & 255] == 12345u) p[0] = 1;
 }
+// holds the stream busy while the host enqueues the chain behind it: the chain then runs at the GPU's own pace
+__global__ void k_spin(unsigned* p, unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (p == nullptr) p[0] = 1;
+}
 // the real dependency: every block reads what block 0 of the predecessor wrote, block 0 writes the next value
 __global__ void __launch_bounds__(256) k_dep(unsigned* p, unsigned seq) {
   const unsigned v = __builtin_nontemporal_load(p + (seq & 1u));
@@ -62,7 +68,29 @@ int main() {
     printf("%-58s %6.2f us per launch\n", name, best * 1e3 / N);
     fflush(stdout);
   };
+  // the same chain enqueued BEHIND a 20 ms kernel (s_memrealtime ticks at 100 MHz): by the time it starts the host has
+  // long finished enqueueing, so what is measured is the GPU-side cost of a dependent same-stream boundary alone
+  auto prequeued = [&](const char* name, hipStream_t s, auto launch) {
+    const int M = 1000;
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+      hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, d, 2000000ull);
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < M; ++i) launch(s, i);
+      CK(hipEventRecord(e1, s));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms < best) best = ms;
+    }
+    printf("%-58s %6.2f us per launch (queued behind a busy stream)\n", name, best * 1e3 / M);
+    fflush(stdout);
+  };
   Arg104 a104{}; Arg1k a1k{};
+  prequeued("empty, 1 block, non-blocking", s_nb, [&](hipStream_t st, int) { hipLaunchKernelGGL(k_empty, dim3(1), dim3(256), 0, st, d); });
+  prequeued("empty, 200 blocks, non-blocking", s_nb, [&](hipStream_t st, int) { hipLaunchKernelGGL(k_empty, dim3(200), dim3(256), 0, st, d); });
+  prequeued("kernarg 104 B, 200 blocks", s_nb, [&](hipStream_t st, int) { hipLaunchKernelGGL(k_arg104, dim3(200), dim3(256), 0, st, d, a104); });
+  prequeued("reads predecessor's word, 200 blocks", s_nb, [&](hipStream_t st, int i) { hipLaunchKernelGGL(k_dep, dim3(200), dim3(256), 0, st, d, (unsigned)i); });
+  prequeued("reads predecessor's word, 38 blocks", s_nb, [&](hipStream_t st, int i) { hipLaunchKernelGGL(k_dep, dim3(38), dim3(256), 0, st, d, (unsigned)i); });
   for (auto [sname, s] : {std::pair<const char*, hipStream_t>{"null stream", nullptr}, {"hipStreamCreate", s_plain},
                            {"non-blocking", s_nb}, {"non-blocking, highest priority", s_prio}}) {
     char buf[128];
