@@ -385,11 +385,12 @@ __global__ void __launch_bounds__(K2_THREADS)
   __syncthreads();
   float4* left_out = rout + s + plan.below;  // behind the points the split kernel put at the left end
   float4* right_out = rout + s + mid;        // in front of the points it put at the right end
-  auto emit = [&](const float4& r, bool right) {
-    (right ? right_out : left_out)[atomicAdd(right ? &n_right : &n_left, 1u)] = r;
+  auto place = [&](const float4& r, bool right, uint32_t at) {  // a point at its place, counted into its child's histogram
+    (right ? right_out : left_out)[at] = r;
     if (nb_next)
       atomicAdd(&hchild[(right ? nb_next : 0u) + bucket_of(canon(comp(r, a2)), lo_a2, hi_a2, nb_next)], 1u);
   };
+  auto emit = [&](const float4& r, bool right) { place(r, right, atomicAdd(right ? &n_right : &n_left, 1u)); };
   // min / max of component `cmp` over the set: one LDS atomic per wave
   auto min_max = [&](auto fetch, uint32_t cnt, uint32_t cmp) {
     if (threadIdx.x == 0) s_mn = ~0u, s_mx = 0u;
@@ -414,16 +415,47 @@ __global__ void __launch_bounds__(K2_THREADS)
     for (uint32_t q = threadIdx.x; q < NSUB; q += K2_THREADS) hsub[q] = 0u;
     if (threadIdx.x == 0) n_keep = 0u;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cnt; i += K2_THREADS) atomicAdd(&hsub[(lkey_comp(fetch(i), level, cmp) - mn) >> sh], 1u);
+    // (a set with few distinct keys — a quantised coordinate — puts whole waves into one bucket: an LDS atomic per lane
+    // on one address is 64 serial operations; the lanes that share the first lane's bucket add as one)
+    for (uint32_t i0 = 0; i0 < cnt; i0 += K2_THREADS) {
+      const uint32_t i = i0 + threadIdx.x;
+      const bool valid = i < cnt;
+      const uint32_t b = valid ? (lkey_comp(fetch(i), level, cmp) - mn) >> sh : 0u;
+      const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
+      if (!act) continue;
+      const uint32_t lead = (uint32_t)__builtin_ctzll(act);
+      const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)lead);
+      const unsigned long long same = __builtin_amdgcn_ballot_w64(valid && b == bl);
+      if (lane_id() == lead) atomicAdd(&hsub[bl], (uint32_t)__builtin_popcountll(same));
+      else if (valid && b != bl) atomicAdd(&hsub[b], 1u);
+    }
     __syncthreads();
     plan_from_hist<K2_THREADS>(hsub, NSUB, t, &sub_plan, tmp);
     __syncthreads();
     const uint32_t star = sub_plan.bucket;
-    for (uint32_t i = threadIdx.x; i < cnt; i += K2_THREADS) {
-      const float4 r = fetch(i);
+    // places are handed out per WAVE (three ballots, one LDS atomic per class and wave-iteration, the lane's rank from
+    // the ballot) instead of one atomic per point on three shared counters
+    const uint32_t lane = lane_id();
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += K2_THREADS) {  // (block-uniform trip count)
+      const uint32_t i = i0 + threadIdx.x;
+      const bool valid = i < cnt;
+      const float4 r = valid ? fetch(i) : make_float4(0.f, 0.f, 0.f, 0.f);
       const uint32_t b = (lkey_comp(r, level, cmp) - mn) >> sh;
-      if (b == star) keep(r, i, atomicAdd(&n_keep, 1u));
-      else emit(r, b > star);
+      const uint32_t cls = !valid ? 3u : (b == star ? 0u : (b > star ? 2u : 1u));  // keep / left / right
+      const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls == 0u), m1 = __builtin_amdgcn_ballot_w64(cls == 1u),
+                               m2 = __builtin_amdgcn_ballot_w64(cls == 2u);
+      uint32_t b0 = 0, b1 = 0, b2 = 0;
+      if (lane == 0) {
+        if (m0) b0 = atomicAdd(&n_keep, (uint32_t)__builtin_popcountll(m0));
+        if (m1) b1 = atomicAdd(&n_left, (uint32_t)__builtin_popcountll(m1));
+        if (m2) b2 = atomicAdd(&n_right, (uint32_t)__builtin_popcountll(m2));
+      }
+      b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0), b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b1),
+      b2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b2);
+      if (cls == 0u) keep(r, i, b0 + (uint32_t)__builtin_popcountll(m0 & lower));
+      else if (cls == 1u) place(r, false, b1 + (uint32_t)__builtin_popcountll(m1 & lower));
+      else if (cls == 2u) place(r, true, b2 + (uint32_t)__builtin_popcountll(m2 & lower));
     }
     __syncthreads();
   };
@@ -595,8 +627,57 @@ __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* l
   __syncthreads();
 }
 
+// The same network on 128-bit words (L_d itself: key, previous axis' key, the one before, original index) with the
+// point's position as payload, words and payload in LDS: the entry level's order when the range holds long runs of equal
+// keys (a cloud from a depth image: thousands of points share a quantised z), where ranking every run by counting would
+// cost its length squared.  Branch-free comparison: a chain of `?:` compiles to a ladder of divergent branches.
+__device__ __forceinline__ bool lt128(const uint4& p, const uint4& q) {
+  const unsigned long long ph = ((unsigned long long)p.x << 32) | p.y, pl = ((unsigned long long)p.z << 32) | p.w;
+  const unsigned long long qh = ((unsigned long long)q.x << 32) | q.y, ql = ((unsigned long long)q.z << 32) | q.w;
+  return (ph < qh) | ((ph == qh) & (pl < ql));
+}
 template <uint32_t SLOTS>
-constexpr size_t nw_lds_bytes() { return SLOTS * sizeof(float4) + (SLOTS + SLOTS / 32) * sizeof(Word); }
+__device__ __forceinline__ void bitonic_lds128(uint4* w, uint32_t* pay, uint32_t cap) {
+  constexpr uint32_t THREADS = SLOTS / 4;
+  auto inside = [&](uint4& lo, uint4& hi, uint32_t& plo, uint32_t& phi, bool up) {
+    if (lt128(hi, lo) == up) {
+      const uint4 t = lo;
+      lo = hi, hi = t;
+      const uint32_t tp = plo;
+      plo = phi, phi = tp;
+    }
+  };
+  for (uint32_t kk = 2; kk <= cap; kk <<= 1) {
+    uint32_t j = kk >> 1;
+    while (j >= 2) {
+      const uint32_t hh = j >> 1, lh = 31u - (uint32_t)__builtin_clz(hh);
+      const uint32_t q = threadIdx.x;
+      const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
+      const bool up = ((base & (cap - 1u)) & kk) == 0u;
+      uint4 a0 = w[base], a1 = w[base + hh], a2 = w[base + j], a3 = w[base + j + hh];
+      uint32_t p0 = pay[base], p1 = pay[base + hh], p2 = pay[base + j], p3 = pay[base + j + hh];
+      inside(a0, a2, p0, p2, up), inside(a1, a3, p1, p3, up);
+      inside(a0, a1, p0, p1, up), inside(a2, a3, p2, p3, up);
+      w[base] = a0, w[base + hh] = a1, w[base + j] = a2, w[base + j + hh] = a3;
+      pay[base] = p0, pay[base + hh] = p1, pay[base + j] = p2, pay[base + j + hh] = p3;
+      __syncthreads();
+      j >>= 2;
+    }
+    if (j == 1) {
+      for (uint32_t q = threadIdx.x; q < SLOTS / 2; q += THREADS) {
+        const uint32_t i = 2 * q;
+        uint4 a0 = w[i], a1 = w[i + 1];
+        uint32_t p0 = pay[i], p1 = pay[i + 1];
+        inside(a0, a1, p0, p1, ((i & (cap - 1u)) & kk) == 0u);
+        w[i] = a0, w[i + 1] = a1, pay[i] = p0, pay[i + 1] = p1;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <uint32_t SLOTS>
+constexpr size_t nw_lds_bytes() { return SLOTS * (sizeof(float4) + sizeof(uint4) + 2 * sizeof(uint32_t)); }  // (>= the padded 64-bit words)
 
 template <uint32_t SLOTS, bool REGS>
 __global__ void __launch_bounds__(SLOTS / 4)
@@ -610,6 +691,7 @@ __global__ void __launch_bounds__(SLOTS / 4)
   // hipcc (ROCm 7.2) turns `axis == 0 ? r.x : axis == 1 ? r.y : r.z` with a wave-uniform axis inside a divergent
   // while-loop into a ladder of scalar branches around a strength-reduced pointer, and the axis-0 arm of that pointer is
   // left one record behind when the loop exits (observed: runs of equal x keys ranked over [lo - 1, hi - 1)).
+  __shared__ uint32_t long_runs;
   const float* recf = (const float*)rec;
   auto coord = [&](uint32_t pos, uint32_t axis) { return recf[4u * pos + axis]; };
   auto lkey_at = [&](uint32_t pos, uint32_t level) {
@@ -675,12 +757,16 @@ __global__ void __launch_bounds__(SLOTS / 4)
       if (mine[e]) rec[rs + pos0 + e] = moved[e];
     __syncthreads();
     if (entry) {  // runs of equal keys into the order of (previous axis' key, the one before, original index)
-      uint32_t* dest = (uint32_t*)xw;  // (the network's buffer is free between sorts)
+      constexpr uint32_t SHORT_RUN = 8;  // a run no longer than this on either side of a point is ranked by counting
+      uint32_t* dest = (uint32_t*)xw;    // (the network's buffer is free between sorts)
+      if (threadIdx.x == 0) long_runs = 0u;
+      __syncthreads();
       for (uint32_t p = threadIdx.x; p < l0; p += THREADS) {
         const uint32_t k = ord_bits(coord(p, a));
         uint32_t lo = p, hi = p + 1;
-        while (lo > 0 && ord_bits(coord(lo - 1, a)) == k) --lo;
-        while (hi < l0 && ord_bits(coord(hi, a)) == k) ++hi;
+        while (lo > 0 && p - lo < SHORT_RUN && ord_bits(coord(lo - 1, a)) == k) --lo;
+        while (hi < l0 && hi - p <= SHORT_RUN && ord_bits(coord(hi, a)) == k) ++hi;
+        if (p - lo >= SHORT_RUN || hi - p > SHORT_RUN) long_runs = 1u;  // (benign race: every writer stores 1)
         uint32_t rnk = p - lo;
         if (hi - lo > 1) {
           const LKey me = lkey_at(p, d);
@@ -690,6 +776,25 @@ __global__ void __launch_bounds__(SLOTS / 4)
         dest[p] = lo + rnk;
       }
       __syncthreads();
+      if (long_runs) {
+        // long runs of equal keys (a cloud from a depth image: thousands of points share a quantised z): the whole range
+        // once more through the network, on the 128-bit words of L_d, instead of run-length-squared counting
+        uint4* w128 = (uint4*)xw;
+        uint32_t* pay = (uint32_t*)(w128 + SLOTS);
+        for (uint32_t q = threadIdx.x; q < SLOTS; q += THREADS) {
+          uint4 word = make_uint4(~0u, ~0u, ~0u, ~0u);
+          if (q < l0) {
+            const LKey lk = lkey_at(q, d);
+            word = make_uint4(lk.k0, lk.k1, lk.k2, lk.idx);
+          }
+          w128[q] = word, pay[q] = q;
+        }
+        __syncthreads();
+        bitonic_lds128<SLOTS>(w128, pay, cap0);
+        dest = (uint32_t*)xw + SLOTS * 5;  // behind the 128-bit words and their payload
+        for (uint32_t q = threadIdx.x; q < l0; q += THREADS) dest[pay[q]] = q;  // the point that stood at pay[q] goes to q
+        __syncthreads();
+      }
       float4 mv[4];
 #pragma unroll
       for (uint32_t e = 0; e < 4; ++e) {
@@ -834,6 +939,8 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   static bool lds_allowed = false;  // more than 64 KiB of dynamic LDS has to be requested once per kernel
   if (!lds_allowed) {
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS_BYTES));
+    A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel<2048, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nw_lds_bytes<2048>()));
+    A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel<2048, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nw_lds_bytes<2048>()));
     lds_allowed = true;
   }
   A3D_HIP_TRY(hipMemsetAsync(base + L.zero_begin, 0, L.zero_bytes, s));  // flags, cursors, both histogram tables
