@@ -145,14 +145,21 @@ def _kd_cases():
     # exactly equal points in bulk (every key of L_d ties: the original index decides) beside distinct ones
     twins = np.repeat(uniform01(8, 3 * 3000).reshape(-1, 3), 5, axis=0)
     rng.shuffle(twins)
-    return {"n1": uniform01(1, 3).reshape(1, 3), "n16": uniform01(2, 48).reshape(16, 3),
+    # a cloud back-projected from a depth image: z quantised to 1 / 5000 m, half of the pixels on one fronto-parallel plane
+    # (tens of thousands of points with the same z), x and y on the pixel lattice scaled by z (round 5: such a cloud cost
+    # the in-block entry level 2 ms in run-length-squared counting before it sorted long runs on 128-bit words)
+    vv, uu = np.mgrid[0:200, 0:300]
+    zz = np.where((uu + vv) % 2 == 0, 2.0, np.round(rng.uniform(1.0, 4.0, size=uu.shape) * 5000) / 5000).astype(np.float32)
+    depth_cloud = np.stack([(uu - 150) * zz / 300, (vv - 100) * zz / 300, zz], axis=-1).reshape(-1, 3).astype(np.float32)
+    return {"n1": uniform01(1, 3).reshape(1, 3), "n16": uniform01(2, 48).reshape(16, 3), "depth_cloud": depth_cloud,
             "n17": uniform01(2, 51).reshape(17, 3), "n33": uniform01(4, 99).reshape(33, 3),
             "n1000": uniform01(5, 3000).reshape(1000, 3), "n2049": uniform01(7, 3 * 2049).reshape(-1, 3),
             "n4099": uniform01(9, 3 * 4099).reshape(-1, 3), "dup": dup, "neg": neg.astype(np.float32),
             "blobs": blobs, "twins": twins, "n270213": uniform01(6, 3 * 270213).reshape(-1, 3)}
 
 
-@pytest.mark.parametrize("case", ["n1", "n16", "n17", "n33", "n1000", "n2049", "n4099", "dup", "neg", "blobs", "twins", "n270213"])
+@pytest.mark.parametrize("case", ["n1", "n16", "n17", "n33", "n1000", "n2049", "n4099", "dup", "neg", "blobs", "twins", "depth_cloud",
+                                  "n270213"])
 @pytest.mark.parametrize("build", list(_KD_BUILDS))
 def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monkeypatch, case, build):
     """Every device build lays out exactly the tree of the host build (std::stable_sort per node = R3dTree::new,
