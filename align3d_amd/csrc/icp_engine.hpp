@@ -141,9 +141,17 @@ __device__ unsigned long long g_tail_stamps[64];  // [0, 16): last-block tail; [
   do {                                                                                     \
     if (threadIdx.x == 0 && job == 0) g_tail_stamps[k] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+// the head-solve path: the block of the job's LAST tile (scripts/head_stamps.py), slots 48 ..
+#define A3D_HSTAMP(k)                                                                                                  \
+  do {                                                                                                                 \
+    if (threadIdx.x == 0 && job == 0 && blockIdx.x + 1 == gridDim.x) g_tail_stamps[48 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define A3D_STAMP(k) \
   do {               \
+  } while (0)
+#define A3D_HSTAMP(k) \
+  do {                \
   } while (0)
 #endif
 
@@ -259,56 +267,72 @@ __device__ __forceinline__ Pose tail_exp_se3(const float update[6]) {
 template <bool COHERENT = false>
 __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const double* sums, const HeadArgs& a, int job,
                                                 uint32_t* s_state, JobState* st_out, bool write_trace) {
-  __shared__ double Lm[36];
   const int tid = threadIdx.x;
   auto wordf = [&](int lane) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)state_bits, lane)); };
   const int status_in = __builtin_amdgcn_readlane((int)state_bits, 15);
   uint32_t mine = state_bits;  // a frozen job, or nothing to apply: the state goes on unchanged
   if (a.mode != SOLVE_NONE && status_in == A3D_OK) {
-    const int r = tid / 6, c = tid % 6;
-    const bool cell = tid < 36;  // lane (r, c) owns matrix element [r][c]
     const bool image_mode = a.mode == SOLVE_IMAGE_ICP;
     const bool merged = a.mode == SOLVE_IMAGE_ICP_MERGED;
-    double v = 0.0;
-    if (cell) {
-      const int t = tri6(r < c ? r : c, r < c ? c : r);
-      const float hg = (float)sums[t], hc = (float)sums[GN_ACC + t];
-      // add_weighted: H = Hg w1^2 + Hc w2^2 ; weight(): H *= w^2   (all f32)
-      const float h = merged ? hg
-                             : image_mode ? hg * (a.weight * a.weight) + hc * (a.color_weight * a.color_weight)
-                                          : hg * (a.weight * a.weight);
-      v = (double)h;
-    }
+    // The lower triangle of H in registers, every lane alike (all inputs are wave-uniform): add_weighted in f32 as the
+    // reference, then the f64 factorisation column by column — sqrt of the pivot, scale the column, rank-1 update of the
+    // trailing columns: the same operations on the same operands, in the same order per element, as nalgebra's
+    // left-looking loop.  (Until round 5 one lane held one element and the operands travelled by wave shuffles: three
+    // ds_bpermute round trips per column and the factor read back from LDS by the substitutions made this the longest
+    // stretch of a lone pair's iteration — 1.5 + 0.9 us of 6.6; in registers the dependent chain is ~70 + ~40 f64
+    // operations.  Same bits: the arithmetic per element did not change.)
+    double A[6][6];  // [r][c], r >= c used
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        const int t = tri6(c, r);
+        const float hg = (float)sums[t], hc = (float)sums[GN_ACC + t];
+        // add_weighted: H = Hg w1^2 + Hc w2^2 ; weight(): H *= w^2   (all f32)
+        const float h = merged ? hg
+                               : image_mode ? hg * (a.weight * a.weight) + hc * (a.color_weight * a.color_weight)
+                                            : hg * (a.weight * a.weight);
+        A[r][c] = (double)h;
+      }
     int ok = 1;
-    const int src_c = cell ? c * 6 : 0, src_r = cell ? r * 6 : 0;
     double rinv[6];
 #ifdef A3D_DIAGNOSTICS
     double lii[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
 #endif
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const double diag = __shfl(v, k * 7, 64);
+      const double diag = A[k][k];
       if (diag == 0.0 || !(diag >= 0.0)) ok = 0;  // zero, negative or NaN pivot: Cholesky::new() == None (wave-uniform)
       double sq;
       rinv[k] = rsqrt_f64(diag, &sq);
 #ifdef A3D_DIAGNOSTICS
       if (a.exact_solve) sq = __builtin_sqrt(diag), lii[k] = sq;
-      if (a.exact_solve && cell && c == k && r > k) v = v / sq;  // nalgebra: col /= sqrt(pivot)
-      else
 #endif
-      if (cell && c == k && r > k) v = v * rinv[k];
-      if (tid == k * 7) v = sq;
-      const double lck = __shfl(v, src_c + k, 64), lrk = __shfl(v, src_r + k, 64);
+#pragma unroll
+      for (int r = k + 1; r < 6; ++r) {
 #ifdef A3D_DIAGNOSTICS
-      if (a.exact_solve && cell && c > k && r >= c) v = v - lck * lrk;
-      else
+        if (a.exact_solve) {
+          A[r][k] = A[r][k] / sq;  // nalgebra: col /= sqrt(pivot)
+          continue;
+        }
 #endif
-      if (cell && c > k && r >= c) v = __builtin_fma(-lck, lrk, v);
+        A[r][k] = A[r][k] * rinv[k];
+      }
+      A[k][k] = sq;
+#pragma unroll
+      for (int c = k + 1; c < 6; ++c)
+#pragma unroll
+        for (int r = c; r < 6; ++r) {
+#ifdef A3D_DIAGNOSTICS
+          if (a.exact_solve) {
+            A[r][c] = A[r][c] - A[c][k] * A[r][k];
+            continue;
+          }
+#endif
+          A[r][c] = __builtin_fma(-A[c][k], A[r][k], A[r][c]);
+        }
     }
-    if (cell) Lm[tid] = v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    A3D_HSTAMP(3);  // factorisation done
     float residual;
     {
       const float ssq_g = (float)sums[27], ssq_c = (float)sums[merged ? 29 : GN_ACC + 27];
@@ -328,7 +352,7 @@ __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const doubl
         const float gg = (float)sums[21 + i], gc = (float)sums[GN_ACC + 21 + i];
         bvec[i] = (double)(merged ? gg : image_mode ? gg * a.weight + gc * a.color_weight : gg * a.weight);
       }
-#define A3D_L(row, col) Lm[(row) * 6 + (col)]
+#define A3D_L(row, col) A[row][col]
 #pragma unroll
       for (int i = 0; i < 6; ++i) {  // solve_lower_triangular (column oriented)
 #ifdef A3D_DIAGNOSTICS
@@ -371,6 +395,7 @@ __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const doubl
       float update[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) update[i] = (float)bvec[i];
+      A3D_HSTAMP(4);  // substitutions done
       Pose pose{{wordf(0), wordf(1), wordf(2)}, {wordf(3), wordf(4), wordf(5), wordf(6)}};
       Pose best{{wordf(7), wordf(8), wordf(9)}, {wordf(10), wordf(11), wordf(12), wordf(13)}};
       float best_residual = wordf(14);
@@ -410,6 +435,7 @@ __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const doubl
         if (k != 15) mine = tid == k ? __float_as_uint(w[k]) : mine;
     }
   }
+  A3D_HSTAMP(5);  // pose updated
   if (tid < JOB_WORDS) {
     if (s_state) s_state[tid] = mine;
     if (st_out) {
@@ -565,6 +591,7 @@ __device__ __forceinline__ void head_sum_and_advance(uint32_t state_bits, const 
                                                      JobState* st_out = nullptr) {
   __shared__ double s_sums[8][64];
   const int tid = threadIdx.x;
+  A3D_HSTAMP(0);  // head entered
   if (h.mode != SOLVE_NONE) {
     const int cg = tid & 31, slice = tid >> 5;
     const uint32_t tiles = h.tiles;
@@ -612,6 +639,7 @@ __device__ __forceinline__ void head_sum_and_advance(uint32_t state_bits, const 
       s_sums[slice][2 * cg] = sum0;
       s_sums[slice][2 * cg + 1] = sum1;
     }
+    A3D_HSTAMP(1);  // this thread's partials loaded and added
     __syncthreads();
     if (tid < GN_PARTIAL) {
       const int c = tid;
@@ -620,8 +648,10 @@ __device__ __forceinline__ void head_sum_and_advance(uint32_t state_bits, const 
     }
     __syncthreads();
   }
+  A3D_HSTAMP(2);  // the 58 totals in LDS
   if (tid < 64) gn_advance_wave<false>(state_bits, s_sums[0], h, job, s_state, st_out, write_trace);
   __syncthreads();
+  A3D_HSTAMP(6);  // state in LDS for every thread
 }
 
 __device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st_out, const float* prev_partials,

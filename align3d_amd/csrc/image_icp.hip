@@ -2076,8 +2076,8 @@ a3d_status a3d_selftest_transform(a3d_context* ctx, const float* updates6, const
 extern "C" int a3d_debug_tail_stamps(unsigned long long out[16]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
-extern "C" int a3d_debug_head_stamps(unsigned long long out[16]) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 16 * sizeof(unsigned long long), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+extern "C" int a3d_debug_head_stamps(unsigned long long out[48]) {  // [0, 16): two launches' kernel stamps, [32, 48): inside the head
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 48 * sizeof(unsigned long long), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif
 
