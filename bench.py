@@ -149,7 +149,7 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         # coordinates read, a 4-byte index read and written: what a level-by-level build moves at least) x `depth` levels
         "build": {"device_ms": float(np.median(dev_wall)), "device_ms_stats": stats(dev_wall),
                   "kernel_ms": float(np.median(dev_kernels)), "kernel_ms_stats": stats(dev_kernels),
-                  "launches": 5 + 2 * max(0, int(np.ceil(np.log2(max(1, n / 2048))))),
+                  "launches": 5 + 2 * max(0, int(np.ceil(np.log2(max(1, n / 2048))))),  # memset, pack, hist0, plan0, 2 per wide level, narrow
                   "roofline": roofline(20 * n * depth, float(np.median(dev_kernels)), kernel="the selection build's launches (kdtree_select.hip), first to last",
                                        levels=int(depth))},
         "roofline": roofline(alg_bytes, ms, traffic, src, kernel="kdtree_nearest_kernel",
@@ -1370,6 +1370,8 @@ def main():
                 ms1.align(sources[0])
                 lat.append((time.perf_counter() - t1) * 1e3)
             extra["single_pair_ms3x15_latency_ms"] = float(np.median(lat))
+            # configs[1] as written (one pair alone): 45 dependent launches; its algorithmic bytes over its latency
+            extra["single_pair_ms3x15_frac"] = (step_alg_bytes / P) / (float(np.median(lat)) * 1e-3) / 1e9 / HBM_PEAK_GBS
             extra["single_pair_ms3x15_latency_ms_stats"] = stats(lat)
             extra["pinned_tiling"] = pinned_tiling_bench(ctx, params, targets, sources, float(np.median(lat)), ms_per_step)
             extra["drop_in_from_host_range_images"] = drop_in_bench(ctx, params, targets[0], sources[0])
