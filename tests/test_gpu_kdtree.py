@@ -208,6 +208,21 @@ def test_kdtree_pairs_of_equal_coordinates_at_every_entry_axis(ctx, diag_ctx, mo
         assert t.stats() == host.stats() and np.array_equal(s_, hs) and np.array_equal(l_, hl), env
 
 
+def test_kdtree_selection_build_at_three_million_points(ctx, diag_ctx, monkeypatch):
+    """Eleven wide levels (2048 nodes resolved per launch at the last of them), 2048 in-block ranges, histogram tables of
+    the deeper levels larger than the top one's: the sizes the 500 k benchmark does not reach.  Same tree as the host build."""
+    n = 3_000_017
+    db = uniform01(41, 3 * n).reshape(-1, 3)
+    db[::977, 2] = db[5, 2]  # ~3000 points share one z exactly
+    host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
+    hs, hl = host.download()
+    t = _build(ctx, db, {}, monkeypatch)
+    s_, l_ = t.download()
+    assert t.build_path() == 1 and t.stats() == host.stats()
+    assert np.array_equal(s_, hs) and np.array_equal(l_, hl)
+    print(f"[kd-tree build, {n} points] {t.build_ms():.3f} ms of launches")
+
+
 def test_kdtree_selection_build_finishes_degenerate_clouds(ctx, diag_ctx, monkeypatch):
     """Clouds whose median bucket is (nearly) the whole node — one coordinate constant, a handful of distinct values,
     every point the same, tens of thousands of values within 1e-27 of zero — cost the resolve block more narrowing rounds
