@@ -72,15 +72,18 @@ a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out) {
 
 a3d_status ctx_block_alloc(a3d_context* ctx, size_t bytes, void** out, size_t* out_bytes) {
   bytes = std::max<size_t>(bytes, 256);
-  size_t best = SIZE_MAX;
-  for (size_t i = 0; i < ctx->spare_blocks.size(); ++i)
-    if (ctx->spare_blocks[i].bytes >= bytes && ctx->spare_blocks[i].bytes <= 2 * bytes &&
-        (best == SIZE_MAX || ctx->spare_blocks[i].bytes < ctx->spare_blocks[best].bytes))
-      best = i;
-  if (best != SIZE_MAX) {
-    *out = ctx->spare_blocks[best].p, *out_bytes = ctx->spare_blocks[best].bytes;
-    ctx->spare_blocks.erase(ctx->spare_blocks.begin() + (long)best);
-    return A3D_OK;
+  {  // (a handle may be freed — its block released — from another thread than the one that builds: same mutex as the arena pool)
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < ctx->spare_blocks.size(); ++i)
+      if (ctx->spare_blocks[i].bytes >= bytes && ctx->spare_blocks[i].bytes <= 2 * bytes &&
+          (best == SIZE_MAX || ctx->spare_blocks[i].bytes < ctx->spare_blocks[best].bytes))
+        best = i;
+    if (best != SIZE_MAX) {
+      *out = ctx->spare_blocks[best].p, *out_bytes = ctx->spare_blocks[best].bytes;
+      ctx->spare_blocks.erase(ctx->spare_blocks.begin() + (long)best);
+      return A3D_OK;
+    }
   }
   A3D_HIP_TRY(hipMalloc(out, bytes));
   *out_bytes = bytes;
@@ -89,14 +92,17 @@ a3d_status ctx_block_alloc(a3d_context* ctx, size_t bytes, void** out, size_t* o
 
 void ctx_block_release(a3d_context* ctx, void* p, size_t bytes) {
   if (!p) return;
-  size_t held = bytes;
-  for (const auto& b : ctx->spare_blocks) held += b.bytes;
-  if (ctx->spare_blocks.size() >= 8 || held > ((size_t)512 << 20)) {
-    hipStreamSynchronize(ctx->stream);  // (what used the block was enqueued on the context's stream)
-    hipFree(p);
-    return;
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    size_t held = bytes;
+    for (const auto& b : ctx->spare_blocks) held += b.bytes;
+    if (ctx->spare_blocks.size() < 8 && held <= ((size_t)512 << 20)) {
+      ctx->spare_blocks.push_back({p, bytes});
+      return;
+    }
   }
-  ctx->spare_blocks.push_back({p, bytes});
+  hipStreamSynchronize(ctx->stream);  // (what used the block was enqueued on the context's stream)
+  hipFree(p);
 }
 
 a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void* host, size_t bytes, void** out) {

@@ -36,6 +36,7 @@
 // constant over a node, thousands of equal points) only costs the resolve block more narrowing rounds.  The sorting
 // build (kdtree_build.hip, diagnostics build) is the cross-check: same tree, bit for bit (tests/test_gpu_kdtree.py).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -936,12 +937,14 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   uint32_t* flags = (uint32_t*)(base + L.flags);
   uint32_t* cursors = (uint32_t*)(base + L.cursors);
   uint32_t* hist[2] = {(uint32_t*)(base + L.hist), (uint32_t*)(base + L.hist) + L.hist_words};
-  static bool lds_allowed = false;  // more than 64 KiB of dynamic LDS has to be requested once per kernel
-  if (!lds_allowed) {
+  // more than 64 KiB of dynamic LDS has to be requested once per kernel AND device (a process may drive several: multi.hip)
+  static std::atomic<bool> lds_allowed_on[64];
+  std::atomic<bool>& lds_allowed = lds_allowed_on[t->ctx->device & 63];
+  if (!lds_allowed.load()) {
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS_BYTES));
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel<2048, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nw_lds_bytes<2048>()));
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel<2048, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nw_lds_bytes<2048>()));
-    lds_allowed = true;
+    lds_allowed.store(true);
   }
   A3D_HIP_TRY(hipMemsetAsync(base + L.zero_begin, 0, L.zero_bytes, s));  // flags, cursors, both histogram tables
   hipLaunchKernelGGL(sel_pack_kernel, dim3(L.pack_blocks), dim3(PACK_THREADS), 0, s, d_points, n, recs[0], partials);

@@ -363,11 +363,11 @@ def pinned_tiling_bench(ctx, params, targets, sources, lone_ms_default, step_ms_
     a = np.concatenate([alone.t, alone.q]).view(np.uint32)
     b = np.concatenate([poses[5 % P].t, poses[5 % P].q]).view(np.uint32)
     step = float(np.median(reps))
-    pinned_tiling_bench.poses = poses  # for the parity leg (cpu_baseline_main: the same 64 pairs under pinned tiling)
+    # (second value: the poses, for the parity leg — cpu_baseline_main checks the same 64 pairs under pinned tiling)
     return {"tiles_per_pair": tiles, "ms_per_step": step, "ms_per_step_stats": stats(reps), "pairs_per_s": P / step * 1e3,
             "cost_vs_throughput_tiling": step / step_ms_default - 1.0,
             "lone_pair_latency_ms": float(np.median(lat)), "lone_pair_latency_ms_throughput_tiling": lone_ms_default,
-            "pair_alone_equals_pair_in_batch_bit_for_bit": bool(np.array_equal(a, b)), "failed_pairs": int(np.count_nonzero(status))}
+            "pair_alone_equals_pair_in_batch_bit_for_bit": bool(np.array_equal(a, b)), "failed_pairs": int(np.count_nonzero(status))}, poses
 
 
 def drop_in_bench(ctx, params, target_pyramid, source_pyramid, reps=15):
@@ -1358,7 +1358,7 @@ def main():
             errs.append((np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)), np.linalg.norm(d[:3, 3])))
         extra["mean_error_vs_synthetic_gt"] = {"angle_rad": float(np.mean([e[0] for e in errs])),
                                                "translation_m": float(np.mean([e[1] for e in errs]))}
-        level0_host = depth0 = clouds = bench_icp_clouds = None
+        level0_host = depth0 = clouds = bench_icp_clouds = poses_pinned = None
         if not args.no_extras and world == 1:
             # configs[1]: one pair alone on the GPU (latency-bound: 45 dependent iterations)
             ms1 = MultiscaleAlign.new(ctx, params, targets[0])
@@ -1373,7 +1373,7 @@ def main():
             # configs[1] as written (one pair alone): 45 dependent launches; its algorithmic bytes over its latency
             extra["single_pair_ms3x15_frac"] = (step_alg_bytes / P) / (float(np.median(lat)) * 1e-3) / 1e9 / HBM_PEAK_GBS
             extra["single_pair_ms3x15_latency_ms_stats"] = stats(lat)
-            extra["pinned_tiling"] = pinned_tiling_bench(ctx, params, targets, sources, float(np.median(lat)), ms_per_step)
+            extra["pinned_tiling"], poses_pinned = pinned_tiling_bench(ctx, params, targets, sources, float(np.median(lat)), ms_per_step)
             extra["drop_in_from_host_range_images"] = drop_in_bench(ctx, params, targets[0], sources[0])
             extra["drop_in_ms3x15_ms_from_host_range_images"] = extra["drop_in_from_host_range_images"]["page_locked"]["ms3x15_ms"]
             extra["named_shapes"] = named_shapes_bench(ctx, targets, sources)
@@ -1407,7 +1407,7 @@ def main():
             model, cores = cpu_info()
             cpu = cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, min(args.cpu_pairs, P), poses, cores,
                                     orders=max(1, args.cpu_orders),
-                                    gpu_poses_pinned=getattr(pinned_tiling_bench, "poses", None))
+                                    gpu_poses_pinned=poses_pinned)
             cpu["cpu_model"], cpu["compiler_flags"] = model, flags
             if level0_host is not None:
                 def oframe(dev_level):
