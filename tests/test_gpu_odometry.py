@@ -169,13 +169,19 @@ def test_alignments_in_flight_give_the_same_trajectory_bit_for_bit(ctx):
     for bit, on the 20 real sample1 frames and on a synthetic stream."""
     for ds in (SlamTbDataset.load(os.path.join(GOLDEN, "rgbd", "sample1")), SyntheticDataset(11, 9)):
         seq, m_seq = run_odometry(ctx, ds, prefetch=False)
-        for k in (2, 3):
-            pred, m = run_odometry(ctx, ds, in_flight=k)
+        # (in_flight, prefetch): without prefetch — and on the two-frame stream below — the frames used to be built on the
+        # very context lane 0 aligns on, from another thread (advisor r4): they are built on the sibling context now
+        for k, prefetch in ((2, True), (3, True), (2, False)):
+            pred, m = run_odometry(ctx, ds, in_flight=k, prefetch=prefetch)
             assert pred.len() == seq.len()
             for a, b in zip(pred.camera_to_world, seq.camera_to_world):
                 assert np.array_equal(np.asarray(a.t).view(np.uint32), np.asarray(b.t).view(np.uint32))
                 assert np.array_equal(np.asarray(a.q).view(np.uint32), np.asarray(b.q).view(np.uint32))
             assert m.angle == m_seq.angle and m.translation == m_seq.translation
+    short, _ = run_odometry(ctx, SyntheticDataset(11, 9), max_frames=2, in_flight=2)  # n < 3: no prefetch of its own
+    ref2, _ = run_odometry(ctx, SyntheticDataset(11, 9), max_frames=2, prefetch=False)
+    assert short.len() == ref2.len() == 2
+    assert np.array_equal(np.asarray(short.camera_to_world[1].t).view(np.uint32), np.asarray(ref2.camera_to_world[1].t).view(np.uint32))
 
 
 def test_masks_derived_from_z_change_nothing(ctx, diag_ctx):
