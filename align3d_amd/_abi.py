@@ -177,6 +177,7 @@ SIGNATURES = {
     "a3d_selftest_transform": (_ST, [_P, _P, _P, _P, C.c_uint64, _P, _P, _P]),
     "a3d_multiscale_new": (_ST, [_P, C.POINTER(IcpParamsC), C.c_uint64, _PP, C.c_uint64, _PP]),
     "a3d_multiscale_align": (_ST, [_P, _PP, C.c_uint64, C.POINTER(PoseC)]),
+    "a3d_multiscale_align_host": (_ST, [_P, C.POINTER(RangeImageViewC), C.c_uint64, C.POINTER(PoseC)]),
     "a3d_multiscale_free": (_ST, [_P]),
     "a3d_multiscale_batch_new": (
         _ST,

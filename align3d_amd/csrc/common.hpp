@@ -76,6 +76,9 @@ namespace a3d {
 // BilateralFilter::filter on device-resident u16 images (bilateral.hip).
 a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint16_t* d_out, uint32_t w, uint32_t h,
                                    double sigma_space, double sigma_color, uint64_t out_grid_dims[3]);
+// a3d_range_image_upload_pyramid, optionally overlapped (image.hip): see there.
+a3d_status upload_pyramid(a3d_context* ctx, const a3d_range_image_view* views, uint64_t n_levels,
+                          a3d_device_image** out_images, hipEvent_t* level_events);
 // RangeImage::compute_normals on device-resident arrays (image.hip).
 a3d_status compute_normals_device(a3d_context* ctx, const float* d_points, const uint8_t* d_mask, float* d_normals,
                                   uint32_t w, uint32_t h);

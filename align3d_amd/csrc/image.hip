@@ -165,7 +165,20 @@ extern "C" {
 // page-locked: a3d_host_alloc), one synchronisation at the end.
 a3d_status a3d_range_image_upload_pyramid(a3d_context* ctx, const a3d_range_image_view* views, uint64_t n_levels,
                                           a3d_device_image** out_images) {
+  return a3d::upload_pyramid(ctx, views, n_levels, out_images, nullptr);
+}
+
+}  // extern "C"
+
+namespace a3d {
+// level_events == nullptr: every array copied on the context's stream, complete on return (the public call).
+// level_events != nullptr (a3d_multiscale_align_host): the copies go on the context's COPY stream, coarsest level first,
+// with one event recorded behind each level's arrays (created here, destroyed by the caller) and NO wait: the alignment's
+// launches of a level wait for that level's event only, so the coarse levels iterate under the upload of the fine ones.
+a3d_status upload_pyramid(a3d_context* ctx, const a3d_range_image_view* views, uint64_t n_levels,
+                          a3d_device_image** out_images, hipEvent_t* level_events) {
   A3D_REQUIRE(ctx && views && out_images && n_levels > 0 && n_levels <= 16, A3D_INVALID_PARAMETER, "bad argument");
+  for (uint64_t l = 0; l < n_levels; ++l) out_images[l] = nullptr;
   size_t total = 0;
   auto take = [&](size_t bytes) {
     const size_t at = total;
@@ -196,12 +209,15 @@ a3d_status a3d_range_image_upload_pyramid(a3d_context* ctx, const a3d_range_imag
     return A3D_HIP_ERROR;
   }
   char* base = (char*)arena->base;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = level_events && ctx->copy_stream ? ctx->copy_stream : ctx->stream;
   bool ok = true;
   auto copy = [&](void* dst, const void* src, size_t bytes) {
     if (ok && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
   };
-  for (uint64_t l = 0; l < n_levels; ++l) {
+  if (level_events)
+    for (uint64_t l = 0; l < n_levels; ++l) level_events[l] = nullptr;
+  for (uint64_t step = 0; step < n_levels; ++step) {
+    const uint64_t l = level_events ? n_levels - 1 - step : step;  // (overlapped: the level the alignment starts with first)
     const a3d_range_image_view* v = &views[l];
     a3d_device_image* im = new a3d_device_image();
     im->ctx = ctx, im->arena = arena;
@@ -226,15 +242,27 @@ a3d_status a3d_range_image_upload_pyramid(a3d_context* ctx, const a3d_range_imag
       copy(im->imap, v->intensity_map, (size_t)(im->width + 2) * (im->height + 2) * 4);
     }
     out_images[l] = im;
+    if (level_events && ok) {
+      if (hipEventCreateWithFlags(&level_events[l], hipEventDisableTiming) != hipSuccess ||
+          hipEventRecord(level_events[l], s) != hipSuccess)
+        ok = false;
+    }
   }
-  if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+  if ((!level_events || !ok) && hipStreamSynchronize(s) != hipSuccess) ok = false;
   if (!ok) {
     set_error("a3d_range_image_upload: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-    for (uint64_t l = 0; l < n_levels; ++l) a3d_range_image_free(out_images[l]), out_images[l] = nullptr;
+    for (uint64_t l = 0; l < n_levels; ++l) {
+      if (out_images[l]) a3d_range_image_free(out_images[l]);
+      out_images[l] = nullptr;
+      if (level_events && level_events[l]) hipEventDestroy(level_events[l]), level_events[l] = nullptr;
+    }
     return A3D_HIP_ERROR;
   }
   return A3D_OK;
 }
+}  // namespace a3d
+
+extern "C" {
 
 a3d_status a3d_range_image_upload(a3d_context* ctx, const a3d_range_image_view* v, a3d_device_image** out) {
   A3D_REQUIRE(ctx && v && out, A3D_INVALID_PARAMETER, "null argument");

@@ -1021,6 +1021,7 @@ struct a3d_multiscale_batch {
   void* d_block = nullptr;  // one allocation behind every small device array below
   LevelDesc* d_descs = nullptr;
   JobState* d_states = nullptr;    // [2][P]: the launches alternate between the two (icp_engine.hpp, head-solve hand-off)
+  hipEvent_t level_ready[16] = {};  // a3d_multiscale_align_host: the launches of level l wait for this event (its upload)
   float* d_partials = nullptr;     // [2][P][max_tiles][58]
   size_t partials_capacity = 0;  // floats
   size_t partials_half = 0;      // floats per buffer
@@ -1507,6 +1508,8 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
   for (uint32_t l = first_per_iteration; l-- > 0;) {  // .rev(): coarsest level first (multiscale.rs:54-60)
     const a3d_icp_params& prm = b->params[l];
     profile_level = l;
+    if (l < 16 && b->level_ready[l])  // the level's source arrays are still on their way (a3d_multiscale_align_host)
+      for (uint32_t g = 0; g < S; ++g) A3D_HIP_TRY(hipStreamWaitEvent(g == 0 ? s : b->aux_streams[g - 1], b->level_ready[l], 0));
     if (head) {
       for (uint64_t it = 0; it < prm.max_iterations; ++it) {
         for (uint32_t g = 0; g < S; ++g) {
@@ -1708,10 +1711,18 @@ a3d_status acquire_single_engine(a3d_context* ctx, const a3d_icp_params* params,
 
 a3d_status align_single(a3d_context* ctx, const a3d_icp_params* params, uint32_t n_levels,
                         const a3d_device_image* const* targets, const a3d_device_image* const* sources,
-                        const a3d_pose* init, a3d_pose* out_pose, float* host_trace) {
+                        const a3d_pose* init, a3d_pose* out_pose, float* host_trace,
+                        const hipEvent_t* level_ready = nullptr) {
   A3D_HIP_TRY(hipSetDevice(ctx->device));  // the caller's thread may have another device current
   a3d_multiscale_batch* b = nullptr;
   A3D_TRY(acquire_single_engine(ctx, params, n_levels, &b));
+  struct ReadyGuard {  // the engine is cached with the context: the events are this call's only
+    a3d_multiscale_batch* b;
+    ~ReadyGuard() {
+      for (auto& e : b->level_ready) e = nullptr;
+    }
+  } ready_guard{b};
+  for (uint32_t l = 0; l < n_levels && l < 16; ++l) b->level_ready[l] = level_ready ? level_ready[l] : nullptr;
   for (uint32_t l = 0; l < n_levels; ++l) A3D_TRY(fill_desc(targets[l], sources[l], &b->h_descs[l]));
   A3D_TRY(batch_commit_descs(b));
   Pose* d_init = nullptr;
@@ -1881,6 +1892,32 @@ a3d_status a3d_multiscale_align(a3d_multiscale* ms, const a3d_device_image* cons
     return A3D_OK;
   }
   return align_single(ms->ctx, ms->params.data(), n, ms->targets.data(), source_pyramid, nullptr, out_pose, nullptr);
+}
+
+a3d_status a3d_multiscale_align_host(a3d_multiscale* ms, const a3d_range_image_view* source_pyramid,
+                                     uint64_t n_source_levels, a3d_pose* out_pose) {
+  A3D_REQUIRE(ms && out_pose && (source_pyramid || n_source_levels == 0), A3D_INVALID_PARAMETER, "null argument");
+  uint32_t n = (uint32_t)std::min<uint64_t>(ms->params.size(), n_source_levels);  // izip! (multiscale.rs:54-59)
+  if (n == 0) {
+    pose_to_c(pose_eye(), out_pose);
+    return A3D_OK;
+  }
+  for (uint32_t l = 0; l < n; ++l)  // the reference's expect() on the source (image_icp.rs:52-57), before anything is copied
+    A3D_REQUIRE(source_pyramid[l].intensities, A3D_MISSING_FIELD, "Please, the source image should have intensity colors.");
+  a3d_device_image* images[16] = {};
+  hipEvent_t ready[16] = {};
+  A3D_TRY(upload_pyramid(ms->ctx, source_pyramid, n, images, ready));
+  const a3d_status st = align_single(ms->ctx, ms->params.data(), n, ms->targets.data(), images, nullptr, out_pose, nullptr, ready);
+  // align_single is host-synchronous when it succeeds; after a failure wait for whatever still copies or runs
+  if (st != A3D_OK && st != A3D_SOLVE_FAILED) {
+    hipStreamSynchronize(ms->ctx->stream);
+    if (ms->ctx->copy_stream) hipStreamSynchronize(ms->ctx->copy_stream);
+  }
+  for (uint32_t l = 0; l < n; ++l) {
+    if (ready[l]) hipEventDestroy(ready[l]);
+    a3d_range_image_free(images[l]);
+  }
+  return st;
 }
 
 a3d_status a3d_multiscale_free(a3d_multiscale* ms) {

@@ -126,8 +126,16 @@ class MultiscaleAlign:
         return MultiscaleAlign(ctx, params, target_pyramid)
 
     def align(self, source_pyramid):
-        srcs = _dev_pyramid(self.ctx, source_pyramid)
+        source_pyramid = list(source_pyramid)
         out = _abi.PoseC()
+        if source_pyramid and all(isinstance(im, RangeImage) and im._device is None for im in source_pyramid):
+            # the reference's literal call: `&[RangeImage]` in host memory.  Uploaded and aligned in ONE call, the coarse
+            # levels iterating under the upload of the fine ones (a3d_multiscale_align_host); nothing stays resident
+            views = (_abi.RangeImageViewC * len(source_pyramid))(*[im.view() for im in source_pyramid])
+            _abi.check(self.ctx.lib.a3d_multiscale_align_host(self.handle, views, len(source_pyramid), C.byref(out)),
+                       "MultiscaleAlign::align")
+            return Transform.from_c(out)
+        srcs = _dev_pyramid(self.ctx, source_pyramid)
         _abi.check(self.ctx.lib.a3d_multiscale_align(self.handle, _handle_array(srcs), len(srcs), C.byref(out)),
                    "MultiscaleAlign::align")
         return Transform.from_c(out)

@@ -315,6 +315,13 @@ class MultiscaleAlign {
     check(a3d_multiscale_align(ms_, s.data(), s.size(), &out));
     return Transform::from_c(out);
   }
+  /// The reference's literal call: the source pyramid as borrowed HOST arrays (views); uploaded and aligned in one call,
+  /// the coarse levels iterating under the upload of the fine ones (a3d_multiscale_align_host).
+  Transform align_host(const std::vector<a3d_range_image_view>& source_pyramid) const {
+    a3d_pose out;
+    check(a3d_multiscale_align_host(ms_, source_pyramid.data(), source_pyramid.size(), &out));
+    return Transform::from_c(out);
+  }
 
  private:
   a3d_multiscale* ms_ = nullptr;

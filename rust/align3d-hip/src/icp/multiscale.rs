@@ -40,9 +40,26 @@ impl<'pyramid_lt> MultiscaleAlign<'pyramid_lt> {
     /// intensity map / intensities: image_icp.rs:44-57; `solve().unwrap()` on `None`: image_icp.rs:152).
     pub fn align(&self, source_pyramid: &[RangeImage]) -> Transform {
         let _ = (&self.params, self.target_pyramid, &self.device_targets);
-        let ctx = device::Context::current();
-        let sources = device::upload_pyramid(ctx, source_pyramid); // one pooled arena, freed on drop
-        let handles: Vec<*const sys::a3d_device_image> = sources.iter().map(|d| d.0 as *const _).collect();
+        for image in source_pyramid {
+            assert!(image.points.is_standard_layout() && image.mask.is_standard_layout());
+        }
+        // one call uploads and aligns: the coarse levels iterate under the upload of the fine ones
+        // (a3d_multiscale_align_host); nothing of the source stays resident, like the borrowed `&[RangeImage]`
+        let views: Vec<sys::a3d_range_image_view> = source_pyramid.iter().map(device::view_of).collect();
+        let mut pose = sys::a3d_pose::default();
+        device::check(
+            unsafe { sys::a3d_multiscale_align_host(self.handle, views.as_ptr(), views.len() as u64, &mut pose) },
+            "MultiscaleAlign::align",
+        );
+        device::transform_of(&pose)
+    }
+}
+
+impl MultiscaleAlign<'_> {
+    /// `align` for a source pyramid that is ALREADY resident (`device::upload_pyramid`, or built on the device): no
+    /// copies; what an odometry loop uses, where the source of one alignment is the target of the next.
+    pub fn align_resident(&self, source_pyramid: &[device::DeviceImage]) -> Transform {
+        let handles: Vec<*const sys::a3d_device_image> = source_pyramid.iter().map(|d| d.0 as *const _).collect();
         let mut pose = sys::a3d_pose::default();
         device::check(
             unsafe { sys::a3d_multiscale_align(self.handle, handles.as_ptr(), handles.len() as u64, &mut pose) },

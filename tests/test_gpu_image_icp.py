@@ -734,8 +734,25 @@ def test_pyramid_upload_shares_one_arena_and_changes_nothing(ctx):
     t_one = [DeviceRangeImage(ctx, im) for im in t_host]           # one upload call per level
     s_one = [DeviceRangeImage(ctx, im) for im in s_host]
     T_one = MultiscaleAlign.new(ctx, prm, t_one).align(s_one)
-    T_pyr = MultiscaleAlign.new(ctx, prm, t_host).align(s_host)    # host pyramids: upload_pyramid inside
+    # a host source pyramid: a3d_multiscale_align_host — uploaded on the copy stream coarsest level first, each level's
+    # launches behind that level's arrays only, nothing left resident (round 5) ...
+    ms_host = MultiscaleAlign.new(ctx, prm, t_host)
+    T_pyr = ms_host.align(s_host)
     assert np.array_equal(T_one.matrix(), T_pyr.matrix())
+    assert all(h._device is None for h in s_host)
+    for _ in range(4):  # ... call after call (the arena and the events of one call are gone before the next)
+        assert np.array_equal(ms_host.align(s_host).matrix(), T_one.matrix())
+    short = ms_host.align(s_host[:2])  # a shorter source pyramid truncates like izip! (multiscale.rs:54-59)
+    assert np.array_equal(short.matrix(), MultiscaleAlign.new(ctx, prm, t_one).align(s_one[:2]).matrix())
+    no_int = to_range_image(sp[0])
+    no_int.intensities = None
+    with pytest.raises(A3dError) as e:  # the reference's expect() on the source (image_icp.rs:52-57), before anything is copied
+        ms_host.align([no_int] + s_host[1:])
+    assert e.value.status == 2
+    assert np.array_equal(ms_host.align(s_host).matrix(), T_one.matrix())  # (and the context is fine afterwards)
+    # ... and the two-call form (a3d_range_image_upload_pyramid, then align on the resident images)
+    upload_pyramid(ctx, s_host)
+    assert np.array_equal(MultiscaleAlign.new(ctx, prm, t_one).align(s_host).matrix(), T_one.matrix())
     for h, f in zip(s_host, sp):
         back = h._device.download(colors=False)
         assert np.array_equal(back.points.view(np.uint32), f.points.view(np.uint32)) and np.array_equal(back.mask, f.mask)
