@@ -351,6 +351,21 @@ __device__ __forceinline__ uint32_t shift_for(uint32_t mn, uint32_t mx) {
 }
 static_assert(NSUB == 1024, "shift_for assumes 2^10 finer buckets");
 
+#ifdef A3D_TAIL_STAMPS
+__device__ unsigned long long g_sel_stamps[64];  // (time, tag << 32 | set size) pairs of one resolve block (scripts/sel_stamps.py)
+__device__ uint32_t g_sel_stamp_level = 2, g_sel_stamp_node = 0;
+#define A3D_SEL_STAMP(tag, cnt)                                                                                   \
+  do {                                                                                                            \
+    if (threadIdx.x == 0 && level == g_sel_stamp_level && node == g_sel_stamp_node && n_stamp < 32) {             \
+      g_sel_stamps[2 * n_stamp] = __builtin_amdgcn_s_memrealtime();                                               \
+      g_sel_stamps[2 * n_stamp + 1] = ((unsigned long long)(tag) << 32) | (cnt);                                  \
+      ++n_stamp;                                                                                                  \
+    }                                                                                                             \
+  } while (0)
+#else
+#define A3D_SEL_STAMP(tag, cnt) do { } while (0)
+#endif
+
 // One block per node: finds the point of rank `t` under L_d among the node's median-bucket points and places them all.
 // The set is narrowed round by round — buckets over the actual [min, max] of one component of L_d at a time (a set
 // whose points all agree in a component moves on to the next one; the original index, unique, ends it) — first from
@@ -372,11 +387,15 @@ __global__ void __launch_bounds__(K2_THREADS)
   __shared__ uint32_t n_left, n_right, n_keep, s_mn, s_mx;
   __shared__ float split_raw;
   const uint32_t node = blockIdx.x;
+#ifdef A3D_TAIL_STAMPS
+  uint32_t n_stamp = 0;
+#endif
   uint32_t s, l;
   bool exists;
   sel_node_range(n, level, node, &s, &l, &exists);
   const uint32_t mid = l >> 1;
   const SelPlan plan = plans[node];
+  A3D_SEL_STAMP(0, plan.count);
   const SelBox box = boxes[node];
   const uint32_t a = level % 3, a2 = (level + 1) % 3;
   const float lo_a2 = pick3(box.lo, a2), hi_a2 = pick3(box.hi, a2);
@@ -468,31 +487,37 @@ __global__ void __launch_bounds__(K2_THREADS)
   while (c > MIDDLE_CAP) {
     auto fetch = [&](uint32_t i) { return src[i]; };
     min_max(fetch, c, cmp);
+    A3D_SEL_STAMP(1, c);
     if (s_mn == s_mx) {  // all agree in this component of L_d: the next one decides
       ++cmp;
       continue;
     }
     round(fetch, [&](const float4& r, uint32_t, uint32_t at) { dst[at] = r; }, c, cmp, t);
     t -= sub_plan.below, c = sub_plan.count;
+    A3D_SEL_STAMP(2, c);
     float4* sw = src;
     src = dst, dst = sw;
   }
   // ---- in LDS
   for (uint32_t i = threadIdx.x; i < c; i += K2_THREADS) rec[i] = src[i], list_a[i] = (uint16_t)i;
   __syncthreads();
+  A3D_SEL_STAMP(3, c);
   uint16_t *cur = list_a, *nxt = list_b;
   while (c > RANK_SMALL) {
     auto fetch = [&](uint32_t i) { return rec[cur[i]]; };
     min_max(fetch, c, cmp);
+    A3D_SEL_STAMP(4, c);
     if (s_mn == s_mx) {
       ++cmp;
       continue;
     }
     round(fetch, [&](const float4&, uint32_t i, uint32_t at) { nxt[at] = cur[i]; }, c, cmp, t);
     t -= sub_plan.below, c = sub_plan.count;
+    A3D_SEL_STAMP(5, c);
     uint16_t* sw = cur;
     cur = nxt, nxt = sw;
   }
+  A3D_SEL_STAMP(6, c);
   // exact rank under L_d among the last <= 64 candidates: one wave, a candidate per lane, every other candidate's key
   // by v_readlane (no LDS round trip per comparison)
   if (threadIdx.x < 64) {
@@ -511,6 +536,7 @@ __global__ void __launch_bounds__(K2_THREADS)
     }
   }
   __syncthreads();
+  A3D_SEL_STAMP(7, c);
   if (threadIdx.x == 0) split[((1u << level) - 1u) + node] = split_raw;
   if (!nb_next) return;  // the children are finished by the narrow kernel: no boxes or plans needed
   if (threadIdx.x < 2) {  // the children's boxes: the parent's, cut at the split value along the split axis
@@ -525,6 +551,7 @@ __global__ void __launch_bounds__(K2_THREADS)
   }
   plan_from_hist<K2_THREADS>(hchild, nb_next, mid >> 1, &plans_next[2 * node], tmp);
   plan_from_hist<K2_THREADS>(hchild + nb_next, nb_next, (l - mid) >> 1, &plans_next[2 * node + 1], tmp);
+  A3D_SEL_STAMP(8, c);
 }
 
 // ---- ranges of <= NARROW points: all remaining levels in one block ---------------------------------------------------
@@ -989,3 +1016,13 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
 }
 
 }  // namespace a3d
+
+#ifdef A3D_TAIL_STAMPS
+extern "C" int a3d_debug_sel_stamps(unsigned long long out[64], uint32_t next_level, uint32_t next_node) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sel_stamps), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long zero[64] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stamps), zero, sizeof(zero)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stamp_level), &next_level, sizeof(uint32_t)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stamp_node), &next_node, sizeof(uint32_t)) == hipSuccess ? 0 : 1;
+}
+#endif

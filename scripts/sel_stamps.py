@@ -1,0 +1,48 @@
+"""Where one sel_resolve_kernel block's time goes on the configs[2] cloud (a depth image's points: thousands share a
+quantised z).  Needs scripts/build_stamps.sh; it loads scripts/stampbuild/libalign3d_hip_stamps.so.
+Stamps: (s_memrealtime at 100 MHz, tag, set size) — tags: 0 entry, 1 streaming min/max, 2 streaming round done, 3 set
+copied to LDS, 4 LDS min/max, 5 LDS round done, 6 before the final ranking, 7 placed, 8 children's plans written."""
+import ctypes
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+os.environ["A3D_LIBRARY"] = str(ROOT / "scripts" / "stampbuild" / "libalign3d_hip_stamps.so")
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+from align3d_amd import Context, R3dTree  # noqa: E402
+
+TAGS = {0: "entry", 1: "stream min/max", 2: "stream round", 3: "to LDS", 4: "lds min/max", 5: "lds round", 6: "pre-final", 7: "placed", 8: "plans"}
+
+
+def main():
+    ctx = Context(0)
+    (tgt, _), _ = bench.pcl_clouds(ctx, 500_000)
+    lib = ctx.lib
+    fn = lib.a3d_debug_sel_stamps
+    fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_uint32, ctypes.c_uint32]
+    fn.restype = ctypes.c_int
+    out = (ctypes.c_ulonglong * 64)()
+    pts = np.ascontiguousarray(tgt.points)
+    R3dTree.new(ctx, pts).free()
+    for level, node in [(2, 0), (2, 1), (2, 2), (2, 3), (3, 0), (4, 0), (5, 0), (6, 0), (7, 0), (0, 0), (1, 0)]:
+        fn(out, level, node)
+        R3dTree.new(ctx, pts).free()
+        fn(out, level, node)
+        v = list(out)
+        print(f"level {level} node {node}")
+        t0 = v[0]
+        prev = t0
+        for k in range(32):
+            t, w = v[2 * k], v[2 * k + 1]
+            if t == 0:
+                break
+            print(f"   {TAGS.get(w >> 32, w >> 32):16s} c={w & 0xffffffff:7d}  +{(t - prev) / 100.0:7.2f} us   at {(t - t0) / 100.0:7.2f}")
+            prev = t
+
+
+if __name__ == "__main__":
+    main()
