@@ -104,6 +104,9 @@ struct a3d_context {
     size_t bytes;
   };
   std::vector<SpareBlock> spare_blocks;
+  // Set by a kd-tree build that met an oversized median bucket (a cloud with thousands of equal coordinates): later
+  // builds of this context add the chip-wide placement launches for such buckets (kdtree_select.hip).
+  std::atomic<bool> kd_wide_place{false};
   // Pyramid arenas handed back by a3d_range_image_free, kept for the next frame of the same size: a frame
   // stream then costs no hipMalloc / hipFree (each of which synchronises the whole device) per frame.
   // Guarded by a mutex because an image may be freed from another thread than the one building frames.

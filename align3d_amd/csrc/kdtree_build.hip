@@ -216,7 +216,7 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
     return kdtree_build_device_sorted(t, d_points);
   }
 #endif
-  t->built_by = 1;
+  t->built_by = 1;  // (3 once the context's builds add the wide placement launches: kdtree_build_device_select)
   auto pad = [](size_t b) { return ((b + 255) / 256) * 256; };
   char* scratch = (char*)t->ctx->scratch[2] + pad((size_t)t->n * 12);  // behind the points the caller may have staged there
   A3D_REQUIRE(t->ctx->scratch[2] && t->ctx->scratch_size[2] >= pad((size_t)t->n * 12) + kdtree_select_scratch_bytes(t->n),

@@ -56,13 +56,21 @@ constexpr uint32_t K1_THREADS = 512, K1_ROUNDS = 4, K1_TILE = K1_THREADS * K1_RO
 constexpr uint32_t K2_THREADS = 1024;
 constexpr uint32_t PACK_THREADS = 256, PACK_ROUNDS = 4, PACK_TILE = PACK_THREADS * PACK_ROUNDS;
 
-enum : uint32_t { FLAG_NAN = 0 };
+enum : uint32_t { FLAG_NAN = 0, FLAG_OVERSIZED = 1 };  // words of the flag table the host reads back after the build
 
 struct SelPlan {   // of one node: which bucket holds rank len / 2
   uint32_t bucket, below, count, pad;
 };
 struct SelBox {    // bounds of the node's points (canonical values), per axis
   float lo[3], hi[3], pad[2];
+};
+// A node whose median bucket holds more than `wide_cap` points (a degenerate cloud: thousands of equal keys): the split
+// kernel also histograms those points one step finer, so that a chip-wide launch (sel_place_kernel) can place all but
+// one finer bucket of them before the node's single resolve block takes over.
+struct SelWide {
+  uint32_t inv_mn0, mx0;  // ~min and max of the set's key bits (zero-initialised tables: both kept by atomicMax)
+  uint32_t cursor[3];     // places handed out by sel_place_kernel: left / kept / right
+  uint32_t pad[3];
 };
 
 __device__ __forceinline__ float canon(float v) { return v + 0.0f; }  // -0.0 -> +0.0 (partial_cmp: equal)
@@ -85,8 +93,11 @@ __device__ __forceinline__ float bucket_pos(float v, float lo, float hi, uint32_
 __device__ __forceinline__ uint32_t bucket_of(float v, float lo, float hi, uint32_t nb) {
   return (uint32_t)bucket_pos(v, lo, hi, nb);
 }
+// NSUB finer buckets inside bucket `b`, monotone in v.  The position is NOT clamped to nb - 1 first: the last bucket also
+// takes everything up to the box's upper bound (a wall of a room is exactly there), which would all land in sub-bucket 0.
 __device__ __forceinline__ uint32_t subbucket_of(float v, float lo, float hi, uint32_t nb, uint32_t b) {
-  const float u = (bucket_pos(v, lo, hi, nb) - (float)b) * (float)NSUB;
+  const float scale = (hi > lo) ? (float)nb / (hi - lo) : 0.0f;
+  const float u = ((v - lo) * scale - (float)b) * (float)NSUB;
   return (uint32_t)fminf(fmaxf(u, 0.0f), (float)(NSUB - 1));
 }
 
@@ -233,13 +244,51 @@ __global__ void __launch_bounds__(K2_THREADS)
   plan_from_hist<K2_THREADS>(h, nb, n >> 1, &plans[0], tmp);
 }
 
+// One count into an LDS table per active lane; the lanes that share the first active lane's bucket add as one (a
+// quantised coordinate puts whole waves into one bucket: an LDS atomic per lane on one address is 64 serial operations).
+__device__ __forceinline__ void hist_add_wave(uint32_t* table, uint32_t b, bool valid) {
+  const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
+  if (!act) return;
+  const uint32_t lead = (uint32_t)__builtin_ctzll(act);
+  const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)lead);
+  const unsigned long long same = __builtin_amdgcn_ballot_w64(valid && b == bl);
+  if (lane_id() == lead) atomicAdd(&table[bl], (uint32_t)__builtin_popcountll(same));
+  else if (valid && b != bl) atomicAdd(&table[b], 1u);
+}
+
+// The two finer histograms of an oversized median bucket (NSUB buckets each), both monotone under L_d on the sets they
+// are used for:  [0] the key itself inside the bucket's bounds;  [1] what decides among EQUAL keys: the previous axis'
+// coordinate over the node's box (level >= 1), the original index (level 0: L_0 = (x, index)).
+__device__ __forceinline__ uint32_t wide_bucket0(const float4& r, uint32_t a, float lo_a, float hi_a, uint32_t nb, uint32_t bucket) {
+  return subbucket_of(canon(comp(r, a)), lo_a, hi_a, nb, bucket);
+}
+__device__ __forceinline__ uint32_t wide_bucket1(const float4& r, uint32_t level, uint32_t n, float lo_p, float hi_p) {
+  if (level == 0) return (uint32_t)(((unsigned long long)__float_as_uint(r.w) * NSUB) / n);
+  return bucket_of(canon(comp(r, (level + 2) % 3)), lo_p, hi_p, NSUB);
+}
+// Which of the two tables decides (1 when every point of the set has the same key) and the finer bucket that holds the
+// set's rank `t`; every thread of the block calls it, `hs` (LDS, NSUB words) receives the table.
+template <uint32_t THREADS>
+__device__ __forceinline__ uint32_t wide_sub_plan(const SelWide* wide, const uint32_t* whist, uint32_t node, uint32_t t,
+                                                  uint32_t* hs, SelPlan* out, uint32_t* tmp) {
+  const uint32_t which = (~wide[node].inv_mn0 == wide[node].mx0) ? 1u : 0u;
+  const uint32_t* g = whist + ((size_t)node * 2 + which) * NSUB;
+  for (uint32_t q = threadIdx.x; q < NSUB; q += THREADS) hs[q] = g[q];
+  __syncthreads();
+  plan_from_hist<THREADS>(hs, NSUB, t, out, tmp);
+  __syncthreads();
+  return which;
+}
+
 // ---- wide levels: route every point of a node below / into / above the bucket of its median -----------------------
 __global__ void __launch_bounds__(K1_THREADS)
     sel_split_kernel(const float4* __restrict__ rin, float4* __restrict__ rout, float4* __restrict__ midbuf, uint32_t n,
                      uint32_t level, uint32_t blocks_per_node, uint32_t nb, uint32_t nb_next,
                      const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes, uint32_t* __restrict__ cursors,
-                     uint32_t* __restrict__ hist_next, uint32_t* __restrict__ flags) {
-  extern __shared__ uint32_t h[];  // [2][nb_next]: the two children's histograms along the next axis
+                     uint32_t* __restrict__ hist_next, uint32_t* __restrict__ flags, uint32_t wide_cap,
+                     SelWide* __restrict__ wide, uint32_t* __restrict__ whist) {
+  extern __shared__ uint32_t h[];  // [2][nb_next]: the two children's histograms along the next axis; oversized: + [2][NSUB]
+  __shared__ uint32_t w_mm[2];
   __shared__ uint32_t wcnt[3][K1_ROUNDS * (K1_THREADS / 64)];  // per class: (round, wave) counts, then exclusive prefixes
   __shared__ uint32_t base[3];
   const uint32_t node = blockIdx.x / blocks_per_node, part = blockIdx.x % blocks_per_node;
@@ -254,7 +303,10 @@ __global__ void __launch_bounds__(K1_THREADS)
   const float lo_a = pick3(box.lo, a), hi_a = pick3(box.hi, a), lo_a2 = pick3(box.lo, a2), hi_a2 = pick3(box.hi, a2);
   const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
   const unsigned long long lower = (1ull << lane) - 1ull;
-  for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K1_THREADS) h[q] = 0u;
+  const bool oversized = plan.count > wide_cap;  // (block-uniform; the launch reserved the LDS for the finer tables)
+  uint32_t* hw = h + 2 * nb_next;
+  for (uint32_t q = threadIdx.x; q < 2 * nb_next + (oversized ? 2 * NSUB : 0u); q += K1_THREADS) h[q] = 0u;
+  if (threadIdx.x < 2) w_mm[threadIdx.x] = 0u;
   float4 r[K1_ROUNDS];
   uint32_t cls[K1_ROUNDS], rank[K1_ROUNDS];
 #pragma unroll
@@ -298,6 +350,27 @@ __global__ void __launch_bounds__(K1_THREADS)
     if (lane < ENTRIES) wcnt[w][lane] = incl - v;
     if (lane == 63 && incl) reserved = atomicAdd(&cursors[node * 4 + w], incl);
   }
+  if (oversized) {  // the median bucket's points, one step finer (see SelWide)
+    const uint32_t ap = (level + 2) % 3;
+    const float lo_p = pick3(box.lo, ap), hi_p = pick3(box.hi, ap);
+    uint32_t inv_mn = 0u, mx = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+      const bool in = cls[k] == 1u;
+      hist_add_wave(hw, wide_bucket0(r[k], a, lo_a, hi_a, nb, plan.bucket), in);
+      hist_add_wave(hw + NSUB, wide_bucket1(r[k], level, n, lo_p, hi_p), in);
+      if (in) {
+        const uint32_t kb = ord_bits(comp(r[k], a));
+        inv_mn = max(inv_mn, ~kb), mx = max(mx, kb);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+      inv_mn = max(inv_mn, (uint32_t)__shfl_xor((int)inv_mn, off, 64));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    }
+    if (lane == 0 && (inv_mn | mx)) atomicMax(&w_mm[0], inv_mn), atomicMax(&w_mm[1], mx);
+  }
   if (nb_next) {  // the points routed left / right, counted into their child's histogram along the next axis
 #pragma unroll
     for (uint32_t k = 0; k < K1_ROUNDS; ++k)
@@ -312,6 +385,14 @@ __global__ void __launch_bounds__(K1_THREADS)
   }
   if (w < 3 && lane == 63) base[w] = reserved;
   __syncthreads();
+  if (oversized) {
+    uint32_t* g = whist + (size_t)node * 2 * NSUB;
+    for (uint32_t q = threadIdx.x; q < 2 * NSUB; q += K1_THREADS) {
+      const uint32_t v = hw[q];
+      if (v) atomicAdd(&g[q], v);
+    }
+    if (threadIdx.x == 0 && (w_mm[0] | w_mm[1])) atomicMax(&wide[node].inv_mn0, w_mm[0]), atomicMax(&wide[node].mx0, w_mm[1]);
+  }
 #pragma unroll
   for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
     if (cls[k] == 3u) continue;
@@ -319,6 +400,98 @@ __global__ void __launch_bounds__(K1_THREADS)
     if (cls[k] == 0u) rout[s + off] = r[k];
     else if (cls[k] == 2u) rout[s + l - 1u - off] = r[k];
     else midbuf[s + off] = r[k];
+  }
+}
+
+// Oversized median buckets only (every other block leaves at once): all of the chip places the set's points that fall
+// below / above the finer bucket of rank t at their final side of the node's range and counts them into the children's
+// histograms, exactly as the split kernel does one step coarser; the points of that finer bucket go to `spare` (this
+// node's range of the level's input, dead since the split kernel read it), where the resolve block finds them.
+__global__ void __launch_bounds__(K1_THREADS)
+    sel_place_kernel(const float4* __restrict__ midbuf, float4* __restrict__ spare, float4* __restrict__ rout, uint32_t n,
+                     uint32_t level, uint32_t blocks_per_node, uint32_t nb, uint32_t nb_next,
+                     const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes, uint32_t* __restrict__ hist_next,
+                     uint32_t wide_cap, SelWide* __restrict__ wide, const uint32_t* __restrict__ whist) {
+  extern __shared__ uint32_t h[];  // [2][nb_next]
+  __shared__ uint32_t hs[NSUB];
+  __shared__ uint32_t tmp[16];
+  __shared__ SelPlan sub_plan;
+  __shared__ uint32_t wcnt[3][K1_ROUNDS * (K1_THREADS / 64)];
+  __shared__ uint32_t base[3];
+  const uint32_t node = blockIdx.x / blocks_per_node, part = blockIdx.x % blocks_per_node;
+  const SelPlan plan = plans[node];
+  const uint32_t c = plan.count, tile_lo = part * K1_TILE;
+  if (c <= wide_cap || tile_lo >= c) return;
+  uint32_t s, l;
+  bool exists;
+  sel_node_range(n, level, node, &s, &l, &exists);
+  const uint32_t mid = l >> 1;
+  const SelBox box = boxes[node];
+  const uint32_t a = level % 3, a2 = (level + 1) % 3, ap = (level + 2) % 3;
+  const float lo_a = pick3(box.lo, a), hi_a = pick3(box.hi, a), lo_a2 = pick3(box.lo, a2), hi_a2 = pick3(box.hi, a2),
+              lo_p = pick3(box.lo, ap), hi_p = pick3(box.hi, ap);
+  const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K1_THREADS) h[q] = 0u;
+  float4 r[K1_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+    const uint32_t i = tile_lo + k * K1_THREADS + threadIdx.x;
+    r[k] = i < c ? midbuf[s + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const uint32_t which = wide_sub_plan<K1_THREADS>(wide, whist, node, mid - plan.below, hs, &sub_plan, tmp);
+  const uint32_t star = sub_plan.bucket;
+  uint32_t cls[K1_ROUNDS], rank[K1_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+    const bool valid = tile_lo + k * K1_THREADS + threadIdx.x < c;
+    const uint32_t b = which ? wide_bucket1(r[k], level, n, lo_p, hi_p) : wide_bucket0(r[k], a, lo_a, hi_a, nb, plan.bucket);
+    cls[k] = !valid ? 3u : (b < star ? 0u : (b > star ? 2u : 1u));  // left / kept / right
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls[k] == 0u), m1 = __builtin_amdgcn_ballot_w64(cls[k] == 1u),
+                             m2 = __builtin_amdgcn_ballot_w64(cls[k] == 2u);
+    const unsigned long long mine = cls[k] == 0u ? m0 : (cls[k] == 1u ? m1 : m2);
+    rank[k] = (uint32_t)__builtin_popcountll(mine & lower);
+    if (lane == 0) {
+      const uint32_t e = k * (K1_THREADS / 64) + w;
+      wcnt[0][e] = (uint32_t)__builtin_popcountll(m0), wcnt[1][e] = (uint32_t)__builtin_popcountll(m1),
+      wcnt[2][e] = (uint32_t)__builtin_popcountll(m2);
+    }
+  }
+  __syncthreads();
+  constexpr uint32_t ENTRIES = K1_ROUNDS * (K1_THREADS / 64);
+  uint32_t reserved = 0;
+  if (w < 3) {
+    const uint32_t v = lane < ENTRIES ? wcnt[w][lane] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= (uint32_t)off) incl += up;
+    }
+    if (lane < ENTRIES) wcnt[w][lane] = incl - v;
+    if (lane == 63 && incl) reserved = atomicAdd(&wide[node].cursor[w], incl);
+  }
+  if (nb_next) {
+#pragma unroll
+    for (uint32_t k = 0; k < K1_ROUNDS; ++k)
+      if (cls[k] == 0u || cls[k] == 2u)
+        atomicAdd(&h[(cls[k] >> 1) * nb_next + bucket_of(canon(comp(r[k], a2)), lo_a2, hi_a2, nb_next)], 1u);
+    __syncthreads();
+    uint32_t* g = hist_next + (size_t)(2 * node) * nb_next;
+    for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K1_THREADS) {
+      const uint32_t v = h[q];
+      if (v) atomicAdd(&g[q], v);
+    }
+  }
+  if (w < 3 && lane == 63) base[w] = reserved;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+    if (cls[k] == 3u) continue;
+    const uint32_t off = base[cls[k]] + wcnt[cls[k]][k * (K1_THREADS / 64) + w] + rank[k];
+    if (cls[k] == 0u) rout[s + plan.below + off] = r[k];  // behind the points the split kernel put at the left end
+    else if (cls[k] == 2u) rout[s + mid + off] = r[k];     // from the median's place upwards
+    else spare[s + off] = r[k];
   }
 }
 
@@ -375,7 +548,8 @@ __global__ void __launch_bounds__(K2_THREADS)
     sel_resolve_kernel(float4* __restrict__ midbuf, float4* __restrict__ spare, float4* __restrict__ rout, uint32_t n,
                        uint32_t level, uint32_t nb_next, const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes,
                        SelPlan* __restrict__ plans_next, SelBox* __restrict__ boxes_next, uint32_t* __restrict__ hist_next,
-                       float* __restrict__ split) {
+                       float* __restrict__ split, uint32_t* __restrict__ flags, uint32_t wide_cap, SelWide* __restrict__ wide,
+                       uint32_t* __restrict__ whist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* rec = (float4*)smem;                         // [MIDDLE_CAP] the candidates once they fit
   uint16_t* list_a = (uint16_t*)(rec + MIDDLE_CAP);    // [MIDDLE_CAP] the current candidate set (indices into rec) ...
@@ -484,6 +658,17 @@ __global__ void __launch_bounds__(K2_THREADS)
   // this node's range of the previous level's input (dead since the split kernel read it)
   float4* src = midbuf + s;
   float4* dst = spare + s;
+  if (c > wide_cap) {  // sel_place_kernel has placed all but one finer bucket of the set: that bucket is in `spare`
+    const uint32_t which = wide_sub_plan<K2_THREADS>(wide, whist, node, t, hsub, &sub_plan, tmp);
+    if (threadIdx.x == 0) n_left = sub_plan.below, n_right = c - sub_plan.below - sub_plan.count;
+    t -= sub_plan.below, c = sub_plan.count, cmp = which;
+    src = spare + s, dst = midbuf + s;
+    uint32_t* g2 = whist + (size_t)node * 2 * NSUB;  // the tables serve the node of this index on the next level too
+    for (uint32_t q = threadIdx.x; q < 2 * NSUB; q += K2_THREADS) g2[q] = 0u;
+    __syncthreads();
+    A3D_SEL_STAMP(9, c);
+  }
+  if (c > MIDDLE_CAP && threadIdx.x == 0) atomicOr(&flags[FLAG_OVERSIZED], 1u);  // (the host's cue for sel_place_kernel)
   while (c > MIDDLE_CAP) {
     auto fetch = [&](uint32_t i) { return src[i]; };
     min_max(fetch, c, cmp);
@@ -889,8 +1074,10 @@ struct SelLayout {
   uint32_t narrow_len = NARROW;
   uint32_t nb[32] = {};                // buckets per node on each wide level
   size_t recs_a = 0, recs_b = 0, mid = 0, hist = 0, hist_words = 0, boxes = 0, plans = 0, cursors = 0, partials = 0,
-         flags = 0, zero_begin = 0, zero_bytes = 0, total = 0;
+         flags = 0, wide = 0, whist = 0, zero_begin = 0, zero_bytes = 0, total = 0;
   uint32_t pack_blocks = 0;
+  uint32_t wide_cap = MIDDLE_CAP;      // a median bucket of more points than this is an oversized one (SelWide)
+  uint32_t place_levels = 0;           // levels 0 .. place_levels - 1 can hold one
 };
 
 uint32_t max_len_at(uint32_t n, uint32_t level) { return (uint32_t)(((uint64_t)n + (1ull << level) - 1) >> level); }
@@ -904,10 +1091,12 @@ uint32_t buckets_setting() {
   return p;
 }
 
-SelLayout sel_layout(uint32_t n, uint32_t narrow_len) {
+SelLayout sel_layout(uint32_t n, uint32_t narrow_len, uint32_t wide_cap) {
   SelLayout L;
   L.narrow_len = narrow_len;
+  L.wide_cap = wide_cap;
   while (max_len_at(n, L.wide_levels) > narrow_len) ++L.wide_levels;
+  while (L.place_levels < L.wide_levels && max_len_at(n, L.place_levels) > wide_cap) ++L.place_levels;
   size_t hist_words = 1;
   const uint32_t nb_cap = buckets_setting();
   for (uint32_t d = 0; d < L.wide_levels; ++d) {
@@ -931,9 +1120,18 @@ SelLayout sel_layout(uint32_t n, uint32_t narrow_len) {
   L.cursors = off, off += pad(nodes * 4 * sizeof(uint32_t));
   L.hist_words = hist_words;
   L.hist = off, off += pad(2 * hist_words * sizeof(uint32_t));
+  L.wide = off, off += pad(((size_t)1 << L.place_levels) * sizeof(SelWide));  // heap-indexed over the levels that can hold one
+  L.whist = off, off += pad(((size_t)1 << (L.place_levels ? L.place_levels - 1 : 0)) * 2 * NSUB * sizeof(uint32_t));  // per node of a level
   L.zero_bytes = off - L.zero_begin;
   L.total = off;
   return L;
+}
+
+uint32_t wide_cap_setting() {
+  uint32_t v = MIDDLE_CAP;
+  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_WIDE_CAP"))  // diagnostics build: oversized median buckets at test sizes
+    if (*env) v = std::min(MIDDLE_CAP, std::max(16u, (uint32_t)atoi(env)));
+  return v;
 }
 
 uint32_t narrow_len_setting() {
@@ -947,14 +1145,24 @@ uint32_t narrow_len_setting() {
 
 namespace a3d {
 
-size_t kdtree_select_scratch_bytes(uint32_t n) { return sel_layout(n, narrow_len_setting()).total; }
+size_t kdtree_select_scratch_bytes(uint32_t n) { return sel_layout(n, narrow_len_setting(), wide_cap_setting()).total; }
 
 // d_points: [n][3] f32 on the device; `scratch`: kdtree_select_scratch_bytes(n) bytes.  Fills t->d_split, t->d_leaves,
 // t->d_slot_of_point (allocated by the caller) and synchronises.
 a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void* scratch, hipEvent_t done) {
   hipStream_t s = t->ctx->stream;
   const uint32_t n = t->n, D = t->max_depth;
-  const SelLayout L = sel_layout(n, narrow_len_setting());
+  const SelLayout L = sel_layout(n, narrow_len_setting(), wide_cap_setting());
+  // sel_place_kernel's launches (one more per level that can hold an oversized median bucket) only once a cloud of this
+  // context has had one: clouds without thousands of equal coordinates never pay for them, a stream of depth-image
+  // clouds pays the lone resolve block's slow rounds on its first build only.  The tree is the same either way.
+  bool place = t->ctx->kd_wide_place.load();
+  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_WIDE_PLACE"))
+    if (*env) place = atoi(env) != 0;
+  const uint32_t wide_cap = place ? L.wide_cap : 0xffffffffu;
+  t->built_by = place ? 3 : 1;
+  SelWide* wide = (SelWide*)((char*)scratch + L.wide);
+  uint32_t* whist = (uint32_t*)((char*)scratch + L.whist);
   char* base = (char*)scratch;
   float4* recs[2] = {(float4*)(base + L.recs_a), (float4*)(base + L.recs_b)};
   float4* mid = (float4*)(base + L.mid);
@@ -965,6 +1173,7 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   uint32_t* cursors = (uint32_t*)(base + L.cursors);
   uint32_t* hist[2] = {(uint32_t*)(base + L.hist), (uint32_t*)(base + L.hist) + L.hist_words};
   // more than 64 KiB of dynamic LDS has to be requested once per kernel AND device (a process may drive several: multi.hip)
+  static_assert((2 * NB_MAX + 2 * NSUB) * sizeof(uint32_t) <= 64 * 1024, "the split kernel's tables fit the default dynamic LDS limit");
   static std::atomic<bool> lds_allowed_on[64];
   std::atomic<bool>& lds_allowed = lds_allowed_on[t->ctx->device & 63];
   if (!lds_allowed.load()) {
@@ -985,12 +1194,20 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
     const uint32_t nodes = 1u << d, off = nodes - 1u;  // heap offset of the level in the per-node tables
     const uint32_t bpn = (max_len_at(n, d) + K1_TILE - 1) / K1_TILE;
     const uint32_t nb_next = d + 1 < W ? L.nb[d + 1] : 0u;
-    hipLaunchKernelGGL(sel_split_kernel, dim3(nodes * bpn), dim3(K1_THREADS), 2 * nb_next * sizeof(uint32_t), s,
-                       recs[d & 1], recs[(d + 1) & 1], mid, n, d, bpn, L.nb[d], nb_next, plans + off, boxes + off,
-                       cursors + 4 * (size_t)off, hist[(d + 1) & 1], flags);
+    const bool placing = place && d < L.place_levels;
+    const uint32_t cap_d = placing ? wide_cap : 0xffffffffu;
+    SelWide* wide_d = wide + (placing ? off : 0u);
+    hipLaunchKernelGGL(sel_split_kernel, dim3(nodes * bpn), dim3(K1_THREADS),
+                       (2 * nb_next + (placing ? 2 * NSUB : 0u)) * sizeof(uint32_t), s, recs[d & 1], recs[(d + 1) & 1], mid, n,
+                       d, bpn, L.nb[d], nb_next, plans + off, boxes + off, cursors + 4 * (size_t)off, hist[(d + 1) & 1], flags,
+                       cap_d, wide_d, whist);
+    if (placing)
+      hipLaunchKernelGGL(sel_place_kernel, dim3(nodes * bpn), dim3(K1_THREADS), 2 * nb_next * sizeof(uint32_t), s, mid,
+                         recs[d & 1], recs[(d + 1) & 1], n, d, bpn, L.nb[d], nb_next, plans + off, boxes + off,
+                         hist[(d + 1) & 1], cap_d, wide_d, whist);
     hipLaunchKernelGGL(sel_resolve_kernel, dim3(nodes), dim3(K2_THREADS), K2_LDS_BYTES, s, mid, recs[d & 1],
                        recs[(d + 1) & 1], n, d, nb_next, plans + off, boxes + off, plans + (2 * nodes - 1u),
-                       boxes + (2 * nodes - 1u), hist[(d + 1) & 1], t->d_split);
+                       boxes + (2 * nodes - 1u), hist[(d + 1) & 1], t->d_split, flags, cap_d, wide_d, whist);
   }
   bool regs = false;  // the network's words in LDS (measured faster: DESIGN.md); diagnostics build: A3D_KDTREE_SORTNET=regs
   if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_SORTNET")) regs = !strcmp(env, "regs");
@@ -1007,9 +1224,10 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
 #undef A3D_NARROW_LAUNCH
   A3D_HIP_TRY(hipGetLastError());
   if (done) A3D_HIP_TRY(hipEventRecord(done, s));
-  uint32_t h_flags[1] = {0};
+  uint32_t h_flags[2] = {0, 0};
   A3D_HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
   A3D_HIP_TRY(hipStreamSynchronize(s));
+  if (h_flags[FLAG_OVERSIZED]) t->ctx->kd_wide_place.store(true);
   A3D_REQUIRE(!h_flags[FLAG_NAN], A3D_NAN_IN_INPUT,
               "NaN coordinate in kd-tree input (the reference panics in partial_cmp().unwrap())");
   return A3D_OK;

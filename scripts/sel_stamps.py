@@ -15,7 +15,7 @@ sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402
 from align3d_amd import Context, R3dTree  # noqa: E402
 
-TAGS = {0: "entry", 1: "stream min/max", 2: "stream round", 3: "to LDS", 4: "lds min/max", 5: "lds round", 6: "pre-final", 7: "placed", 8: "plans"}
+TAGS = {9: "after place kernel", 0: "entry", 1: "stream min/max", 2: "stream round", 3: "to LDS", 4: "lds min/max", 5: "lds round", 6: "pre-final", 7: "placed", 8: "plans"}
 
 
 def main():
@@ -28,11 +28,22 @@ def main():
     out = (ctypes.c_ulonglong * 64)()
     pts = np.ascontiguousarray(tgt.points)
     R3dTree.new(ctx, pts).free()
-    for level, node in [(2, 0), (2, 1), (2, 2), (2, 3), (3, 0), (4, 0), (5, 0), (6, 0), (7, 0), (0, 0), (1, 0)]:
+    todo = [(2, j) for j in range(4)] + [(0, 0), (1, 0)]
+    if len(sys.argv) > 1:  # `sel_stamps.py LEVEL`: every node of that level, the slowest one printed in full
+        level = int(sys.argv[1])
+        todo = [(level, j) for j in range(1 << level)]
+    rows = []
+    for level, node in todo:
         fn(out, level, node)
         R3dTree.new(ctx, pts).free()
         fn(out, level, node)
-        v = list(out)
+        rows.append((level, node, list(out)))
+    if len(sys.argv) > 1:
+        for level, node, v in rows:
+            last = max(k for k in range(32) if v[2 * k])
+            print(f"level {level} node {node}: {(v[2 * last] - v[0]) / 100.0:7.2f} us, set of {v[1] & 0xffffffff}")
+        rows = [max(rows, key=lambda r: r[2][2 * max(k for k in range(32) if r[2][2 * k])] - r[2][0])]
+    for level, node, v in rows:
         print(f"level {level} node {node}")
         t0 = v[0]
         prev = t0
@@ -40,7 +51,7 @@ def main():
             t, w = v[2 * k], v[2 * k + 1]
             if t == 0:
                 break
-            print(f"   {TAGS.get(w >> 32, w >> 32):16s} c={w & 0xffffffff:7d}  +{(t - prev) / 100.0:7.2f} us   at {(t - t0) / 100.0:7.2f}")
+            print(f"   {TAGS.get(w >> 32, w >> 32):18s} c={w & 0xffffffff:7d}  +{(t - prev) / 100.0:7.2f} us   at {(t - t0) / 100.0:7.2f}")
             prev = t
 
 

@@ -94,17 +94,24 @@ def test_kdtree_full_size_500k_bit_exact(ctx):
 
 
 _KD_KNOBS = ("A3D_KDTREE_BUILD", "A3D_KDTREE_SORT", "A3D_KDTREE_WIDE_LEN", "A3D_KDTREE_NARROW_LEN", "A3D_KDTREE_SCAN",
-             "A3D_KDTREE_SORTNET", "A3D_KDTREE_BUCKETS")
+             "A3D_KDTREE_SORTNET", "A3D_KDTREE_BUCKETS", "A3D_KDTREE_WIDE_PLACE", "A3D_KDTREE_WIDE_CAP")
 
 # The device builds (diagnostics build: knobs).  "select" is what the product library runs: the selection build
 # (kdtree_select.hip); NARROW_LEN makes its wide-level kernels run at test sizes; "sorted" is the sorting build (the
 # cross-check, diagnostics build only: hand-written radix + bitonic sorts, or rocPRIM's), WIDE_LEN moves its wide / narrow border.
+# WIDE_PLACE=1 adds the chip-wide placement launches for oversized median buckets (what a context switches to by itself
+# once a cloud had one; 0 keeps them off whatever the context has seen), WIDE_CAP makes buckets count as oversized at test sizes.
 _KD_BUILDS = {
-    "select": {},
-    "select_narrow32": {"A3D_KDTREE_NARROW_LEN": "32"},
-    "select_narrow64": {"A3D_KDTREE_NARROW_LEN": "64"},
-    "select_narrow512": {"A3D_KDTREE_NARROW_LEN": "512"},
+    "select": {"A3D_KDTREE_WIDE_PLACE": "0"},
+    "select_narrow32": {"A3D_KDTREE_NARROW_LEN": "32", "A3D_KDTREE_WIDE_PLACE": "0"},
+    "select_narrow64": {"A3D_KDTREE_NARROW_LEN": "64", "A3D_KDTREE_WIDE_PLACE": "0"},
+    "select_narrow512": {"A3D_KDTREE_NARROW_LEN": "512", "A3D_KDTREE_WIDE_PLACE": "0"},
     "select_regs": {"A3D_KDTREE_SORTNET": "regs"},  # the in-block network with its words in registers / lane exchanges
+    "select_place": {"A3D_KDTREE_WIDE_PLACE": "1"},
+    "select_place_cap64": {"A3D_KDTREE_WIDE_PLACE": "1", "A3D_KDTREE_WIDE_CAP": "64"},
+    "select_place_cap16_narrow64": {"A3D_KDTREE_WIDE_PLACE": "1", "A3D_KDTREE_WIDE_CAP": "16", "A3D_KDTREE_NARROW_LEN": "64"},
+    "select_place_cap256_narrow512": {"A3D_KDTREE_WIDE_PLACE": "1", "A3D_KDTREE_WIDE_CAP": "256", "A3D_KDTREE_NARROW_LEN": "512",
+                                      "A3D_KDTREE_BUCKETS": "64"},
     "sorted": {"A3D_KDTREE_BUILD": "sorted"},
     "sorted_wide64": {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_WIDE_LEN": "64"},
     "sorted_all_wide": {"A3D_KDTREE_BUILD": "sorted", "A3D_KDTREE_WIDE_LEN": str(1 << 30)},
@@ -167,7 +174,7 @@ def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monke
     median under the closed-form order L_d + an unordered partition; the last levels sorted in LDS) against the sorting
     build (one stable sort per level) against rocPRIM's sorts against the host."""
     db = _kd_cases()[case]
-    if case == "n270213" and build not in ("select", "select_narrow512", "select_regs", "sorted", "sorted_rocprim"):
+    if case == "n270213" and build not in ("select", "select_narrow512", "select_regs", "select_place_cap64", "sorted", "sorted_rocprim"):
         pytest.skip("the large case runs on the default borders only")
     host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
     dev = _build(diag_ctx, db, _KD_BUILDS[build], monkeypatch)
@@ -184,7 +191,7 @@ def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monke
             prod = _build(ctx, db, {}, monkeypatch, device_pointer=dp)
             ps, pl = prod.download()
             assert prod.stats() == host.stats() and np.array_equal(ps, hs) and np.array_equal(pl, hl)
-            assert prod.build_path() == dev.build_path() == 1
+            assert dev.build_path() == 1 and prod.build_path() in (1, 3)  # (3: the context has met an oversized bucket before)
 
 
 @pytest.mark.parametrize("n", [16384, 20000, 40000, 100000])
@@ -218,7 +225,7 @@ def test_kdtree_selection_build_at_three_million_points(ctx, diag_ctx, monkeypat
     hs, hl = host.download()
     t = _build(ctx, db, {}, monkeypatch)
     s_, l_ = t.download()
-    assert t.build_path() == 1 and t.stats() == host.stats()
+    assert t.build_path() in (1, 3) and t.stats() == host.stats()
     assert np.array_equal(s_, hs) and np.array_equal(l_, hl)
     print(f"[kd-tree build, {n} points] {t.build_ms():.3f} ms of launches")
 
@@ -234,14 +241,45 @@ def test_kdtree_selection_build_finishes_degenerate_clouds(ctx, diag_ctx, monkey
     same = np.tile(np.array([[1.5, -2.0, 0.0]], np.float32), (30000, 1))  # only the original index tells points apart
     tiny = (uniform01(3, 3 * 70001).reshape(-1, 3) - 0.5) * np.float32(1e3)
     tiny[::3] *= np.float32(1e-30)  # a third of the cloud within 5e-28 of the origin, all distinct
-    for db in (plane, ties, same, tiny.astype(np.float32)):
+    # a depth image's cloud at the benchmark's scale: a fronto-parallel wall (one z for 60 % of the pixels, one y per row)
+    vv, uu = np.mgrid[0:400, 0:600]
+    zz = np.where(uu < 360, 3.0, np.round(rng.uniform(1.0, 4.0, size=uu.shape) * 5000) / 5000).astype(np.float32)
+    wall = np.stack([(uu - 300) * zz / 500, (vv - 200) * zz / 500, zz], axis=-1).reshape(-1, 3).astype(np.float32)
+    for db in (plane, ties, same, tiny.astype(np.float32), wall):
         host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
         hs, hl = host.download()
-        for c, env in ((ctx, {}), (diag_ctx, {"A3D_KDTREE_NARROW_LEN": "64"})):
+        for c, env in ((ctx, {}), (diag_ctx, {"A3D_KDTREE_NARROW_LEN": "64", "A3D_KDTREE_WIDE_PLACE": "0"}),
+                       (diag_ctx, {"A3D_KDTREE_WIDE_PLACE": "0"}), (diag_ctx, {"A3D_KDTREE_WIDE_PLACE": "1"}),
+                       (diag_ctx, {"A3D_KDTREE_WIDE_PLACE": "1", "A3D_KDTREE_WIDE_CAP": "100", "A3D_KDTREE_NARROW_LEN": "64"}),
+                       (diag_ctx, {"A3D_KDTREE_WIDE_PLACE": "1", "A3D_KDTREE_WIDE_CAP": "1000", "A3D_KDTREE_BUCKETS": "128"})):
             t = _build(c, db, env, monkeypatch)
-            assert t.build_path() == 1
+            assert t.build_path() == (3 if env.get("A3D_KDTREE_WIDE_PLACE") == "1" else 1) or c is ctx
             s_, l_ = t.download()
-            assert t.stats() == host.stats() and np.array_equal(s_, hs) and np.array_equal(l_, hl)
+            assert t.stats() == host.stats() and np.array_equal(s_, hs) and np.array_equal(l_, hl), env
+
+
+def test_kdtree_context_switches_to_wide_placement_after_an_oversized_bucket(diag_ctx, monkeypatch):
+    """The product's policy: a context's builds add sel_place_kernel's launches once one of its clouds had a median bucket
+    larger than the resolve block's LDS.  Same tree before and after; a cloud without such buckets never switches."""
+    from align3d_amd import Context
+
+    for k in _KD_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    fresh = Context(0)
+    benign = uniform01(12, 3 * 50000).reshape(-1, 3)
+    wall = benign.copy()
+    wall[:30000, 2] = 0.5
+    host_b = _build(diag_ctx, benign, {"A3D_KDTREE_BUILD": "host"}, monkeypatch).download()
+    host_w = _build(diag_ctx, wall, {"A3D_KDTREE_BUILD": "host"}, monkeypatch).download()
+    paths = []
+    for db, want in ((benign, host_b), (benign, host_b), (wall, host_w), (wall, host_w), (benign, host_b)):
+        t = R3dTree.new(fresh, db)
+        got = t.download()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        paths.append(t.build_path())
+        t.free()
+    assert paths == [1, 1, 1, 3, 3]
+    fresh.close()
 
 
 @pytest.mark.parametrize("case", ["n1000", "dup", "n270213"])
