@@ -32,6 +32,14 @@
 //     (+inf padding included) and slot_of_point are written from there.  A thread holds four consecutive words in
 //     registers: partner distances 1, 2 stay in the thread, 4 .. 128 are lane exchanges, only 256+ go through LDS.
 //
+//     sel_place_kernel    (a THIRD launch on the levels whose ranges can hold more than 4096 points in one bucket, only
+//                         once a cloud of the context had such a bucket: a wall facing the camera is tens of thousands
+//                         of equal z.)  One resolve block narrows such a set at one CU's rate (30-60 GB/s: 133 us for
+//                         63 k points); instead the split kernel histograms the bucket's points one step finer — by the
+//                         key inside the bucket's bounds and, for a set of EQUAL keys, by the next component of L_d —
+//                         and this launch places all but one finer bucket of them with the whole chip (12 us then).
+//   ranges of <= 2048 points: sel_narrow_kernel (below).
+//
 // 500 k points: 21 launches instead of ~110.  Exact for every input: a degenerate cloud (one coordinate
 // constant over a node, thousands of equal points) only costs the resolve block more narrowing rounds.  The sorting
 // build (kdtree_build.hip, diagnostics build) is the cross-check: same tree, bit for bit (tests/test_gpu_kdtree.py).

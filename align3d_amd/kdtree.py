@@ -30,7 +30,8 @@ class R3dTree:
         return R3dTree(ctx, None, device_points=d_points, n=n)
 
     def build_path(self):
-        """1 = the selection build, 2 = the sorting build (its fallback), 0 = host build (diagnostics)."""
+        """1 = the selection build, 3 = the same with the chip-wide placement launches for oversized median buckets (a
+        context adds them once one of its clouds had such a bucket); diagnostics build only: 2 sorting build, 0 host build."""
         v = C.c_int32()
         _abi.check(self.ctx.lib.a3d_kdtree_build_path(self.handle, C.byref(v)))
         return v.value

@@ -120,6 +120,7 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         tree = R3dTree.new_device(ctx, d_db, n)
         dev_wall.append((time.perf_counter() - t0) * 1e3)
         dev_kernels.append(tree.build_ms())
+        path_seen = tree.build_path()
         tree.free()
     ctx.free(d_db)
     tree = R3dTree.new(ctx, db)
@@ -150,6 +151,7 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         "build": {"device_ms": float(np.median(dev_wall)), "device_ms_stats": stats(dev_wall),
                   "kernel_ms": float(np.median(dev_kernels)), "kernel_ms_stats": stats(dev_kernels),
                   "launches": 5 + 2 * max(0, int(np.ceil(np.log2(max(1, n / 2048))))),  # memset, pack, hist0, plan0, 2 per wide level, narrow
+                  "build_path": int(path_seen),
                   "roofline": roofline(20 * n * depth, float(np.median(dev_kernels)), kernel="the selection build's launches (kdtree_select.hip), first to last",
                                        levels=int(depth))},
         "roofline": roofline(alg_bytes, ms, traffic, src, kernel="kdtree_nearest_kernel",
@@ -210,6 +212,14 @@ def pcl_icp_bench(ctx, n=500_000):
         d_new.append((t1 - t0) * 1e3), d_align.append((t2 - t1) * 1e3), d_both.append((t2 - t0) * 1e3)
         icp_d.free()
     same_bits = bool(np.array_equal(np.concatenate([Td.t, Td.q]).view(np.uint32), np.concatenate([T.t, T.q]).view(np.uint32)))
+    # the kd-tree build inside Icp::new on THIS cloud (a depth image's points: a wall facing the camera is tens of
+    # thousands of equal z, which the uniform cloud of the kd-tree benchmark never has)
+    kd_ms, kd_path = [], 0
+    for _ in range(7):
+        tr = R3dTree.new_device(ctx, dt.d_points, tgt.len())
+        kd_ms.append(tr.build_ms())
+        kd_path = tr.build_path()
+        tr.free()
     dt.free(), dsrc.free()
     gt = synth.relative_pose(poses[0], poses[1])
     dm = np.linalg.inv(gt) @ T.matrix().astype(np.float64)
@@ -222,6 +232,8 @@ def pcl_icp_bench(ctx, n=500_000):
         "icp_new_device_ms": float(np.median(d_new)), "align_device_wall_ms": float(np.median(d_align)),
         "new_plus_align_device_ms": float(np.median(d_both)), "new_plus_align_device_ms_stats": stats(d_both),
         "device_forms_give_the_same_pose_bits": same_bits,
+        "kd_build_kernel_ms": float(np.median(kd_ms)), "kd_build_kernel_ms_stats": stats(kd_ms),
+        "kd_build_path": int(kd_path),  # 3: with the chip-wide placement of oversized median buckets (a3d_kdtree_build_path)
         "align_wall_ms_incl_pcie": float(np.median(walls)),  # Icp::align from host clouds: 12 MB upload + 15 iterations
         "error_vs_synthetic_gt": {"angle_rad": float(np.arccos(np.clip((np.trace(dm[:3, :3]) - 1) / 2, -1, 1))),
                                   "translation_m": float(np.linalg.norm(dm[:3, 3]))},
