@@ -228,6 +228,13 @@ def test_kdtree_selection_build_at_three_million_points(ctx, diag_ctx, monkeypat
     assert t.build_path() in (1, 3) and t.stats() == host.stats()
     assert np.array_equal(s_, hs) and np.array_equal(l_, hl)
     print(f"[kd-tree build, {n} points] {t.build_ms():.3f} ms of launches")
+    # and with the chip-wide placement launches on all ten levels that can hold an oversized bucket at this size (the
+    # ~3000 equal z make one at every level down to ranges of 256 points with the threshold lowered to 256)
+    for env in ({"A3D_KDTREE_WIDE_PLACE": "1"}, {"A3D_KDTREE_WIDE_PLACE": "1", "A3D_KDTREE_WIDE_CAP": "256"}):
+        t = _build(diag_ctx, db, env, monkeypatch)
+        s_, l_ = t.download()
+        assert t.build_path() == 3 and np.array_equal(s_, hs) and np.array_equal(l_, hl), env
+        t.free()
 
 
 def test_kdtree_selection_build_finishes_degenerate_clouds(ctx, diag_ctx, monkeypatch):
