@@ -810,15 +810,26 @@ __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* l
   // the first phases (kk = 2, 4: distances 1 | 2, 1) stay inside the thread, then everything through LDS.  Word i lives
   // at i + (i >> 5): one padding word per 32 keeps the quads of the short distances (8 .. 64 bytes apart in a plain
   // layout: four-way bank conflicts on 64-bit accesses) on different banks.
+  // Wave w's threads own the quads of words [256 w, 256 w + 256) in every stage pair of distances <= 128 (and the words
+  // 4 t .. 4 t + 3 on entry, exit and in the distance-1 stage): such a stage reads only what its own wave wrote, the LDS
+  // serves a wave's instructions in order, so between two of them no block barrier is needed — only the stage pairs of
+  // distances >= 256 (5 of the 33 of a 2048-word sort, none below 512 words) exchange words between waves.  With two
+  // waves per SIMD and a barrier per stage pair the network was bound by LDS round trips the barrier kept from overlapping.
   auto at = [&](uint32_t i) -> Word& { return lds[i + (i >> 5)]; };
+  bool prev_cross = true;  // (the buffer's previous use may have been anyone's)
+  auto stage_sync = [&](bool cross) {
+    if (cross || prev_cross) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"), __builtin_amdgcn_wave_barrier();
+    prev_cross = cross;
+  };
   inside(x[0], x[1], ((i0 & (cap - 1u)) & 2u) == 0u), inside(x[2], x[3], (((i0 + 2u) & (cap - 1u)) & 2u) == 0u);
   {
     const bool up = ((i0 & (cap - 1u)) & 4u) == 0u;
     inside(x[0], x[2], up), inside(x[1], x[3], up), inside(x[0], x[1], up), inside(x[2], x[3], up);
   }
+  stage_sync(false);
 #pragma unroll
   for (int e = 0; e < 4; ++e) at(i0 + e) = x[e];
-  __syncthreads();
   for (uint32_t kk = 8; kk <= cap; kk <<= 1) {
     uint32_t j = kk >> 1;
     while (j >= 2) {
@@ -826,23 +837,22 @@ __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* l
       const uint32_t q = threadIdx.x;  // SLOTS / 4 quads, one per thread
       const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
       const bool up = ((base & (cap - 1u)) & kk) == 0u;
+      stage_sync(j > 128u);
       Word a0 = at(base), a1 = at(base + hh), a2 = at(base + j), a3 = at(base + j + hh);
       inside(a0, a2, up), inside(a1, a3, up);
       inside(a0, a1, up), inside(a2, a3, up);
       at(base) = a0, at(base + hh) = a1, at(base + j) = a2, at(base + j + hh) = a3;
-      __syncthreads();
       j >>= 2;
     }
-    if (j == 1) {
-      for (uint32_t q = threadIdx.x; q < SLOTS / 2; q += THREADS) {
-        const uint32_t i = 2 * q;
-        Word a0 = at(i), a1 = at(i + 1);
-        inside(a0, a1, ((i & (cap - 1u)) & kk) == 0u);
-        at(i) = a0, at(i + 1) = a1;
-      }
-      __syncthreads();
+    if (j == 1) {  // the thread's own four consecutive words
+      const bool up = ((i0 & (cap - 1u)) & kk) == 0u;  // (kk >= 8: one direction for all four)
+      stage_sync(false);
+      Word a0 = at(i0), a1 = at(i0 + 1), a2 = at(i0 + 2), a3 = at(i0 + 3);
+      inside(a0, a1, up), inside(a2, a3, up);
+      at(i0) = a0, at(i0 + 1) = a1, at(i0 + 2) = a2, at(i0 + 3) = a3;
     }
   }
+  stage_sync(false);
 #pragma unroll
   for (int e = 0; e < 4; ++e) x[e] = at(i0 + e);
   __syncthreads();
@@ -868,6 +878,14 @@ __device__ __forceinline__ void bitonic_lds128(uint4* w, uint32_t* pay, uint32_t
       plo = phi, phi = tp;
     }
   };
+  // (block barriers only around the stage pairs that exchange words between waves: see bitonic_sort)
+  bool prev_cross = true;
+  auto stage_sync = [&](bool cross) {
+    if (cross || prev_cross) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"), __builtin_amdgcn_wave_barrier();
+    prev_cross = cross;
+  };
+  const uint32_t i0 = 4u * threadIdx.x;
   for (uint32_t kk = 2; kk <= cap; kk <<= 1) {
     uint32_t j = kk >> 1;
     while (j >= 2) {
@@ -875,26 +893,28 @@ __device__ __forceinline__ void bitonic_lds128(uint4* w, uint32_t* pay, uint32_t
       const uint32_t q = threadIdx.x;
       const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
       const bool up = ((base & (cap - 1u)) & kk) == 0u;
+      stage_sync(j > 128u);
       uint4 a0 = w[base], a1 = w[base + hh], a2 = w[base + j], a3 = w[base + j + hh];
       uint32_t p0 = pay[base], p1 = pay[base + hh], p2 = pay[base + j], p3 = pay[base + j + hh];
       inside(a0, a2, p0, p2, up), inside(a1, a3, p1, p3, up);
       inside(a0, a1, p0, p1, up), inside(a2, a3, p2, p3, up);
       w[base] = a0, w[base + hh] = a1, w[base + j] = a2, w[base + j + hh] = a3;
       pay[base] = p0, pay[base + hh] = p1, pay[base + j] = p2, pay[base + j + hh] = p3;
-      __syncthreads();
       j >>= 2;
     }
-    if (j == 1) {
-      for (uint32_t q = threadIdx.x; q < SLOTS / 2; q += THREADS) {
-        const uint32_t i = 2 * q;
+    if (j == 1) {  // the thread's own four consecutive words: two pairs, each with its own direction (kk = 2: they differ)
+      stage_sync(false);
+#pragma unroll
+      for (uint32_t h2 = 0; h2 < 2; ++h2) {
+        const uint32_t i = i0 + 2 * h2;
         uint4 a0 = w[i], a1 = w[i + 1];
         uint32_t p0 = pay[i], p1 = pay[i + 1];
         inside(a0, a1, p0, p1, ((i & (cap - 1u)) & kk) == 0u);
         w[i] = a0, w[i + 1] = a1, pay[i] = p0, pay[i + 1] = p1;
       }
-      __syncthreads();
     }
   }
+  __syncthreads();
 }
 
 template <uint32_t SLOTS>
