@@ -975,6 +975,25 @@ __global__ void __launch_bounds__(SLOTS / 4)
         sorted = ok && lc > 16;
       }
     }
+    constexpr uint32_t SHORT_RUN = 8;  // a run no longer than this on either side of a point is ranked by counting
+    // Entry level: does the range hold long runs of equal keys?  Every key is counted into a 4096-entry hash table (the
+    // network's buffer, free here); equal keys share an entry, so a run of more than SHORT_RUN keys always shows (a few
+    // unequal keys that collide can show too: that only picks the slower of two exact paths).  A range with long runs
+    // skips the network on 64-bit words — its result would be thrown away — and goes through the one on L_d itself at once.
+    bool heavy = false;
+    if (d == d0 && l0 > 16) {
+      uint32_t* tbl = (uint32_t*)xw;
+      if (threadIdx.x == 0) long_runs = 0u;
+      for (uint32_t q = threadIdx.x; q < 4096u; q += THREADS) tbl[q] = 0u;
+      __syncthreads();
+      bool seen = false;
+      for (uint32_t p = threadIdx.x; p < l0; p += THREADS)
+        seen |= atomicAdd(&tbl[(ord_bits(coord(p, a)) * 0x9E3779B1u) >> 20], 1u) >= SHORT_RUN;
+      if (seen) long_runs = 1u;  // (benign race: every writer stores 1)
+      __syncthreads();
+      heavy = long_runs != 0u;
+      __syncthreads();
+    }
     float4 moved[4];
     bool mine[4];
     Word x[4];
@@ -988,21 +1007,22 @@ __global__ void __launch_bounds__(SLOTS / 4)
         x[e] = ((Word)ord_bits(v) << 32) | (pos0 + e);
       }
     }
-    bitonic_sort<SLOTS, REGS>(x, cap, xw);
+    if (!heavy) {
+      bitonic_sort<SLOTS, REGS>(x, cap, xw);
 #pragma unroll
-    for (uint32_t e = 0; e < 4; ++e)
-      if (mine[e]) moved[e] = rec[rs + (uint32_t)x[e]];
-    __syncthreads();
-#pragma unroll
-    for (uint32_t e = 0; e < 4; ++e)
-      if (mine[e]) rec[rs + pos0 + e] = moved[e];
-    __syncthreads();
-    if (entry) {  // runs of equal keys into the order of (previous axis' key, the one before, original index)
-      constexpr uint32_t SHORT_RUN = 8;  // a run no longer than this on either side of a point is ranked by counting
-      uint32_t* dest = (uint32_t*)xw;    // (the network's buffer is free between sorts)
-      if (threadIdx.x == 0) long_runs = 0u;
+      for (uint32_t e = 0; e < 4; ++e)
+        if (mine[e]) moved[e] = rec[rs + (uint32_t)x[e]];
       __syncthreads();
-      for (uint32_t p = threadIdx.x; p < l0; p += THREADS) {
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e)
+        if (mine[e]) rec[rs + pos0 + e] = moved[e];
+      __syncthreads();
+    }
+    if (entry) {  // runs of equal keys into the order of (previous axis' key, the one before, original index)
+      uint32_t* dest = (uint32_t*)xw;    // (the network's buffer is free between sorts)
+      if (threadIdx.x == 0) long_runs = heavy ? 1u : 0u;
+      __syncthreads();
+      for (uint32_t p = threadIdx.x; p < l0 && !heavy; p += THREADS) {
         const uint32_t k = ord_bits(coord(p, a));
         uint32_t lo = p, hi = p + 1;
         while (lo > 0 && p - lo < SHORT_RUN && ord_bits(coord(lo - 1, a)) == k) --lo;
