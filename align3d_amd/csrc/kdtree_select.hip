@@ -554,7 +554,7 @@ __device__ uint32_t g_sel_stamp_level = 2, g_sel_stamp_node = 0;
 // coordinates), then in LDS; the last <= 64 candidates are ranked by brute force.  Exact for every input.
 __global__ void __launch_bounds__(K2_THREADS)
     sel_resolve_kernel(float4* __restrict__ midbuf, float4* __restrict__ spare, float4* __restrict__ rout, uint32_t n,
-                       uint32_t level, uint32_t nb_next, const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes,
+                       uint32_t level, uint32_t nb, uint32_t nb_next, const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes,
                        SelPlan* __restrict__ plans_next, SelBox* __restrict__ boxes_next, uint32_t* __restrict__ hist_next,
                        float* __restrict__ split, uint32_t* __restrict__ flags, uint32_t wide_cap, SelWide* __restrict__ wide,
                        uint32_t* __restrict__ whist) {
@@ -610,10 +610,13 @@ __global__ void __launch_bounds__(K2_THREADS)
     if (lane_id() == 0) atomicMin(&s_mn, mn), atomicMax(&s_mx, mx);
     __syncthreads();
   };
-  // one narrowing round: histogram over [mn, mx], the bucket of rank t, everything else placed; returns through
-  // sub_plan / n_keep.  `keep(r, i)` stores a candidate of the next round.
-  auto round = [&](auto fetch, auto keep, uint32_t cnt, uint32_t cmp, uint32_t t) {
+  // one narrowing round: histogram of `bucket` (a monotone map of the set under L_d onto < NSUB buckets), the bucket of
+  // rank t, everything else placed; returns through sub_plan / n_keep.  `keep(r, i, at)` stores a candidate of the next round.
+  auto by_component = [&](uint32_t cmp) {  // buckets over the [min, max] min_max has just found for component `cmp`
     const uint32_t mn = s_mn, sh = shift_for(s_mn, s_mx);
+    return [=](const float4& r) { return (lkey_comp(r, level, cmp) - mn) >> sh; };
+  };
+  auto round = [&](auto fetch, auto keep, uint32_t cnt, auto bucket, uint32_t t) {
     for (uint32_t q = threadIdx.x; q < NSUB; q += K2_THREADS) hsub[q] = 0u;
     if (threadIdx.x == 0) n_keep = 0u;
     __syncthreads();
@@ -622,7 +625,7 @@ __global__ void __launch_bounds__(K2_THREADS)
     for (uint32_t i0 = 0; i0 < cnt; i0 += K2_THREADS) {
       const uint32_t i = i0 + threadIdx.x;
       const bool valid = i < cnt;
-      const uint32_t b = valid ? (lkey_comp(fetch(i), level, cmp) - mn) >> sh : 0u;
+      const uint32_t b = valid ? bucket(fetch(i)) : 0u;
       const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
       if (!act) continue;
       const uint32_t lead = (uint32_t)__builtin_ctzll(act);
@@ -643,7 +646,7 @@ __global__ void __launch_bounds__(K2_THREADS)
       const uint32_t i = i0 + threadIdx.x;
       const bool valid = i < cnt;
       const float4 r = valid ? fetch(i) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const uint32_t b = (lkey_comp(r, level, cmp) - mn) >> sh;
+      const uint32_t b = bucket(r);
       const uint32_t cls = !valid ? 3u : (b == star ? 0u : (b > star ? 2u : 1u));  // keep / left / right
       const unsigned long long m0 = __builtin_amdgcn_ballot_w64(cls == 0u), m1 = __builtin_amdgcn_ballot_w64(cls == 1u),
                                m2 = __builtin_amdgcn_ballot_w64(cls == 2u);
@@ -666,7 +669,9 @@ __global__ void __launch_bounds__(K2_THREADS)
   // this node's range of the previous level's input (dead since the split kernel read it)
   float4* src = midbuf + s;
   float4* dst = spare + s;
-  if (c > wide_cap) {  // sel_place_kernel has placed all but one finer bucket of the set: that bucket is in `spare`
+  bool fresh = true;  // nothing has narrowed the set yet
+  if (c > wide_cap) {
+    fresh = false;  // sel_place_kernel has placed all but one finer bucket of the set: that bucket is in `spare`
     const uint32_t which = wide_sub_plan<K2_THREADS>(wide, whist, node, t, hsub, &sub_plan, tmp);
     if (threadIdx.x == 0) n_left = sub_plan.below, n_right = c - sub_plan.below - sub_plan.count;
     t -= sub_plan.below, c = sub_plan.count, cmp = which;
@@ -685,7 +690,8 @@ __global__ void __launch_bounds__(K2_THREADS)
       ++cmp;
       continue;
     }
-    round(fetch, [&](const float4& r, uint32_t, uint32_t at) { dst[at] = r; }, c, cmp, t);
+    fresh = false;
+    round(fetch, [&](const float4& r, uint32_t, uint32_t at) { dst[at] = r; }, c, by_component(cmp), t);
     t -= sub_plan.below, c = sub_plan.count;
     A3D_SEL_STAMP(2, c);
     float4* sw = src;
@@ -698,13 +704,28 @@ __global__ void __launch_bounds__(K2_THREADS)
   uint16_t *cur = list_a, *nxt = list_b;
   while (c > RANK_SMALL) {
     auto fetch = [&](uint32_t i) { return rec[cur[i]]; };
+    if (fresh) {
+      // the set as the split kernel left it — one bucket of the node's box along the axis: its first round takes its
+      // buckets from the bucket's bounds (NSUB finer ones) instead of a pass for the set's own [min, max]; a set of
+      // equal keys stays whole and goes on below
+      fresh = false;
+      const float lo_a = pick3(box.lo, a), hi_a = pick3(box.hi, a);
+      const uint32_t bk = plan.bucket;
+      round(fetch, [&](const float4&, uint32_t i, uint32_t at) { nxt[at] = cur[i]; }, c,
+            [=](const float4& r) { return wide_bucket0(r, a, lo_a, hi_a, nb, bk); }, t);
+      t -= sub_plan.below, c = sub_plan.count;
+      A3D_SEL_STAMP(5, c);
+      uint16_t* sw = cur;
+      cur = nxt, nxt = sw;
+      continue;
+    }
     min_max(fetch, c, cmp);
     A3D_SEL_STAMP(4, c);
     if (s_mn == s_mx) {
       ++cmp;
       continue;
     }
-    round(fetch, [&](const float4&, uint32_t i, uint32_t at) { nxt[at] = cur[i]; }, c, cmp, t);
+    round(fetch, [&](const float4&, uint32_t i, uint32_t at) { nxt[at] = cur[i]; }, c, by_component(cmp), t);
     t -= sub_plan.below, c = sub_plan.count;
     A3D_SEL_STAMP(5, c);
     uint16_t* sw = cur;
@@ -1254,7 +1275,7 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
                          recs[d & 1], recs[(d + 1) & 1], n, d, bpn, L.nb[d], nb_next, plans + off, boxes + off,
                          hist[(d + 1) & 1], cap_d, wide_d, whist);
     hipLaunchKernelGGL(sel_resolve_kernel, dim3(nodes), dim3(K2_THREADS), K2_LDS_BYTES, s, mid, recs[d & 1],
-                       recs[(d + 1) & 1], n, d, nb_next, plans + off, boxes + off, plans + (2 * nodes - 1u),
+                       recs[(d + 1) & 1], n, d, L.nb[d], nb_next, plans + off, boxes + off, plans + (2 * nodes - 1u),
                        boxes + (2 * nodes - 1u), hist[(d + 1) & 1], t->d_split, flags, cap_d, wide_d, whist);
   }
   bool regs = false;  // the network's words in LDS (measured faster: DESIGN.md); diagnostics build: A3D_KDTREE_SORTNET=regs
