@@ -1138,6 +1138,371 @@ __global__ void __launch_bounds__(SLOTS / 4)
   }
 }
 
+#ifdef A3D_DIAGNOSTICS
+// ---- ranges of <= NARROW points by SELECTION inside the block: diagnostics build only (A3D_KDTREE_SORTNET=select) ------
+// Measured SLOWER than the network kernel above (145 against 91 us at 500 k points; 0.48 against 0.36 ms for Icp::new on
+// the sample1 cloud): a narrowing round is ten block-wide phases of an LDS round trip + barrier each (4.4 us of a round
+// are fixed, 4.5 us the points' work), a level takes one to two rounds, and the cells of <= 33 points count 33 keys per
+// point.  Kept as a third, independent construction of the in-block levels for the identity tests.
+// A level needs what the wide levels need: per cell the point of rank len / 2 under L_d and a partition around it, in
+// any order — only the leaves have an order, L of their parent's depth, and they hold <= 16 points.  Per level, for all
+// cells of the range at once:
+//   rounds  every cell narrows its candidates (at first all its points): [min, max] of one component of L_d over them
+//           (a component all candidates agree in passes the turn to the next one), up to `cap` buckets over it by a
+//           shift of the key bits, histogram, block-wide scan, the bucket of the sought rank; candidates below / above
+//           it take places at the cell's left / right end, the bucket's own stay candidates — until no cell has more
+//           than NS_RANK of them (one round on ordinary data; an outlier or a run of equal keys costs its cell more);
+//   rank    the last candidates of a cell are ranked among themselves under L_d by counting and fill the gap in that
+//           order: the one that lands on len / 2 is the median (split value, children's places follow).
+// A cell of <= 33 points, which has a leaf among its children, is sorted outright (every point counts the points before it, key
+// bits first, the rest of L_d on equal ones): the leaves then stand as the reference's sort of their parent leaves them.
+constexpr uint32_t NS_CELLS = 256;  // most cells of a level (2^(levels inside the block))
+constexpr uint32_t NS_RANK = 8;     // candidates a selecting cell ranks by counting
+constexpr uint32_t NS_SORTS = 33;   // a cell of up to this many points has a leaf among its children (33 -> 16 + 17): it is sorted
+
+// counters[idx]++ for every valid lane, the old value returned; the lanes that share the first valid lane's idx add as one
+__device__ __forceinline__ uint32_t take_wave(uint32_t* counters, uint32_t idx, bool valid) {
+  const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
+  if (!act) return 0u;
+  const uint32_t lane = lane_id(), lead = (uint32_t)__builtin_ctzll(act);
+  const uint32_t il = (uint32_t)__builtin_amdgcn_readlane((int)idx, (int)lead);
+  const bool with_lead = valid && idx == il;
+  const unsigned long long same = __builtin_amdgcn_ballot_w64(with_lead);
+  uint32_t base = 0u;
+  if (lane == lead) base = atomicAdd(&counters[il], (uint32_t)__builtin_popcountll(same));
+  base = (uint32_t)__shfl((int)base, (int)lead, 64);
+  if (with_lead) return base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+  return valid ? atomicAdd(&counters[idx], 1u) : 0u;
+}
+// mn[idx] = min(mn[idx], k), mx[idx] = max(...) for every valid lane; the first valid lane's group reduces in the wave first
+__device__ __forceinline__ void minmax_wave(uint32_t* mn, uint32_t* mx, uint32_t idx, uint32_t k, bool valid) {
+  const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
+  if (!act) return;
+  const uint32_t lane = lane_id(), lead = (uint32_t)__builtin_ctzll(act);
+  const uint32_t il = (uint32_t)__builtin_amdgcn_readlane((int)idx, (int)lead);
+  const bool with_lead = valid && idx == il;
+  uint32_t lo = with_lead ? k : ~0u, hi = with_lead ? k : 0u;
+#pragma unroll
+  for (int off = 32; off; off >>= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+  }
+  if (lane == lead) atomicMin(&mn[il], lo), atomicMax(&mx[il], hi);
+  else if (valid && !with_lead) atomicMin(&mn[idx], k), atomicMax(&mx[idx], k);
+}
+
+template <uint32_t SLOTS>
+constexpr size_t ns_lds_bytes() { return SLOTS * (2 * sizeof(float4) + 3 * sizeof(uint32_t)); }
+
+template <uint32_t SLOTS>
+__global__ void __launch_bounds__(SLOTS / 4)
+    sel_narrow_select_kernel(const float4* __restrict__ recs, uint32_t n, uint32_t d0, uint32_t D, float* __restrict__ split,
+                             float4* __restrict__ leaves, uint32_t* __restrict__ slot_of_point, uint32_t* __restrict__ flags) {
+  constexpr uint32_t THREADS = SLOTS / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* rec = (float4*)smem;               // [SLOTS] the range's points in their current arrangement
+  float4* rec_next = rec + SLOTS;            // [SLOTS] ... and in the next one
+  uint32_t* hist = (uint32_t*)(rec_next + SLOTS);  // [SLOTS] bins: cell c owns [c * cap, (c + 1) * cap)
+  uint32_t* pre = hist + SLOTS;              // [SLOTS] exclusive prefix of the bins
+  uint32_t* cand = pre + SLOTS;              // [SLOTS] positions of a cell's last candidates, in its bins' range
+  // per cell of the current level
+  __shared__ uint32_t c_start[NS_CELLS], c_len[NS_CELLS];  // its range inside the block; len 0: no such cell / a leaf
+  __shared__ uint32_t c_ncand[NS_CELLS], c_rank[NS_CELLS], c_left[NS_CELLS], c_right[NS_CELLS];  // candidates, the rank sought among them, points placed at either end
+  __shared__ uint32_t c_cmp[NS_CELLS], c_mn[NS_CELLS], c_mx[NS_CELLS], c_shift[NS_CELLS];         // this round: component of L_d, its [min, max], the bucket shift (~0: no round)
+  __shared__ uint32_t c_star[NS_CELLS], c_below[NS_CELLS], c_count[NS_CELLS];                     // this round's bucket of the sought rank
+  __shared__ uint32_t cur_l[NS_CELLS], cur_r[NS_CELLS], cur_c[NS_CELLS];
+  __shared__ uint32_t tmp[16];
+  __shared__ uint32_t more;
+  // (a coordinate by ADDRESS, never by a select on the axis: see sel_narrow_kernel)
+  auto coord = [](const float4* buf, uint32_t pos, uint32_t axis) { return ((const float*)buf)[4u * pos + axis]; };
+  auto lkey_at = [&](const float4* buf, uint32_t pos, uint32_t level) {
+    const uint32_t ax = level % 3;
+    return LKey{ord_bits(coord(buf, pos, ax)), level >= 1 ? ord_bits(coord(buf, pos, (ax + 2) % 3)) : 0u,
+                level >= 2 ? ord_bits(coord(buf, pos, (ax + 1) % 3)) : 0u, __float_as_uint(coord(buf, pos, 3))};
+  };
+  auto lkey_comp_at = [&](const float4* buf, uint32_t pos, uint32_t level, uint32_t cmp) {
+    const uint32_t ax = level % 3;
+    if (cmp == 0) return ord_bits(coord(buf, pos, ax));
+    if (cmp == 1) return level >= 1 ? ord_bits(coord(buf, pos, (ax + 2) % 3)) : 0u;
+    if (cmp == 2) return level >= 2 ? ord_bits(coord(buf, pos, (ax + 1) % 3)) : 0u;
+    return __float_as_uint(coord(buf, pos, 3));
+  };
+  const uint32_t node0 = blockIdx.x;
+#ifdef A3D_TAIL_STAMPS
+  uint32_t n_stamp = 0;
+#define A3D_NS_STAMP(tag, val)                                                                      \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && n_stamp < 32) { \
+      g_sel_stamps[2 * n_stamp] = __builtin_amdgcn_s_memrealtime();                                 \
+      g_sel_stamps[2 * n_stamp + 1] = ((unsigned long long)(tag) << 32) | (val);                    \
+      ++n_stamp;                                                                                    \
+    }                                                                                               \
+  } while (0)
+#else
+#define A3D_NS_STAMP(tag, val) do { } while (0)
+#endif
+  uint32_t s0, l0;
+  bool exists0;
+  sel_node_range(n, d0, node0, &s0, &l0, &exists0);
+  uint32_t cap0 = 32;
+  while (cap0 < l0) cap0 <<= 1;
+  A3D_NS_STAMP(20, l0);
+  for (uint32_t p = threadIdx.x; p < l0; p += THREADS) rec[p] = recs[s0 + p];
+  __syncthreads();
+  A3D_NS_STAMP(21, l0);
+  // the cell of position p at level d0 + rel: id (its path below the range), start, length; false: no cell that splits
+  // (a leaf, there or above: its id is shifted up so that it stays unique)
+  auto locate = [&](uint32_t p, uint32_t rel, uint32_t* c, uint32_t* s, uint32_t* l) {
+    uint32_t cc = 0, ss = 0, ll = l0;
+    for (uint32_t t = 0; t < rel; ++t) {
+      if (ll <= 16) {
+        *c = cc << (rel - t), *s = ss, *l = ll;
+        return false;
+      }
+      const uint32_t mid = ll >> 1;
+      if (p - ss < mid) ll = mid, cc = 2 * cc;
+      else ss += mid, ll -= mid, cc = 2 * cc + 1;
+    }
+    *c = cc, *s = ss, *l = ll;
+    return ll > 16;
+  };
+  const uint32_t levels = D > d0 ? D - d0 : 0u;  // levels d0 .. D - 1 can split
+  for (uint32_t rel = 0; rel < levels; ++rel) {
+    const uint32_t d = d0 + rel, a = d % 3, cap = cap0 >> rel;
+    if (cap < 32) break;  // everything below is a leaf
+    const uint32_t cap_log = 31u - (uint32_t)__builtin_clz(cap), cells = 1u << rel;
+    // ---- this level's cells.  A cell of <= 33 points (a child of <= 16 is a leaf) is SORTED under L_d — every point counts
+    // the cell's points before it — so that the leaves stand in the order the reference's sort leaves them in; a larger
+    // one only finds its median and partitions (rounds below).
+    if (threadIdx.x == 0) more = 0u;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < cells; c += THREADS) {
+      uint32_t s = 0, l = l0;
+      bool ok = true;
+      for (uint32_t t = 0; t < rel; ++t) {
+        if (l <= 16) {
+          ok = false;
+          break;
+        }
+        const uint32_t mid = l >> 1;
+        if ((c >> (rel - 1 - t)) & 1u) s += mid, l -= mid;
+        else l = mid;
+      }
+      const bool selects = ok && l > NS_SORTS;
+      c_ncand[c] = selects ? l : 0u, c_rank[c] = l >> 1, c_left[c] = 0u, c_right[c] = 0u, c_cmp[c] = 0u;
+      if (selects) more = 1u;  // (benign race: every writer stores 1)
+    }
+    // every point: its cell, its place once it has one (a candidate of a selecting cell: none yet)
+    uint32_t e_cell[4], e_start[4], e_len[4], e_dest[4];
+    bool e_cand[4], e_sorts[4];
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e) {
+      const uint32_t p = threadIdx.x + e * THREADS;
+      e_cell[e] = 0u, e_start[e] = 0u, e_len[e] = 0u, e_dest[e] = p, e_cand[e] = false, e_sorts[e] = false;
+      if (p < l0) {
+        const bool splits = locate(p, rel, &e_cell[e], &e_start[e], &e_len[e]);
+        e_cand[e] = splits && e_len[e] > NS_SORTS, e_sorts[e] = splits && e_len[e] <= NS_SORTS;
+        const float v = coord(rec, p, a);
+        if (splits && v != v) atomicOr(&flags[FLAG_NAN], 1u);  // partial_cmp().unwrap() would panic (kdtree.rs:43)
+        cand[p] = ord_bits(v);  // (the sorting cells compare these first)
+      }
+    }
+    __syncthreads();
+    // ---- sorting cells
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e) {
+      if (!e_sorts[e]) continue;
+      const uint32_t p = threadIdx.x + e * THREADS, k = cand[p];
+      uint32_t r = 0;
+      for (uint32_t q = e_start[e]; q < e_start[e] + e_len[e]; ++q) {
+        const uint32_t kq = cand[q];
+        bool before = kq < k;
+        if (kq == k && q != p) before = lkey_less(lkey_at(rec, q, d), lkey_at(rec, p, d));  // (rare: equal keys)
+        r += before ? 1u : 0u;
+      }
+      e_dest[e] = e_start[e] + r;
+      if (r == (e_len[e] >> 1))  // the point of rank len / 2: `points[mid][k]` (kdtree.rs:47-49)
+        split[((1u << d) - 1u) + (node0 << rel) + e_cell[e]] = coord(rec, p, a);
+    }
+    A3D_NS_STAMP(22, rel);
+    // ---- selecting cells: narrowing rounds
+    while (more) {  // (block-uniform: read after a barrier, written before the next one)
+      for (uint32_t c = threadIdx.x; c < cells; c += THREADS) {
+        c_mn[c] = ~0u, c_mx[c] = 0u, cur_l[c] = 0u, cur_r[c] = 0u;
+        c_shift[c] = ~0u;
+      }
+      for (uint32_t q = threadIdx.x; q < cap0; q += THREADS) hist[q] = 0u;
+      __syncthreads();
+      if (threadIdx.x == 0) more = 0u;
+      uint32_t e_key[4];
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e) {
+        const uint32_t p = threadIdx.x + e * THREADS, c = e_cell[e];
+        const bool in = e_cand[e] && c_ncand[c] > NS_RANK;
+        e_key[e] = in ? lkey_comp_at(rec, p, d, c_cmp[c]) : 0u;
+        minmax_wave(c_mn, c_mx, c, e_key[e], in);
+      }
+      __syncthreads();
+      for (uint32_t c = threadIdx.x; c < cells; c += THREADS) {
+        if (c_ncand[c] > NS_RANK) {
+          if (c_mn[c] == c_mx[c]) {
+            c_cmp[c] += 1u;  // all candidates agree in this component: the next one decides (the index, unique, ends it)
+            more = 1u;
+          } else {
+            const uint32_t span = c_mx[c] - c_mn[c], bits = 32u - (uint32_t)__builtin_clz(span);
+            c_shift[c] = bits > cap_log ? bits - cap_log : 0u;  // (mn and mx land in different buckets, all below `cap`)
+          }
+        }
+      }
+      __syncthreads();
+      uint32_t e_bin[4];
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e) {
+        const uint32_t c = e_cell[e];
+        const bool in = e_cand[e] && c_shift[c] != ~0u;
+        e_bin[e] = in ? (e_key[e] - c_mn[c]) >> c_shift[c] : 0u;
+        hist_add_wave(hist, (c << cap_log) + e_bin[e], in);
+      }
+      __syncthreads();
+      {  // exclusive prefix of the bins (four consecutive ones per thread)
+        const uint32_t b0 = 4u * threadIdx.x;
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) v[e] = b0 + e < cap0 ? hist[b0 + e] : 0u;
+        const uint32_t ex = block_exclusive_scan<THREADS>(v[0] + v[1] + v[2] + v[3], tmp);
+        uint32_t run = ex;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+          if (b0 + e < cap0) pre[b0 + e] = run;
+          run += v[e];
+        }
+      }
+      __syncthreads();
+      {  // the bucket that holds the sought rank, per cell
+        const uint32_t b0 = 4u * threadIdx.x;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+          const uint32_t bin = b0 + e;
+          if (bin >= cap0) continue;
+          const uint32_t cnt = hist[bin], c = bin >> cap_log;
+          if (!cnt || c >= cells || c_shift[c] == ~0u) continue;
+          const uint32_t before = pre[bin] - pre[c << cap_log], t = c_rank[c];
+          if (before <= t && t < before + cnt) c_star[c] = bin - (c << cap_log), c_below[c] = before, c_count[c] = cnt;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t e = 0; e < 4; ++e) {
+        const uint32_t c = e_cell[e];
+        const bool in = e_cand[e] && c_shift[c] != ~0u;
+        const uint32_t star = in ? c_star[c] : 0u;
+        const bool left = in && e_bin[e] < star, right = in && e_bin[e] > star;
+        const uint32_t tl = take_wave(cur_l, c, left), tr = take_wave(cur_r, c, right);
+        if (left) e_dest[e] = e_start[e] + c_left[c] + tl, e_cand[e] = false;
+        if (right) e_dest[e] = e_start[e] + e_len[e] - 1u - c_right[c] - tr, e_cand[e] = false;
+      }
+      __syncthreads();
+      for (uint32_t c = threadIdx.x; c < cells; c += THREADS) {
+        if (c_shift[c] != ~0u) {
+          c_left[c] += c_below[c], c_right[c] += c_ncand[c] - c_below[c] - c_count[c];
+          c_rank[c] -= c_below[c], c_ncand[c] = c_count[c];
+          if (c_count[c] > NS_RANK) more = 1u;
+        }
+      }
+      __syncthreads();
+      A3D_NS_STAMP(23, rel);
+    }
+    // ---- the last candidates of every selecting cell: ranked among themselves under L_d, they fill the gap in that order
+    for (uint32_t c = threadIdx.x; c < cells; c += THREADS) cur_c[c] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e) {
+      const uint32_t c = e_cell[e];
+      const uint32_t slot = take_wave(cur_c, c, e_cand[e]);
+      if (e_cand[e]) hist[(c << cap_log) + slot] = threadIdx.x + e * THREADS;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e) {
+      if (!e_cand[e]) continue;
+      const uint32_t p = threadIdx.x + e * THREADS, c = e_cell[e], nc = c_ncand[c];
+      const LKey me = lkey_at(rec, p, d);
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < nc; ++j) r += lkey_less(lkey_at(rec, hist[(c << cap_log) + j], d), me) ? 1u : 0u;
+      e_dest[e] = e_start[e] + c_left[c] + r;
+      if (c_left[c] + r == (e_len[e] >> 1))
+        split[((1u << d) - 1u) + (node0 << rel) + c] = coord(rec, p, a);
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e) {
+      const uint32_t p = threadIdx.x + e * THREADS;
+      if (p < l0) rec_next[e_dest[e]] = rec[p];
+    }
+    __syncthreads();
+    float4* sw = rec;
+    rec = rec_next, rec_next = sw;
+    A3D_NS_STAMP(24, rel);
+  }
+  // ---- a range that is a leaf itself (a lowered wide / narrow border only): the order its parent's sort left it in, L of
+  // the parent's depth; the whole tree as one leaf (depth 0) keeps the order it came in
+  if (l0 <= 16 && d0 >= 1) {
+    const uint32_t p = threadIdx.x;
+    float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t dest = p;
+    if (p < l0) {
+      mine = rec[p];
+      const LKey me = lkey_at(rec, p, d0 - 1);
+      uint32_t r = 0;
+      for (uint32_t q = 0; q < l0; ++q) r += lkey_less(lkey_at(rec, q, d0 - 1), me) ? 1u : 0u;
+      dest = r;
+    }
+    __syncthreads();
+    if (p < l0) rec[dest] = mine;
+    __syncthreads();
+  }
+  // leaves: slot r of the leaf reached by `path` at depth `depth` lives at (path << (D - depth)) * 16 + r (kdtree.hpp)
+  for (uint32_t p = threadIdx.x; p < l0; p += THREADS) {
+    uint32_t rs = 0, rl = l0, path = node0, depth = d0;
+    while (depth < D && rl > 16) {
+      const uint32_t mid = rl >> 1;
+      if (p - rs < mid) rl = mid, path = 2 * path;
+      else rs += mid, rl -= mid, path = 2 * path + 1;
+      ++depth;
+    }
+    const uint32_t slot = (path << (D - depth)) * 16u + (p - rs);
+    const float4 r = rec[p];
+    leaves[slot] = r;
+    slot_of_point[__float_as_uint(r.w)] = slot;
+  }
+  // +inf in the slots no point took, 0 in the split entries of this subtree's nodes that are leaves at depth D - 1
+  const uint32_t sub = D - d0, first_leaf = node0 << sub;
+  for (uint32_t q = threadIdx.x; q < (16u << sub); q += THREADS) {
+    const uint32_t P = first_leaf + (q >> 4), r = q & 15u;
+    bool used;
+    if (D == 0) {
+      used = r < n;
+    } else {
+      uint32_t ps, pl;
+      bool pe;
+      sel_node_range(n, D - 1, P >> 1, &ps, &pl, &pe);  // (every node of depth D - 1 exists: leaves sit at D - 1 or D)
+      if (pl <= 16) used = (P & 1u) == 0u && r < pl;      // a leaf at depth D - 1 fills the even child's slots
+      else used = r < ((P & 1u) ? pl - (pl >> 1) : (pl >> 1));
+    }
+    if (!used) leaves[(size_t)first_leaf * 16u + q] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f);
+  }
+  if (D >= 1 && D - 1 >= d0) {
+    const uint32_t subm = D - 1 - d0;
+    for (uint32_t q = threadIdx.x; q < (1u << subm); q += THREADS) {
+      const uint32_t pth = (node0 << subm) + q;
+      uint32_t ps, pl;
+      bool pe;
+      sel_node_range(n, D - 1, pth, &ps, &pl, &pe);
+      if (!(pe && pl > 16)) split[((1u << (D - 1)) - 1u) + pth] = 0.0f;
+    }
+  }
+}
+#endif  // A3D_DIAGNOSTICS
+
 struct SelLayout {
   uint32_t wide_levels = 0;            // levels 0 .. wide_levels - 1 run the split / resolve kernels
   uint32_t narrow_len = NARROW;
@@ -1249,6 +1614,9 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS_BYTES));
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel<2048, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nw_lds_bytes<2048>()));
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel<2048, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nw_lds_bytes<2048>()));
+#ifdef A3D_DIAGNOSTICS
+    A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_select_kernel<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ns_lds_bytes<2048>()));
+#endif
     lds_allowed.store(true);
   }
   A3D_HIP_TRY(hipMemsetAsync(base + L.zero_begin, 0, L.zero_bytes, s));  // flags, cursors, both histogram tables
@@ -1278,19 +1646,31 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
                        recs[(d + 1) & 1], n, d, L.nb[d], nb_next, plans + off, boxes + off, plans + (2 * nodes - 1u),
                        boxes + (2 * nodes - 1u), hist[(d + 1) & 1], t->d_split, flags, cap_d, wide_d, whist);
   }
-  bool regs = false;  // the network's words in LDS (measured faster: DESIGN.md); diagnostics build: A3D_KDTREE_SORTNET=regs
-  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_SORTNET")) regs = !strcmp(env, "regs");
+  // the in-block levels by the sorting network with its words in LDS (measured fastest: DESIGN.md); diagnostics build:
+  // A3D_KDTREE_SORTNET=regs (its words in registers and lane exchanges) / =select (selection inside the block): the cross-checks
+  int net = 1;
+  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_SORTNET")) net = !strcmp(env, "regs") ? 2 : (!strcmp(env, "select") ? 0 : 1);
 #define A3D_NARROW_LAUNCH(SLOTS, REGS)                                                                                  \
   hipLaunchKernelGGL((sel_narrow_kernel<SLOTS, REGS>), dim3(1u << W), dim3(SLOTS / 4), nw_lds_bytes<SLOTS>(), s, recs[W & 1], n, \
                      W, D, t->d_split, t->d_leaves, t->d_slot_of_point, flags)
+#ifdef A3D_DIAGNOSTICS
+#define A3D_NARROW_SELECT(SLOTS)                                                                                        \
+  hipLaunchKernelGGL((sel_narrow_select_kernel<SLOTS>), dim3(1u << W), dim3(SLOTS / 4), ns_lds_bytes<SLOTS>(), s, recs[W & 1], n, \
+                     W, D, t->d_split, t->d_leaves, t->d_slot_of_point, flags)
+#else
+#define A3D_NARROW_SELECT(SLOTS) A3D_NARROW_LAUNCH(SLOTS, false)
+#endif
   if (L.narrow_len <= 1024) {
-    if (regs) A3D_NARROW_LAUNCH(1024, true);
-    else A3D_NARROW_LAUNCH(1024, false);
+    if (net == 2) A3D_NARROW_LAUNCH(1024, true);
+    else if (net == 1) A3D_NARROW_LAUNCH(1024, false);
+    else A3D_NARROW_SELECT(1024);
   } else {
-    if (regs) A3D_NARROW_LAUNCH(2048, true);
-    else A3D_NARROW_LAUNCH(2048, false);
+    if (net == 2) A3D_NARROW_LAUNCH(2048, true);
+    else if (net == 1) A3D_NARROW_LAUNCH(2048, false);
+    else A3D_NARROW_SELECT(2048);
   }
 #undef A3D_NARROW_LAUNCH
+#undef A3D_NARROW_SELECT
   A3D_HIP_TRY(hipGetLastError());
   if (done) A3D_HIP_TRY(hipEventRecord(done, s));
   uint32_t h_flags[2] = {0, 0};

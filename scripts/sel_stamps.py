@@ -1,5 +1,7 @@
 """Where one sel_resolve_kernel block's time goes on the configs[2] cloud (a depth image's points: thousands share a
 quantised z).  Needs scripts/build_stamps.sh; it loads scripts/stampbuild/libalign3d_hip_stamps.so.
+`sel_stamps.py narrow`: block 0 of sel_narrow_select_kernel (the in-block selection kernel, diagnostics build) on the
+uniform cloud: set-up, rounds and the rest of every level.
 Stamps: (s_memrealtime at 100 MHz, tag, set size) — tags: 0 entry, 1 streaming min/max, 2 streaming round done, 3 set
 copied to LDS, 4 LDS min/max, 5 LDS round done, 6 before the final ranking, 7 placed, 8 children's plans written."""
 import ctypes
@@ -15,7 +17,7 @@ sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402
 from align3d_amd import Context, R3dTree  # noqa: E402
 
-TAGS = {9: "after place kernel", 0: "entry", 1: "stream min/max", 2: "stream round", 3: "to LDS", 4: "lds min/max", 5: "lds round", 6: "pre-final", 7: "placed", 8: "plans"}
+TAGS = {20: "narrow: entry", 21: "narrow: range in LDS", 22: "narrow: level set up, small cells sorted", 23: "narrow: round done", 24: "narrow: level done", 9: "after place kernel", 0: "entry", 1: "stream min/max", 2: "stream round", 3: "to LDS", 4: "lds min/max", 5: "lds round", 6: "pre-final", 7: "placed", 8: "plans"}
 
 
 def main():
@@ -29,7 +31,25 @@ def main():
     pts = np.ascontiguousarray(tgt.points)
     R3dTree.new(ctx, pts).free()
     todo = [(2, j) for j in range(4)] + [(0, 0), (1, 0)]
-    if len(sys.argv) > 1:  # `sel_stamps.py LEVEL`: every node of that level, the slowest one printed in full
+    if len(sys.argv) > 1 and sys.argv[1] == "narrow":  # block 0 (and 100) of the in-block kernel, on the uniform cloud too
+        todo = [(99, 0)]  # (the in-block selection kernel's block 0 stamps whatever level is asked for; 99 keeps the resolve blocks quiet)
+        os.environ["A3D_KDTREE_SORTNET"] = "select"  # diagnostics build: the in-block levels by selection (the stamped kernel)
+        sys.argv = sys.argv[:1]
+        import bench as _b
+        uni = np.ascontiguousarray(_b.synth.uniform01_f32(10, 3 * 500_000).reshape(-1, 3))
+        for level, node in todo:
+            fn(out, level, node)
+            R3dTree.new(ctx, uni).free()
+            fn(out, level, node)
+            v = list(out)
+            print(f"uniform cloud, block {node}")
+            prev = v[0]
+            for k in range(32):
+                if v[2 * k] == 0:
+                    break
+                print(f"   {TAGS.get(v[2 * k + 1] >> 32):44s} {v[2 * k + 1] & 0xffffffff:5d}  +{(v[2 * k] - prev) / 100.0:7.2f} us   at {(v[2 * k] - v[0]) / 100.0:7.2f}")
+                prev = v[2 * k]
+    elif len(sys.argv) > 1:  # `sel_stamps.py LEVEL`: every node of that level, the slowest one printed in full
         level = int(sys.argv[1])
         todo = [(level, j) for j in range(1 << level)]
     rows = []
