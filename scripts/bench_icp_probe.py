@@ -4,6 +4,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from align3d_amd import Context
 import bench
-ctx = Context(0)
+ctx = Context(0, library=os.environ.get("A3D_LIBRARY"))
 r, _ = bench.bench_icp_shape(ctx)
 print({k: r[k] for k in ("icp_new_device_ms", "new_plus_align_device_ms", "device_ms_per_align", "icp_new_ms_incl_pcie")})
