@@ -91,6 +91,7 @@ struct a3d_context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t kd_ev[2] = {nullptr, nullptr};  // around a kd-tree build's launches (a3d_kdtree_build_ms): made once
   int num_cus = 0;
   // Grow-only scratch regions for per-call temporaries (all work on a context is ordered on its one stream,
   // so successive calls may reuse them): [0] frame builder temporaries, [1] bilateral grids, [2] kd-tree build.
@@ -126,6 +127,7 @@ struct a3d_context {
   void (*icp_engine_free)(void*) = nullptr;
   uint32_t* pinned_words = nullptr;  // PINNED_WORDS page-locked words: scalar results copied back asynchronously
   static constexpr size_t PINNED_WORDS = 16384;
+  static constexpr size_t PINNED_EXTRA = 16;  // behind them: the kd-tree build's flag words (its own slot: nothing else lands there)
   // Second stream of the frame builder: the uploads of chunk k + 1 run under the kernels of chunk k.
   hipStream_t copy_stream = nullptr;
   std::vector<hipEvent_t> copy_events;

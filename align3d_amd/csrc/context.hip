@@ -372,7 +372,9 @@ a3d_status a3d_context_create_on_pipe(int32_t device_index, int32_t priority, in
   }
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_start));
   A3D_HIP_TRY(hipEventCreate(&ctx->ev_stop));
-  A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, a3d_context::PINNED_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  A3D_HIP_TRY(hipEventCreate(&ctx->kd_ev[0]));
+  A3D_HIP_TRY(hipEventCreate(&ctx->kd_ev[1]));
+  A3D_HIP_TRY(hipHostMalloc((void**)&ctx->pinned_words, (a3d_context::PINNED_WORDS + a3d_context::PINNED_EXTRA) * sizeof(uint32_t), hipHostMallocDefault));
   *out_ctx = guard.release();
   return A3D_OK;
 }
@@ -446,6 +448,8 @@ void ctx_destroy_now(a3d_context* ctx) {
   hipFree(ctx->scratch[2]);
   if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
+  for (hipEvent_t e : ctx->kd_ev)
+    if (e) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }

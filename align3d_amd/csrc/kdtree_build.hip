@@ -222,13 +222,10 @@ a3d_status kdtree_build_device(a3d_kdtree* t, const float* d_points) {
   A3D_REQUIRE(t->ctx->scratch[2] && t->ctx->scratch_size[2] >= pad((size_t)t->n * 12) + kdtree_select_scratch_bytes(t->n),
               A3D_INVALID_PARAMETER, "internal: kd-tree scratch region too small");
   // instrumentation (a3d_kdtree_build_ms): the build's launches between two events on the stream
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool timed = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-  if (timed) hipEventRecord(e0, t->ctx->stream);
+  hipEvent_t e0 = t->ctx->kd_ev[0], e1 = t->ctx->kd_ev[1];  // (the context's: an event made and destroyed per build cost ~10 us)
+  const bool timed = e0 && e1 && hipEventRecord(e0, t->ctx->stream) == hipSuccess;
   const a3d_status st = kdtree_build_device_select(t, d_points, scratch, timed ? e1 : nullptr);
-  if (timed && st == A3D_OK) hipEventElapsedTime(&t->build_ms, e0, e1);
-  if (e0) hipEventDestroy(e0);
-  if (e1) hipEventDestroy(e1);
+  if (timed && st == A3D_OK) (void)hipEventElapsedTime(&t->build_ms, e0, e1);
   return st;
 }
 

@@ -1673,8 +1673,9 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
 #undef A3D_NARROW_SELECT
   A3D_HIP_TRY(hipGetLastError());
   if (done) A3D_HIP_TRY(hipEventRecord(done, s));
-  uint32_t h_flags[2] = {0, 0};
-  A3D_HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+  // (page-locked words of the context: a copy into pageable memory is staged by the runtime and blocks for longer)
+  volatile uint32_t* h_flags = t->ctx->pinned_words + a3d_context::PINNED_WORDS;
+  A3D_HIP_TRY(hipMemcpyAsync((void*)h_flags, flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   A3D_HIP_TRY(hipStreamSynchronize(s));
   if (h_flags[FLAG_OVERSIZED]) t->ctx->kd_wide_place.store(true);
   A3D_REQUIRE(!h_flags[FLAG_NAN], A3D_NAN_IN_INPUT,
