@@ -1206,7 +1206,6 @@ __global__ void __launch_bounds__(SLOTS / 4)
   uint32_t* pre = hist + SLOTS;              // [SLOTS] exclusive prefix of the bins
   uint32_t* cand = pre + SLOTS;              // [SLOTS] positions of a cell's last candidates, in its bins' range
   // per cell of the current level
-  __shared__ uint32_t c_start[NS_CELLS], c_len[NS_CELLS];  // its range inside the block; len 0: no such cell / a leaf
   __shared__ uint32_t c_ncand[NS_CELLS], c_rank[NS_CELLS], c_left[NS_CELLS], c_right[NS_CELLS];  // candidates, the rank sought among them, points placed at either end
   __shared__ uint32_t c_cmp[NS_CELLS], c_mn[NS_CELLS], c_mx[NS_CELLS], c_shift[NS_CELLS];         // this round: component of L_d, its [min, max], the bucket shift (~0: no round)
   __shared__ uint32_t c_star[NS_CELLS], c_below[NS_CELLS], c_count[NS_CELLS];                     // this round's bucket of the sought rank
