@@ -64,3 +64,23 @@ def test_traffic_profile_is_chosen_by_recorded_keys_not_by_file_name():
     t2, src2 = bench.measured_traffic("normals", frames=64, pixels=307200, layout="plain_order")
     assert src2.endswith("plain_order.json") and t2 > t
     assert bench.measured_traffic("normals", frames=63, pixels=307200, layout="xcd_contiguous") == (None, None)
+
+
+def test_line_from_the_round5_detail_matches_the_line_that_was_printed():
+    """The round-5 detail file (the full result `main` wrote beside the line) rebuilds the very line the run printed."""
+    detail = os.path.join(ROOT, "profiles", "round5_bench_detail.json")
+    printed = os.path.join(ROOT, "profiles", "round5_bench.json")
+    if not (os.path.exists(detail) and os.path.exists(printed)):
+        import pytest
+
+        pytest.skip("round-5 profiles not present")
+    full = json.loads(open(detail).read())
+    was = json.loads(open(printed).read())
+    now = json.loads(bench.compact_line(full, was.get("detail_file")))
+    assert len(json.dumps(now)) < bench.LINE_BUDGET_BYTES
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "cpu_baseline"):
+        assert now[k] == was[k], k
+    # the secondary workloads the round added are on the line as scalars
+    for k in ("kdtree_build_kernel_ms", "kdtree_build_frac", "pcl_icp_new_plus_align_device_ms", "bench_icp_new_plus_align_device_ms",
+              "frame_build_traffic_per_frame"):
+        assert k in now["extra"], k
