@@ -1,5 +1,6 @@
-"""BASELINE's full sizes through size-independent properties (no oracle run at this size): a 64-pair batch of
-640x480 synthetic frame pairs, 3 levels x 15 iterations (the benchmark's workload)."""
+"""BASELINE's full sizes: a 64-pair batch of 640x480 synthetic frame pairs, 3 levels x 15 iterations (the benchmark's
+workload) through size-independent properties (its per-pair oracle comparison is tests/test_gpu_headline_parity.py), and
+configs[2] (500 000 x 500 000 points, 15 iterations) through properties AND against the oracle run at that size."""
 import numpy as np
 import pytest
 
@@ -96,6 +97,42 @@ def test_full_size_point_cloud_icp_properties(ctx):
     ang = np.arccos(np.clip((np.trace(dm[:3, :3]) - 1) / 2, -1, 1))
     ident_ang = np.arccos(np.clip((np.trace(rel[:3, :3]) - 1) / 2, -1, 1))
     assert ang < 0.2 * ident_ang + 1e-4 and np.linalg.norm(dm[:3, 3]) < 0.5 * np.linalg.norm(rel[:3, 3]) + 1e-3
+    # configs[2] at its stated size against the ORACLE (src/icp/pcl_icp.rs:49-107 over
+    # src/kdtree.rs:28-105; the oracle builds its tree in ~0.15 s and aligns in ~0.5 s): the end pose within the
+    # north-star tolerance, and at iterations 0 / 7 / 14 — from the oracle's own transform before that iteration — the
+    # inlier count exact (bit-exact neighbours of bit-exact transformed points) and H, g, sum r^2 within 1e-6 of the
+    # f64-summed oracle (g, which vanishes at convergence, relative to the size of its terms)
+    import ctypes as C
+
+    import oracle_lib as O
+    from align3d_amd import Transform
+    from align3d_amd._abi import GnStateC, PoseC
+    from gpu_util import gn_rel_err, transform_diff
+
+    prm = IcpParams.default()
+    tree = O.KdTree(tgt.points)
+    assert tree.status == 0
+    tv, sv = O.pcl_view(tgt.points, tgt.normals), O.pcl_view(src.points, src.normals)
+    pc, out = prm.to_c(), PoseC()
+    trace = np.zeros((int(prm.max_iterations), 8), np.float32)
+    assert O.load().orc_pcl_icp_align(C.byref(pc), tree.h, C.byref(tv), C.byref(sv), C.byref(out), O.ptr(trace)) == 0
+    ang, tr = transform_diff(T, out)
+    print(f"[configs[2] 500k x 500k x 15 vs oracle] d_angle={ang:.3e} rad d_trans={tr:.3e} m")
+    assert ang <= 1e-4 and tr <= 1e-4
+    for it in (0, 7, 14):
+        T_in = Transform.eye() if it == 0 else Transform(trace[it - 1, 1:4], trace[it - 1, 4:8])
+        g = GnStateC()
+        t_in = T_in.to_c()
+        assert O.load().orc_pcl_icp_accumulate(C.byref(pc), tree.h, C.byref(tv), C.byref(sv), C.byref(t_in), 1, C.byref(g)) == 0
+        ref, gpu = g.as_dict(), icp.accumulate(src, T_in)
+        assert gpu["count"] == ref["count"] and ref["count"] > 100_000, (it, gpu["count"], ref["count"])
+        eh, eg, es = gn_rel_err(gpu, ref)
+        print(f"[configs[2] iteration {it}] inliers {ref['count']}, rel. err H {eh:.1e} g {eg:.1e} ssq {es:.1e}")
+        # g vanishes at convergence (4e-6 of its own size is 1e-10 of its terms): its error is measured against the size
+        # of what it sums, |g_i| <= sqrt(H_ii * sum r^2) (Cauchy-Schwarz over the inliers), not against max |g|
+        Hd = np.sqrt(np.diag(np.asarray(ref["H"], np.float64).reshape(6, 6)) * float(ref["ssq"]))
+        eg_terms = float(np.max(np.abs(np.asarray(gpu["g"], np.float64) - np.asarray(ref["g"], np.float64)) / Hd))
+        assert eh < 1e-6 and es < 1e-6 and eg_terms < 1e-6 and (eg < 1e-6 or it > 0), (eh, eg, es, eg_terms)
     # a cloud aligned to itself stays where it is: almost every point finds itself in its leaf (the leaf-only
     # search misses the few that tie with a split value), so the residual is ~0 and the estimate the identity
     self_icp = Icp.new(ctx, IcpParams.default(), src)

@@ -103,3 +103,34 @@ def test_all_64_headline_pairs_against_the_oracle_and_its_own_envelope(ctx, head
             assert tf["max_one_step_angle_rad"] <= 5e-6 and tf["max_one_step_translation_m"] <= 5e-6
     finally:
         ctx.set_tiling(0)
+
+
+def test_all_64_headline_pairs_literally_within_tolerance_under_msdefault(ctx, headline):
+    """the SAME 64 synthetic pairs whose throughput is the headline, under the reference's own
+    contractive parameter set MsIcpParams::default() (src/icp/icp_params.rs:112-133: 20 / 20 / 30 iterations, weight 1,
+    max_color_distance 2.75): every pair LITERALLY within 1e-4 rad / 1e-4 m of the oracle's chunk-order run — no envelope.
+    This is what shows that the three ms3x15 outliers belong to that parameter set (IcpParams::default() on every level is
+    not contractive) and not to the kernel."""
+    pyr, pairs, cores = headline["pyr"], headline["pairs"], headline["cores"]
+    prm = MsIcpParams.default()
+    batch = MultiscaleAlignBatch(ctx, prm, [pyr[a] for a, _ in pairs], [pyr[b] for _, b in pairs])
+    poses, status = batch.align()
+    batch.free()
+    assert not np.any(status)
+    worst_ang = worst_tr = 0.0
+    over = 0
+    for p, (a, b) in enumerate(pairs):
+        ta, tb = [HP.host_frame(lv) for lv in pyr[a]], [HP.host_frame(lv) for lv in pyr[b]]
+        run = HP.oracle_runs(prm, ta, tb, cores, 1)[0]
+        ang, tr = O_metrics(poses[p], run)
+        worst_ang, worst_tr = max(worst_ang, ang), max(worst_tr, tr)
+        over += int(ang > 1e-4 or tr > 1e-4)
+    print(f"[headline pairs under msdefault] 64 pairs: max d_angle={worst_ang:.2e} rad, max d_trans={worst_tr:.2e} m, over 1e-4: {over}")
+    assert over == 0 and worst_ang <= 1e-4 and worst_tr <= 1e-4
+
+
+def O_metrics(gpu_pose, oracle_pose):
+    import oracle_lib as O
+
+    ang, tr = O.transform_metrics(gpu_pose.to_c(), oracle_pose)
+    return abs(ang), tr

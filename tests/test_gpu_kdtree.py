@@ -265,6 +265,21 @@ def test_kdtree_selection_build_finishes_degenerate_clouds(ctx, diag_ctx, monkey
             assert t.build_path() == (3 if env.get("A3D_KDTREE_WIDE_PLACE") == "1" else 1) or c is ctx
             s_, l_ = t.download()
             assert t.stats() == host.stats() and np.array_equal(s_, hs) and np.array_equal(l_, hl), env
+        # the same five clouds against the ORACLE's node-graph tree (src/kdtree.rs:28-105), not only
+        # against this library's host build: tree shape, and `nearest` of every point of the cloud plus 20 000 random
+        # queries over (and beyond) its bounding box — indices and squared distances bit for bit
+        ref = O.KdTree(db)
+        assert ref.status == 0
+        lo, hi = db.min(axis=0), db.max(axis=0)
+        span = np.maximum(hi - lo, np.float32(1e-3))
+        rq = (lo - 0.25 * span + uniform01(77, 3 * 20000).reshape(-1, 3) * 1.5 * span).astype(np.float32)
+        queries = np.concatenate([db, rq])
+        ri, rd = ref.nearest(queries)
+        t = R3dTree.new(ctx, db)
+        assert t.stats() == ref.stats()
+        gi, gd = t.nearest(queries)
+        assert np.array_equal(gi, ri) and np.array_equal(gd.view(np.uint32), rd.view(np.uint32))
+        t.free()
 
 
 def test_kdtree_context_switches_to_wide_placement_after_an_oversized_bucket(diag_ctx, monkeypatch):
