@@ -343,14 +343,25 @@ __global__ void __launch_bounds__(256)
   // The blur tiles whose 16^3 window (12^3 tile + 2 cells of halo) contains a cell of this column: rows and columns of
   // tiles are the thread's own (a0..a1 x b0..b1); the channel tiles depend on the cells and are collected as bits of
   // `ztiles` (grids of up to 64 channel tiles, i.e. 768 channels; deeper grids mark as they write), marked once at the end.
+  // WHICH tiles (round 6).  The slice reads, for a pixel, the eight cells around its grid position: each within ONE cell
+  // of the pixel's own splat cell on every axis (grid.rs:60-78 against :132-146: floor(t + 0.5) against floor(t), floor(t)
+  // + 1).  So a blurred cell is only ever read if a splat cell lies within one cell of it, and a tile's 12^3 cells only if
+  // a splat cell lies in the 14^3 box around them (MARGIN 1) — not in the whole 16^3 window the tile loads (margin 2, what
+  // rounds 3-5 marked: 340 instead of 293 tiles on the benchmark's frames).  A marked tile still loads its whole window, so
+  // what it writes is complete.  The exception are the zero pixels, which are sliced but not splatted: they read channels
+  // 2 and 3 (colour minimum 0) of the FIRST channel tile, where a splat cell two cells away still leaves a non-zero value:
+  // first-channel tiles keep margin 2 (and are written as zeros when unmarked, blur_fused_kernel).
   const uint32_t ta = gr / BT, tb = gc / BT, la = gr % BT, lb = gc % BT;
-  const uint32_t a0 = (la < 2 && ta > 0) ? ta - 1 : ta, a1 = (la >= BT - 2 && ta + 1 < tx) ? ta + 1 : ta;
-  const uint32_t b0 = (lb < 2 && tb > 0) ? tb - 1 : tb, b1 = (lb >= BT - 2 && tb + 1 < ty) ? tb + 1 : tb;
+  const uint32_t a0 = (la < 1 && ta > 0) ? ta - 1 : ta, a1 = (la >= BT - 1 && ta + 1 < tx) ? ta + 1 : ta;
+  const uint32_t b0 = (lb < 1 && tb > 0) ? tb - 1 : tb, b1 = (lb >= BT - 1 && tb + 1 < ty) ? tb + 1 : tb;
+  const uint32_t a0w = (la < 2 && ta > 0) ? ta - 1 : ta, a1w = (la >= BT - 2 && ta + 1 < tx) ? ta + 1 : ta;
+  const uint32_t b0w = (lb < 2 && tb > 0) ? tb - 1 : tb, b1w = (lb >= BT - 2 && tb + 1 < ty) ? tb + 1 : tb;
   const bool ztiles_fit = tz <= 64;
   unsigned long long ztiles = 0;
   auto mark = [&](uint32_t z) {
-    for (uint32_t i = a0; i <= a1; ++i)
-      for (uint32_t j = b0; j <= b1; ++j) {
+    const uint32_t i0 = z == 0 ? a0w : a0, i1 = z == 0 ? a1w : a1, j0 = z == 0 ? b0w : b0, j1 = z == 0 ? b1w : b1;
+    for (uint32_t i = i0; i <= i1; ++i)
+      for (uint32_t j = j0; j <= j1; ++j) {
         if (marks_in_lds) s_marks[((i - ia) * ty + j) * tz + z] = 1;
         else tile_flags[(i * ty + j) * tz + z] = 1;
       }
@@ -411,8 +422,10 @@ __global__ void __launch_bounds__(256)
             s_slot[q][threadIdx.x] = 0;
             if (tile_flags) {
               const uint32_t tc = ch / BT, lc = ch - tc * BT;
-              const uint32_t z0 = (lc < 2 && tc > 0) ? tc - 1 : tc, z1 = (lc >= BT - 2 && tc + 1 < tz) ? tc + 1 : tc;
-              if (ztiles_fit) ztiles |= (1ull << z0) | (1ull << z1);
+              // (margin 1 along the channels as well; the first channel tile from two cells away: channels 12 and 13)
+              const uint32_t z0 = ((lc < 1 || (tc == 1 && lc < 2)) && tc > 0) ? tc - 1 : tc,
+                             z1 = (lc >= BT - 1 && tc + 1 < tz) ? tc + 1 : tc;
+              if (ztiles_fit) ztiles |= (1ull << z0) | (1ull << z1);  // (one of the two is tc itself)
               else mark(z0), mark(z1);
             }
           }
@@ -565,10 +578,12 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     // DPP row, so "previous" and "next" are row shifts by one lane (zero shifted in at the ends of the window: stale
     // layers there, and the reference's aliased always-zero "previous" at grid channel 0).  The axes commute exactly:
     // every intermediate grid is zero outside the box of written cells, and the arithmetic is exact.
+    // (round 6: only the 12 central ROWS go on — the two outermost on either side are stale after the row passes and nothing
+    // reads them; the row passes above are straight-line code, so what only feeds those four rows is not computed either)
     {
       const bool lane_ok = col_ok(gc) && chan_ok(gz);
 #pragma unroll
-      for (int i = 0; i < BR; ++i) {
+      for (int i = 2; i < BR - 2; ++i) {
         const bool ok = inside || (lane_ok && row_ok(r0 + i));
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
@@ -581,21 +596,27 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
       }
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) tile_x[at(i, hi, lo)] = vx[i], tile_w[at(i, hi, lo)] = vw[i];
+    for (int i = 2; i < BR - 2; ++i) tile_x[at(i, hi, lo)] = vx[i], tile_w[at(i, hi, lo)] = vw[i];
   }
   __syncthreads();
-  // ---- axis 1: thread = (row hi, channel lo) owns the 16 columns; the central 12^3 cells go straight to the grid ----
-  {
+  // ---- axis 1: thread = (row, channel lo) owns the 16 columns; the central 12^3 cells go straight to the grid.  Round 6:
+  // the 12 central rows on the block's first 192 threads (row = 2 + t / 16): three waves do what four did with half of the
+  // first and of the last wave's lanes on stale rows; the fourth wave goes on to the tile loop's barrier. ----
+#ifndef A3D_BLUR_3WAVES
+#define A3D_BLUR_3WAVES 1
+#endif
+  if (A3D_BLUR_3WAVES ? hi < BR - 4 : (hi >= 2 && hi < BR - 2)) {
+    constexpr int SHIFT = A3D_BLUR_3WAVES ? 2 : 0;  // window row of thread row `hi`
     double vx[BR];  // (results up to 2^36: f64 from here on; the counts, below 2^20, in Pack<CELL>::Weight)
     W vw[BR];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) vx[i] = (double)tile_x[at(hi, i, lo)], vw[i] = (W)tile_w[at(hi, i, lo)];
-    const int gr = r0 + hi, gz = z0 + lo;
+    for (int i = 0; i < BR; ++i) vx[i] = (double)tile_x[at(hi + SHIFT, i, lo)], vw[i] = (W)tile_w[at(hi + SHIFT, i, lo)];
+    const int gr = r0 + hi + SHIFT, gz = z0 + lo;
     const bool line_ok = row_ok(gr) && chan_ok(gz);
     if (inside) blur_line_twice<false>(vx, vw, [](int) { return true; });
     else blur_line_twice<true>(vx, vw, [&](int i) { return line_ok && col_ok(c0 + i); });
     // (a wave stores 4 rows x 12 channels = four 192-byte runs per column)
-    if (hi >= 2 && hi < BR - 2 && lo >= 2 && lo < BR - 2 && gr < gh && gz < gd) {
+    if (lo >= 2 && lo < BR - 2 && gr < gh && gz < gd) {
       const int col_stride = gd * 8;
       int at_col = ((gr * gw + c0 + 2) * gd + gz) * 8;  // byte offset of cell (gr, c0 + i, gz) in the f64 grid
 #pragma unroll
@@ -969,6 +990,10 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
     A3D_HIP_TRY(hipMemsetAsync(out->packed, 0, packed_bytes, s));
   }
   ctx->grid_clean = a3d_context::GridLayoutKey{};  // unknown until the whole sequence is enqueued
+  // Diagnostics build, A3D_BILATERAL_POISON=1: every blurred cell starts as NaN, so a slice that read a cell no marked tile
+  // wrote (the tile marking's margin argument, splat_packed_kernel) fails the u16 cast check instead of passing on the stale
+  // value of an earlier, similar frame (tests/test_gpu_frame_prep.py).
+  if (A3D_DIAG_ENV("A3D_BILATERAL_POISON")) A3D_HIP_TRY(hipMemsetAsync(out->blurred, 0xFF, (size_t)lf * capacity * 8, s));
   const uint32_t mm_blocks = std::min<uint32_t>((n + 255) / 256, PARTIALS);
   hipLaunchKernelGGL(minmax_u16_kernel, dim3(mm_blocks, n_frames), dim3(256), 0, s, d_depth, n, (uint32_t*)nullptr, partials);
   const double inv_sc = 1.0 / sigma_color;

@@ -105,6 +105,42 @@ __device__ __forceinline__ bool slice_pixel_axes(uint32_t color, const SliceAxis
   *out = 0;
   return false;
 }
+// The same slice in two steps, so that a thread can have the gathers of SEVERAL pixels in flight before it combines the
+// first (level0_quad_kernel: the blurred grids of a launch sequence are far larger than the L2, every gather is a trip to
+// the Infinity Cache or to HBM): slice_gather issues the eight loads (32-bit cell offsets: grid_fits_idx32), slice_combine
+// is the 8-term sum of grid.rs:152-159 in the written order and the cast.
+struct SliceTaps {
+  double v[8];  // v000, v010, v100, v110, v001, v011, v101, v111 (row, column, channel)
+  double za;
+};
+__device__ __forceinline__ void slice_gather(uint32_t color, const SliceAxis& ry, const SliceAxis& cx, double inv_sc,
+                                             uint32_t color_min, GridDims g, const double* __restrict__ grid, SliceTaps* t) {
+  const SliceAxis cz = slice_axis((double)(color - color_min) * inv_sc + 2.0, g.gd);
+  const uint32_t ry0 = __umul24(ry.lo, g.gw), ry1 = __umul24(ry.hi, g.gw);
+  const uint32_t b00 = __umul24(ry0 + cx.lo, g.gd), b01 = __umul24(ry0 + cx.hi, g.gd), b10 = __umul24(ry1 + cx.lo, g.gd),
+                 b11 = __umul24(ry1 + cx.hi, g.gd);
+  t->v[0] = cell_value32(grid, b00, cz.lo), t->v[1] = cell_value32(grid, b01, cz.lo), t->v[2] = cell_value32(grid, b10, cz.lo);
+  t->v[3] = cell_value32(grid, b11, cz.lo), t->v[4] = cell_value32(grid, b00, cz.hi), t->v[5] = cell_value32(grid, b01, cz.hi);
+  t->v[6] = cell_value32(grid, b10, cz.hi), t->v[7] = cell_value32(grid, b11, cz.hi);
+  t->za = cz.frac;
+}
+__device__ __forceinline__ bool slice_combine(const SliceTaps& t, double ya, double xa, uint16_t* out) {
+  const double za = t.za;
+  const double value = (1.0 - ya) * (1.0 - xa) * (1.0 - za) * t.v[0] +
+                       (1.0 - ya) * xa * (1.0 - za) * t.v[1] +
+                       ya * (1.0 - xa) * (1.0 - za) * t.v[2] +
+                       ya * xa * (1.0 - za) * t.v[3] +
+                       (1.0 - ya) * (1.0 - xa) * za * t.v[4] +
+                       (1.0 - ya) * xa * za * t.v[5] +
+                       ya * (1.0 - xa) * za * t.v[6] +
+                       ya * xa * za * t.v[7];
+  if (value > -1.0 && value < 65536.0) {
+    *out = (uint16_t)value;  // truncation toward zero
+    return true;
+  }
+  *out = 0;
+  return false;
+}
 template <bool IDX32 = false>
 __device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t c, double inv_ss, double inv_sc,
                                             uint32_t color_min, GridDims g, const double* __restrict__ grid,

@@ -113,6 +113,7 @@ __device__ __forceinline__ V3 pick_nearest_to_mean(const V3 (&cand)[4], const bo
   return nearest;
 }
 
+#ifdef A3D_DIAGNOSTICS  // the round-2..5 level-0 kernel: the cross-check of level0_quad_kernel (A3D_BUILDER_L0=patch)
 // ---- level 0: bilateral slice + back-projection + normals in one pass ---------------------------------------
 // A block stages the points of a 32 x 16 patch (the 30 x 14 pixels it owns plus a one-pixel halo) in LDS: every
 // staged pixel's filtered depth (BilateralGrid::slice, grid.rs:106-162 — same f64 arithmetic as slice_kernel) is
@@ -127,7 +128,7 @@ constexpr int ST_W = 32, ST_H = 16, OWN_W = ST_W - 2, OWN_H = ST_H - 2;
 // the latency of its dependent phases (depth load -> eight grid gathers -> LDS -> normals -> stores) times the rounds of
 // resident blocks, so a wave that carries two independent pixel chains halves the rounds.
 constexpr int L0_PPT = 2, L0_THREADS = ST_W * ST_H / L0_PPT;
-#if !defined(A3D_L0_PROBE) || !defined(A3D_DIAGNOSTICS)  // diagnostic builds (scripts/build_variant.sh -DA3D_L0_PROBE=n): 1 no level-0 stores, 2 no normals,
+#ifndef A3D_L0_PROBE  // (scripts/build_frame_variant.sh -DA3D_L0_PROBE=n): 1 no level-0 stores, 2 no normals,
 #define A3D_L0_PROBE 0  // 3 no level-1 picks, 4 nothing but the staging
 #endif
 template <bool FILTER>
@@ -247,6 +248,323 @@ __global__ void __launch_bounds__(L0_THREADS)
   const uint32_t i1 = __umul24(r0 >> 1, L1.w) + (c0 >> 1);
   st_v3u(base + (normals_task ? L1.normals : L1.points), i1, pk);  // (a per-lane choice of array: two bases, one select)
   if (!normals_task) st_u8u(base + L1.mask, i1, n_valid > 0 ? 1 : 0);
+}
+#endif  // A3D_DIAGNOSTICS
+
+// ---- level 0, round 6: a block owns an aligned 32 x 32 patch, a thread a 2 x 2 quad of it ------------------------
+// What the round-5 probes of the kernel above showed (profiles/round6_level0_phase_probes.txt; us per 32 frames):
+// slice + back-projection + staging alone 73, + normals + level-1 picks 115, + the level-0 stores 154 — the stores were a
+// quarter of it and the picks (210 tasks behind a second barrier, candidates back from LDS) a sixth, although together they
+// are a fifth of the instructions.  The 30-pixel-wide owned patches start at multiples of 360 bytes: every row of every
+// patch ends inside a 128-byte line its neighbour block completes later, and streaming stores leave such lines partial
+// (write traffic 1.24 x the arrays).  So:
+//  * owned patch = 32 x 32 pixels at multiples of 32: a patch row of points or normals is 384 bytes = three whole lines
+//    when the image width is a multiple of 32 / 3 pixels (640: yes), a mask row one 32-byte sector; nothing is shared;
+//  * a thread owns the 2 x 2 quad (2 ty .. 2 ty + 1, 2 tx .. 2 tx + 1): both pyramid picks of its level-1 pixel take their
+//    four candidates from the thread's own registers (no second staging array, no barrier, every lane busy), two of a
+//    pixel's four neighbours for the normals are the thread's own, and the slice's row / column parts serve two pixels each;
+//  * the one-pixel halo (4 x 32 pixels) is sliced by the block's first 128 threads as a fifth pixel: 4.5 slices per thread for
+//    four owned pixels (0.89) against 2 for 1.64 (0.82), and a 640 x 480 image is 20 x 15 whole patches (the 30 x 14 grid
+//    overhung it by 5 %);
+//  * level 2 as well when the sides are multiples of four: the level-1 picks of a patch are 16 x 16 = whole 2 x 2 blocks, so
+//    they meet in LDS and 128 threads pick level 2's 8 x 8 points and normals: resize_pick_kernel's launch (0.57 us per
+//    frame) is gone for three-level pyramids.
+// The arithmetic per pixel is the kernel above's, expression by expression (slice_pixel_axes, the back-projection's
+// shared-reciprocal quotients, normal_from_neighbours_dev, pick_nearest_to_mean): same bits.
+constexpr int QS = 32, QT = QS / 2;
+
+// CameraIntrinsics::backproject (camera.rs:101-107) of a filtered depth: x = (u - cx) z / fx, y = (v - cy) z / fy; (0,0,0)
+// for an invalid pixel (mask = depth > 0, structure.rs:56-95).
+__device__ __forceinline__ V3 backproject_px(uint32_t d, int row, int col, float fx, float fy, float cx, float cy, float scale,
+                                             const DivBy dfx, const DivBy dfy, bool focal_ok) {
+  V3 p{0.f, 0.f, 0.f};
+  if (d > 0) {
+    p.z = (float)d * scale;
+    const float ax = ((float)col - cx) * p.z, ay = ((float)row - cy) * p.z;
+    // the two IEEE quotients by the (uniform) focal lengths through their refined reciprocals (div_by: bit-identical to `/`
+    // inside its operand range, devmath.hpp); plain division for the wave when anything is outside it
+    const bool fast = focal_ok & div_num_ok(ax) & div_num_ok(ay);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0ull, 0)) {
+      p.x = ax / fx, p.y = ay / fy;
+    } else {
+      p.x = ax == 0.0f ? ax : div_by(ax, dfx), p.y = ay == 0.0f ? ay : div_by(ay, dfy);
+    }
+  }
+  return p;
+}
+
+template <bool FILTER>
+__global__ void __launch_bounds__(256)
+    level0_quad_kernel(const uint16_t* __restrict__ depth, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
+                       const double* __restrict__ grids, unsigned long long capacity, uint32_t* __restrict__ scal, float fx,
+                       float fy, float cx, float cy, float scale, FrameBases bases, size_t off_points, size_t off_mask,
+                       size_t off_normals, bool with_normals, LevelLayout L1, bool emit_l1, LevelLayout L2, bool emit_l2,
+                       bool l2_is_last) {
+  __shared__ float sp[3][QS + 2][QS + 3];  // the patch's points at (y + 1, x + 1), halo included
+  __shared__ float s1[2][3][QT][QT + 1];   // level-1 picks (0: points, 1: normals) for the level-2 picks
+  __shared__ uint8_t s1m[QT][QT];          // level-1 masks
+  __shared__ __attribute__((aligned(4))) uint8_t sm[QS][QS];  // the owned pixels' masks (1: depth > 0), for the row-ordered stores
+  const uint32_t f = blockIdx.z;
+  const int t = (int)threadIdx.x, tx = t & (QT - 1), ty = t >> 4;
+  const int r0 = (int)blockIdx.y * QS, c0 = (int)blockIdx.x * QS;
+  const uint16_t __attribute__((address_space(1)))* dimg =
+      (const uint16_t __attribute__((address_space(1)))*)(depth + (size_t)f * w * h);
+  // (unconditional loads at clamped coordinates: a conditional load is a branch with its own wait, and the kernel lives on
+  // how many loads a thread has in flight; a pixel outside the image counts as depth 0 and is never stored)
+  auto load_depth = [&](int row, int col) -> uint32_t {
+    const uint32_t r = (uint32_t)min(max(row, 0), (int)h - 1), c = (uint32_t)min(max(col, 0), (int)w - 1);
+    return *(const uint16_t __attribute__((address_space(1)))*)((a3d_gptr_c)dimg + (__umul24(r, w) + c) * 2u);
+  };
+  // ---- the thread's pixels: its quad and (threads 0 .. 127: the first two waves) one pixel of the halo ----
+  int row[2], col[2];
+  bool rin[2], cin[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    row[a] = r0 + 2 * ty + a, col[a] = c0 + 2 * tx + a;
+    rin[a] = row[a] < (int)h, cin[a] = col[a] < (int)w;
+  }
+  const bool halo_thread = t < 4 * QS;  // (wave-uniform)
+  const int side = t >> 5, hi = t & (QS - 1);  // 0: the row above, 1: the row below, 2: the column left, 3: the column right
+  const int hy = side == 0 ? 0 : (side == 1 ? QS + 1 : hi + 1), hx = side == 2 ? 0 : (side == 3 ? QS + 1 : hi + 1);  // in sp
+  const int hrow = r0 + hy - 1, hcol = c0 + hx - 1;
+  const bool hin = halo_thread && hrow >= 0 && hrow < (int)h && hcol >= 0 && hcol < (int)w;
+  uint32_t d[2][2], dh = 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) d[a][b] = load_depth(row[a], col[b]);
+  if (halo_thread) dh = load_depth(hrow, hcol);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) d[a][b] = (rin[a] && cin[b]) ? d[a][b] : 0u;
+  dh = hin ? dh : 0u;
+  const DivBy dfx = div_prepare(fx), dfy = div_prepare(fy);
+  const bool focal_ok = div_den_ok(fx) & div_den_ok(fy);
+  if (FILTER) {
+    uint32_t* sc = scal + f * SC_STRIDE;
+    GridDims g;
+    uint32_t cmin;
+    if (dyn_dims(sc, &g, &cmin)) {  // (false: this frame's grid did not fit; the host grows the region and repeats)
+      // BilateralGrid::slice (grid.rs:106-162) of every pixel in the image, zeros included.  The 32 gathers of the quad (and
+      // the halo pixel's eight) are ALL issued before the first is combined: the blurred grids of a launch sequence (150 MB)
+      // do not fit the L2, a gather is a trip to the Infinity Cache, and five pixels one after the other were five such
+      // trips per thread (189 us per 32 frames; the two-pixel kernel it replaced: 154 + 18 for level 2).
+      const double* grid = grids + f * capacity;
+      SliceAxis ry[2], cxs[2];  // the row / column parts (grid.rs:132-146) serve two pixels each
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        ry[a] = slice_axis_spatial((uint32_t)min(row[a], (int)h - 1), inv_ss, g.gh);
+        cxs[a] = slice_axis_spatial((uint32_t)min(col[a], (int)w - 1), inv_ss, g.gw);
+      }
+      bool overflow = false;
+#ifndef A3D_LQ_MLP  // pixels whose gathers are in flight together: 4 = the whole quad (+ the halo pixel), 2 = a quad row, 1
+#define A3D_LQ_MLP 2
+#endif
+      SliceAxis hry{}, hcx{};
+      if (halo_thread) {
+        hry = slice_axis_spatial((uint32_t)min(max(hrow, 0), (int)h - 1), inv_ss, g.gh);
+        hcx = slice_axis_spatial((uint32_t)min(max(hcol, 0), (int)w - 1), inv_ss, g.gw);
+      }
+      auto finish = [&](const SliceTaps& tp, double ya, double xa, bool in) -> uint32_t {
+        uint16_t v;
+        const bool fits = slice_combine(tp, ya, xa, &v);
+        overflow |= in && !fits;
+        return in ? (uint32_t)v : 0u;
+      };
+      if (A3D_LQ_MLP >= 4) {
+        SliceTaps taps[2][2], htaps;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) slice_gather(d[a][b], ry[a], cxs[b], inv_sc, cmin, g, grid, &taps[a][b]);
+        if (halo_thread) slice_gather(dh, hry, hcx, inv_sc, cmin, g, grid, &htaps);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) d[a][b] = finish(taps[a][b], ry[a].frac, cxs[b].frac, rin[a] && cin[b]);
+        if (halo_thread) dh = finish(htaps, hry.frac, hcx.frac, hin);
+      } else if (A3D_LQ_MLP == 3) {  // two at a time, the halo pixel on its own
+        SliceTaps taps[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          slice_gather(d[a][0], ry[a], cxs[0], inv_sc, cmin, g, grid, &taps[0]);
+          slice_gather(d[a][1], ry[a], cxs[1], inv_sc, cmin, g, grid, &taps[1]);
+          d[a][0] = finish(taps[0], ry[a].frac, cxs[0].frac, rin[a] && cin[0]);
+          d[a][1] = finish(taps[1], ry[a].frac, cxs[1].frac, rin[a] && cin[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (halo_thread) {
+          slice_gather(dh, hry, hcx, inv_sc, cmin, g, grid, &taps[0]);
+          dh = finish(taps[0], hry.frac, hcx.frac, hin);
+        }
+      } else if (A3D_LQ_MLP == 2) {
+        SliceTaps taps[2], htaps;
+        slice_gather(d[0][0], ry[0], cxs[0], inv_sc, cmin, g, grid, &taps[0]);
+        slice_gather(d[0][1], ry[0], cxs[1], inv_sc, cmin, g, grid, &taps[1]);
+        if (halo_thread) slice_gather(dh, hry, hcx, inv_sc, cmin, g, grid, &htaps);
+        d[0][0] = finish(taps[0], ry[0].frac, cxs[0].frac, rin[0] && cin[0]);
+        d[0][1] = finish(taps[1], ry[0].frac, cxs[1].frac, rin[0] && cin[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        slice_gather(d[1][0], ry[1], cxs[0], inv_sc, cmin, g, grid, &taps[0]);
+        slice_gather(d[1][1], ry[1], cxs[1], inv_sc, cmin, g, grid, &taps[1]);
+        if (halo_thread) dh = finish(htaps, hry.frac, hcx.frac, hin);
+        d[1][0] = finish(taps[0], ry[1].frac, cxs[0].frac, rin[1] && cin[0]);
+        d[1][1] = finish(taps[1], ry[1].frac, cxs[1].frac, rin[1] && cin[1]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            SliceTaps tp;
+            slice_gather(d[a][b], ry[a], cxs[b], inv_sc, cmin, g, grid, &tp);
+            d[a][b] = finish(tp, ry[a].frac, cxs[b].frac, rin[a] && cin[b]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        if (halo_thread) {
+          SliceTaps tp;
+          slice_gather(dh, hry, hcx, inv_sc, cmin, g, grid, &tp);
+          dh = finish(tp, hry.frac, hcx.frac, hin);
+        }
+      }
+      if (overflow) atomicOr(&sc[SC_OVERFLOW], 1u);  // the reference's .unwrap() would panic
+    }
+  }
+  V3 P[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      P[a][b] = backproject_px(d[a][b], row[a], col[b], fx, fy, cx, cy, scale, dfx, dfy, focal_ok);  // (outside the image: d = 0)
+      const int y = 2 * ty + a + 1, x = 2 * tx + b + 1;
+      sp[0][y][x] = P[a][b].x, sp[1][y][x] = P[a][b].y, sp[2][y][x] = P[a][b].z;
+      sm[y - 1][x - 1] = d[a][b] > 0 ? 1 : 0;
+    }
+  if (halo_thread) {
+    const V3 ph = backproject_px(dh, hrow, hcol, fx, fy, cx, cy, scale, dfx, dfy, focal_ok);
+    sp[0][hy][hx] = ph.x, sp[1][hy][hx] = ph.y, sp[2][hy][hx] = ph.z;
+  }
+  __syncthreads();
+  char* base = bases.arena[f];
+  auto at = [&](int y, int x) { return V3{sp[0][y][x], sp[1][y][x], sp[2][y][x]}; };
+  // ---- normals (structure.rs:184-262): an invalid neighbour's point is (0,0,0) already (= get_point(..).unwrap_or_else(
+  // zeros)), so is everything outside the image; the centre is used as stored, its mask is NOT checked (structure.rs:207).
+  // Of a pixel's four neighbours two are the thread's own.
+  V3 N[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      N[a][b] = V3{0.f, 0.f, 0.f};
+      if (with_normals && rin[a] && cin[b]) {
+        const int y = 2 * ty + a + 1, x = 2 * tx + b + 1;
+        const V3 left = b ? P[a][0] : at(y, x - 1), right = b ? at(y, x + 1) : P[a][1];
+        const V3 top = a ? P[0][b] : at(y - 1, x), bottom = a ? at(y + 1, x) : P[1][b];
+        N[a][b] = normal_from_neighbours_dev(P[a][b], left, right, top, bottom);
+      }
+    }
+#ifndef A3D_LQ_PROBE  // (scripts/build_frame_variant.sh -DA3D_LQ_PROBE=n: 1 no level-0 stores, 3 no picks)
+#define A3D_LQ_PROBE 0
+#endif
+  // ---- level-0 stores in ROW order: a store instruction of the quad layout would write every other 12-byte element of
+  // four rows — twelve half-written lines that the next instruction completes — and cost 80 of the kernel's 180 us per 32
+  // frames (plain instead of streaming stores: 66).  The arrays leave in the order they lie in memory instead: store k of
+  // thread t is pixel (t / 32 + 8 k, t % 32) of the patch, read back from LDS, so a wave's instruction writes two whole
+  // patch rows (2 x 384 bytes of points or normals = six whole lines).  The normals take the points' place in `sp` once
+  // every wave has stored its points (two more barriers, no more LDS: seven blocks per CU).
+  const int sx = t & (QS - 1), sy0 = t >> 5;
+  const bool scol_in = c0 + sx < (int)w;
+  auto store_rows = [&](size_t off, bool with_mask) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = sy0 + 8 * k;
+      if (scol_in && r0 + y < (int)h && (A3D_LQ_PROBE != 1 || sp[0][y + 1][sx + 1] == 12345.678f)) {
+        const uint32_t idx = __umul24((uint32_t)(r0 + y), w) + (uint32_t)(c0 + sx);
+        st_v3u_stream(base + off, idx, at(y + 1, sx + 1));
+        if (with_mask) st_u8u_stream(base + off_mask, idx, sm[y][sx]);
+      }
+    }
+  };
+  // the patch's masks are 32 rows x 32 bytes = 256 words: ONE word per thread (row t / 8, pixels 4 (t % 8) ..) when the
+  // image width is a multiple of four (rows of the mask array then start word-aligned), else a byte per pixel with the points
+  const bool mask_words = (w & 3u) == 0;  // (block-uniform)
+  if (mask_words) {
+    const int my = t >> 3, mx = 4 * (t & 7);
+    if (r0 + my < (int)h && c0 + mx < (int)w && A3D_LQ_PROBE != 1)
+      __builtin_nontemporal_store(*(const uint32_t*)&sm[my][mx],
+                                  (uint32_t __attribute__((address_space(1)))*)((a3d_gptr)(base + off_mask) +
+                                                                               (__umul24((uint32_t)(r0 + my), w) + (uint32_t)(c0 + mx))));
+  }
+  store_rows(off_points, !mask_words);
+  if (with_normals) {  // (block-uniform)
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int y = 2 * ty + a + 1, x = 2 * tx + b + 1;
+        sp[0][y][x] = N[a][b].x, sp[1][y][x] = N[a][b].y, sp[2][y][x] = N[a][b].z;
+      }
+    __syncthreads();
+    store_rows(off_normals, false);
+  }
+  if (!emit_l1 || A3D_LQ_PROBE == 3) return;  // (block-uniform)
+  // ---- level 1 (pyr_scale_down: resize_range_points / _normals, src/range_image/resize.rs:42-104): the image sides are
+  // even (the host checks), so the quad is source block (2 dv .. 2 dv + 1, 2 du .. 2 du + 1) of level-1 pixel (dv, du) and
+  // lies inside the image whole or not at all; candidates in block order 00, 01, 10, 11 from the registers
+  const bool quad_in = rin[0] && cin[0];
+  V3 cand[4];
+  bool ok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cand[q] = P[q >> 1][q & 1], ok[q] = d[q >> 1][q & 1] > 0;
+  int n_valid = 0;
+  const V3 pk_p = pick_nearest_to_mean(cand, ok, &n_valid);
+  V3 pk_n{0.f, 0.f, 0.f};
+  if (with_normals) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cand[q] = N[q >> 1][q & 1];
+    int unused;
+    pk_n = pick_nearest_to_mean(cand, ok, &unused);
+  }
+  if (quad_in) {
+    const uint32_t i1 = __umul24((uint32_t)row[0] >> 1, L1.w) + ((uint32_t)col[0] >> 1);
+    if (emit_l2) {  // (nothing in the builder reads level 1 again)
+      st_v3u_stream(base + L1.points, i1, pk_p);
+      st_u8u_stream(base + L1.mask, i1, n_valid > 0 ? 1 : 0);
+      if (with_normals) st_v3u_stream(base + L1.normals, i1, pk_n);
+    } else {
+      st_v3u(base + L1.points, i1, pk_p);
+      st_u8u(base + L1.mask, i1, n_valid > 0 ? 1 : 0);
+      if (with_normals) st_v3u(base + L1.normals, i1, pk_n);
+    }
+  }
+  if (!emit_l2) return;  // (block-uniform)
+  // ---- level 2 from the patch's 16 x 16 level-1 picks: the level-1 sides are even too (the host checks), blocks are whole
+  s1[0][0][ty][tx] = pk_p.x, s1[0][1][ty][tx] = pk_p.y, s1[0][2][ty][tx] = pk_p.z;
+  s1[1][0][ty][tx] = pk_n.x, s1[1][1][ty][tx] = pk_n.y, s1[1][2][ty][tx] = pk_n.z;
+  s1m[ty][tx] = (quad_in && n_valid > 0) ? 1 : 0;
+  __syncthreads();
+  const int which = t >> 6;  // 0: points (and the mask), 1: normals; threads 128 .. 255 have no task
+  if (which > 1 || (which == 1 && !with_normals)) return;
+  const int ly = (t >> 3) & 7, lx = t & 7;
+  const uint32_t r2 = ((uint32_t)r0 >> 2) + (uint32_t)ly, c2 = ((uint32_t)c0 >> 2) + (uint32_t)lx;
+  if (r2 >= L2.h || c2 >= L2.w) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int y = 2 * ly + (q >> 1), x = 2 * lx + (q & 1);
+    cand[q] = V3{s1[which][0][y][x], s1[which][1][y][x], s1[which][2][y][x]};
+    ok[q] = s1m[y][x] == 1;
+  }
+  const V3 pk2 = pick_nearest_to_mean(cand, ok, &n_valid);
+  const uint32_t i2 = __umul24(r2, L2.w) + c2;
+  char* dst = base + (which ? L2.normals : L2.points);
+  if (l2_is_last) {
+    st_v3u_stream(dst, i2, pk2);
+    if (!which) st_u8u_stream(base + L2.mask, i2, n_valid > 0 ? 1 : 0);
+  } else {
+    st_v3u(dst, i2, pk2);
+    if (!which) st_u8u(base + L2.mask, i2, n_valid > 0 ? 1 : 0);
+  }
 }
 
 // Colours that arrived as ONE upload for the whole chunk ([F][h][w][3] in the staging region) to each frame's arena.
@@ -645,23 +963,49 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   hipStream_t color_stream = s;
   const PyramidLayout& P = plan.layout;
   const LevelLayout& L0 = P.lv[0];
-  const dim3 grid0((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F);
-  // level 1's points / mask / normals come out of level0_kernel when the sides are even (2 x 2 blocks are whole and the
-  // resize's float index arithmetic is exactly 2 dv, 2 du); A3D_BUILDER_FUSE_L1=0 keeps the separate kernel (cross-check)
-  static const bool fuse_allowed = !(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L1") && atoi(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L1")) == 0);
+  // level 1's points / mask / normals come out of the level-0 kernel when the sides are even (2 x 2 blocks are whole and the
+  // resize's float index arithmetic is exactly 2 dv, 2 du), level 2's as well when they are multiples of four;
+  // A3D_BUILDER_FUSE_L1=0 / A3D_BUILDER_FUSE_L2=0 keep the separate kernel (cross-checks, diagnostics build, read per call)
+  const bool fuse_allowed = !(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L1") && atoi(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L1")) == 0);
+  const bool fuse2_allowed = !(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L2") && atoi(A3D_DIAG_ENV("A3D_BUILDER_FUSE_L2")) == 0);
   const bool fuse_l1 = fuse_allowed && prm->pyramid_levels >= 2 && w % 2 == 0 && h % 2 == 0;
+  bool fuse_l2 = fuse_l1 && fuse2_allowed && prm->pyramid_levels >= 3 && w % 4 == 0 && h % 4 == 0;
+  bool quad = true;
+#ifdef A3D_DIAGNOSTICS
+  const bool patch_kernel = A3D_DIAG_ENV("A3D_BUILDER_L0") && !strcmp(A3D_DIAG_ENV("A3D_BUILDER_L0"), "patch");
+  quad = !patch_kernel;
+  if (!quad) fuse_l2 = false;
+#endif
+  const LevelLayout& L2 = P.lv[prm->pyramid_levels >= 3 ? 2 : 0];
+  const bool l2_is_last = prm->pyramid_levels == 3;
+  const dim3 gridq((w + QS - 1) / QS, (h + QS - 1) / QS, F);
   if (!depth_part) {
   } else if (prm->use_bilateral) {  // builder.rs:75-77
     GridBatch gb;
     A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb));
-    hipLaunchKernelGGL(level0_kernel<true>, grid0, dim3(L0_THREADS), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
-                       1.0 / prm->sigma_color, (const double*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
-                       bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1);
+    if (quad)
+      hipLaunchKernelGGL(level0_quad_kernel<true>, gridq, dim3(256), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
+                         1.0 / prm->sigma_color, (const double*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
+                         bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last);
+#ifdef A3D_DIAGNOSTICS
+    else
+      hipLaunchKernelGGL(level0_kernel<true>, dim3((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F), dim3(L0_THREADS), 0, s,
+                         d_depth, w, h, 1.0 / prm->sigma_space, 1.0 / prm->sigma_color, (const double*)gb.blurred, gb.capacity,
+                         gb.scal, fx, fy, cx, cy, depth_scale, bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0,
+                         P.lv[1], fuse_l1);
+#endif
     A3D_HIP_TRY(hipMemcpyAsync(result, gb.scal, (size_t)F * SC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   } else {
-    hipLaunchKernelGGL(level0_kernel<false>, grid0, dim3(L0_THREADS), 0, s, d_depth, w, h, 0.0, 0.0,
-                       (const double*)nullptr, 0ull, (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points,
-                       L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1);
+    if (quad)
+      hipLaunchKernelGGL(level0_quad_kernel<false>, gridq, dim3(256), 0, s, d_depth, w, h, 0.0, 0.0, (const double*)nullptr, 0ull,
+                         (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points, L0.mask, L0.normals,
+                         prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last);
+#ifdef A3D_DIAGNOSTICS
+    else
+      hipLaunchKernelGGL(level0_kernel<false>, dim3((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F), dim3(L0_THREADS), 0, s,
+                         d_depth, w, h, 0.0, 0.0, (const double*)nullptr, 0ull, (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale,
+                         bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1);
+#endif
   }
   // RangeImage::pyramid (structure.rs:342-351): normals exist at level 0 only (builder.rs:79-82), coarser levels
   // inherit picked normals; colours are blurred and halved level by level
@@ -669,7 +1013,7 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   if (sigma <= 0.0f) sigma = 1.0f;
   for (uint64_t l = 1; l < prm->pyramid_levels; ++l) {
     const LevelLayout &S = P.lv[l - 1], &D = P.lv[l];
-    if (depth_part && !(l == 1 && fuse_l1))
+    if (depth_part && !(l == 1 && fuse_l1) && !(l == 2 && fuse_l2))
       hipLaunchKernelGGL(resize_pick_kernel, dim3((D.w * D.h + 255) / 256, prm->with_normals ? 2 : 1, F), dim3(256), 0, s, S,
                          D, bases);
     if (!color_part) continue;

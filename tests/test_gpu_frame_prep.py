@@ -520,3 +520,54 @@ def test_bilateral_wide_cells_for_a_large_sigma_space():
                     lv.free()
     finally:
         own.close()
+
+
+@pytest.mark.parametrize("w,h,levels,bilateral", [(640, 480, 3, True), (640, 480, 4, False), (100, 68, 3, True), (97, 61, 3, True),
+                                                  (160, 96, 4, True), (34, 30, 2, True), (36, 40, 3, False)])
+def test_level0_quad_kernel_equals_the_patch_kernel_and_the_oracle(ctx, diag_ctx, monkeypatch, w, h, levels, bilateral):
+    """Round 6: level0_quad_kernel (32 x 32 aligned patches, a 2 x 2 quad per thread, level-1 picks from registers, level-2
+    picks from the patch's level-1 picks) against the round-2..5 kernel (A3D_BUILDER_L0=patch), against the separate
+    resize kernel for level 2 / for levels 1 and 2 (A3D_BUILDER_FUSE_L2=0 / _L1=0) and against the oracle: sizes that are
+    multiples of 32, of 4 only, of 2 only, odd; three- and four-level pyramids; with and without the bilateral filter.
+    The diagnostics-build runs start from a blurred grid full of NaN (A3D_BILATERAL_POISON): a slice that read a cell no
+    marked tile wrote (the margin-1 tile marking of splat_packed_kernel) fails the u16 cast check instead of passing on
+    an earlier frame's value."""
+    from align3d_amd import CameraIntrinsics, RangeImageBuilder
+
+    rng = np.random.default_rng(w * 977 + h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    depth = (900 + 6.0 * xx + 3.0 * yy + 250 * (xx > w // 2) + rng.integers(0, 25, size=(h, w))).astype(np.uint16)
+    depth[rng.random((h, w)) < 0.08] = 0
+    depth[h // 3: h // 3 + 7, w // 4: w // 4 + 9] = 0
+    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    cam = CameraIntrinsics(0.9 * w, 0.9 * w, w / 2.0, h / 2.0, w, h)
+    if levels > 1 and ((w >> (levels - 1)) < 2 or (h >> (levels - 1)) < 2):
+        pytest.skip("image too small")
+
+    def build(c):
+        b = RangeImageBuilder(c).pyramid_levels(levels)
+        if bilateral:
+            b = b.with_bilateral_filter(BilateralFilter.default())
+        pyr = b.build_device(cam, depth, rgb, 0.001)
+        out = [lv.download() for lv in pyr]
+        for lv in pyr:
+            lv.free()
+        return out
+
+    for k in ("A3D_BUILDER_L0", "A3D_BUILDER_FUSE_L1", "A3D_BUILDER_FUSE_L2"):
+        monkeypatch.delenv(k, raising=False)
+    got = build(ctx)
+    ref = O.build_pyramid(depth, rgb, cam.fx, cam.fy, cam.cx, cam.cy, 0.001, levels=levels, use_bilateral=bilateral)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.mask, r.mask) and np.array_equal(_bits(g.points), _bits(r.points))
+        assert np.array_equal(_bits(g.normals), _bits(r.normals))
+    monkeypatch.setenv("A3D_BILATERAL_POISON", "1")
+    for env in ({}, {"A3D_BUILDER_L0": "patch"}, {"A3D_BUILDER_FUSE_L2": "0"}, {"A3D_BUILDER_FUSE_L1": "0"}):
+        for k in ("A3D_BUILDER_L0", "A3D_BUILDER_FUSE_L1", "A3D_BUILDER_FUSE_L2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = build(diag_ctx)
+        for g, o in zip(got, other):
+            for name in ("points", "mask", "normals", "colors", "intensities", "intensity_map"):
+                assert np.array_equal(getattr(g, name), getattr(o, name), equal_nan=True), (env, name)
