@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256)
   if (threadIdx.x == 0) {
     const uint32_t bmin = min(min(s_mi[0], s_mi[1]), min(s_mi[2], s_mi[3]));
     const uint32_t bmax = max(max(s_ma[0], s_ma[1]), max(s_ma[2], s_ma[3]));
-    if (partials) {  // batches: one (min, max) per block, reduced by dims_table_kernel — nothing to initialise, no atomics
+    if (partials) {  // batches: one (min, max) per block, reduced by the frame's last block — no atomics on the values
       partials[(blockIdx.y * gridDim.x + blockIdx.x) * 2 + 0] = bmin;
       partials[(blockIdx.y * gridDim.x + blockIdx.x) * 2 + 1] = bmax;
     } else {         // one atomic pair per block: 64 blocks, not thousands of waves, meet on the two words
@@ -67,6 +67,78 @@ __global__ void __launch_bounds__(256)
     }
   }
 }
+
+__device__ __forceinline__ void dims_table_body(uint32_t cmin, uint32_t cmax, uint32_t part, uint32_t parts, uint32_t* __restrict__ sc,
+                                                uint32_t w, uint32_t h, double sigma_space, double sigma_color,
+                                                unsigned long long capacity_cells, uint32_t* __restrict__ channel_of, double inv_sc);
+#ifdef A3D_DIAGNOSTICS  // (A3D_BILATERAL_MINMAX=fused: measured no faster than the two launches, kept as a cross-check)
+// The batch form, round 6: min / max AND what dims_table_kernel did, in one launch.  The frame's blocks fold their
+// (min, max) into two accumulator words and take a ticket (scal[SC_ACC_NMIN], [SC_ACC_MAX], [SC_TICKET], zero between
+// enqueues: the last block puts the zeros back with the rest of the scalar block); whoever draws the last ticket sizes the
+// grid and fills the colour -> channel table alone (a few thousand entries; 16 blocks did it before) — one dependent launch and its boundary less in front of
+// the splat (4.8 + ~2 us per launch sequence).
+__global__ void __launch_bounds__(256)
+    minmax_dims_kernel(const uint16_t* __restrict__ img, uint32_t n, uint32_t* __restrict__ scal,
+                       uint32_t w, uint32_t h, double sigma_space, double sigma_color, unsigned long long capacity_cells,
+                       uint32_t* __restrict__ channel_of, double inv_sc) {
+  img += (size_t)blockIdx.y * n;  // blockIdx.y = frame of a batch ([frames][n] pixels)
+  uint32_t mi = 0xFFFFu, ma = 0u;
+  const bool aligned = ((uintptr_t)img & 15u) == 0;
+  const uint32_t n8 = aligned ? n / 8 : 0;
+  const uint4* img8 = (const uint4*)img;
+  const uint32_t step = gridDim.x * blockDim.x;
+  for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n8; i0 += 4 * step) {  // (as minmax_u16_kernel)
+    uint4 q[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) q[u] = img8[min(i0 + u * step, n8 - 1)];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t wd[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = wd[k] & 0xFFFFu, hi = wd[k] >> 16;
+        mi = min(mi, min(lo, hi));
+        ma = max(ma, max(lo, hi));
+      }
+    }
+  }
+  for (uint32_t i = n8 * 8 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t v = img[i];
+    mi = min(mi, v);
+    ma = max(ma, v);
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    mi = min(mi, (uint32_t)__shfl_xor((int)mi, off, 64));
+    ma = max(ma, (uint32_t)__shfl_xor((int)ma, off, 64));
+  }
+  __shared__ uint32_t s_mi[4], s_ma[4], s_last;
+  if ((threadIdx.x & 63) == 0) s_mi[threadIdx.x >> 6] = mi, s_ma[threadIdx.x >> 6] = ma;
+  __syncthreads();
+  uint32_t* sc = scal + blockIdx.y * SC_STRIDE;
+  if (threadIdx.x == 0) {
+    // Relaxed agent-scope atomics only: a release / acquire pair at agent scope is a write-back and an invalidate of the
+    // XCD's whole L2 on this part, per block (the first form of this kernel took 66 us instead of 11).  Two running maxima
+    // (of 0xFFFF - min and of max: both start at the zero the scalar block holds between enqueues), each WITH its return
+    // value, and the ticket's increment made to depend on those values: an atomic has been performed at the memory side
+    // when its value comes back, so whoever draws the last ticket sees every block's contribution.
+    const uint32_t bmin = min(min(s_mi[0], s_mi[1]), min(s_mi[2], s_mi[3]));
+    const uint32_t bmax = max(max(s_ma[0], s_ma[1]), max(s_ma[2], s_ma[3]));
+    const uint32_t a = __hip_atomic_fetch_max(&sc[SC_ACC_NMIN], 0xFFFFu - bmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t b = __hip_atomic_fetch_max(&sc[SC_ACC_MAX], bmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t one = 1u + (((a | b) >> 31) & 1u);  // (= 1: the accumulators stay below 2^16)
+    s_last = __hip_atomic_fetch_add(&sc[SC_TICKET], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    s_mi[0] = 0xFFFFu - __hip_atomic_load(&sc[SC_ACC_NMIN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ma[0] = __hip_atomic_load(&sc[SC_ACC_MAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // (the body rewrites the whole scalar block: ticket and accumulators are zero again for the next enqueue)
+  dims_table_body(s_mi[0], s_ma[0], 0u, 1u, sc, w, h, sigma_space, sigma_color, capacity_cells, channel_of, inv_sc);
+}
+#endif  // A3D_DIAGNOSTICS
 
 // BilateralGrid::from_image splat (src/bilateral/grid.rs:60-78); grid cell = {value sum, count}
 __global__ void __launch_bounds__(256)
@@ -212,6 +284,35 @@ __device__ __forceinline__ double quotient_of_counts(double value, double weight
 // (grid.rs:74: floor((v - min) / sigma_color + 0.5) + 2 for each of the 65 536 values of v, in the splat's own f64
 // arithmetic): the splat then looks a channel up instead of converting u16 -> f64 -> usize per pixel (conversions run at
 // a quarter of the f64 rate).
+// `part` of `parts` blocks (or the only one) of frame blockIdx.y: the shared body of dims_table_kernel and of the fused tail
+// of minmax_dims_kernel.
+__device__ __forceinline__ void dims_table_body(uint32_t cmin, uint32_t cmax, uint32_t part, uint32_t parts, uint32_t* __restrict__ sc,
+                                                uint32_t w, uint32_t h, double sigma_space, double sigma_color,
+                                                unsigned long long capacity_cells, uint32_t* __restrict__ channel_of, double inv_sc) {
+  const uint32_t gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4;
+  const uint32_t gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
+  const uint32_t gd = (uint32_t)((double)(cmax - cmin) / sigma_color) + 1 + 4;
+  // (a grid beyond 32-bit cell offsets is refused like one beyond the capacity: the host reports it, frame.hip)
+  const bool too_big = (unsigned long long)gh * gw * gd > capacity_cells || !grid_fits_idx32(gh, gw, gd);
+  if (part == 0 && threadIdx.x < SC_STRIDE) {
+    uint32_t v = 0;  // SC_OVERFLOW, SC_TICKET, the accumulators, SC_NLIST, SC_NZERO and the unused words start at zero
+    switch (threadIdx.x) {
+      case SC_MIN: v = cmin; break;
+      case SC_MAX: v = cmax; break;
+      case SC_GH: v = gh; break;
+      case SC_GW: v = gw; break;
+      case SC_GD: v = gd; break;
+      case SC_TOO_BIG: v = too_big ? 1u : 0u; break;
+      default: break;
+    }
+    sc[threadIdx.x] = v;
+  }
+  if (too_big) return;
+  // (only the colours the frame holds, cmin .. cmax, and 0 — an invalid pixel, looked up but not used — are ever read)
+  if (part == 0 && threadIdx.x == 0 && cmin > 0) channel_of[blockIdx.y * 65536u] = 0u;
+  for (uint32_t v = cmin + part * 256u + threadIdx.x; v <= cmax; v += parts * 256u)
+    channel_of[blockIdx.y * 65536u + v] = f64_as_usize((double)(v - cmin) * inv_sc + 0.5) + 2;
+}
 __global__ void __launch_bounds__(256)
     dims_table_kernel(const uint32_t* __restrict__ partials, uint32_t n_partials, uint32_t* __restrict__ scal, uint32_t w,
                       uint32_t h, double sigma_space, double sigma_color, unsigned long long capacity_cells,
@@ -229,30 +330,7 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) s_mm[0] = mi, s_mm[1] = ma;
   }
   __syncthreads();
-  const uint32_t cmin = s_mm[0], cmax = s_mm[1];
-  const uint32_t gh = (uint32_t)((double)(h - 1) / sigma_space) + 1 + 4;
-  const uint32_t gw = (uint32_t)((double)(w - 1) / sigma_space) + 1 + 4;
-  const uint32_t gd = (uint32_t)((double)(cmax - cmin) / sigma_color) + 1 + 4;
-  // (a grid beyond 32-bit cell offsets is refused like one beyond the capacity: the host reports it, frame.hip)
-  const bool too_big = (unsigned long long)gh * gw * gd > capacity_cells || !grid_fits_idx32(gh, gw, gd);
-  if (blockIdx.x == 0 && threadIdx.x < SC_STRIDE) {
-    uint32_t v = 0;  // SC_OVERFLOW, SC_NLIST, SC_NZERO and the unused words start at zero
-    switch (threadIdx.x) {
-      case SC_MIN: v = cmin; break;
-      case SC_MAX: v = cmax; break;
-      case SC_GH: v = gh; break;
-      case SC_GW: v = gw; break;
-      case SC_GD: v = gd; break;
-      case SC_TOO_BIG: v = too_big ? 1u : 0u; break;
-      default: break;
-    }
-    sc[threadIdx.x] = v;
-  }
-  if (too_big) return;
-  // (only the colours the frame holds, cmin .. cmax, and 0 — an invalid pixel, looked up but not used — are ever read)
-  if (blockIdx.x == 0 && threadIdx.x == 0 && cmin > 0) channel_of[blockIdx.y * 65536u] = 0u;
-  for (uint32_t v = cmin + blockIdx.x * 256u + threadIdx.x; v <= cmax; v += gridDim.x * 256u)
-    channel_of[blockIdx.y * 65536u + v] = f64_as_usize((double)(v - cmin) * inv_sc + 0.5) + 2;
+  dims_table_body(s_mm[0], s_mm[1], blockIdx.x, gridDim.x, sc, w, h, sigma_space, sigma_color, capacity_cells, channel_of, inv_sc);
 }
 
 // The last kernel of a filter enqueue: puts back the zeros.  The splat left, per (row, column) of the grid, the range of
@@ -520,9 +598,11 @@ __device__ __forceinline__ void load_window(uint32_t tile_id, const CELL* __rest
 
 // One tile.  `known_occupied`: the tile comes from the splat's list of marked windows; otherwise emptiness is decided
 // from the loaded window `u` (load_window).  `zeros_only`: an unmarked first-channel tile, written as zeros (see below).
-template <typename CELL>
+// `nx` (TAKE_NEXT): the NEXT tile's window, in flight since before this tile's first pass (load_window); it is moved into
+// `u` between this tile's last arithmetic and its stores — see "the order of waits" at the stores.
+template <typename CELL, bool TAKE_NEXT = false>
 __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_x, typename Pack<CELL>::EarlyWeight* tile_w,
-                                          uint32_t tile_id, const CELL (&u)[BR],
+                                          uint32_t tile_id, CELL (&u)[BR], const CELL (&nx)[TAKE_NEXT ? BR : 1],
                                           const GridDims g, double* __restrict__ out, bool known_occupied,
                                           bool zeros_only) {
   const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT;
@@ -541,6 +621,7 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     write_zeros();
     return;
   }
+  static_assert(!TAKE_NEXT || sizeof(CELL) == 4, "the prefetching walk is the narrow cells' (registers)");
   auto at = [](int lr, int lc, int lz) { return (lr * BR + lc) * BZP + lz; };
   auto row_ok = [&](int gr) { return gr >= 1 && gr <= gh - 2; };
   auto col_ok = [&](int gc) { return gc >= 1 && gc <= gw - 2; };
@@ -605,30 +686,47 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
 #ifndef A3D_BLUR_3WAVES
 #define A3D_BLUR_3WAVES 1
 #endif
+  double o[BT];  // the thread's twelve normalised cells
+  bool stores = false;
+  const int gr2 = r0 + hi + (A3D_BLUR_3WAVES ? 2 : 0), gz2 = z0 + lo;
   if (A3D_BLUR_3WAVES ? hi < BR - 4 : (hi >= 2 && hi < BR - 2)) {
     constexpr int SHIFT = A3D_BLUR_3WAVES ? 2 : 0;  // window row of thread row `hi`
     double vx[BR];  // (results up to 2^36: f64 from here on; the counts, below 2^20, in Pack<CELL>::Weight)
     W vw[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) vx[i] = (double)tile_x[at(hi + SHIFT, i, lo)], vw[i] = (W)tile_w[at(hi + SHIFT, i, lo)];
-    const int gr = r0 + hi + SHIFT, gz = z0 + lo;
-    const bool line_ok = row_ok(gr) && chan_ok(gz);
+    const bool line_ok = row_ok(gr2) && chan_ok(gz2);
     if (inside) blur_line_twice<false>(vx, vw, [](int) { return true; });
     else blur_line_twice<true>(vx, vw, [&](int i) { return line_ok && col_ok(c0 + i); });
-    // (a wave stores 4 rows x 12 channels = four 192-byte runs per column)
-    if (lo >= 2 && lo < BR - 2 && gr < gh && gz < gd) {
-      const int col_stride = gd * 8;
-      int at_col = ((gr * gw + c0 + 2) * gd + gz) * 8;  // byte offset of cell (gr, c0 + i, gz) in the f64 grid
+    stores = lo >= 2 && lo < BR - 2 && gr2 < gh && gz2 < gd;
+    // normalised (grid.rs:90-104): value / weight — the common factor 4^6 cancels exactly — or, where the weight is zero,
+    // the value itself (x 4^-6: the six divisions by four)
 #pragma unroll
-      for (int i = 2; i < BR - 2; ++i, at_col += col_stride) {
-        const int gc = c0 + i;
-        // normalised (grid.rs:90-104): value / weight — the common factor 4^6 cancels exactly — or, where the weight
-        // is zero, the value itself (x 4^-6: the six divisions by four)
-        if (gc < gw)
-          *(double __attribute__((address_space(1)))*)((a3d_gptr)out + (uint32_t)at_col) =
-              vw[i] > (W)0 ? quotient_of_counts(vx[i], (double)vw[i]) : vx[i] * 0x1p-12;
-      }
+    for (int i = 2; i < BR - 2; ++i) o[i - 2] = vw[i] > (W)0 ? quotient_of_counts(vx[i], (double)vw[i]) : vx[i] * 0x1p-12;
+  }
+  // THE ORDER OF WAITS (round 6).  Loads and stores share one in-order counter (vmcnt), and the compiler cannot know how many
+  // of this tile's stores a wave issues (grid borders, the idle fourth wave), so a wait for the next window's loads placed
+  // AFTER the stores is a wait for the stores' completion as well: every tile ended with a store round trip to memory, and
+  // the "prefetch" was waited for before the first pass (the ISA had s_waitcnt vmcnt(0) at both places; the kernel kept the
+  // VALU pipe under half busy).  Taking the next window BEFORE the stores waits for loads issued a whole tile ago and for
+  // the PREVIOUS tile's stores, both long complete; this tile's stores then drain under the next tile's passes.
+  if constexpr (TAKE_NEXT) {
+    // (an empty asm that reads and writes every word of the next window: the loads must have landed HERE — a plain copy the
+    // compiler sinks to the loop's latch, behind the stores — and no memory operation moves across)
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      CELL v = nx[i];
+      asm volatile("" : "+v"(v) : : "memory");
+      u[i] = v;
     }
+  }
+  // (a wave stores 4 rows x 12 channels = four 192-byte runs per column)
+  if (stores) {
+    const int col_stride = gd * 8;
+    int at_col = ((gr2 * gw + c0 + 2) * gd + gz2) * 8;  // byte offset of cell (gr, c0 + i, gz) in the f64 grid
+#pragma unroll
+    for (int i = 2; i < BR - 2; ++i, at_col += col_stride)
+      if (c0 + i < gw) *(double __attribute__((address_space(1)))*)((a3d_gptr)out + (uint32_t)at_col) = o[i - 2];
   }
 }
 
@@ -721,21 +819,30 @@ __global__ void __launch_bounds__(256, sizeof(CELL) == 4 ? 4 : 2)  // (waves per
     if (blockIdx.x == 0 && threadIdx.x == 0) dyn[SC_NLIST] = n_work, dyn[SC_NZERO] = n_zero;  // (statistics for the host)
     auto entry = [&](uint32_t j) { return (uint32_t)(j < n_work ? s_list[j] : s_list[BLUR_LIST_MAX - 1u - (j - n_work)]); };
     constexpr bool PREFETCH = sizeof(CELL) == 4;  // (the wide cells' kernel has no registers to spare for a second window)
-    CELL cur[BR] = {}, nxt[PREFETCH ? BR : 1] = {};
-    if (PREFETCH && blockIdx.x < n_work) load_window<CELL>(entry(blockIdx.x), packed, g, cur);
-    for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {
-      const bool work = j < n_work;
-      if constexpr (PREFETCH) {
-        if (j + gridDim.x < n_work) load_window<CELL>(entry(j + gridDim.x), packed, g, nxt);  // in flight under this tile
-      } else {
-        if (work) load_window<CELL>(entry(j), packed, g, cur);
-      }
-      blur_tile<CELL>(tile_x, tile_w, entry(j), cur, g, out, true, !work);
-      if constexpr (PREFETCH) {
+    if constexpr (PREFETCH) {
+      // marked tiles first, the next tile's sixteen loads in flight under this tile; then the zero tiles (their own loop: a
+      // loop of stores inside the walk would leave the compiler no count of what is outstanding)
+      CELL cur[BR] = {}, nxt[BR] = {};
+      uint32_t j = blockIdx.x;
+      if (j < n_work) load_window<CELL>(entry(j), packed, g, cur);
+      // (the first window has landed before the walk starts: entered with these loads outstanding, the loop's first use of
+      // `cur` gets a wait that every later trip pays too — right behind the next window's loads)
 #pragma unroll
-        for (int i = 0; i < BR; ++i) cur[i] = nxt[i];
+      for (int i = 0; i < BR; ++i) asm volatile("" : "+v"(cur[i]) : : "memory");
+      for (; j < n_work; j += gridDim.x) {
+        if (j + gridDim.x < n_work) load_window<CELL>(entry(j + gridDim.x), packed, g, nxt);
+        blur_tile<CELL, true>(tile_x, tile_w, entry(j), cur, nxt, g, out, true, false);
+        __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
       }
-      __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
+      for (; j < n_work + n_zero; j += gridDim.x) blur_tile<CELL>(tile_x, tile_w, entry(j), cur, {}, g, out, true, true);
+    } else {
+      CELL cur[BR] = {};
+      for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {
+        const bool work = j < n_work;
+        if (work) load_window<CELL>(entry(j), packed, g, cur);
+        blur_tile<CELL>(tile_x, tile_w, entry(j), cur, {}, g, out, true, !work);
+        __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
+      }
     }
     return;
   }
@@ -744,7 +851,7 @@ __global__ void __launch_bounds__(256, sizeof(CELL) == 4 ? 4 : 2)  // (waves per
     if (blockIdx.x < tx * ty * tz) {
       CELL u[BR];
       load_window<CELL>(blockIdx.x, packed, g, u);
-      blur_tile<CELL>(tile_x, tile_w, blockIdx.x, u, g, out, false, false);
+      blur_tile<CELL>(tile_x, tile_w, blockIdx.x, u, {}, g, out, false, false);
     }
     return;
   }
@@ -755,7 +862,7 @@ __global__ void __launch_bounds__(256, sizeof(CELL) == 4 ? 4 : 2)  // (waves per
     const uint32_t tile = work ? lists[j] : lists[flags_stride + (j - n_work)];
     CELL u[BR] = {};
     if (work) load_window<CELL>(tile, packed, g, u);
-    blur_tile<CELL>(tile_x, tile_w, tile, u, g, out, true, !work);
+    blur_tile<CELL>(tile_x, tile_w, tile, u, {}, g, out, true, !work);
     __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
   }
 }
@@ -915,7 +1022,7 @@ static void enqueue_splat_blur(hipStream_t s, const uint16_t* d_depth, uint32_t 
                                const uint32_t* row_starts, const uint32_t* col_starts, double inv_sc, dim3 splat_grid,
                                dim3 blur_grid, dim3 list_grid, GridBatch* out, unsigned long long capacity, uint8_t* flags,
                                uint32_t flags_stride, uint32_t* lists, bool lists_in_blur, const uint32_t* channel_of,
-                               uint2* extent, uint32_t columns) {
+                               uint2* extent, uint32_t columns, bool defer_unsplat) {
   const GridDims none{0, 0, 0};
   hipLaunchKernelGGL(splat_packed_kernel<CELL>, splat_grid, dim3(256), 0, s, d_depth, w, h, row_starts, col_starts, inv_sc, 0u,
                      none, (CELL*)out->packed, (const uint32_t*)out->scal, capacity, flags, flags_stride, channel_of, extent, columns);
@@ -924,13 +1031,15 @@ static void enqueue_splat_blur(hipStream_t s, const uint16_t* d_depth, uint32_t 
   hipLaunchKernelGGL(blur_fused_kernel<CELL>, blur_grid, dim3(256), 0, s, (const CELL*)out->packed, none, out->blurred, out->scal,
                      capacity, lists_in_blur ? (const uint32_t*)nullptr : (const uint32_t*)lists, flags_stride,
                      lists_in_blur ? (const uint32_t*)flags : (const uint32_t*)nullptr);
-  hipLaunchKernelGGL(unsplat_kernel<CELL>, splat_grid, dim3(256), 0, s, (CELL*)out->packed, (const uint32_t*)out->scal, capacity,
-                     (const uint2*)extent, columns, (uint32_t*)flags, flags_stride);
+  if (!defer_unsplat)
+    hipLaunchKernelGGL(unsplat_kernel<CELL>, splat_grid, dim3(256), 0, s, (CELL*)out->packed, (const uint32_t*)out->scal, capacity,
+                       (const uint2*)extent, columns, (uint32_t*)flags, flags_stride);
   (void)n_frames;
 }
 
 a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, uint32_t n_frames, uint32_t w, uint32_t h,
-                                   double sigma_space, double sigma_color, unsigned long long capacity, GridBatch* out) {
+                                   double sigma_space, double sigma_color, unsigned long long capacity, GridBatch* out,
+                                   bool defer_unsplat) {
   const uint32_t n = w * h;
   A3D_REQUIRE(n < (1u << PACK_SHIFT), A3D_INVALID_PARAMETER,
               "the device frame builder's bilateral filter handles images below 2^24 pixels");
@@ -986,6 +1095,7 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   const a3d_context::GridLayoutKey& have = ctx->grid_clean;
   if (!(have.region == key.region && have.capacity == key.capacity && have.cell_bytes == key.cell_bytes &&
         have.flags_stride == key.flags_stride && have.frames == key.frames && have.columns == key.columns)) {
+    A3D_HIP_TRY(hipMemsetAsync(out->scal, 0, scal_only, s));  // (the tickets of minmax_dims_kernel)
     A3D_HIP_TRY(hipMemsetAsync(flags, 0, flag_bytes, s));
     A3D_HIP_TRY(hipMemsetAsync(out->packed, 0, packed_bytes, s));
   }
@@ -995,10 +1105,20 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   // value of an earlier, similar frame (tests/test_gpu_frame_prep.py).
   if (A3D_DIAG_ENV("A3D_BILATERAL_POISON")) A3D_HIP_TRY(hipMemsetAsync(out->blurred, 0xFF, (size_t)lf * capacity * 8, s));
   const uint32_t mm_blocks = std::min<uint32_t>((n + 255) / 256, PARTIALS);
-  hipLaunchKernelGGL(minmax_u16_kernel, dim3(mm_blocks, n_frames), dim3(256), 0, s, d_depth, n, (uint32_t*)nullptr, partials);
   const double inv_sc = 1.0 / sigma_color;
-  hipLaunchKernelGGL(dims_table_kernel, dim3(16, n_frames), dim3(256), 0, s, (const uint32_t*)partials, mm_blocks, out->scal, w, h,
-                     sigma_space, sigma_color, capacity, channel_of, inv_sc);
+  // (diagnostics build, A3D_BILATERAL_MINMAX=fused: both in one launch, the frame's last block sizing the grid — measured
+  // round 6: 12.5 us against 6.5 + 4.8 us for the two launches per 32 frames, no gain; kept as a cross-check)
+  const char* mm_mode = A3D_DIAG_ENV("A3D_BILATERAL_MINMAX");
+  if (mm_mode && !strcmp(mm_mode, "fused")) {
+#ifdef A3D_DIAGNOSTICS
+    hipLaunchKernelGGL(minmax_dims_kernel, dim3(mm_blocks, n_frames), dim3(256), 0, s, d_depth, n, out->scal, w, h,
+                       sigma_space, sigma_color, capacity, channel_of, inv_sc);
+#endif
+  } else {
+    hipLaunchKernelGGL(minmax_u16_kernel, dim3(mm_blocks, n_frames), dim3(256), 0, s, d_depth, n, (uint32_t*)nullptr, partials);
+    hipLaunchKernelGGL(dims_table_kernel, dim3(16, n_frames), dim3(256), 0, s, (const uint32_t*)partials, mm_blocks, out->scal, w, h,
+                       sigma_space, sigma_color, capacity, channel_of, inv_sc);
+  }
   // (gh and gw depend on the image size only: the launch covers every (row, column) pixels can splat into)
   const dim3 splat_grid((columns + 255) / 256, n_frames);
   // one resident round of blur blocks, shared out over the frames: four blocks per CU with the narrow cells (39 KiB of
@@ -1016,13 +1136,20 @@ a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, ui
   const dim3 list_grid((std::max(1u, tiles) + 255) / 256, n_frames), blur_grid(per_frame, n_frames);
   if (narrow)
     enqueue_splat_blur<uint32_t>(s, d_depth, n_frames, w, h, row_starts, col_starts, inv_sc, splat_grid, blur_grid, list_grid, out,
-                                 capacity, flags, flags_stride, lists, lists_in_blur, channel_of, extent, columns);
+                                 capacity, flags, flags_stride, lists, lists_in_blur, channel_of, extent, columns, defer_unsplat);
   else
     enqueue_splat_blur<unsigned long long>(s, d_depth, n_frames, w, h, row_starts, col_starts, inv_sc, splat_grid, blur_grid,
                                            list_grid, out, capacity, flags, flags_stride, lists, lists_in_blur, channel_of, extent,
-                                           columns);
+                                           columns, defer_unsplat);
   A3D_HIP_TRY(hipGetLastError());
-  ctx->grid_clean = key;
+  out->clean = key;
+  if (defer_unsplat) {  // (the caller's next kernel puts the zeros back, then commits out->clean)
+    out->unsplat.packed = out->packed, out->unsplat.extent = extent, out->unsplat.flags = (uint32_t*)flags;
+    out->unsplat.capacity = capacity, out->unsplat.columns = columns, out->unsplat.flag_words = flags_stride / 4;
+    out->unsplat.cell_bytes = cell_bytes;
+  } else {
+    ctx->grid_clean = key;
+  }
   return A3D_OK;
 }
 

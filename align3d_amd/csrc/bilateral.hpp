@@ -15,8 +15,9 @@ __host__ __device__ __forceinline__ uint32_t f64_as_usize(double x) { return x >
 // Device-side scalars of one filter call.  When a kernel gets a non-null `dyn` pointer, the grid dimensions and the
 // colour minimum come from there instead of from its arguments: the host then enqueues the whole filter without
 // the min/max round trip.  A batch of frames has one block of SC_STRIDE words per frame.
-enum { SC_MIN = 0, SC_MAX = 1, SC_OVERFLOW = 2, SC_GH = 4, SC_GW = 5, SC_GD = 6, SC_TOO_BIG = 7, SC_WORDS = 8,
-       SC_NLIST = 8, SC_NZERO = 9 };  // (device only) lengths of the frame's blur tile lists
+enum { SC_MIN = 0, SC_MAX = 1, SC_OVERFLOW = 2, SC_TICKET = 3 /* minmax_dims_kernel's block counter */, SC_GH = 4, SC_GW = 5, SC_GD = 6, SC_TOO_BIG = 7, SC_WORDS = 8,
+       SC_NLIST = 8, SC_NZERO = 9,    // (device only) lengths of the frame's blur tile lists
+       SC_ACC_NMIN = 10, SC_ACC_MAX = 11 };  // (device only) minmax_dims_kernel's running maxima of 0xFFFF - min and of max
 constexpr uint32_t SC_STRIDE = 16;  // words between the scalar blocks of consecutive frames (64 B: one per line)
 
 __device__ __forceinline__ bool dyn_dims(const uint32_t* __restrict__ dyn, GridDims* g, uint32_t* color_min) {
@@ -149,6 +150,42 @@ __device__ __forceinline__ bool slice_pixel(uint32_t color, uint32_t r, uint32_t
                                  color_min, g, grid, out);
 }
 
+// What puts the zeros back (a3d_context::grid_clean) when the kernel behind the filter does it instead of unsplat_kernel:
+// the splat's per-(row, column) channel extents, the packed cells and the tile flags of the batch.
+struct Unsplat {
+  void* packed = nullptr;          // null: nothing deferred
+  const uint2* extent = nullptr;   // [frames][columns]: lowest, highest channel the splat wrote (lowest > highest: none)
+  uint32_t* flags = nullptr;       // [frames][flag_words]
+  unsigned long long capacity = 0;
+  uint32_t columns = 0, flag_words = 0, cell_bytes = 0;
+};
+// One block's share of a frame's unsplat: the grid (row, column)s whose FIRST image row / column lie in the block's patch
+// [r0, r1) x [c0, c1) of the image — t(x) = floor(x / sigma + 0.5) is the splat's own expression (grid.rs:60-78), so grid row
+// t + 2 receives the image rows {x : t(x) = t} and its first one is in the patch iff t(r0 - 1) < t <= t(r1 - 1) — and an equal
+// share of the frame's flag words.  Thread = one (row, column); `block`, `blocks`: this block's rank among the frame's.
+// (256 threads per block: written out, `blockDim.x` is a load from the dispatch packet and its wait a wait for every store before it)
+__device__ __forceinline__ void unsplat_columns(const Unsplat& U, uint32_t frame, GridDims g, double inv_ss, int r0, int r1, int c0,
+                                                int c1, uint32_t block, uint32_t blocks) {
+  constexpr uint32_t THREADS = 256;
+  auto t_of = [&](int x) { return f64_as_usize((double)x * inv_ss + 0.5); };
+  const uint32_t tr_lo = r0 == 0 ? 0u : t_of(r0 - 1) + 1u, tr_hi = t_of(r1 - 1) + 1u;
+  const uint32_t tc_lo = c0 == 0 ? 0u : t_of(c0 - 1) + 1u, tc_hi = t_of(c1 - 1) + 1u;
+  const uint32_t nr = tr_hi - tr_lo, nc = tc_hi - tc_lo, cols = g.gw - 3;
+  char* cells = (char*)U.packed + (size_t)frame * U.capacity * U.cell_bytes;
+  for (uint32_t e = threadIdx.x; e < nr * nc; e += THREADS) {
+    const uint32_t t_row = tr_lo + e / nc, t_col = tc_lo + e % nc;
+    if (t_row >= g.gh - 3 || t_col >= cols) continue;
+    const uint2 x = U.extent[(size_t)frame * U.columns + (t_row * cols + t_col)];
+    const uint32_t column = __umul24(__umul24(t_row + 2, g.gw) + t_col + 2, g.gd);
+    for (uint32_t ch = x.x; ch <= x.y; ++ch) {  // (an untouched column has x.x > x.y)
+      if (U.cell_bytes == 4) *(uint32_t __attribute__((address_space(1)))*)((a3d_gptr)cells + (column + ch) * 4u) = 0u;
+      else *(unsigned long long __attribute__((address_space(1)))*)((a3d_gptr)cells + (size_t)(column + ch) * 8u) = 0ull;
+    }
+  }
+  for (uint32_t k = block * THREADS + threadIdx.x; k < U.flag_words; k += blocks * THREADS)
+    U.flags[(size_t)frame * U.flag_words + k] = 0u;
+}
+
 // Where the blurred grids of a batch of frames live (the context's grid scratch region):
 // [n_frames x SC_STRIDE words of scalars][n_frames x capacity packed u32 / u64 cells][n_frames x capacity f64 cells (normalised values)]
 struct GridBatch {
@@ -156,6 +193,10 @@ struct GridBatch {
   void* packed = nullptr;  // u32 or u64 cells (bilateral.hip: Pack)
   double* blurred = nullptr;
   unsigned long long capacity = 0;  // cells per frame
+  // `defer_unsplat`: the enqueue stopped before its last kernel (unsplat_kernel: the zeros go back where the splat wrote);
+  // the caller's next kernel on the stream does it (unsplat_columns: level0_quad_kernel) and then commits `clean`
+  Unsplat unsplat{};
+  a3d_context::GridLayoutKey clean{};
 };
 
 // Enqueues min/max, grid sizing, splat and the fused blur for `n_frames` depth images ([n_frames][h][w] u16,
@@ -164,7 +205,7 @@ struct GridBatch {
 // not fit `capacity` cells: the caller checks that after its own synchronisation and calls again with more room).
 a3d_status bilateral_grids_enqueue(a3d_context* ctx, const uint16_t* d_depth, uint32_t n_frames, uint32_t w, uint32_t h,
                                    double sigma_space, double sigma_color, unsigned long long capacity_cells,
-                                   GridBatch* out);
+                                   GridBatch* out, bool defer_unsplat = false);
 // Cells a frame's grid needs: enough for a depth range of `depth_span` units (BilateralGrid::from_image, grid.rs:37-56)
 unsigned long long bilateral_grid_cells(uint32_t w, uint32_t h, double sigma_space, double sigma_color, uint32_t depth_span);
 

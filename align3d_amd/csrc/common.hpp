@@ -206,6 +206,7 @@ struct UseFence {
   hipEvent_t ev = nullptr;
   bool recorded = false;
   hipStream_t deferred = nullptr;  // record_later(): the stream the event is recorded on when somebody first waits
+  int deferred_device = -1;        // ... and the device that stream lives on
   void record_locked(hipStream_t s) {
     if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
       ev = nullptr;
@@ -220,12 +221,24 @@ struct UseFence {
   // "Whatever is on `s` by the time somebody waits": no event record on the enqueue path (a single-frame
   // compute_normals is a 1.3 us kernel: the record cost as much as the launch); the first waiter records it, which
   // covers this work and whatever the stream was given since — the right trade where the caller synchronises anyway.
-  void record_later(hipStream_t s) {
+  // `device`: the stream's device.  The first waiter may be a thread whose current device is another one (a process that
+  // drives several GPUs frees an image while the last context it used is current): an event created there cannot be recorded
+  // on this stream (round 5 advisor: hipErrorInvalidHandle, `recorded` stayed false, wait() returned at once and the arena
+  // went back to the pool under a running kernel).  settle_locked() switches to the stream's device for the record and back;
+  // if the record fails all the same it waits for the stream itself rather than call the fence satisfied.
+  void record_later(hipStream_t s, int device) {
     std::lock_guard<std::mutex> lock(m);
-    deferred = s;
+    deferred = s, deferred_device = device;
   }
   void settle_locked() {
-    if (deferred && !recorded) record_locked(deferred);
+    if (deferred && !recorded) {
+      int current = -1;
+      const bool switched = deferred_device >= 0 && hipGetDevice(&current) == hipSuccess && current != deferred_device &&
+                            hipSetDevice(deferred_device) == hipSuccess;
+      record_locked(deferred);
+      if (!recorded) (void)hipStreamSynchronize(deferred);  // (no event: the stream's own completion is the fence)
+      if (switched) (void)hipSetDevice(current);
+    }
     deferred = nullptr;
   }
   void wait() {  // host wait: the arena is about to be handed to another stream's build
@@ -235,10 +248,9 @@ struct UseFence {
   }
   bool wait_on(hipStream_t s) {  // device-side wait: `s` continues after everything recorded so far
     std::lock_guard<std::mutex> lock(m);
-    if (deferred == s && !recorded) {  // the waiting stream is the one the work is on: stream order is the fence
-      deferred = nullptr;
-      return true;
-    }
+    // the waiting stream is the one the work is on: stream order is the fence — for THIS waiter; `deferred` stays set, so a
+    // later wait() or wait_on(another stream) still records and waits (round 5 advisor, low)
+    if (deferred == s && !recorded) return true;
     settle_locked();
     return !(ev && recorded) || hipStreamWaitEvent(s, ev, 0) == hipSuccess;
   }

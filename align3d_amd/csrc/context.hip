@@ -70,6 +70,20 @@ a3d_status ctx_scratch(a3d_context* ctx, int which, size_t bytes, void** out) {
   return A3D_OK;
 }
 
+// The idle kd-tree / Icp blocks a context keeps (up to 8 blocks, 512 MiB) go back to the device when an allocation fails
+// (round 5 advisor: a process with several contexts could fail hipMalloc while holding gigabytes of them).  What used a
+// block was enqueued on the context's stream: synchronise it first.
+static void drop_spare_blocks(a3d_context* ctx) {
+  std::vector<a3d_context::SpareBlock> spare;
+  {
+    std::lock_guard<std::mutex> lock(ctx->pool_mutex);
+    spare.swap(ctx->spare_blocks);
+  }
+  if (spare.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (const auto& b : spare) (void)hipFree(b.p);
+}
+
 a3d_status ctx_block_alloc(a3d_context* ctx, size_t bytes, void** out, size_t* out_bytes) {
   bytes = std::max<size_t>(bytes, 256);
   {  // (a handle may be freed — its block released — from another thread than the one that builds: same mutex as the arena pool)
@@ -85,7 +99,11 @@ a3d_status ctx_block_alloc(a3d_context* ctx, size_t bytes, void** out, size_t* o
       return A3D_OK;
     }
   }
-  A3D_HIP_TRY(hipMalloc(out, bytes));
+  if (hipMalloc(out, bytes) != hipSuccess) {  // out of memory: give the idle spare blocks back and try once more
+    (void)hipGetLastError();
+    drop_spare_blocks(ctx);
+    A3D_HIP_TRY(hipMalloc(out, bytes));
+  }
   *out_bytes = bytes;
   return A3D_OK;
 }
@@ -200,7 +218,12 @@ a3d_status ctx_arena_acquire(a3d_context* ctx, size_t bytes, DeviceArena* out) {
   }
   if (hipMalloc(&out->base, bytes) != hipSuccess) {
     (void)hipGetLastError();
-    trim_pool_locked(ctx);  // give back what the pool holds, then try once more
+    trim_pool_locked(ctx);  // give back what the pool holds (and the idle kd-tree blocks), then try once more
+    if (!ctx->spare_blocks.empty()) {
+      (void)hipStreamSynchronize(ctx->stream);
+      for (const auto& b : ctx->spare_blocks) (void)hipFree(b.p);
+      ctx->spare_blocks.clear();
+    }
     A3D_HIP_TRY(hipMalloc(&out->base, bytes));
   }
   ctx->single_arenas.push_back(out->base);

@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256)
                        const double* __restrict__ grids, unsigned long long capacity, uint32_t* __restrict__ scal, float fx,
                        float fy, float cx, float cy, float scale, FrameBases bases, size_t off_points, size_t off_mask,
                        size_t off_normals, bool with_normals, LevelLayout L1, bool emit_l1, LevelLayout L2, bool emit_l2,
-                       bool l2_is_last) {
+                       bool l2_is_last, Unsplat unsplat) {
   __shared__ float sp[3][QS + 2][QS + 3];  // the patch's points at (y + 1, x + 1), halo included
   __shared__ float s1[2][3][QT][QT + 1];   // level-1 picks (0: points, 1: normals) for the level-2 picks
   __shared__ uint8_t s1m[QT][QT];          // level-1 masks
@@ -341,11 +341,13 @@ __global__ void __launch_bounds__(256)
   dh = hin ? dh : 0u;
   const DivBy dfx = div_prepare(fx), dfy = div_prepare(fy);
   const bool focal_ok = div_den_ok(fx) & div_den_ok(fy);
+  GridDims g{0, 0, 0};
+  bool grid_ok = false;
   if (FILTER) {
     uint32_t* sc = scal + f * SC_STRIDE;
-    GridDims g;
     uint32_t cmin;
-    if (dyn_dims(sc, &g, &cmin)) {  // (false: this frame's grid did not fit; the host grows the region and repeats)
+    grid_ok = dyn_dims(sc, &g, &cmin);
+    if (grid_ok) {  // (false: this frame's grid did not fit; the host grows the region and repeats)
       // BilateralGrid::slice (grid.rs:106-162) of every pixel in the image, zeros included.  The 32 gathers of the quad (and
       // the halo pixel's eight) are ALL issued before the first is combined: the blurred grids of a launch sequence (150 MB)
       // do not fit the L2, a gather is a trip to the Infinity Cache, and five pixels one after the other were five such
@@ -445,6 +447,16 @@ __global__ void __launch_bounds__(256)
     sp[0][hy][hx] = ph.x, sp[1][hy][hx] = ph.y, sp[2][hy][hx] = ph.z;
   }
   __syncthreads();
+#ifdef A3D_DIAGNOSTICS
+  // A3D_BUILDER_UNSPLAT=fused: the filter's last step, taken over from unsplat_kernel: the blur is done with the packed cells,
+  // so the grid (row, column)s that begin in this patch get their zeros back here — a few dozen small stores per block,
+  // behind the kernel's last global load (in front of the gathers a later load's wait became a wait for these stores' round
+  // trip: loads and stores share one in-order counter).  Measured: 140 against 123 us per 32 frames — more than the
+  // 10 us launch it saves; not the product's path.
+  if (FILTER && grid_ok && unsplat.packed)
+    unsplat_columns(unsplat, f, g, inv_ss, r0, min(r0 + QS, (int)h), c0, min(c0 + QS, (int)w),
+                    blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+#endif
   char* base = bases.arena[f];
   auto at = [&](int y, int x) { return V3{sp[0][y][x], sp[1][y][x], sp[2][y][x]}; };
   // ---- normals (structure.rs:184-262): an invalid neighbour's point is (0,0,0) already (= get_point(..).unwrap_or_else(
@@ -982,11 +994,20 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
   if (!depth_part) {
   } else if (prm->use_bilateral) {  // builder.rs:75-77
     GridBatch gb;
-    A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb));
-    if (quad)
+    // (diagnostics build, A3D_BUILDER_UNSPLAT=fused: the level-0 kernel puts the filter's zeros back instead of unsplat_kernel —
+    // measured round 6: level 0 140 instead of 123 us per 32 frames for a 10 us launch saved; kept as a cross-check)
+    const bool defer = quad && A3D_DIAG_ENV("A3D_BUILDER_UNSPLAT") && !strcmp(A3D_DIAG_ENV("A3D_BUILDER_UNSPLAT"), "fused");
+    A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb, defer));
+    if (quad) {
       hipLaunchKernelGGL(level0_quad_kernel<true>, gridq, dim3(256), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
                          1.0 / prm->sigma_color, (const double*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
-                         bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last);
+                         bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last,
+                         gb.unsplat);
+      if (defer) {
+        A3D_HIP_TRY(hipGetLastError());
+        ctx->grid_clean = gb.clean;  // (the zeros are back once this kernel has run)
+      }
+    }
 #ifdef A3D_DIAGNOSTICS
     else
       hipLaunchKernelGGL(level0_kernel<true>, dim3((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F), dim3(L0_THREADS), 0, s,
@@ -999,7 +1020,7 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
     if (quad)
       hipLaunchKernelGGL(level0_quad_kernel<false>, gridq, dim3(256), 0, s, d_depth, w, h, 0.0, 0.0, (const double*)nullptr, 0ull,
                          (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points, L0.mask, L0.normals,
-                         prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last);
+                         prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last, Unsplat{});
 #ifdef A3D_DIAGNOSTICS
     else
       hipLaunchKernelGGL(level0_kernel<false>, dim3((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F), dim3(L0_THREADS), 0, s,

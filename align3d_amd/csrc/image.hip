@@ -123,7 +123,7 @@ void fence_self_work(a3d_context* ctx, a3d_device_image* const* images, uint64_t
     if (!a) continue;
     if (!fence) {
       fence = std::make_shared<UseFence>();
-      fence->record_later(ctx->stream);  // (no event on the enqueue path: UseFence::record_later)
+      fence->record_later(ctx->stream, ctx->device);  // (no event on the enqueue path: UseFence::record_later)
     }
     std::lock_guard<std::mutex> lock(a->fence_mutex);
     bool replaced = false;

@@ -1448,6 +1448,8 @@ a3d_status batch_enqueue(a3d_multiscale_batch* b, const Pose* d_init, uint32_t l
 #ifdef A3D_DIAGNOSTICS
   uint32_t pmask = head ? (b->persist_mask & ((1u << levels_to_run) - 1u)) : 0u;
   if (pmask && !((pmask >> (levels_to_run - 1)) & 1u)) pmask = 0;  // (a truncated pyramid: the run must start at its coarsest level)
+  for (uint32_t l = 0; l < levels_to_run && l < 16; ++l)  // a3d_multiscale_align_host: levels still being uploaded run as
+    if (b->level_ready[l]) pmask = 0;                     // per-iteration launches, each behind its level's event (advisor r5)
   if (pmask) {
     PersistPlan plan{};
     plan.seq0 = 0, plan.counter_base = b->counter_base, plan.trace_index0 = 0, plan.trace_stride = trace_stride;
@@ -1904,6 +1906,8 @@ a3d_status a3d_multiscale_align_host(a3d_multiscale* ms, const a3d_range_image_v
   }
   for (uint32_t l = 0; l < n; ++l)  // the reference's expect() on the source (image_icp.rs:52-57), before anything is copied
     A3D_REQUIRE(source_pyramid[l].intensities, A3D_MISSING_FIELD, "Please, the source image should have intensity colors.");
+  A3D_REQUIRE(n <= 16, A3D_INVALID_PARAMETER, "a3d_multiscale_align_host handles pyramids of up to 16 levels (upload with "
+              "a3d_range_image_upload_pyramid and call a3d_multiscale_align for more)");
   a3d_device_image* images[16] = {};
   hipEvent_t ready[16] = {};
   A3D_TRY(upload_pyramid(ms->ctx, source_pyramid, n, images, ready));

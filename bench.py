@@ -807,7 +807,7 @@ def load_cpu_oracle():
 
 
 def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_poses, cores, orders=13, budget_s=25.0,
-                      gpu_poses_pinned=None):
+                      gpu_poses_pinned=None, teacher=True):
     """ms3x15 on the batch's pairs, threaded like the reference (4096-pixel chunks over the host's cores).
     TIMED: the chunk-order run of every pair (until `budget_s` of CPU work is spent) -> `value`.
     UNTIMED (parity of the headline): every pair also under `orders` - 1 seeded chunk-merge orders
@@ -875,16 +875,17 @@ def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_p
             out["pinned_tiling_max_gpu_vs_cpu_translation_m"] = sp["max_gpu_vs_cpu_translation_m"]
         worst = sorted(keep, key=lambda q: -next(x for x in entries if x["pair"] == q)["gpu_vs_cpu_translation_m"])[:2]
         tfs = []
-        for p in worst:
+        for p in (worst if teacher else []):
             fa, fb = pair_frames[p]
             ta, tb = keep[p]
             tf = HP.teacher_forced(ctx, params, ta, tb, host_pyramids[fa], host_pyramids[fb], threads=cores)
             tf["pair"] = p
             tfs.append(tf)
-        out["teacher_forced_most_sensitive_pairs"] = tfs
-        out["teacher_forced_count_mismatches"] = sum(t["count_mismatches"] for t in tfs)
-        out["teacher_forced_max_rel_err_sums"] = max((t["max_rel_err_sums"] for t in tfs), default=0.0)
-        out["teacher_forced_max_one_step_translation_m"] = max((t["max_one_step_translation_m"] for t in tfs), default=0.0)
+        if teacher:
+            out["teacher_forced_most_sensitive_pairs"] = tfs
+            out["teacher_forced_count_mismatches"] = sum(t["count_mismatches"] for t in tfs)
+            out["teacher_forced_max_rel_err_sums"] = max((t["max_rel_err_sums"] for t in tfs), default=0.0)
+            out["teacher_forced_max_one_step_translation_m"] = max((t["max_one_step_translation_m"] for t in tfs), default=0.0)
     return out
 
 
@@ -1092,14 +1093,18 @@ def compact_line(full, detail_file=None):
     return text
 
 
-def hbm_copy_ceiling():
+def hbm_copy_ceiling(device=0):
     """What the memory system of THIS chip delivers to a compute-free kernel: scripts/copy_ceiling (built by
-    __graft_entry__.build()) as a child process -> {"read_GBs", "copy_GBs"} or None when the probe is not built."""
+    __graft_entry__.build()) as a child process on HIP device `device` -> {"read_GBs", "copy_GBs"} or None when the probe is
+    not built."""
     exe = os.path.join(ROOT, "scripts", "copy_ceiling")
     if not os.path.exists(exe):
         return None
     try:
-        return json.loads(subprocess.run([exe], capture_output=True, timeout=120, check=True).stdout.decode().strip().splitlines()[-1])
+        env = dict(os.environ)
+        visible = [v for v in env.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
+        env["HIP_VISIBLE_DEVICES"] = visible[device] if device < len(visible) else str(device)  # (the child sees one device: its 0)
+        return json.loads(subprocess.run([exe], capture_output=True, timeout=120, check=True, env=env).stdout.decode().strip().splitlines()[-1])
     except Exception as e:
         log(f"copy ceiling probe failed: {e}")
         return None
@@ -1137,6 +1142,273 @@ def launch_ranks(n, argv):
                     q.terminate()
         time.sleep(0.05)
     return rc
+
+
+def run_leg(errors, name, fn, *a, **kw):
+    """One secondary measurement.  A failure costs that leg only: it is logged, recorded under extra.errors and the line is
+    still printed (an exception in any leg after the timed region used to lose the whole line)."""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:  # noqa: BLE001 — whatever a probe raises must not reach the contract line
+        log(f"[bench] leg '{name}' failed: {e!r}")
+        errors[name] = repr(e)[:300]
+        return None
+
+
+def repeated_step_timings(ctx, batch, rep_steps, repeats=20):
+    """the same step again, `repeats` x `rep_steps` steps: per-step ms of each repetition."""
+    reps = []
+    for _ in range(repeats):
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(rep_steps):
+            batch.enqueue()
+        ctx.synchronize()
+        reps.append((time.perf_counter() - t1) / rep_steps * 1e3)
+    return reps
+
+
+def headline_roofline(ctx, batch, params, P, W, H, distinct, ms_per_step):
+    """Roofline of the dominant kernel (image_icp_head_kernel), HIP events on the launch streams.
+    The batch runs `conc` pair groups on separate streams, so `conc` launches are in flight at once.  per_launch: what one
+    launch does (its own bytes / its own duration: what rocprofv3 --kernel-trace shows per kernel).  achieved: the
+    chip-level figure = the step's algorithmic bytes / the device time of the whole launch sequence (first launch start ->
+    last launch end, events on the context stream), i.e. the concurrent launches summed without double counting."""
+    conc = batch.concurrency()
+    kernel_ms, region_ms, launches = [], [], 0
+    level_ms = [[] for _ in range(len(params))]
+    level_launches = [0] * len(params)
+    for _ in range(20):  # launch sequence as it runs in the timed steps (no per-launch events)
+        batch.enqueue()
+        ctx.synchronize()
+        region_ms.append(batch.last_timing()[0])
+    batch.set_profiling(True)
+    for _ in range(20):  # per-launch durations, events around every launch on its stream
+        batch.enqueue()
+        ctx.synchronize()
+        kernel_ms.append(batch.last_kernel_ms())
+        launches = batch.last_timing()[1]
+        for l in range(len(params)):
+            ms_l, level_launches[l] = batch.last_level_ms(l)
+            level_ms[l].append(ms_l)
+    batch.set_profiling(False)
+    kms, rms = float(np.median(kernel_ms)), float(np.median(region_ms))
+    iters = [int(p.max_iterations) for p in params]
+    step_alg_bytes = P * sum(iters[l] * level_bytes(W >> l, H >> l) for l in range(len(params)))
+    bytes_per_launch = step_alg_bytes / max(1, launches)
+    avg_launch_ms = kms / max(1, launches)
+    achieved = step_alg_bytes / (rms * 1e-3) / 1e9
+    traffic, traffic_src = (measured_traffic("bench", pairs_per_gpu=P, concurrent_launches=conc, distinct_frames=int(distinct))
+                            if (W, H) == (640, 480) else (None, None))
+    batch_kernel_name = "image_icp_kernel" if os.environ.get("A3D_ICP_HANDOFF") == "ticket" else "image_icp_head_kernel"
+    roof = {
+        "bound": "hbm", "kernel": batch_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
+        "traffic_source": traffic_src,
+        "launches_per_step": int(launches), "concurrent_launches": conc,
+        "avg_launch_us": avg_launch_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
+        "per_launch_GBs": bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9,
+        "launch_sequence_ms": rms, "launch_sequence_ms_stats": stats(region_ms),
+        "kernel_share_of_step": rms / ms_per_step,
+        # The frames come from the device builder, whose images carry "mask == (z > 0)": the kernel derives both masks
+        # from z and never reads the two mask bytes per pixel that SURVEY §8(d)'s 39 B per pixel credit it with, so
+        # the rate it actually delivers from HBM is 37/39 of `achieved` (the PMC `traffic` above shows the same).
+        "delivered_GBs": achieved * (37 * W * H + 4 * (W + 2) * (H + 2)) / level_bytes(W, H),
+        "delivered_frac": achieved * (37 * W * H + 4 * (W + 2) * (H + 2)) / level_bytes(W, H) / HBM_PEAK_GBS,
+        "delivered_note": "masks derived from z (builder-made frames): 37 instead of 39 B per pixel are read",
+    }
+    # per pyramid level: `conc` launches of a level run at once (the pair groups move in step), so the level's share
+    # of the sequence is its summed launch time / conc, and its bandwidth the level's bytes over that
+    per_level = []
+    for l in range(len(params)):
+        ms_l = float(np.median(level_ms[l])) / max(1, conc)
+        b_l = P * iters[l] * level_bytes(W >> l, H >> l)
+        per_level.append({"level": l, "size": f"{W >> l}x{H >> l}", "launches": int(level_launches[l]),
+                          "avg_launch_us": float(np.median(level_ms[l])) / max(1, level_launches[l]) * 1e3,
+                          "ms_of_sequence": ms_l, "algorithmic_bytes": b_l,
+                          "achieved_GBs": (b_l / (ms_l * 1e-3) / 1e9) if ms_l > 0 else None,
+                          "frac": (b_l / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_l > 0 else None})
+    roof["per_level"] = per_level
+    for lv in per_level:  # flat copies: the driver's record keeps scalars only
+        roof[f"level{lv['level']}_frac"] = lv["frac"]
+        roof[f"level{lv['level']}_avg_launch_us"] = lv["avg_launch_us"]
+        roof[f"level{lv['level']}_share_of_sequence"] = lv["ms_of_sequence"] / rms if rms > 0 else None
+    return roof, step_alg_bytes, iters
+
+
+def add_copy_ceiling(roof, device):
+    """The chip's own ceiling beside the nominal 8 TB/s: scripts/copy_ceiling as a child process on this rank's device."""
+    ceil = hbm_copy_ceiling(device)
+    if ceil and "read_GBs" in ceil:
+        roof["hbm_copy_ceiling"] = ceil
+        roof["hbm_copy_ceiling_GBs"] = max(ceil["read_GBs"], ceil["copy_GBs"])
+        roof["frac_of_copy_ceiling"] = roof["achieved"] / roof["hbm_copy_ceiling_GBs"]
+
+
+def lone_pair_leg(ctx, params, target, source, step_alg_bytes, P):
+    """configs[1]: one pair alone on the GPU (latency-bound: 45 dependent iterations)."""
+    ms1 = MultiscaleAlign.new(ctx, params, target)
+    for _ in range(2):
+        ms1.align(source)
+    lat = []
+    for _ in range(15):
+        t1 = time.perf_counter()
+        ms1.align(source)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    med = float(np.median(lat))
+    return {"single_pair_ms3x15_latency_ms": med,
+            # configs[1] as written (one pair alone): 45 dependent launches; its algorithmic bytes over its latency
+            "single_pair_ms3x15_frac": (step_alg_bytes / P) / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "single_pair_ms3x15_latency_ms_stats": stats(lat)}
+
+
+def secondary_legs(ctx, errors, extra, params, targets, sources, P, W, H, build_ms, ms_per_step, step_alg_bytes):
+    """Everything beside the headline (N = 1 only), each leg on its own (run_leg).  Returns what the CPU legs need."""
+    keep = {"level0_host": None, "depth0": None, "clouds": None, "bench_icp_clouds": None, "poses_pinned": None}
+    lone = run_leg(errors, "lone_pair", lone_pair_leg, ctx, params, targets[0], sources[0], step_alg_bytes, P)
+    if lone:
+        extra.update(lone)
+        r = run_leg(errors, "pinned_tiling", pinned_tiling_bench, ctx, params, targets, sources,
+                    lone["single_pair_ms3x15_latency_ms"], ms_per_step)
+        if r:
+            extra["pinned_tiling"], keep["poses_pinned"] = r
+    r = run_leg(errors, "drop_in", drop_in_bench, ctx, params, targets[0], sources[0])
+    if r:
+        extra["drop_in_from_host_range_images"] = r
+        extra["drop_in_ms3x15_ms_from_host_range_images"] = r["page_locked"]["ms3x15_ms"]
+    extra["named_shapes"] = run_leg(errors, "named_shapes", named_shapes_bench, ctx, targets, sources) or {}
+    r = run_leg(errors, "bench_icp", bench_icp_shape, ctx)
+    if r and r[0] is not None:
+        extra["named_shapes"]["bench_icp"], keep["bench_icp_clouds"] = r
+    r = run_leg(errors, "kdtree", kdtree_bench, ctx)
+    if r:
+        r["x_vs_published_cpu_101.75ms"] = 101.75 / r["ms_per_500k_queries"]
+        extra["kdtree"] = r
+    r = run_leg(errors, "pcl_icp", pcl_icp_bench, ctx)
+    if r:
+        extra["pcl_icp"], keep["clouds"] = r
+    r = run_leg(errors, "odometry", odometry_bench, ctx)
+    if r:
+        extra["odometry"] = r
+    run_leg(errors, "release_lanes", ctx.release_lanes)  # (the lanes' contexts of the in-flight runs: no idle streams beside what follows)
+
+    def frame_prep():
+        keep["level0_host"] = targets[0][0].download()
+        keep["depth0"] = synth.frame_stream(1000, 1, W, H)[0][0][0]
+        return frame_prep_bench(ctx, keep["level0_host"], keep["depth0"])
+
+    r = run_leg(errors, "frame_prep", frame_prep)
+    if r:
+        extra["frame_prep"] = r
+    r = run_leg(errors, "bilateral_device", bilateral_device_bench, ctx, W, H)
+    if r:
+        extra["bilateral_device"] = r
+    # what a caller with host buffers pays per new frame: u16 depth + u8 RGB over PCIe, then bilateral,
+    # back-projection, normals, pyramid, luma and intensity maps on the device (batched build of 65 frames)
+    extra["frame_build_ms_incl_pcie"] = build_ms  # pageable host frames, cold arena pool (the run's first batch)
+    r = run_leg(errors, "frame_build_page_locked", frame_build_bench, ctx, P + 1, W, H)
+    if r:
+        extra["frame_build_page_locked"] = r
+    r = run_leg(errors, "frame_build_roofline", frame_build_roofline, ctx, W, H)
+    if r:
+        extra["frame_build"] = {"roofline": r}
+    extra["pairs_per_s_including_one_frame_build_per_pair"] = 1e3 / (build_ms + ms_per_step / P)
+
+    def streaming():
+        # the pipelined loop is sensitive to how its two host threads and the two launch chains interleave (10-15 k
+        # pairs/s between otherwise identical runs): five repetitions, the median reported, all of them kept
+        runs = [streaming_bench(ctx, params, P, W, H) for _ in range(5)]
+        runs.sort(key=lambda x: x["pairs_per_s"])
+        return dict(runs[len(runs) // 2], pairs_per_s_stats=stats([x["pairs_per_s"] for x in runs]),
+                    failed_pairs=int(sum(x["failed_pairs"] for x in runs)))
+
+    r = run_leg(errors, "streaming", streaming)
+    if r:
+        extra["streaming_from_host_frames"] = r
+    return keep
+
+
+def msdefault_parity_leg(ctx, O, host_pyramids, pair_frames, n_pairs, cores):
+    """VERDICT r5 item 1b: the headline's own pairs under the reference's contractive parameter set MsIcpParams::default()
+    (icp_params.rs:112-133), one oracle run per pair (chunk order): how many differ from the oracle by more than the
+    north-star tolerance 1e-4 rad / 1e-4 m — literally, no envelope."""
+    import headline_parity as HP
+
+    prm = MsIcpParams.default()
+    pairs = pair_frames[:n_pairs]
+    batch = MultiscaleAlignBatch(ctx, prm, [host_pyramids[a] for a, _ in pairs], [host_pyramids[b] for _, b in pairs])
+    poses, status = batch.align()
+    batch.free()
+    worst_a = worst_t = 0.0
+    over = 0
+    t0 = time.perf_counter()
+    for p, (fa, fb) in enumerate(pairs):
+        ta, tb = [HP.host_frame(r) for r in host_pyramids[fa]], [HP.host_frame(r) for r in host_pyramids[fb]]
+        run = HP.oracle_runs(prm, ta, tb, cores, 1)[0]
+        ang, tr = O.transform_metrics(poses[p].to_c(), run)
+        ang = abs(ang)
+        worst_a, worst_t = max(worst_a, ang), max(worst_t, tr)
+        over += int(ang > 1e-4 or tr > 1e-4)
+    return {"msdefault_pairs_compared": len(pairs), "msdefault_pairs_over_1e-4": over,
+            "msdefault_max_gpu_vs_cpu_angle_rad": float(worst_a), "msdefault_max_gpu_vs_cpu_translation_m": float(worst_t),
+            "msdefault_failed_pairs": int(np.count_nonzero(status)), "msdefault_oracle_seconds": time.perf_counter() - t0}
+
+
+def cpu_legs(ctx, errors, extra, args, world, host_pyramids, pair_frames, params, P, poses, targets, sources, keep):
+    """cpu_baseline (rank 0).  N = 1: all pairs, 13 merge orders, the teacher-forced check, msdefault parity and the
+    secondary baselines.  N > 1: a BOUNDED sample so that the scaling line carries a cpu_baseline
+    too — chunk-order timing of at most 8 pairs (<= 5 s) and the envelope of those pairs under 5 merge orders."""
+    r = run_leg(errors, "load_cpu_oracle", load_cpu_oracle)
+    if not r:
+        return None
+    O, flags = r
+    model, cores = cpu_info()
+    if world == 1:
+        cpu = run_leg(errors, "cpu_baseline", cpu_baseline_main, ctx, O, host_pyramids, pair_frames, params,
+                      min(args.cpu_pairs, P), poses, cores, orders=max(1, args.cpu_orders), gpu_poses_pinned=keep["poses_pinned"])
+    else:
+        cpu = run_leg(errors, "cpu_baseline", cpu_baseline_main, ctx, O, host_pyramids, pair_frames, params,
+                      min(args.cpu_pairs, P, 8), poses, cores, orders=min(5, max(1, args.cpu_orders)), budget_s=5.0,
+                      teacher=False)
+    if not cpu:
+        return None
+    cpu["cpu_model"], cpu["compiler_flags"] = model, flags
+    if world > 1:
+        return cpu
+    r = run_leg(errors, "msdefault_parity", msdefault_parity_leg, ctx, O, host_pyramids, pair_frames, min(args.cpu_pairs, P), cores)
+    if r:
+        cpu.update(r)
+    if keep["level0_host"] is not None and keep["clouds"] is not None:
+        def oframe(dev_level):
+            ri = dev_level.download(colors=False)
+            k = ri.intrinsics
+            return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
+
+        sec = run_leg(errors, "cpu_baselines_secondary", cpu_baselines_secondary, O, cores, keep["level0_host"], keep["depth0"],
+                      (oframe(targets[0][0]), oframe(sources[0][0])), keep["clouds"], keep["bench_icp_clouds"],
+                      gpu_pcl_pose=(extra.get("pcl_icp") or {}).get("gpu_pose_t_q"))
+        if sec:
+            for v in sec.values():
+                v["cpu_model"], v["compiler_flags"] = model, flags
+            extra["cpu_baselines"] = sec
+
+            def ratios():
+                # GPU / CPU beside each other (a reported baseline, not the target: the roofline fraction is)
+                g = {
+                    "kdtree_500k": extra["kdtree"]["value"] / sec["kdtree_500k"]["value"],
+                    "pcl_icp_iteration": sec["pcl_icp_500k"]["ms_per_iteration"] * 1e3 / extra["pcl_icp"]["us_per_iteration"],
+                    "compute_normals": sec["compute_normals_640x480"]["value"] / extra["frame_prep"]["compute_normals_ms"],
+                    "bilateral": sec["bilateral_640x480"]["value"] / extra["frame_prep"]["bilateral_filter_ms_host_to_host"],
+                    "bench10_single_pair": sec["bench10"]["value"] / extra["named_shapes"]["bench10"]["single_pair_latency_ms"],
+                }
+                if "bench_icp" in sec and "bench_icp" in extra["named_shapes"]:
+                    g["bench_icp_align"] = sec["bench_icp"]["value"] / extra["named_shapes"]["bench_icp"]["device_ms_per_align"]
+                return g
+
+            r = run_leg(errors, "gpu_vs_cpu", ratios)
+            if r:
+                extra["gpu_vs_cpu"] = r
+    return cpu
 
 
 def main():
@@ -1263,95 +1535,32 @@ def main():
 
     out = None
     if rank == 0:
+        errors = {}
         # ---- repeated short timings of the same step (>= 20 repetitions, min / median / max) ----
         rep_steps = max(1, min(30, args.steps))
-        reps = []
-        if not multi:
-            for _ in range(20):
-                ctx.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(rep_steps):
-                    batch.enqueue()
-                ctx.synchronize()
-                reps.append((time.perf_counter() - t1) / rep_steps * 1e3)
-        # ---- roofline of the dominant kernel (image_icp_kernel), HIP events on the launch stream ----
-        # The batch runs `conc` pair groups on separate streams, so `conc` launches are in flight at once.
-        # per_launch: what one launch does (its own bytes / its own duration: what rocprofv3 --kernel-trace
-        # shows per kernel).  achieved: the chip-level figure = the step's algorithmic bytes / the device time of
-        # the whole launch sequence (first launch start -> last launch end, events on the context stream), i.e.
-        # the concurrent launches summed without double counting their overlap.
-        conc = batch.concurrency()
-        kernel_ms, region_ms, launches = [], [], 0
-        level_ms = [[] for _ in range(len(params))]
-        level_launches = [0] * len(params)
-        for _ in range(20):  # launch sequence as it runs in the timed steps (no per-launch events)
-            batch.enqueue()
-            ctx.synchronize()
-            region_ms.append(batch.last_timing()[0])
-        batch.set_profiling(True)
-        for _ in range(20):  # per-launch durations, events around every launch on its stream
-            batch.enqueue()
-            ctx.synchronize()
-            kernel_ms.append(batch.last_kernel_ms())
-            launches = batch.last_timing()[1]
-            for l in range(len(params)):
-                ms_l, level_launches[l] = batch.last_level_ms(l)
-                level_ms[l].append(ms_l)
-        batch.set_profiling(False)
-        kms, rms = float(np.median(kernel_ms)), float(np.median(region_ms))
+        reps = [] if multi else (run_leg(errors, "repeated_timings", repeated_step_timings, ctx, batch, rep_steps) or [])
+        r = run_leg(errors, "roofline", headline_roofline, ctx, batch, params, P, W, H, distinct, ms_per_step)
         iters = [int(p.max_iterations) for p in params]
-        step_alg_bytes = P * sum(iters[l] * level_bytes(W >> l, H >> l) for l in range(3))
-        bytes_per_launch = step_alg_bytes / max(1, launches)
-        avg_launch_ms = kms / max(1, launches)
-        achieved = step_alg_bytes / (rms * 1e-3) / 1e9
-        traffic, traffic_src = (measured_traffic("bench", pairs_per_gpu=P, concurrent_launches=conc, distinct_frames=int(distinct))
-                                if (W, H) == (640, 480) else (None, None))
-        batch_kernel_name = "image_icp_kernel" if os.environ.get("A3D_ICP_HANDOFF") == "ticket" else "image_icp_head_kernel"
-        roof = {
-            "bound": "hbm", "kernel": batch_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
-            "traffic_source": traffic_src,
-            "launches_per_step": int(launches), "concurrent_launches": conc,
-            "avg_launch_us": avg_launch_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "per_launch_GBs": bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9,
-            "launch_sequence_ms": rms, "launch_sequence_ms_stats": stats(region_ms),
-            "kernel_share_of_step": rms / ms_per_step,
-            # The frames come from the device builder, whose images carry "mask == (z > 0)": the kernel derives both masks
-            # from z and never reads the two mask bytes per pixel that SURVEY §8(d)'s 39 B per pixel credit it with, so
-            # the rate it actually delivers from HBM is 37/39 of `achieved` (the PMC `traffic` above shows the same).
-            "delivered_GBs": achieved * (37 * W * H + 4 * (W + 2) * (H + 2)) / level_bytes(W, H),
-            "delivered_frac": achieved * (37 * W * H + 4 * (W + 2) * (H + 2)) / level_bytes(W, H) / HBM_PEAK_GBS,
-            "delivered_note": "masks derived from z (builder-made frames): 37 instead of 39 B per pixel are read",
-        }
-        # per pyramid level: `conc` launches of a level run at once (the pair groups move in step), so the level's share
-        # of the sequence is its summed launch time / conc, and its bandwidth the level's bytes over that
-        per_level = []
-        for l in range(len(params)):
-            ms_l = float(np.median(level_ms[l])) / max(1, conc)
-            b_l = P * iters[l] * level_bytes(W >> l, H >> l)
-            per_level.append({"level": l, "size": f"{W >> l}x{H >> l}", "launches": int(level_launches[l]),
-                              "avg_launch_us": float(np.median(level_ms[l])) / max(1, level_launches[l]) * 1e3,
-                              "ms_of_sequence": ms_l, "algorithmic_bytes": b_l,
-                              "achieved_GBs": (b_l / (ms_l * 1e-3) / 1e9) if ms_l > 0 else None,
-                              "frac": (b_l / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_l > 0 else None})
-        roof["per_level"] = per_level
-        if world == 1 and not args.no_extras:  # the chip's own ceiling beside the nominal 8 TB/s
-            ceil = hbm_copy_ceiling()
-            if ceil and "read_GBs" in ceil:
-                roof["hbm_copy_ceiling"] = ceil
-                roof["hbm_copy_ceiling_GBs"] = max(ceil["read_GBs"], ceil["copy_GBs"])
-                roof["frac_of_copy_ceiling"] = achieved / roof["hbm_copy_ceiling_GBs"]
-        for lv in per_level:  # flat copies: the driver's record keeps scalars only
-            roof[f"level{lv['level']}_frac"] = lv["frac"]
-            roof[f"level{lv['level']}_avg_launch_us"] = lv["avg_launch_us"]
-            roof[f"level{lv['level']}_share_of_sequence"] = lv["ms_of_sequence"] / rms if rms > 0 else None
+        if r:
+            roof, step_alg_bytes, iters = r
+        else:  # (the contract's object even when the event-timed passes failed: the step's bytes over the timed step)
+            step_alg_bytes = P * sum(iters[l] * level_bytes(W >> l, H >> l) for l in range(len(params)))
+            ach = step_alg_bytes / (ms_per_step * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "image_icp_head_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "note": "from the timed step: the per-launch passes failed"}
+        if not args.no_extras:  # the chip's own ceiling beside the nominal 8 TB/s (N > 1 too: VERDICT r5 item 2)
+            run_leg(errors, "copy_ceiling", add_copy_ceiling, roof, device)
         poses, status = batch.align()
         failed_pairs = int(np.count_nonzero(status))
         roof["failed_pairs"] = failed_pairs  # a failed pair freezes and its blocks stop working: must be 0
-        # proof of work: the share of source pixels that pass every gate and reach the Jacobian stage, per level (one
-        # accumulate pass per level at the pair's final pose; dead pixels skip that stage)
-        for l, fr in enumerate(live_pixel_fractions(ctx, params, targets[0], sources[0], poses[0])):
-            roof[f"level{l}_live_pixel_frac_pair0"] = fr
+
+        def live_fractions():
+            # proof of work: the share of source pixels that pass every gate and reach the Jacobian stage, per level (one
+            # accumulate pass per level at the pair's final pose; dead pixels skip that stage)
+            for l, fr in enumerate(live_pixel_fractions(ctx, params, targets[0], sources[0], poses[0])):
+                roof[f"level{l}_live_pixel_frac_pair0"] = fr
+
+        run_leg(errors, "live_pixel_fractions", live_fractions)
         extra = {"failed_pairs": failed_pairs,
                  "timing": {"timed_region_s": elapsed, "ms_per_step_repeated": stats(reps) if reps else None,
                             "steps_per_repeat": rep_steps, "repeats_x_steps": f"{len(reps)} x {rep_steps}"}}
@@ -1370,78 +1579,14 @@ def main():
             errs.append((np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)), np.linalg.norm(d[:3, 3])))
         extra["mean_error_vs_synthetic_gt"] = {"angle_rad": float(np.mean([e[0] for e in errs])),
                                                "translation_m": float(np.mean([e[1] for e in errs]))}
-        level0_host = depth0 = clouds = bench_icp_clouds = poses_pinned = None
+        keep = {"level0_host": None, "depth0": None, "clouds": None, "bench_icp_clouds": None, "poses_pinned": None}
         if not args.no_extras and world == 1:
-            # configs[1]: one pair alone on the GPU (latency-bound: 45 dependent iterations)
-            ms1 = MultiscaleAlign.new(ctx, params, targets[0])
-            for _ in range(2):
-                ms1.align(sources[0])
-            lat = []
-            for _ in range(15):
-                t1 = time.perf_counter()
-                ms1.align(sources[0])
-                lat.append((time.perf_counter() - t1) * 1e3)
-            extra["single_pair_ms3x15_latency_ms"] = float(np.median(lat))
-            # configs[1] as written (one pair alone): 45 dependent launches; its algorithmic bytes over its latency
-            extra["single_pair_ms3x15_frac"] = (step_alg_bytes / P) / (float(np.median(lat)) * 1e-3) / 1e9 / HBM_PEAK_GBS
-            extra["single_pair_ms3x15_latency_ms_stats"] = stats(lat)
-            extra["pinned_tiling"], poses_pinned = pinned_tiling_bench(ctx, params, targets, sources, float(np.median(lat)), ms_per_step)
-            extra["drop_in_from_host_range_images"] = drop_in_bench(ctx, params, targets[0], sources[0])
-            extra["drop_in_ms3x15_ms_from_host_range_images"] = extra["drop_in_from_host_range_images"]["page_locked"]["ms3x15_ms"]
-            extra["named_shapes"] = named_shapes_bench(ctx, targets, sources)
-            bi, bench_icp_clouds = bench_icp_shape(ctx)
-            if bi is not None:
-                extra["named_shapes"]["bench_icp"] = bi
-            extra["kdtree"] = kdtree_bench(ctx)
-            extra["kdtree"]["x_vs_published_cpu_101.75ms"] = 101.75 / extra["kdtree"]["ms_per_500k_queries"]
-            extra["pcl_icp"], clouds = pcl_icp_bench(ctx)
-            extra["odometry"] = odometry_bench(ctx)
-            ctx.release_lanes()  # (the lanes' contexts of the in-flight runs: no idle streams beside what follows)
-            level0_host = targets[0][0].download()
-            depth0 = synth.frame_stream(1000, 1, W, H)[0][0][0]
-            extra["frame_prep"] = frame_prep_bench(ctx, level0_host, depth0)
-            # what a caller with host buffers pays per new frame: u16 depth + u8 RGB over PCIe, then bilateral,
-            # back-projection, normals, pyramid, luma and intensity maps on the device (batched build of 65 frames)
-            extra["frame_build_ms_incl_pcie"] = build_ms  # pageable host frames, cold arena pool (the run's first batch)
-            extra["frame_build_page_locked"] = frame_build_bench(ctx, P + 1, W, H)
-            extra["frame_build"] = {"roofline": frame_build_roofline(ctx, W, H)}
-            extra["pairs_per_s_including_one_frame_build_per_pair"] = 1e3 / (build_ms + ms_per_step / P)
-            # the pipelined loop is sensitive to how its two host threads and the two launch chains interleave (10-15 k
-            # pairs/s between otherwise identical runs): five repetitions, the median reported, all of them kept
-            runs = [streaming_bench(ctx, params, P, W, H) for _ in range(5)]
-            runs.sort(key=lambda r: r["pairs_per_s"])
-            extra["streaming_from_host_frames"] = dict(runs[len(runs) // 2],
-                                                       pairs_per_s_stats=stats([r["pairs_per_s"] for r in runs]),
-                                                       failed_pairs=int(sum(r["failed_pairs"] for r in runs)))
+            keep = secondary_legs(ctx, errors, extra, params, targets, sources, P, W, H, build_ms, ms_per_step, step_alg_bytes)
         cpu = None
-        if world == 1 and args.cpu_pairs > 0:
-            O, flags = load_cpu_oracle()
-            model, cores = cpu_info()
-            cpu = cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, min(args.cpu_pairs, P), poses, cores,
-                                    orders=max(1, args.cpu_orders),
-                                    gpu_poses_pinned=poses_pinned)
-            cpu["cpu_model"], cpu["compiler_flags"] = model, flags
-            if level0_host is not None:
-                def oframe(dev_level):
-                    ri = dev_level.download(colors=False)
-                    k = ri.intrinsics
-                    return O.Frame(ri.points, ri.mask, k.fx, k.fy, k.cx, k.cy, ri.normals, ri.intensities, ri.intensity_map)
-                sec = cpu_baselines_secondary(O, cores, level0_host, depth0,
-                                              (oframe(targets[0][0]), oframe(sources[0][0])), clouds, bench_icp_clouds)
-                for v in sec.values():
-                    v["cpu_model"], v["compiler_flags"] = model, flags
-                extra["cpu_baselines"] = sec
-                # GPU / CPU beside each other (a reported baseline, not the target: the roofline fraction is)
-                extra["gpu_vs_cpu"] = {
-                    "kdtree_500k": extra["kdtree"]["value"] / sec["kdtree_500k"]["value"],
-                    "pcl_icp_iteration": sec["pcl_icp_500k"]["ms_per_iteration"] * 1e3 / extra["pcl_icp"]["us_per_iteration"],
-                    "compute_normals": sec["compute_normals_640x480"]["value"] / extra["frame_prep"]["compute_normals_ms"],
-                    "bilateral": sec["bilateral_640x480"]["value"] / extra["frame_prep"]["bilateral_filter_ms_host_to_host"],
-                    "bench10_single_pair": sec["bench10"]["value"] / extra["named_shapes"]["bench10"]["single_pair_latency_ms"],
-                }
-                if "bench_icp" in sec and "bench_icp" in extra["named_shapes"]:
-                    extra["gpu_vs_cpu"]["bench_icp_align"] = (sec["bench_icp"]["value"]
-                                                              / extra["named_shapes"]["bench_icp"]["device_ms_per_align"])
+        if args.cpu_pairs > 0:
+            cpu = cpu_legs(ctx, errors, extra, args, world, host_pyramids, pair_frames, params, P, poses, targets, sources, keep)
+        if errors:
+            extra["errors"] = errors
         out = {
             "metric": "ICP frame-pairs/sec (640x480, 3-lvl, 15 iters)",
             "value": value, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -334,7 +334,9 @@ a3d_status a3d_multiscale_align(a3d_multiscale* ms, const a3d_device_image* cons
 /* The same with the source pyramid as the reference holds it: `&[RangeImage]` in HOST memory (src/icp/multiscale.rs:51).
  * One call uploads and aligns: the arrays go up on the context's copy stream, coarsest level first, and the launches of
  * a level wait for that level's arrays only, so the coarse levels iterate under the upload of the fine ones (0.65 against
- * 0.84 ms for upload-then-align at 640x480, 3 levels x 15 iterations, page-locked arrays).  Nothing stays resident. */
+ * 0.84 ms for upload-then-align at 640x480, 3 levels x 15 iterations, page-locked arrays).  Nothing stays resident.
+ * At most 16 levels (A3D_INVALID_PARAMETER beyond — a 17-level pyramid needs an image side of 2^17 pixels; a3d_multiscale_align
+ * over resident images has no such limit). */
 a3d_status a3d_multiscale_align_host(a3d_multiscale* ms, const a3d_range_image_view* source_pyramid,
                                      uint64_t n_source_levels, a3d_pose* out_pose);
 a3d_status a3d_multiscale_free(a3d_multiscale* ms);

@@ -1,0 +1,65 @@
+// Issue cost of the VALU instructions the bilateral blur is made of, on this chip: cycles per wave-instruction with one
+// wave per SIMD (dependent chains of 8 interleaved accumulators, so latency is hidden) — hipcc --offload-arch=gfx950 -O3.
+//   ./valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define REP 512
+#define OPS(name, decl, stmt)                                                                                  \
+  __global__ void k_##name(unsigned long long* out, unsigned seed) {                                           \
+    decl;                                                                                                      \
+    unsigned long long t0 = __builtin_readcyclecounter();                                                      \
+    _Pragma("unroll 1") for (int r = 0; r < REP; ++r) { stmt stmt stmt stmt stmt stmt stmt stmt }               \
+    unsigned long long t1 = __builtin_readcyclecounter();                                                      \
+    if (threadIdx.x == 0) out[blockIdx.x * 2] = t1 - t0;                                                       \
+    SINK                                                                                                       \
+  }
+#define SINK
+typedef unsigned long long u64;
+// eight independent accumulators per statement group keep the pipe full
+#undef SINK
+#define SINK out[1 + (threadIdx.x & 0)] += (u64)a0 + (u64)a1 + (u64)a2 + (u64)a3;
+OPS(add_u32, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7,
+    asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %2\n v_add_u32 %2, %2, %3\n v_add_u32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+OPS(lshl_add_u32, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7,
+    asm volatile("v_lshl_add_u32 %0, %0, 1, %1\n v_lshl_add_u32 %1, %1, 1, %2\n v_lshl_add_u32 %2, %2, 1, %3\n v_lshl_add_u32 %3, %3, 1, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+OPS(lshl_add_u64, u64 a0 = seed + threadIdx.x; u64 a1 = a0 * 3; u64 a2 = a0 * 5; u64 a3 = a0 * 7,
+    asm volatile("v_lshl_add_u64 %0, %0, 1, %1\n v_lshl_add_u64 %1, %1, 1, %2\n v_lshl_add_u64 %2, %2, 1, %3\n v_lshl_add_u64 %3, %3, 1, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+OPS(add_f64, double a0 = seed + threadIdx.x; double a1 = a0 * 3; double a2 = a0 * 5; double a3 = a0 * 7,
+    asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %1, %1, %2\n v_add_f64 %2, %2, %3\n v_add_f64 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+OPS(fma_f64, double a0 = seed + threadIdx.x; double a1 = a0 * 3; double a2 = a0 * 5; double a3 = a0 * 7,
+    asm volatile("v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %1, %1, %2, %3\n v_fma_f64 %2, %2, %3, %0\n v_fma_f64 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+OPS(mul_f64, double a0 = seed + threadIdx.x; double a1 = a0 * 3; double a2 = a0 * 5; double a3 = a0 * 7,
+    asm volatile("v_mul_f64 %0, %0, %1\n v_mul_f64 %1, %1, %2\n v_mul_f64 %2, %2, %3\n v_mul_f64 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+OPS(add_f32, float a0 = seed + threadIdx.x; float a1 = a0 * 3; float a2 = a0 * 5; float a3 = a0 * 7,
+    asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %1, %1, %2\n v_add_f32 %2, %2, %3\n v_add_f32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+OPS(rcp_f64, double a0 = seed + threadIdx.x + 1; double a1 = a0 * 3; double a2 = a0 * 5; double a3 = a0 * 7,
+    asm volatile("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+#undef SINK
+#define SINK out[1 + (threadIdx.x & 0)] += (u64)a0 + (u64)a1 + (u64)b0 + (u64)b1;
+OPS(cvt_f64_u32, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; double b0 = 0; double b1 = 0,
+    asm volatile("v_cvt_f64_u32 %2, %0\n v_cvt_f64_u32 %3, %1\n v_cvt_f64_u32 %2, %1\n v_cvt_f64_u32 %3, %0" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));)
+OPS(cvt_u32_f64, unsigned a0 = 0; unsigned a1 = 0; double b0 = seed + threadIdx.x; double b1 = b0 * 3,
+    asm volatile("v_cvt_u32_f64 %0, %2\n v_cvt_u32_f64 %1, %3\n v_cvt_u32_f64 %0, %3\n v_cvt_u32_f64 %1, %2" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));)
+OPS(cvt_f32_u32, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; float b0 = 0; float b1 = 0,
+    asm volatile("v_cvt_f32_u32 %2, %0\n v_cvt_f32_u32 %3, %1\n v_cvt_f32_u32 %2, %1\n v_cvt_f32_u32 %3, %0" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));)
+OPS(mov_dpp, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned b0 = 0; unsigned b1 = 0,
+    asm volatile("v_mov_b32_dpp %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %3, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));)
+OPS(add_dpp, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned b0 = 0; unsigned b1 = 0,
+    asm volatile("v_add_u32_dpp %2, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %3, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %0, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %1, %2, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));)
+#define RUN(name, per)                                                                                   \
+  for (int waves = 1; waves <= 4; waves *= 4) {                                                          \
+    hipLaunchKernelGGL(k_##name, dim3(1), dim3(256 * waves), 0, 0, d, 1u);                                \
+    hipDeviceSynchronize();                                                                              \
+    hipMemcpy(h.data(), d, 16, hipMemcpyDeviceToHost);                                                   \
+    printf("%-14s %d wave(s)/SIMD: %.2f cycles per instruction per wave (shader clock counter)\n", #name, waves, (double)h[0] / (REP * 8.0 * per) * 1.0); \
+  }
+int main() {
+  u64* d;
+  hipMalloc(&d, 1024);
+  hipMemset(d, 0, 1024);
+  std::vector<u64> h(2);
+  RUN(add_u32, 4) RUN(lshl_add_u32, 4) RUN(lshl_add_u64, 4) RUN(add_f32, 4) RUN(add_f64, 4) RUN(mul_f64, 4) RUN(fma_f64, 4) RUN(rcp_f64, 4)
+  RUN(cvt_f64_u32, 4) RUN(cvt_u32_f64, 4) RUN(cvt_f32_u32, 4) RUN(mov_dpp, 4) RUN(add_dpp, 4)
+  return 0;
+}
