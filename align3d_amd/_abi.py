@@ -130,6 +130,7 @@ SIGNATURES = {
     "a3d_context_destroy": (_ST, [_P]),
     "a3d_context_synchronize": (_ST, [_P]),
     "a3d_context_stream": (_P, [_P]),
+    "a3d_context_device": (C.c_int32, [_P]),
     "a3d_timer_start": (_ST, [_P]),
     "a3d_timer_stop": (_ST, [_P, C.POINTER(C.c_float)]),
     "a3d_malloc": (_ST, [_P, C.c_size_t, _PP]),
@@ -227,6 +228,7 @@ SIGNATURES = {
         _ST,
         [_P, _P, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _P, C.POINTER(C.c_uint64)],
     ),
+    "a3d_bilateral_filter_u16_device": (_ST, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _P]),
 }
 
 # Exported by the diagnostics build only (csrc/Makefile `diag`: -DA3D_DIAGNOSTICS).

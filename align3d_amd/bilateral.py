@@ -37,3 +37,12 @@ class BilateralFilter:
         )
         self.last_grid_dims = tuple(dims)
         return out
+
+    def filter_device(self, ctx, d_images, n_images, width, height, d_out):
+        """The same filter on `n_images` images that are already resident ([n][height][width] u16 at device pointer
+        `d_images`, result at `d_out`: ctx.malloc / ctx.to_device): a3d_bilateral_filter_u16_device."""
+        _abi.check(
+            ctx.lib.a3d_bilateral_filter_u16_device(ctx.handle, d_images, n_images, width, height, self.sigma_space,
+                                                    self.sigma_color, d_out),
+            "a3d_bilateral_filter_u16_device",
+        )

@@ -42,6 +42,10 @@ class Context:
         alone and in any batch."""
         _abi.check(self.lib.a3d_context_set_tiling(self.handle, int(tiles_per_pair)), "a3d_context_set_tiling")
 
+    def device(self):
+        """The HIP device the context sits on (a3d_context_device)."""
+        return int(self.lib.a3d_context_device(self.handle))
+
     def synchronize(self):
         _abi.check(self.lib.a3d_context_synchronize(self.handle))
 

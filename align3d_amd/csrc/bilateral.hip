@@ -868,10 +868,16 @@ __global__ void __launch_bounds__(256, sizeof(CELL) == 4 ? 4 : 2)  // (waves per
 }
 
 // BilateralGrid::slice (grid.rs:106-130): every pixel, zeros included; num::cast::<f64,u16>
+// (blockIdx.y = image of a batch — [images][h][w] in and out, grids `capacity` cells apart, scalar blocks SC_STRIDE words
+// apart, each image's overflow flag in its own scalar block: a3d_bilateral_filter_u16_device; one image otherwise)
 __global__ void __launch_bounds__(256)
     slice_kernel(const uint16_t* __restrict__ img, uint32_t w, uint32_t h, double inv_ss, double inv_sc,
                  uint32_t color_min, GridDims g, const double* __restrict__ grid, uint16_t* __restrict__ out,
-                 uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ dyn) {
+                 uint32_t* __restrict__ overflow_flag, const uint32_t* __restrict__ dyn, unsigned long long capacity) {
+  if (blockIdx.y) {
+    img += (size_t)blockIdx.y * w * h, out += (size_t)blockIdx.y * w * h, grid += blockIdx.y * capacity;
+    dyn += blockIdx.y * SC_STRIDE, overflow_flag += blockIdx.y * SC_STRIDE;
+  }
   if (!dyn_dims(dyn, &g, &color_min)) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w * h) return;
@@ -992,7 +998,7 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
         src = dst;
       }
       hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
-                         (const double*)src, d_out, d_scal + 2, (const uint32_t*)nullptr);
+                         (const double*)src, d_out, d_scal + 2, (const uint32_t*)nullptr, 0ull);
       if (hipGetLastError() != hipSuccess) fail("kernel launch");
     }
     if (st == A3D_OK && (hipMemcpyAsync(h_scal + 2, d_scal + 2, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1194,7 +1200,7 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
     if (st != A3D_OK) break;
     const GridDims none{0, 0, 0};
     hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, 1.0 / sigma_space, 1.0 / sigma_color,
-                       0u, none, (const double*)gb.blurred, d_out, gb.scal + SC_OVERFLOW, (const uint32_t*)gb.scal);
+                       0u, none, (const double*)gb.blurred, d_out, gb.scal + SC_OVERFLOW, (const uint32_t*)gb.scal, gb.capacity);
     uint32_t* r = ctx->pinned_words;
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(r, gb.scal, SC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1224,4 +1230,88 @@ extern "C" a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t*
     break;
   }
   return st;
+}
+
+// The same filter on images that are ALREADY in device memory (the shape of benches/bench_bilateral.rs
+// without PCIe in it): `n_images` images [n][height][width] u16 in HBM in, the same layout out.  Launch sequences of up to
+// 32 images (min / max + grid sizing, splat, blur, slice, zeros back: six launches whatever the count); per sequence 64
+// bytes of scalars per image come back to the host (did the grid fit its scratch region? — the sequence runs again with
+// more room if not — and the cast check).
+extern "C" a3d_status a3d_bilateral_filter_u16_device(a3d_context* ctx, const uint16_t* d_images, uint64_t n_images,
+                                                      uint64_t width, uint64_t height, double sigma_space,
+                                                      double sigma_color, uint16_t* d_out) {
+  A3D_REQUIRE(ctx && d_images && d_out, A3D_INVALID_PARAMETER, "null argument");
+  A3D_REQUIRE(n_images >= 1 && n_images <= (1u << 20), A3D_INVALID_PARAMETER, "bad image count");
+  A3D_REQUIRE(width > 0 && height > 0 && width * height < (1ull << PACK_SHIFT), A3D_INVALID_PARAMETER,
+              "a3d_bilateral_filter_u16_device handles images below 2^24 pixels");
+  A3D_REQUIRE(sigma_space > 0.0 && sigma_color > 0.0 && std::isfinite(sigma_space) && std::isfinite(sigma_color),
+              A3D_INVALID_PARAMETER, "sigmas must be positive and finite");
+  A3D_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint32_t w = (uint32_t)width, h = (uint32_t)height, n = w * h;
+  ctx->last_build_kernel_ms = 0.f;
+  for (uint64_t& v : ctx->build_stats) v = 0;  // (a3d_context_last_build_stats: images, grid cells, marked / zero-written tiles)
+  constexpr uint64_t MAX_SEQ = 32;
+  for (uint64_t f0 = 0; f0 < n_images;) {
+    if (ctx->grid_capacity == 0) ctx->grid_capacity = bilateral_grid_cells(w, h, sigma_space, sigma_color, 4096);
+    // (a sequence's grids — 12 B per cell of capacity, narrow cells — stay below 4 GB of scratch)
+    const uint64_t fit = std::max<uint64_t>(1, (4ull << 30) / (ctx->grid_capacity * 16 + 1));
+    const uint32_t F = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(MAX_SEQ, fit), n_images - f0);
+    bool done = false;
+    for (int attempt = 0; attempt < 3 && !done; ++attempt) {
+      GridBatch gb;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (ctx->build_profiling) {
+        while (ctx->build_events.size() < 2) {
+          hipEvent_t e;
+          A3D_HIP_TRY(hipEventCreate(&e));
+          ctx->build_events.push_back(e);
+        }
+        e0 = ctx->build_events[0], e1 = ctx->build_events[1];
+        (void)hipEventRecord(e0, s);
+      }
+      A3D_TRY(bilateral_grids_enqueue(ctx, d_images + f0 * n, F, w, h, sigma_space, sigma_color, ctx->grid_capacity, &gb));
+      const GridDims none{0, 0, 0};
+      hipLaunchKernelGGL(slice_kernel, dim3((n + 255) / 256, F), dim3(256), 0, s, d_images + f0 * n, w, h, 1.0 / sigma_space,
+                         1.0 / sigma_color, 0u, none, (const double*)gb.blurred, d_out + f0 * n, gb.scal + SC_OVERFLOW,
+                         (const uint32_t*)gb.scal, gb.capacity);
+      if (e1) (void)hipEventRecord(e1, s);
+      uint32_t* r = ctx->pinned_words;
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(r, gb.scal, (size_t)F * SC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) {
+        set_error("a3d_bilateral_filter_u16_device: %s", hipGetErrorString(hipGetLastError()));
+        return A3D_HIP_ERROR;
+      }
+      unsigned long long need = 0;
+      bool overflow = false;
+      for (uint32_t f = 0; f < F; ++f) {
+        const uint32_t* q = r + f * SC_STRIDE;
+        if (q[SC_TOO_BIG]) need = std::max<unsigned long long>(need, (unsigned long long)q[SC_GH] * q[SC_GW] * q[SC_GD]);
+        else overflow |= q[SC_OVERFLOW] != 0;
+      }
+      if (overflow) {  // (cannot happen for these sigmas: see a3d_bilateral_filter_u16)
+        set_error("bilateral slice produced a value outside u16 (the reference panics in num::cast().unwrap())");
+        return A3D_CAST_OVERFLOW;
+      }
+      if (need) {
+        A3D_REQUIRE(need < (1ull << 29), A3D_INVALID_PARAMETER,
+                    "an image's bilateral grid would exceed 2^29 cells (raise sigma_color or sigma_space)");
+        A3D_REQUIRE(attempt < 2, A3D_HIP_ERROR, "a3d_bilateral_filter_u16_device: the grid kept outgrowing its scratch region");
+        ctx->grid_capacity = need + need / 4;
+        continue;  // (the sequence again, with room; F is recomputed from the new capacity by the outer loop's next trip)
+      }
+      float ms = 0.f;
+      if (e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->last_build_kernel_ms += ms;
+      ctx->build_stats[0] += F;
+      for (uint32_t f = 0; f < F; ++f) {
+        const uint32_t* q = r + f * SC_STRIDE;
+        ctx->build_stats[1] += (uint64_t)q[SC_GH] * q[SC_GW] * q[SC_GD];
+        ctx->build_stats[2] += q[SC_NLIST], ctx->build_stats[3] += q[SC_NZERO];
+      }
+      done = true;
+    }
+    if (done) f0 += F;
+  }
+  return A3D_OK;
 }

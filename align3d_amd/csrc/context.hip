@@ -487,6 +487,7 @@ a3d_status a3d_context_synchronize(a3d_context* ctx) {
 }
 
 void* a3d_context_stream(a3d_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int32_t a3d_context_device(a3d_context* ctx) { return ctx ? (int32_t)ctx->device : -1; }
 
 a3d_status a3d_timer_start(a3d_context* ctx) {
   A3D_REQUIRE(ctx, A3D_INVALID_PARAMETER, "ctx is null");

@@ -232,6 +232,7 @@ def pcl_icp_bench(ctx, n=500_000):
         "icp_new_device_ms": float(np.median(d_new)), "align_device_wall_ms": float(np.median(d_align)),
         "new_plus_align_device_ms": float(np.median(d_both)), "new_plus_align_device_ms_stats": stats(d_both),
         "device_forms_give_the_same_pose_bits": same_bits,
+        "gpu_pose_t_q": [float(x) for x in list(T.t) + list(T.q)],
         "kd_build_kernel_ms": float(np.median(kd_ms)), "kd_build_kernel_ms_stats": stats(kd_ms),
         "kd_build_path": int(kd_path),  # 3: with the chip-wide placement of oversized median buckets (a3d_kdtree_build_path)
         "align_wall_ms_incl_pcie": float(np.median(walls)),  # Icp::align from host clouds: 12 MB upload + 15 iterations
@@ -302,6 +303,48 @@ def frame_prep_bench(ctx, host_pyramid_level0, depth_u16):
                           "is quoted for it; the filter's kernels are part of extra.frame_build.roofline",
         "bilateral_grid_cells": cells,
     }
+
+
+def bilateral_device_bench(ctx, W, H, n_images=32, reps=7):
+    """benches/bench_bilateral.rs's shape without PCIe (VERDICT r5 item 6): BilateralFilter::default() on `n_images` synthetic
+    depth images resident in HBM, u16 in -> u16 out (a3d_bilateral_filter_u16_device).  Device time of the call's launch
+    sequence by hipEvents; bytes as DESIGN §4 counts the filter: per image the depth read twice (min / max, splat) and once
+    more by the slice, the result written, 4 B per packed cell and 8 B per blurred cell over the marked tiles' 12^3 cells,
+    and the slice's eight 8-byte gathers per pixel counted once per distinct cell (= the blurred cells again)."""
+    frames, _ = synth.frame_stream(4242, n_images, W, H)
+    depth = np.ascontiguousarray(np.stack([d for d, _ in frames]), np.uint16)
+    f = BilateralFilter.default()
+    d_in = ctx.to_device(depth)
+    d_out = ctx.malloc(depth.nbytes)
+    try:
+        f.filter_device(ctx, d_in, n_images, W, H, d_out)  # first use: grid scratch sized
+        out = np.empty_like(depth)
+        ctx.to_host(d_out, out)
+        same = bool(np.array_equal(out[0], f.filter(ctx, depth[0])))  # (the host-pointer form: the tests' bit-exact path)
+        ctx.set_build_profiling(True)
+        ms, wall = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f.filter_device(ctx, d_in, n_images, W, H, d_out)
+            wall.append((time.perf_counter() - t0) * 1e3)
+            ms.append(ctx.last_build_kernel_ms())
+        ctx.set_build_profiling(False)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    # marked tiles of the last call's images (the blur's own statistics), as frame_build_roofline counts them
+    st = ctx.last_build_stats()
+    us = float(np.median(ms)) * 1e3 / n_images
+    px = W * H
+    tiles = st["marked_tiles"] / st["frames"] if st["frames"] else None
+    alg = 4 * 2 * px + ((4 + 8 + 8) * 1728 * tiles if tiles else 0)
+    return {"workload": f"BilateralFilter::default() on {n_images} resident {W}x{H} u16 depth images per call (bench_bilateral.rs shape, no PCIe)",
+            "kernel_us_per_image": us, "kernel_us_per_image_stats": stats([m * 1e3 / n_images for m in ms]),
+            "wall_us_per_image": float(np.median(wall)) * 1e3 / n_images, "images_per_s": 1e6 / us,
+            "equals_host_pointer_form_bit_for_bit": same, "marked_tiles_per_image": tiles,
+            "algorithmic_bytes_per_image": alg,
+            "roofline": roofline(alg, us * 1e-3, kernel="minmax + dims + splat + blur_fused + slice + unsplat (six launches)",
+                                 binding_resource="VALU issue of blur_fused and the latency of six dependent launches")}
 
 
 def frame_build_bench(ctx, n_frames, W, H):
@@ -889,7 +932,7 @@ def cpu_baseline_main(ctx, O, host_pyramids, pair_frames, params, n_pairs, gpu_p
     return out
 
 
-def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clouds, bench_icp_clouds=None):
+def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clouds, bench_icp_clouds=None, gpu_pcl_pose=None):
     """The reference's other benches (benches/bench_{kdtree,icp,compute_normals,bilateral,image_icp}.rs,
     README.md:130-134) on the oracle, threaded as the reference threads them, each bounded to a few seconds."""
     out = {}
@@ -932,6 +975,13 @@ def cpu_baselines_secondary(O, cores, level0_host, depth_u16, bench10_pair, clou
     out["pcl_icp_500k"] = {"value": 1e3 / (15 * it_ms), "unit": "aligns/s (15 iterations)", "cores": 1, "kind": "port",
                            "ms_per_iteration": it_ms, "icp_new_ms": icp_new_ms,
                            "sample": "2 of the 15 iterations timed, single thread like Icp::align; x 7.5 for an align"}
+    if gpu_pcl_pose is not None:
+        # configs[2] at its stated size against the oracle — the full 15-iteration Icp::align on the CPU
+        # (~0.5 s, untimed) and the GPU's pose beside it (north-star tolerance: 1e-4 rad / 1e-4 m)
+        prm15, full = O.params(max_iterations=15), O.pose()
+        assert O.load().orc_pcl_icp_align(C.byref(prm15), ptree.h, C.byref(tv), C.byref(sv), C.byref(full), None) == 0
+        ang, tr = O.transform_metrics(O.pose(gpu_pcl_pose[:3], gpu_pcl_pose[3:]), full)
+        out["pcl_icp_500k"]["gpu_vs_cpu_angle_rad"], out["pcl_icp_500k"]["gpu_vs_cpu_translation_m"] = abs(float(ang)), float(tr)
     del ptree
     # benches/bench_icp.rs on the oracle: sample1 0 <- 5 clouds, 10 iterations, single thread like the reference
     if bench_icp_clouds is not None:
@@ -1009,6 +1059,10 @@ _EXTRA_SCALARS = [
     ("pcl_icp_frac", "extra.pcl_icp.roofline.frac"),
     ("pcl_icp_new_device_ms", "extra.pcl_icp.icp_new_device_ms"),
     ("pcl_icp_new_plus_align_device_ms", "extra.pcl_icp.new_plus_align_device_ms"),
+    ("pcl_icp_gpu_vs_cpu_translation_m", "extra.cpu_baselines.pcl_icp_500k.gpu_vs_cpu_translation_m"),
+    ("pcl_icp_gpu_vs_cpu_angle_rad", "extra.cpu_baselines.pcl_icp_500k.gpu_vs_cpu_angle_rad"),
+    ("bilateral_device_us_per_image", "extra.bilateral_device.kernel_us_per_image"),
+    ("bilateral_device_frac", "extra.bilateral_device.roofline.frac"),
     ("odometry_frames_per_s", "extra.odometry.frames_per_s"),
     ("odometry_frames_per_s_two_in_flight", "extra.odometry.two_alignments_in_flight.frames_per_s"),
     ("odometry_frames_per_s_recorded_batched", "extra.odometry.recorded_sequence_batched.frames_per_s"),
@@ -1042,7 +1096,9 @@ _CPU_KEYS = ["value", "unit", "cores", "kind", "sample", "cpu_model", "compiler_
              "ranks_of_pairs_over_1e-4", "pinned_tiling_pairs_over_1e-4", "max_gpu_vs_cpu_angle_rad", "max_gpu_vs_cpu_translation_m",
              "median_gpu_vs_cpu_translation_m", "max_cpu_spread_translation_m", "pairs_whose_cpu_spread_exceeds_1e-4",
              "teacher_forced_count_mismatches", "teacher_forced_max_rel_err_sums", "teacher_forced_max_one_step_translation_m",
-             "pinned_tiling_pairs_over_1e-4_and_outside_the_cpu_envelope", "pinned_tiling_max_gpu_vs_cpu_translation_m"]
+             "pinned_tiling_pairs_over_1e-4_and_outside_the_cpu_envelope", "pinned_tiling_max_gpu_vs_cpu_translation_m",
+             "msdefault_pairs_compared", "msdefault_pairs_over_1e-4", "msdefault_max_gpu_vs_cpu_translation_m",
+             "msdefault_max_gpu_vs_cpu_angle_rad"]
 
 
 def _dig(d, path):
@@ -1084,6 +1140,9 @@ def compact_line(full, detail_file=None):
         v = _dig(full, path)
         if v is not None and not isinstance(v, (dict, list)):
             extra[short] = v
+    errs = _dig(full, "extra.errors")
+    if errs:  # which secondary legs failed (their messages are in the detail file)
+        extra["failed_legs"] = ",".join(sorted(errs))
     line["extra"] = extra
     line["detail_file"] = detail_file
     text = json.dumps(_short(line), separators=(",", ":"))
@@ -1127,6 +1186,9 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
         env.setdefault("OMP_NUM_THREADS", "4")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    # A rank that hangs (a dead GPU, a rendezvous that never completes) must not hang the bench: A3D_RANK_TIMEOUT_S
+    # (default 900 s) after the start every rank still running is stopped and named.
+    deadline = time.time() + float(os.environ.get("A3D_RANK_TIMEOUT_S", "900"))
     rc = 0
     pending = dict(enumerate(procs))
     while pending:
@@ -1137,9 +1199,19 @@ def launch_ranks(n, argv):
             del pending[r]
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
-                log(f"rank {r} exited with {code}: stopping the other ranks")
+                log(f"rank {r} (HIP device {r}, pid {p.pid}) exited with {code}: stopping ranks {sorted(pending)}")
                 for q in pending.values():  # exactly the processes started above
                     q.terminate()
+        if pending and time.time() > deadline:
+            log(f"ranks {sorted(pending)} (HIP devices {sorted(pending)}) still running after A3D_RANK_TIMEOUT_S: stopping them")
+            for q in pending.values():
+                q.terminate()
+            for q in pending.values():
+                try:
+                    q.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            return rc or 124
         time.sleep(0.05)
     return rc
 
@@ -1467,7 +1539,20 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    # one rank per GPU: the node must show at least as many devices as there are local ranks, and this rank's context must
+    # sit on ITS device before any work (a wrong LOCAL_RANK -> device mapping would silently stack ranks on one GPU)
+    if use_nccl and args.device is None:
+        from align3d_amd.multi import device_count
+
+        n_dev = device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if n_dev < local_world:
+            log(f"rank {rank}: {n_dev} HIP device(s) visible but {local_world} local ranks: refusing to stack ranks on a GPU")
+            sys.exit(3)
     ctx = Context(device)
+    if ctx.device() != device:
+        log(f"rank {rank}: the context sits on HIP device {ctx.device()}, expected {device}")
+        sys.exit(3)
     P, W, H = args.pairs_per_gpu, args.width, args.height
     params = MsIcpParams.repeat(3, IcpParams.default())  # ms3x15
     # ONE global list of world x P pairs, sharded in contiguous blocks.  Global pair j = frames

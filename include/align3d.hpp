@@ -213,6 +213,11 @@ class BilateralFilter {
     check(a3d_bilateral_filter_u16(ctx.raw(), image, width, height, sigma_space, sigma_color, out.data(), nullptr));
     return out;
   }
+  /// the same on `n_images` images already resident ([n][height][width] u16, device pointers)
+  void filter_device(const Context& ctx, const uint16_t* d_images, uint64_t n_images, uint64_t width, uint64_t height,
+                     uint16_t* d_out) const {
+    check(a3d_bilateral_filter_u16_device(ctx.raw(), d_images, n_images, width, height, sigma_space, sigma_color, d_out));
+  }
 };
 
 /// CameraIntrinsics (src/camera.rs:9-22)

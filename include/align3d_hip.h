@@ -175,6 +175,9 @@ a3d_status a3d_context_destroy(a3d_context* ctx);
 a3d_status a3d_context_synchronize(a3d_context* ctx);
 /* The context's hipStream_t, for callers that want to order their own work after ours. */
 void* a3d_context_stream(a3d_context* ctx);
+/* The HIP device the context was created on (-1 for a null context): what a rank of a multi-process job checks against
+ * its LOCAL_RANK before it does any work (bench.py). */
+int32_t a3d_context_device(a3d_context* ctx);
 
 /* hipEvent pair on the context stream: start, ..., stop -> elapsed milliseconds (stop synchronises). */
 a3d_status a3d_timer_start(a3d_context* ctx);
@@ -483,6 +486,13 @@ void a3d_bilateral_default_sigmas(double* out_sigma_space, double* out_sigma_col
 a3d_status a3d_bilateral_filter_u16(a3d_context* ctx, const uint16_t* image, uint64_t width,
                                     uint64_t height, double sigma_space, double sigma_color,
                                     uint16_t* out_image, uint64_t out_grid_dims[3]);
+/* The same filter (edge_aware_filter.rs:126-135) for images that are already in DEVICE memory: n_images images
+ * [n][height][width] u16 in, the same layout out (d_out may not alias d_images); the shape of benches/bench_bilateral.rs
+ * without PCIe in it.  Images below 2^24 pixels.  With a3d_context_set_build_profiling on, the device time of the call's
+ * launch sequences is left in a3d_context_last_build_kernel_ms. */
+a3d_status a3d_bilateral_filter_u16_device(a3d_context* ctx, const uint16_t* d_images, uint64_t n_images,
+                                           uint64_t width, uint64_t height, double sigma_space, double sigma_color,
+                                           uint16_t* d_out);
 
 #ifdef __cplusplus
 }

@@ -17,3 +17,18 @@ pub fn filter_hip(filter: &align3d::bilateral::BilateralFilter<u16>, image: &Arr
     );
     out
 }
+
+/// The same filter on `n_images` images that are already resident in device memory (`[n][height][width]` u16 at
+/// `d_images`, the result at `d_out`): `a3d_bilateral_filter_u16_device` — the shape of benches/bench_bilateral.rs without
+/// PCIe in it.
+///
+/// # Safety
+/// `d_images` and `d_out` must be device pointers of the current context with room for `n_images * width * height` u16 each.
+pub unsafe fn filter_hip_device(filter: &align3d::bilateral::BilateralFilter<u16>, d_images: *const u16, n_images: usize,
+                                width: usize, height: usize, d_out: *mut u16) {
+    device::check(
+        sys::a3d_bilateral_filter_u16_device(device::Context::current(), d_images, n_images as u64, width as u64, height as u64,
+                                             filter.sigma_space, filter.sigma_color, d_out),
+        "BilateralFilter::filter (device)",
+    );
+}

@@ -576,3 +576,41 @@ def test_level0_quad_kernel_equals_the_patch_kernel_and_the_oracle(ctx, diag_ctx
         for g, o in zip(got, other):
             for name in ("points", "mask", "normals", "colors", "intensities", "intensity_map"):
                 assert np.array_equal(getattr(g, name), getattr(o, name), equal_nan=True), (env, name)
+
+
+def test_bilateral_filter_on_resident_images_equals_the_oracle(ctx):
+    """a3d_bilateral_filter_u16_device: u16 images in device memory in, u16 out, a batch per call —
+    every image bit for bit the oracle's BilateralFilter::filter (and so the host-pointer form's): real depth frames, a
+    synthetic scene with depth edges and holes, an all-zero image, a batch larger than one launch sequence, a grid that
+    outgrows the scratch region on a fresh context."""
+    from align3d_amd import Context
+
+    s = SlamTbSample("sample1")
+    real = np.stack([s.load(i)[0] for i in (0, 5, 11)]).astype(np.uint16)
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:96, 0:128]
+    synth_imgs = []
+    for k in range(37):  # more than one launch sequence of 32
+        d = (700 + 9.0 * xx + 4.0 * yy + 600 * ((xx + 5 * k) % 128 > 70) + rng.integers(0, 30, size=xx.shape)).astype(np.uint16)
+        d[rng.random(d.shape) < 0.05] = 0
+        if k == 7:
+            d[:] = 0
+        if k == 9:
+            d = (d.astype(np.uint32) * 13 % 60000).astype(np.uint16)  # a deep grid: the scratch region grows
+        synth_imgs.append(d)
+    synth_imgs = np.stack(synth_imgs)
+    f = BilateralFilter.default()
+    own = Context(0)
+    try:
+        for imgs in (real, synth_imgs):
+            n, h, w = imgs.shape
+            d_in, d_out = own.to_device(np.ascontiguousarray(imgs)), own.malloc(imgs.nbytes)
+            f.filter_device(own, d_in, n, w, h, d_out)
+            got = np.empty_like(imgs)
+            own.to_host(d_out, got)
+            own.free(d_in), own.free(d_out)
+            for k in range(n):
+                st, ref, _ = O.bilateral(imgs[k], f.sigma_space, f.sigma_color)
+                assert st == 0 and np.array_equal(got[k], ref), k
+    finally:
+        own.close()

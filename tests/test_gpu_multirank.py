@@ -78,9 +78,9 @@ def test_two_fresh_ranks_align_their_own_blocks_and_gather(ctx, tmp_path, shared
 def test_launcher_fails_loudly_when_a_rank_fails(tmp_path):
     """On a machine without a GPU every rank fails at a3d_context_create: the launcher must return non-zero (and not
     hang waiting for the other ranks).  On a GPU box the ranks succeed, which the gpu test above covers."""
-    import torch
+    from align3d_amd.multi import device_count
 
-    if torch.cuda.is_available():
+    if device_count() > 0:  # (the library's own count: torch.cuda.is_available() can be False on a box that has a GPU)
         pytest.skip("needs a machine without a GPU")
     r = run_bench(["--gpus", "2", "--backend", "gloo", "--device", "0", "--pairs-per-gpu", "2", "--steps", "1", "--warmup", "0",
                    "--no-extras", "--cpu-pairs", "0"], timeout=600)
@@ -130,7 +130,7 @@ def test_four_fresh_ranks_keep_global_pair_order(ctx, tmp_path):
     P, N = 2, 4
     dump = str(tmp_path / "gathered.npy")
     r = run_bench(["--gpus", str(N), "--backend", "gloo", "--device", "0", "--pairs-per-gpu", str(P), "--steps", "2",
-                   "--warmup", "1", "--no-extras", "--cpu-pairs", "0", "--dump-gathered", dump])
+                   "--warmup", "1", "--no-extras", "--cpu-pairs", "2", "--cpu-orders", "3", "--dump-gathered", dump])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -141,7 +141,15 @@ def test_four_fresh_ranks_keep_global_pair_order(ctx, tmp_path):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in out, k
-    assert out["scaling"] == "weak" and out["unit"] == "frame-pairs/s" and out["cpu_baseline"] is None
+    assert out["scaling"] == "weak" and out["unit"] == "frame-pairs/s"
+    # the N > 1 line carries `roofline` AND `cpu_baseline` (a bounded sample on rank 0: chunk-order timing
+    # and the parity envelope of a few of its pairs), so that a scaling record made of it does not read as unmeasured
+    cpu, roof = out["cpu_baseline"], out["roofline"]
+    assert cpu is not None and cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["pairs_compared"] == P
+    assert cpu["pairs_over_1e-4_and_outside_the_cpu_envelope"] == 0
+    for k in ("bound", "achieved", "peak", "unit", "frac"):
+        assert k in roof, k
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] < 1 and "failed_legs" not in out["extra"]
     assert abs(out["value"] - N * P * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"])) <= 1e-3 * out["value"]
     assert out["n_gpus"] == N and out["config"]["ranks_in_collective"] == N and out["config"]["gathered_pairs"] == N * P
     assert out["config"]["gather_matches_local_poses"] is True and out["roofline"]["failed_pairs"] == 0
@@ -164,3 +172,20 @@ def test_four_fresh_ranks_keep_global_pair_order(ctx, tmp_path):
             lv.free()
         assert not status.any()
         assert np.array_equal(gathered[rank * P:(rank + 1) * P].view(np.uint32), mats.view(np.uint32)), rank
+
+
+@pytest.mark.gpu
+def test_two_rank_line_carries_the_copy_ceiling():
+    """The default N > 1 run (no --no-extras) also measures the chip's own copy ceiling on rank 0's device (a child
+    process, while the other ranks wait at the barrier): `hbm_copy_ceiling_GBs` and `frac_of_copy_ceiling` in the line."""
+    r = run_bench(["--gpus", "2", "--backend", "gloo", "--device", "0", "--pairs-per-gpu", "2", "--steps", "2", "--warmup", "1",
+                   "--cpu-pairs", "1", "--cpu-orders", "2"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks_in_collective"] == 2
+    if not os.path.exists(os.path.join(ROOT, "scripts", "copy_ceiling")):
+        pytest.skip("scripts/copy_ceiling is not built")
+    assert out["roofline"]["hbm_copy_ceiling_GBs"] > 1000 and 0 < out["roofline"]["frac_of_copy_ceiling"] < 1.5
+    assert out["cpu_baseline"] is not None
