@@ -260,6 +260,18 @@ __device__ __forceinline__ uint32_t blur3_across_lanes(uint32_t c) {
 __device__ __forceinline__ double blur3_across_lanes(double c) { return blur3(row_neighbour(c, true), c, row_neighbour(c, false)); }
 __device__ __forceinline__ float blur3_across_lanes(float c) { return blur3(row_neighbour(c, true), c, row_neighbour(c, false)); }
 constexpr int BT = 12, BR = BT + 4;  // blur tiles: 16^3 cells per tile, 12^3 of them final
+#if defined(A3D_DIAGNOSTICS) && defined(A3D_BLUR_STAMPS)
+// s_memtime stamps (shader clock) of wave 0 of block 0 of frame 0 in blur_fused_kernel's walk, tile by tile (8 stamps per
+// tile, the first 8 tiles): scripts/blur_stamps.py via a3d_debug_blur_stamps.
+__device__ unsigned long long g_blur_stamps[80];
+__device__ int g_blur_tile;
+#define A3D_BSTAMP(k)                                                                                                      \
+  do {                                                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_blur_tile < 8) g_blur_stamps[8 * g_blur_tile + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define A3D_BSTAMP(k) do { } while (0)
+#endif
 
 // value / weight of a blurred cell: both are integers times 4^6 — 0 <= value < 2^48, 1 <= weight < 2^32 — so neither the
 // operands nor the quotient come near the ends of the f64 range, and the compiler's correctly rounded division
@@ -622,6 +634,7 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     return;
   }
   static_assert(!TAKE_NEXT || sizeof(CELL) == 4, "the prefetching walk is the narrow cells' (registers)");
+  A3D_BSTAMP(0);  // tile entered (the next window's loads are out)
   auto at = [](int lr, int lc, int lz) { return (lr * BR + lc) * BZP + lz; };
   auto row_ok = [&](int gr) { return gr >= 1 && gr <= gh - 2; };
   auto col_ok = [&](int gc) { return gc >= 1 && gc <= gw - 2; };
@@ -676,10 +689,12 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
         }
       }
     }
+    A3D_BSTAMP(1);  // row and channel passes done
 #pragma unroll
     for (int i = 2; i < BR - 2; ++i) tile_x[at(i, hi, lo)] = vx[i], tile_w[at(i, hi, lo)] = vw[i];
   }
   __syncthreads();
+  A3D_BSTAMP(2);  // window in LDS, barrier passed
   // ---- axis 1: thread = (row, channel lo) owns the 16 columns; the central 12^3 cells go straight to the grid.  Round 6:
   // the 12 central rows on the block's first 192 threads (row = 2 + t / 16): three waves do what four did with half of the
   // first and of the last wave's lanes on stale rows; the fourth wave goes on to the tile loop's barrier. ----
@@ -695,9 +710,11 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     W vw[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) vx[i] = (double)tile_x[at(hi + SHIFT, i, lo)], vw[i] = (W)tile_w[at(hi + SHIFT, i, lo)];
+    A3D_BSTAMP(3);  // the thread's 16 columns read back and converted
     const bool line_ok = row_ok(gr2) && chan_ok(gz2);
     if (inside) blur_line_twice<false>(vx, vw, [](int) { return true; });
     else blur_line_twice<true>(vx, vw, [&](int i) { return line_ok && col_ok(c0 + i); });
+    A3D_BSTAMP(4);  // column passes done
     stores = lo >= 2 && lo < BR - 2 && gr2 < gh && gz2 < gd;
     // normalised (grid.rs:90-104): value / weight — the common factor 4^6 cancels exactly — or, where the weight is zero,
     // the value itself (x 4^-6: the six divisions by four)
@@ -710,6 +727,7 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
   // the "prefetch" was waited for before the first pass (the ISA had s_waitcnt vmcnt(0) at both places; the kernel kept the
   // VALU pipe under half busy).  Taking the next window BEFORE the stores waits for loads issued a whole tile ago and for
   // the PREVIOUS tile's stores, both long complete; this tile's stores then drain under the next tile's passes.
+  A3D_BSTAMP(5);  // twelve cells normalised
   if constexpr (TAKE_NEXT) {
     // (an empty asm that reads and writes every word of the next window: the loads must have landed HERE — a plain copy the
     // compiler sinks to the loop's latch, behind the stores — and no memory operation moves across)
@@ -720,6 +738,7 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
       u[i] = v;
     }
   }
+  A3D_BSTAMP(6);  // next window taken (its loads had landed)
   // (a wave stores 4 rows x 12 channels = four 192-byte runs per column)
   if (stores) {
     const int col_stride = gd * 8;
@@ -728,6 +747,7 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     for (int i = 2; i < BR - 2; ++i, at_col += col_stride)
       if (c0 + i < gw) *(double __attribute__((address_space(1)))*)((a3d_gptr)out + (uint32_t)at_col) = o[i - 2];
   }
+  A3D_BSTAMP(7);  // stores issued
 }
 
 // (Grids of more than BLUR_LIST_MAX tiles only: otherwise the blur's blocks compact the flags themselves.)
@@ -771,18 +791,32 @@ template <typename CELL>
 __global__ void __launch_bounds__(256, sizeof(CELL) == 4 ? 4 : 2)  // (waves per SIMD: 128 / 256 registers a thread)
     blur_fused_kernel(const CELL* __restrict__ packed, GridDims g, double* __restrict__ out,
                       uint32_t* __restrict__ dyn, unsigned long long capacity,
-                      const uint32_t* __restrict__ lists, uint32_t flags_stride, const uint32_t* __restrict__ tile_flags) {
+                      const uint32_t* __restrict__ lists, uint32_t flags_stride, const uint32_t* __restrict__ tile_flags,
+                      uint32_t per_frame) {
   __shared__ typename Pack<CELL>::EarlyValue tile_x[BCELLS];   // 16 KiB (narrow cells) / 32 KiB
   __shared__ typename Pack<CELL>::EarlyWeight tile_w[BCELLS];  // 16 KiB / 32 KiB
-  if (dyn) dyn += blockIdx.y * SC_STRIDE;  // blockIdx.y = frame of a batch
-  packed += blockIdx.y * capacity;
-  out += blockIdx.y * capacity;
+  // (frame, rank of this block among the frame's `blocks`).  per_frame != 0: a 1-D launch of frames x per_frame blocks with
+  // the frames placed XCD by XCD (round 6, below); otherwise blockIdx.y = frame, blockIdx.x = rank.
+#ifndef A3D_BLUR_XCD  // 1: a frame's blocks share an XCD (its L2), 0: frames spread over all eight (the round-3..5 placement)
+#define A3D_BLUR_XCD 1
+#endif
+#ifndef A3D_BLUR_CHUNKED  // 1: a block walks a contiguous piece of the frame's tile list, 0: every blocks-th entry
+#define A3D_BLUR_CHUNKED 0
+#endif
+  uint32_t frame = blockIdx.y, rank = blockIdx.x, blocks = gridDim.x;
+  if (per_frame) {
+    const uint32_t v = A3D_BLUR_XCD ? xcd_contiguous_index(blockIdx.x, gridDim.x) : blockIdx.x;
+    frame = v / per_frame, rank = v - frame * per_frame, blocks = per_frame;
+  }
+  if (dyn) dyn += frame * SC_STRIDE;
+  packed += frame * capacity;
+  out += frame * capacity;
   if (!dyn_dims(dyn, &g, nullptr)) return;
   const uint32_t tz = (g.gd + BT - 1) / BT, ty = (g.gw + BT - 1) / BT, tx = (g.gh + BT - 1) / BT;
   if (tile_flags) {
     __shared__ uint16_t s_list[BLUR_LIST_MAX];
     __shared__ uint32_t s_wave[2][4];
-    tile_flags += blockIdx.y * (flags_stride / 4);
+    tile_flags += frame * (flags_stride / 4);
     const uint32_t tiles = tx * ty * tz, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t n_work = 0, n_zero = 0;
     for (uint32_t base = 0; base < tiles; base += 1024u) {  // 256 threads x one flag word (four tiles) per round
@@ -816,28 +850,48 @@ __global__ void __launch_bounds__(256, sizeof(CELL) == 4 ? 4 : 2)  // (waves per
       n_zero += s_wave[1][0] + s_wave[1][1] + s_wave[1][2] + s_wave[1][3];
       __syncthreads();  // the wave totals are read before the next round replaces them; the lists before they are used
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) dyn[SC_NLIST] = n_work, dyn[SC_NZERO] = n_zero;  // (statistics for the host)
+    if (rank == 0 && threadIdx.x == 0) dyn[SC_NLIST] = n_work, dyn[SC_NZERO] = n_zero;  // (statistics for the host)
     auto entry = [&](uint32_t j) { return (uint32_t)(j < n_work ? s_list[j] : s_list[BLUR_LIST_MAX - 1u - (j - n_work)]); };
     constexpr bool PREFETCH = sizeof(CELL) == 4;  // (the wide cells' kernel has no registers to spare for a second window)
     if constexpr (PREFETCH) {
       // marked tiles first, the next tile's sixteen loads in flight under this tile; then the zero tiles (their own loop: a
       // loop of stores inside the walk would leave the compiler no count of what is outstanding)
+      // WHICH tiles, WHERE (round 6).  A window's lines are shared: consecutive list entries are channel neighbours (tile
+      // id = ((row tile, column tile), channel tile), channel fastest) whose 16-channel windows overlap by four channels
+      // and split 128-byte lines between them, the next column tile shares four of sixteen columns, the next row tile four
+      // rows.  With a frame's blocks on all eight XCDs no L2 ever saw a line twice: the kernel fetched 16.4 MB per frame for
+      // 4.8 MB of windows, and its loads and stores queued at issue (250 / 130 cycles each of a tile's 27 000,
+      // profiles/round6_blur_tile_stamps.txt).  Now the frame's blocks sit on ONE XCD (the 1-D launch above) and walk the
+      // list every blocks-th entry, i.e. at any moment they hold neighbouring tiles: what neighbours share is fetched into
+      // that L2 once (109 -> 100.5 us per 32 frames).  A block walking a CONTIGUOUS piece of the list instead — reuse in
+      // time rather than between concurrent blocks — was slower than either (112-114 us: A3D_BLUR_CHUNKED).
       CELL cur[BR] = {}, nxt[BR] = {};
-      uint32_t j = blockIdx.x;
-      if (j < n_work) load_window<CELL>(entry(j), packed, g, cur);
+      const uint32_t step = A3D_BLUR_CHUNKED ? 1u : blocks;
+      uint32_t j = A3D_BLUR_CHUNKED ? (uint32_t)(((unsigned long long)rank * n_work) / blocks) : rank;
+      const uint32_t j_end = A3D_BLUR_CHUNKED ? (uint32_t)(((unsigned long long)(rank + 1) * n_work) / blocks) : n_work;
+      if (j < j_end) load_window<CELL>(entry(j), packed, g, cur);
       // (the first window has landed before the walk starts: entered with these loads outstanding, the loop's first use of
       // `cur` gets a wait that every later trip pays too — right behind the next window's loads)
 #pragma unroll
       for (int i = 0; i < BR; ++i) asm volatile("" : "+v"(cur[i]) : : "memory");
-      for (; j < n_work; j += gridDim.x) {
-        if (j + gridDim.x < n_work) load_window<CELL>(entry(j + gridDim.x), packed, g, nxt);
+      for (; j < j_end; j += step) {
+        if (j + step < j_end) load_window<CELL>(entry(j + step), packed, g, nxt);
         blur_tile<CELL, true>(tile_x, tile_w, entry(j), cur, nxt, g, out, true, false);
         __syncthreads();  // the tile's last reads of the LDS window are done before the next tile overwrites it
+#if defined(A3D_DIAGNOSTICS) && defined(A3D_BLUR_STAMPS)
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+          if (g_blur_tile < 8) g_blur_stamps[64 + g_blur_tile] = __builtin_amdgcn_s_memtime();  // behind the tile's last barrier
+          ++g_blur_tile;
+        }
+#endif
       }
-      for (; j < n_work + n_zero; j += gridDim.x) blur_tile<CELL>(tile_x, tile_w, entry(j), cur, {}, g, out, true, true);
+      // the unmarked first-channel tiles (written as zeros), shared out the same way
+      uint32_t z = A3D_BLUR_CHUNKED ? (uint32_t)(((unsigned long long)rank * n_zero) / blocks) : rank;
+      const uint32_t z_end = A3D_BLUR_CHUNKED ? (uint32_t)(((unsigned long long)(rank + 1) * n_zero) / blocks) : n_zero;
+      for (; z < z_end; z += step) blur_tile<CELL>(tile_x, tile_w, entry(n_work + z), cur, {}, g, out, true, true);
     } else {
       CELL cur[BR] = {};
-      for (uint32_t j = blockIdx.x; j < n_work + n_zero; j += gridDim.x) {
+      for (uint32_t j = rank; j < n_work + n_zero; j += blocks) {
         const bool work = j < n_work;
         if (work) load_window<CELL>(entry(j), packed, g, cur);
         blur_tile<CELL>(tile_x, tile_w, entry(j), cur, {}, g, out, true, !work);
@@ -980,7 +1034,7 @@ a3d_status bilateral_filter_device(a3d_context* ctx, const uint16_t* d_img, uint
         hipLaunchKernelGGL(blur_fused_kernel<unsigned long long>,
                            dim3(((g.gd + BT - 1) / BT) * ((g.gw + BT - 1) / BT) * ((g.gh + BT - 1) / BT)), dim3(256), 0, s,
                            (const unsigned long long*)d_b, g, (double*)d_a, (uint32_t*)nullptr, 0ull,
-                           (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
+                           (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, 0u);
       } else {
         hipLaunchKernelGGL(splat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_img, w, h, inv_ss, inv_sc, cmin, g,
                            (double*)d_a);
@@ -1034,9 +1088,12 @@ static void enqueue_splat_blur(hipStream_t s, const uint16_t* d_depth, uint32_t 
                      none, (CELL*)out->packed, (const uint32_t*)out->scal, capacity, flags, flags_stride, channel_of, extent, columns);
   if (!lists_in_blur)
     hipLaunchKernelGGL(tile_list_kernel, list_grid, dim3(256), 0, s, (const uint8_t*)flags, flags_stride, out->scal, lists);
-  hipLaunchKernelGGL(blur_fused_kernel<CELL>, blur_grid, dim3(256), 0, s, (const CELL*)out->packed, none, out->blurred, out->scal,
-                     capacity, lists_in_blur ? (const uint32_t*)nullptr : (const uint32_t*)lists, flags_stride,
-                     lists_in_blur ? (const uint32_t*)flags : (const uint32_t*)nullptr);
+  if (lists_in_blur)  // 1-D: the kernel places the frames XCD by XCD (blur_grid.x blocks per frame)
+    hipLaunchKernelGGL(blur_fused_kernel<CELL>, dim3(blur_grid.x * blur_grid.y), dim3(256), 0, s, (const CELL*)out->packed, none,
+                       out->blurred, out->scal, capacity, (const uint32_t*)nullptr, flags_stride, (const uint32_t*)flags, blur_grid.x);
+  else
+    hipLaunchKernelGGL(blur_fused_kernel<CELL>, blur_grid, dim3(256), 0, s, (const CELL*)out->packed, none, out->blurred, out->scal,
+                       capacity, (const uint32_t*)lists, flags_stride, (const uint32_t*)nullptr, 0u);
   if (!defer_unsplat)
     hipLaunchKernelGGL(unsplat_kernel<CELL>, splat_grid, dim3(256), 0, s, (CELL*)out->packed, (const uint32_t*)out->scal, capacity,
                        (const uint2*)extent, columns, (uint32_t*)flags, flags_stride);
@@ -1315,3 +1372,14 @@ extern "C" a3d_status a3d_bilateral_filter_u16_device(a3d_context* ctx, const ui
   }
   return A3D_OK;
 }
+
+#if defined(A3D_DIAGNOSTICS) && defined(A3D_BLUR_STAMPS)
+// scripts/blur_stamps.py: the stamps of the most recent blur launch's block 0 (and the tile counter back to zero)
+extern "C" int a3d_debug_blur_stamps(unsigned long long out[80]) {
+  const int zero = 0;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blur_stamps), 80 * sizeof(unsigned long long)) == hipSuccess &&
+                 hipMemcpyToSymbol(HIP_SYMBOL(g_blur_tile), &zero, sizeof(int)) == hipSuccess
+             ? 0
+             : 1;
+}
+#endif

@@ -263,6 +263,16 @@ struct UseFence {
     if (ev) hipEventDestroy(ev);
   }
 };
+#ifdef __HIPCC__
+// Workgroups of a 1-D grid go to the eight XCDs round-robin (workgroup b on XCD b % 8, scripts/xcd_probe.hip) and each XCD
+// has its own L2.  Virtual index of workgroup `b` of `n` such that every XCD owns one CONTIGUOUS range of virtual indices:
+// work items that share cache lines (the tiles of one frame) are given neighbouring virtual indices and meet in one L2.
+__device__ __forceinline__ uint32_t xcd_contiguous_index(uint32_t b, uint32_t n) {
+  const uint32_t g = b & 7u, k = b >> 3, q = n >> 3, r = n & 7u;
+  return (g < r ? g * (q + 1u) : r * (q + 1u) + (g - r) * q) + k;
+}
+#endif
+
 // Device copy of a small host table, uploaded on first use and kept until the context dies.
 a3d_status ctx_cached_table(a3d_context* ctx, const uint32_t key[4], const void* host, size_t bytes, void** out);
 

@@ -299,14 +299,24 @@ __global__ void __launch_bounds__(256)
                        const double* __restrict__ grids, unsigned long long capacity, uint32_t* __restrict__ scal, float fx,
                        float fy, float cx, float cy, float scale, FrameBases bases, size_t off_points, size_t off_mask,
                        size_t off_normals, bool with_normals, LevelLayout L1, bool emit_l1, LevelLayout L2, bool emit_l2,
-                       bool l2_is_last, Unsplat unsplat) {
+                       bool l2_is_last, Unsplat unsplat, uint32_t patches_x, uint32_t patches_y) {
   __shared__ float sp[3][QS + 2][QS + 3];  // the patch's points at (y + 1, x + 1), halo included
   __shared__ float s1[2][3][QT][QT + 1];   // level-1 picks (0: points, 1: normals) for the level-2 picks
   __shared__ uint8_t s1m[QT][QT];          // level-1 masks
   __shared__ __attribute__((aligned(4))) uint8_t sm[QS][QS];  // the owned pixels' masks (1: depth > 0), for the row-ordered stores
-  const uint32_t f = blockIdx.z;
+#ifndef A3D_LQ_XCD  // 1: the patches placed XCD by XCD (a frame's neighbouring patches share an L2) — measured 144 against
+#define A3D_LQ_XCD 0  // 139-140 us per 32 frames in the plain order (patches share few grid lines; the stores spread worse)
+#endif
+  uint32_t f = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+  if (patches_x) {  // 1-D launch of frames x patches_y x patches_x blocks
+    const uint32_t v = A3D_LQ_XCD ? xcd_contiguous_index(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t per_frame = patches_x * patches_y;
+    f = v / per_frame;
+    const uint32_t in_frame = v - f * per_frame;
+    by = in_frame / patches_x, bx = in_frame - by * patches_x;
+  }
   const int t = (int)threadIdx.x, tx = t & (QT - 1), ty = t >> 4;
-  const int r0 = (int)blockIdx.y * QS, c0 = (int)blockIdx.x * QS;
+  const int r0 = (int)by * QS, c0 = (int)bx * QS;
   const uint16_t __attribute__((address_space(1)))* dimg =
       (const uint16_t __attribute__((address_space(1)))*)(depth + (size_t)f * w * h);
   // (unconditional loads at clamped coordinates: a conditional load is a branch with its own wait, and the kernel lives on
@@ -348,10 +358,7 @@ __global__ void __launch_bounds__(256)
     uint32_t cmin;
     grid_ok = dyn_dims(sc, &g, &cmin);
     if (grid_ok) {  // (false: this frame's grid did not fit; the host grows the region and repeats)
-      // BilateralGrid::slice (grid.rs:106-162) of every pixel in the image, zeros included.  The 32 gathers of the quad (and
-      // the halo pixel's eight) are ALL issued before the first is combined: the blurred grids of a launch sequence (150 MB)
-      // do not fit the L2, a gather is a trip to the Infinity Cache, and five pixels one after the other were five such
-      // trips per thread (189 us per 32 frames; the two-pixel kernel it replaced: 154 + 18 for level 2).
+      // BilateralGrid::slice (grid.rs:106-162) of every pixel in the image, zeros included.
       const double* grid = grids + f * capacity;
       SliceAxis ry[2], cxs[2];  // the row / column parts (grid.rs:132-146) serve two pixels each
 #pragma unroll
@@ -359,75 +366,56 @@ __global__ void __launch_bounds__(256)
         ry[a] = slice_axis_spatial((uint32_t)min(row[a], (int)h - 1), inv_ss, g.gh);
         cxs[a] = slice_axis_spatial((uint32_t)min(col[a], (int)w - 1), inv_ss, g.gw);
       }
-      bool overflow = false;
-#ifndef A3D_LQ_MLP  // pixels whose gathers are in flight together: 4 = the whole quad (+ the halo pixel), 2 = a quad row, 1
-#define A3D_LQ_MLP 2
-#endif
       SliceAxis hry{}, hcx{};
       if (halo_thread) {
         hry = slice_axis_spatial((uint32_t)min(max(hrow, 0), (int)h - 1), inv_ss, g.gh);
         hcx = slice_axis_spatial((uint32_t)min(max(hcol, 0), (int)w - 1), inv_ss, g.gw);
       }
+      auto colour_axis = [&](uint32_t dv) { return slice_axis((double)(dv - cmin) * inv_sc + 2.0, g.gd); };
+      SliceAxis cz[2][2], czh{};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) cz[a][b] = colour_axis(d[a][b]);
+      if (halo_thread) czh = colour_axis(dh);
+      // (Round 6, measured and removed: the grid cells under the patch staged in LDS — the block's valid pixels' channel range
+      // found by a block-wide min / max, the <= 10 x 10 (row, column)s x <= 16 channels loaded along the channels, the
+      // eight gathers of a pixel then ds_read_b64 — on the idea that a CU's L1 turns line requests around too slowly for
+      // eight scattered gathers per pixel.  Bit-identical, 178 against 137 us per 32 frames: the two extra barriers and the
+      // third dependent trip to memory (depth -> range -> cells) cost far more than the gathers' queueing.)
+      auto gather = [&](const SliceAxis& ry_, const SliceAxis& cx_, const SliceAxis& cz_, SliceTaps* tp) {
+        tp->za = cz_.frac;
+        const uint32_t g0 = __umul24(ry_.lo, g.gw), g1 = __umul24(ry_.hi, g.gw);
+        const uint32_t b00 = __umul24(g0 + cx_.lo, g.gd), b01 = __umul24(g0 + cx_.hi, g.gd), b10 = __umul24(g1 + cx_.lo, g.gd),
+                       b11 = __umul24(g1 + cx_.hi, g.gd);
+        tp->v[0] = cell_value32(grid, b00, cz_.lo), tp->v[1] = cell_value32(grid, b01, cz_.lo);
+        tp->v[2] = cell_value32(grid, b10, cz_.lo), tp->v[3] = cell_value32(grid, b11, cz_.lo);
+        tp->v[4] = cell_value32(grid, b00, cz_.hi), tp->v[5] = cell_value32(grid, b01, cz_.hi);
+        tp->v[6] = cell_value32(grid, b10, cz_.hi), tp->v[7] = cell_value32(grid, b11, cz_.hi);
+      };
+      bool overflow = false;
       auto finish = [&](const SliceTaps& tp, double ya, double xa, bool in) -> uint32_t {
         uint16_t v;
         const bool fits = slice_combine(tp, ya, xa, &v);
         overflow |= in && !fits;
         return in ? (uint32_t)v : 0u;
       };
-      if (A3D_LQ_MLP >= 4) {
-        SliceTaps taps[2][2], htaps;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) slice_gather(d[a][b], ry[a], cxs[b], inv_sc, cmin, g, grid, &taps[a][b]);
-        if (halo_thread) slice_gather(dh, hry, hcx, inv_sc, cmin, g, grid, &htaps);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) d[a][b] = finish(taps[a][b], ry[a].frac, cxs[b].frac, rin[a] && cin[b]);
-        if (halo_thread) dh = finish(htaps, hry.frac, hcx.frac, hin);
-      } else if (A3D_LQ_MLP == 3) {  // two at a time, the halo pixel on its own
-        SliceTaps taps[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          slice_gather(d[a][0], ry[a], cxs[0], inv_sc, cmin, g, grid, &taps[0]);
-          slice_gather(d[a][1], ry[a], cxs[1], inv_sc, cmin, g, grid, &taps[1]);
-          d[a][0] = finish(taps[0], ry[a].frac, cxs[0].frac, rin[a] && cin[0]);
-          d[a][1] = finish(taps[1], ry[a].frac, cxs[1].frac, rin[a] && cin[1]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (halo_thread) {
-          slice_gather(dh, hry, hcx, inv_sc, cmin, g, grid, &taps[0]);
-          dh = finish(taps[0], hry.frac, hcx.frac, hin);
-        }
-      } else if (A3D_LQ_MLP == 2) {
+      // The gathers of a quad row's two pixels (and the halo pixel's, with the first row) are in flight together: the blurred
+      // grids of a launch sequence (150 MB) do not fit the L2, a gather is a trip to the Infinity Cache.  Measured per 32
+      // frames: one pixel at a time 150 us, two 127-138, two + the halo pixel on its own 145, all five 151 (131 registers).
+      {
         SliceTaps taps[2], htaps;
-        slice_gather(d[0][0], ry[0], cxs[0], inv_sc, cmin, g, grid, &taps[0]);
-        slice_gather(d[0][1], ry[0], cxs[1], inv_sc, cmin, g, grid, &taps[1]);
-        if (halo_thread) slice_gather(dh, hry, hcx, inv_sc, cmin, g, grid, &htaps);
+        gather(ry[0], cxs[0], cz[0][0], &taps[0]);
+        gather(ry[0], cxs[1], cz[0][1], &taps[1]);
+        if (halo_thread) gather(hry, hcx, czh, &htaps);
         d[0][0] = finish(taps[0], ry[0].frac, cxs[0].frac, rin[0] && cin[0]);
         d[0][1] = finish(taps[1], ry[0].frac, cxs[1].frac, rin[0] && cin[1]);
         __builtin_amdgcn_sched_barrier(0);
-        slice_gather(d[1][0], ry[1], cxs[0], inv_sc, cmin, g, grid, &taps[0]);
-        slice_gather(d[1][1], ry[1], cxs[1], inv_sc, cmin, g, grid, &taps[1]);
+        gather(ry[1], cxs[0], cz[1][0], &taps[0]);
+        gather(ry[1], cxs[1], cz[1][1], &taps[1]);
         if (halo_thread) dh = finish(htaps, hry.frac, hcx.frac, hin);
         d[1][0] = finish(taps[0], ry[1].frac, cxs[0].frac, rin[1] && cin[0]);
         d[1][1] = finish(taps[1], ry[1].frac, cxs[1].frac, rin[1] && cin[1]);
-      } else {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            SliceTaps tp;
-            slice_gather(d[a][b], ry[a], cxs[b], inv_sc, cmin, g, grid, &tp);
-            d[a][b] = finish(tp, ry[a].frac, cxs[b].frac, rin[a] && cin[b]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        if (halo_thread) {
-          SliceTaps tp;
-          slice_gather(dh, hry, hcx, inv_sc, cmin, g, grid, &tp);
-          dh = finish(tp, hry.frac, hcx.frac, hin);
-        }
       }
       if (overflow) atomicOr(&sc[SC_OVERFLOW], 1u);  // the reference's .unwrap() would panic
     }
@@ -454,8 +442,8 @@ __global__ void __launch_bounds__(256)
   // trip: loads and stores share one in-order counter).  Measured: 140 against 123 us per 32 frames — more than the
   // 10 us launch it saves; not the product's path.
   if (FILTER && grid_ok && unsplat.packed)
-    unsplat_columns(unsplat, f, g, inv_ss, r0, min(r0 + QS, (int)h), c0, min(c0 + QS, (int)w),
-                    blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    unsplat_columns(unsplat, f, g, inv_ss, r0, min(r0 + QS, (int)h), c0, min(c0 + QS, (int)w), by * patches_x + bx,
+                    patches_x * patches_y);
 #endif
   char* base = bases.arena[f];
   auto at = [&](int y, int x) { return V3{sp[0][y][x], sp[1][y][x], sp[2][y][x]}; };
@@ -999,10 +987,10 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
     const bool defer = quad && A3D_DIAG_ENV("A3D_BUILDER_UNSPLAT") && !strcmp(A3D_DIAG_ENV("A3D_BUILDER_UNSPLAT"), "fused");
     A3D_TRY(bilateral_grids_enqueue(ctx, d_depth, F, w, h, prm->sigma_space, prm->sigma_color, ctx->grid_capacity, &gb, defer));
     if (quad) {
-      hipLaunchKernelGGL(level0_quad_kernel<true>, gridq, dim3(256), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
+      hipLaunchKernelGGL(level0_quad_kernel<true>, dim3(gridq.x * gridq.y * gridq.z), dim3(256), 0, s, d_depth, w, h, 1.0 / prm->sigma_space,
                          1.0 / prm->sigma_color, (const double*)gb.blurred, gb.capacity, gb.scal, fx, fy, cx, cy, depth_scale,
                          bases, L0.points, L0.mask, L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last,
-                         gb.unsplat);
+                         gb.unsplat, gridq.x, gridq.y);
       if (defer) {
         A3D_HIP_TRY(hipGetLastError());
         ctx->grid_clean = gb.clean;  // (the zeros are back once this kernel has run)
@@ -1018,9 +1006,9 @@ a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32
     A3D_HIP_TRY(hipMemcpyAsync(result, gb.scal, (size_t)F * SC_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   } else {
     if (quad)
-      hipLaunchKernelGGL(level0_quad_kernel<false>, gridq, dim3(256), 0, s, d_depth, w, h, 0.0, 0.0, (const double*)nullptr, 0ull,
-                         (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points, L0.mask, L0.normals,
-                         prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last, Unsplat{});
+      hipLaunchKernelGGL(level0_quad_kernel<false>, dim3(gridq.x * gridq.y * gridq.z), dim3(256), 0, s, d_depth, w, h, 0.0, 0.0,
+                         (const double*)nullptr, 0ull, (uint32_t*)nullptr, fx, fy, cx, cy, depth_scale, bases, L0.points, L0.mask,
+                         L0.normals, prm->with_normals != 0, P.lv[1], fuse_l1, L2, fuse_l2, l2_is_last, Unsplat{}, gridq.x, gridq.y);
 #ifdef A3D_DIAGNOSTICS
     else
       hipLaunchKernelGGL(level0_kernel<false>, dim3((w + OWN_W - 1) / OWN_W, (h + OWN_H - 1) / OWN_H, F), dim3(L0_THREADS), 0, s,

@@ -33,10 +33,7 @@ typedef nf32x3 __attribute__((aligned(4))) nf32x3_u;
 // launch against 256 MB of points and masks (`profiles/round4_normals_traffic.json`), at 6.4 TB/s of fabric traffic.
 // Here group g takes the g-th CONTIGUOUS eighth of the tiles (whole frames at 64 frames per launch), so a tile's
 // neighbours hit in the L2 that already holds their lines.  The remap is bijective for any tile count (CDNA guide, T1).
-__device__ __forceinline__ uint32_t xcd_contiguous_tile(uint32_t b, uint32_t n) {
-  const uint32_t g = b & 7u, k = b >> 3, q = n >> 3, r = n & 7u;
-  return (g < r ? g * (q + 1u) : r * (q + 1u) + (g - r) * q) + k;
-}
+__device__ __forceinline__ uint32_t xcd_contiguous_tile(uint32_t b, uint32_t n) { return xcd_contiguous_index(b, n); }
 template <int NT_W, int NT_H, int NT_PPT>
 __global__ void __launch_bounds__(256)
     compute_normals_kernel(NormalsBatch batch, int w, int h, uint32_t tiles_x, uint32_t tiles_y) {
