@@ -144,7 +144,8 @@ __device__ unsigned long long g_tail_stamps[64];  // [0, 16): last-block tail; [
 // the head-solve path: the block of the job's LAST tile (scripts/head_stamps.py), slots 48 ..
 #define A3D_HSTAMP(k)                                                                                                  \
   do {                                                                                                                 \
-    if (threadIdx.x == 0 && job == 0 && blockIdx.x + 1 == gridDim.x) g_tail_stamps[48 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0 && job == 0 && blockIdx.x + 1 == gridDim.x)                                                   \
+      g_tail_stamps[48 + (k)] = __builtin_amdgcn_s_memrealtime(), g_tail_stamps[56 + (k)] = __builtin_amdgcn_s_memtime(); /* (100 MHz; shader clock) */ \
   } while (0)
 #else
 #define A3D_STAMP(k) \
@@ -267,7 +268,7 @@ __device__ __forceinline__ Pose tail_exp_se3(const float update[6]) {
 template <bool COHERENT = false>
 __device__ __forceinline__ void gn_advance_wave(uint32_t state_bits, const double* sums, const HeadArgs& a, int job,
                                                 uint32_t* s_state, JobState* st_out, bool write_trace) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 63;  // lane: the solving wave need not be the block's first (head_sum_and_advance)
   auto wordf = [&](int lane) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)state_bits, lane)); };
   const int status_in = __builtin_amdgcn_readlane((int)state_bits, 15);
   uint32_t mine = state_bits;  // a frozen job, or nothing to apply: the state goes on unchanged
@@ -588,7 +589,7 @@ __device__ __forceinline__ unsigned long long ld_partial_pair(const unsigned lon
 template <bool COHERENT>
 __device__ __forceinline__ void head_sum_and_advance(uint32_t state_bits, const float* prev_partials, const HeadArgs& h,
                                                      int job, uint32_t* s_state, bool write_trace,
-                                                     JobState* st_out = nullptr) {
+                                                     JobState* st_out = nullptr, int solver_wave = 0) {
   __shared__ double s_sums[8][64];
   const int tid = threadIdx.x;
   A3D_HSTAMP(0);  // head entered
@@ -649,16 +650,25 @@ __device__ __forceinline__ void head_sum_and_advance(uint32_t state_bits, const 
     __syncthreads();
   }
   A3D_HSTAMP(2);  // the 58 totals in LDS
-  if (tid < 64) gn_advance_wave<false>(state_bits, s_sums[0], h, job, s_state, st_out, write_trace);
+  if ((tid >> 6) == solver_wave) gn_advance_wave<false>(state_bits, s_sums[0], h, job, s_state, st_out, write_trace);
   __syncthreads();
   A3D_HSTAMP(6);  // state in LDS for every thread
 }
 
+// WHICH wave solves (round 6).  The solve is ~1 250 wave-uniform instructions on ONE wave (every lane alike) while the
+// block's other three waves wait: it runs at one wave's issue rate.  A CU holds up to four blocks of the batch kernel, and
+// the runtime places wave w of every block on SIMD w: with the solve always on wave 0, four resident blocks' solves queued
+// on one SIMD while three SIMDs idled.  The solving wave now rotates with the block's position in the grid.
+#ifndef A3D_HEAD_ROTATE
+#define A3D_HEAD_ROTATE 1
+#endif
 __device__ __forceinline__ void head_advance(const JobState* st_in, JobState* st_out, const float* prev_partials,
                                              const HeadArgs& h, int job, uint32_t* s_state, bool write_trace) {
+  const int solver_wave = A3D_HEAD_ROTATE ? (int)((blockIdx.x + blockIdx.y) & 3u) : 0;
   uint32_t state_bits = 0;
-  if (threadIdx.x < JOB_WORDS) state_bits = ((const uint32_t*)st_in)[threadIdx.x];
-  head_sum_and_advance<false>(state_bits, prev_partials, h, job, s_state, write_trace, st_out);
+  const int lane = (int)threadIdx.x - 64 * solver_wave;
+  if (lane >= 0 && lane < (int)JOB_WORDS) state_bits = ((const uint32_t*)st_in)[lane];
+  head_sum_and_advance<false>(state_bits, prev_partials, h, job, s_state, write_trace, st_out, solver_wave);
 }
 
 // acc[0..21) += J J^T (upper triangle), acc[21..27) += J r, acc[27] += r^2, acc[28] += 1

@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256, 1)
 #ifdef A3D_DIAGNOSTICS
 // ---- many iterations in one launch: the persistent head-solve kernel (round 4; measured SLOWER than kernel
 // boundaries on MI355X — DESIGN.md, ruled out — and therefore only in the diagnostics build: A3D_ICP_PERSIST=mask) ----
-// What a kernel boundary costs between two dependent iterations (launch + completion, ~4.5 us on MI355X) is more than
+// What separates two dependent iterations (a 1.5 us kernel boundary + the ~4 us head that finishes the previous one) is more than
 // the pixel pass of a coarse level or of a lone pair.  Here the blocks of a pair stay resident and run a whole schedule
 // of (level, iterations) entries.  The hand-off between two iterations is ONE hop: a block stores its partials
 // write-through, drains, and adds their number to the pair's counter; every block of the pair waits until the counter
@@ -2117,7 +2117,7 @@ a3d_status a3d_selftest_transform(a3d_context* ctx, const float* updates6, const
 extern "C" int a3d_debug_tail_stamps(unsigned long long out[16]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
-extern "C" int a3d_debug_head_stamps(unsigned long long out[48]) {  // [0, 16): two launches' kernel stamps, [32, 48): inside the head
+extern "C" int a3d_debug_head_stamps(unsigned long long out[48]) {  // [0, 16): two launches' kernel stamps, [32, 40): inside the head, [40, 48): the same in shader-clock cycles
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(a3d::g_tail_stamps), 48 * sizeof(unsigned long long), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -29,8 +29,11 @@
 //   ranges of <= 2048 points: sel_narrow_kernel, ONE launch, one block per range: a bitonic network on 128-bit words
 //     (L_d itself, + the point's position as payload) puts the range into L_d order; each further level is the network
 //     on 64-bit words `key bits << 32 | position in the range` (the position carries L_{d-1}); split values, leaf slots
-//     (+inf padding included) and slot_of_point are written from there.  A thread holds four consecutive words in
-//     registers: partner distances 1, 2 stay in the thread, 4 .. 128 are lane exchanges, only 256+ go through LDS.
+//     (+inf padding included) and slot_of_point are written from there.  The product runs the network with its words in
+//     LDS (sel_narrow_kernel<2048, false>: two stages per LDS round trip, block barriers only around the five stage pairs
+//     of a 2048-word sort that exchange words between waves); the form with four consecutive words per thread in registers
+//     and lane exchanges for partner distances 4 .. 128 (<2048, true>, A3D_KDTREE_SORTNET=regs) was measured slower
+//     (141 against 84 us) and is a cross-check of the diagnostics build.
 //
 //     sel_place_kernel    (a THIRD launch on the levels whose ranges can hold more than 4096 points in one bucket, only
 //                         once a cloud of the context had such a bucket: a wall facing the camera is tens of thousands

@@ -150,7 +150,10 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         # coordinates read, a 4-byte index read and written: what a level-by-level build moves at least) x `depth` levels
         "build": {"device_ms": float(np.median(dev_wall)), "device_ms_stats": stats(dev_wall),
                   "kernel_ms": float(np.median(dev_kernels)), "kernel_ms_stats": stats(dev_kernels),
-                  "launches": 5 + 2 * max(0, int(np.ceil(np.log2(max(1, n / 2048))))),  # memset, pack, hist0, plan0, 2 per wide level, narrow
+                  # memset, pack, hist0, plan0, split + resolve per wide level, narrow — and, on build path 3 (a context that has
+                  # seen an oversized median bucket), one sel_place launch more on each of the first place_levels = 7 wide levels
+                  "launches": (lambda wide: 5 + 2 * wide + (min(wide, 7) if int(path_seen) == 3 else 0))(
+                      max(0, int(np.ceil(np.log2(max(1, n / 2048)))))),
                   "build_path": int(path_seen),
                   "roofline": roofline(20 * n * depth, float(np.median(dev_kernels)), kernel="the selection build's launches (kdtree_select.hip), first to last",
                                        levels=int(depth))},

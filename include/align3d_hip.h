@@ -301,6 +301,15 @@ a3d_status a3d_image_icp_accumulate_weighted(a3d_context* ctx, const a3d_icp_par
                                              const a3d_pose* pose, a3d_gn_state* out_state);
 #endif /* A3D_DIAGNOSTICS */
 
+/* ---- instrumentation that SHIPS in the product library -------------------------------------------------------
+ * The four entry points below (a3d_image_icp_align_trace, a3d_selftest_transform, a3d_selftest_division and, further
+ * down, a3d_multiscale_batch_persistent_levels) and the timing getters (…_last_kernel_ms, …_last_level_ms, …_last_timing,
+ * a3d_context_last_build_*) have no reference counterpart.  They are part of the product library on purpose: they run or
+ * time the PRODUCT's own device functions (the iteration tail's pose arithmetic, the shared-reciprocal division, the
+ * launches of an alignment), so the parity tests and bench.py check and time the code that ships — no second kernel sits
+ * behind any of them.  What only exists to cross-check the product (exact-arithmetic accumulate, merged accumulators,
+ * every A3D_* environment knob and the kernel variants behind them) is compiled into the diagnostics build alone
+ * (#ifdef A3D_DIAGNOSTICS above). */
 /* Instrumentation (no reference counterpart): a3d_image_icp_align that also writes, per iteration,
  * [residual, t(3), q_ijkw(4)] of the transform after that iteration's update; out_trace holds
  * 8 * params->max_iterations floats. */
@@ -379,7 +388,8 @@ a3d_status a3d_multiscale_batch_last_kernel_ms(a3d_multiscale_batch* batch, floa
  * level to the last pair leaving it; their `launches` are iterations x groups. */
 a3d_status a3d_multiscale_batch_last_level_ms(a3d_multiscale_batch* batch, uint32_t level, float* out_ms,
                                               uint32_t* out_launches);
-/* Which levels the most recent batch_align ran inside the persistent kernel (bit l = level l). */
+/* Which levels the most recent batch_align ran inside the persistent kernel (bit l = level l): always 0 in the product
+ * library (the persistent kernel is a diagnostics-build variant, measured slower); see "instrumentation that ships". */
 a3d_status a3d_multiscale_batch_persistent_levels(a3d_multiscale_batch* batch, uint32_t* out_mask);
 a3d_status a3d_multiscale_batch_concurrency(a3d_multiscale_batch* batch, uint32_t* out_streams);
 /* Time of the most recent batch_align on the device, between hipEvents recorded on the context

@@ -22,9 +22,11 @@ for level in (2, 1, 0):
         a, b = [st[k] for k in range(5)], [st[8 + k] for k in range(5)]
         late, early = (a, b) if a[0] > b[0] else (b, a)  # the later launch and the one before it
         hs = [st[32 + k] for k in range(7)]  # inside the head of the last launch that ran one (job_finish_head_kernel has no such block)
+        hc = [st[40 + k] for k in range(7)]  # the same stamps in shader-clock cycles (s_memtime)
         rows.append([late[1] - late[0], late[2] - late[1], late[3] - late[2], late[4] - late[3], late[4] - late[0], late[0] - early[4]]
-                    + [hs[k + 1] - hs[k] for k in range(6)])
+                    + [hs[k + 1] - hs[k] for k in range(6)] + [(hc[5] - hc[2]) / max(1, hs[5] - hs[2])])
     r = np.median(np.array(rows, np.float64), axis=0) / 100.0
     print(f"{level} | {batch.last_timing()[1]} launches | " + " | ".join(f"{v:.2f} us" for v in r[:6]))
     print("      inside the head: partials loaded + added %.2f | totals in LDS (2 barriers) %.2f | Cholesky %.2f | substitutions %.2f | exp + compose + best %.2f | state to LDS + barrier %.2f us" % tuple(r[6:12]))
+    print("      shader clock during the solve (s_memtime cycles per s_memrealtime tick x 100 MHz): %.0f MHz" % (r[12] * 100.0 * 100.0))
     batch.free()

@@ -1,5 +1,6 @@
 // Issue cost of the VALU instructions the bilateral blur is made of, on this chip: cycles per wave-instruction with one
 // wave per SIMD (dependent chains of 8 interleaved accumulators, so latency is hidden) — hipcc --offload-arch=gfx950 -O3.
+// The loop's own overhead (s_add, s_cmp, s_cbranch per 32 instructions) is inside the figures: read them relative to each other.
 //   ./valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -47,6 +48,19 @@ OPS(mov_dpp, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned b0
     asm volatile("v_mov_b32_dpp %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %3, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));)
 OPS(add_dpp, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned b0 = 0; unsigned b1 = 0,
     asm volatile("v_add_u32_dpp %2, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %3, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %0, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %1, %2, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));)
+// dependent chains (one accumulator, every instruction waits for the one before): latency per instruction
+#undef SINK
+#define SINK out[1 + (threadIdx.x & 0)] += (u64)a0;
+OPS(dep_fma_f64, double a0 = 1.0 + 1e-9 * (seed + threadIdx.x); double a1 = 1.0000001,
+    asm volatile("v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1\n v_fma_f64 %0, %0, %1, %1" : "+v"(a0) : "v"(a1));)
+OPS(dep_mul_f64, double a0 = 1.0 + 1e-9 * (seed + threadIdx.x); double a1 = 1.0000001,
+    asm volatile("v_mul_f64 %0, %0, %1\n v_mul_f64 %0, %0, %1\n v_mul_f64 %0, %0, %1\n v_mul_f64 %0, %0, %1" : "+v"(a0) : "v"(a1));)
+OPS(dep_rsq_f64, double a0 = 1.0 + 1e-9 * (seed + threadIdx.x); double a1 = 1.0000001,
+    asm volatile("v_rsq_f64 %0, %0\n v_rsq_f64 %0, %0\n v_rsq_f64 %0, %0\n v_rsq_f64 %0, %0" : "+v"(a0) : "v"(a1));)
+OPS(dep_fma_f32, float a0 = 1.0f + 1e-6f * (seed + threadIdx.x); float a1 = 1.0001f,
+    asm volatile("v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1" : "+v"(a0) : "v"(a1));)
+OPS(dep_cvt_f32_f64, double a0 = 1.0 + 1e-9 * (seed + threadIdx.x); float a1 = 0.f,
+    asm volatile("v_cvt_f32_f64 %1, %0\n v_cvt_f64_f32 %0, %1\n v_cvt_f32_f64 %1, %0\n v_cvt_f64_f32 %0, %1" : "+v"(a0), "+v"(a1));)
 #define RUN(name, per)                                                                                   \
   for (int waves = 1; waves <= 4; waves *= 4) {                                                          \
     hipLaunchKernelGGL(k_##name, dim3(1), dim3(256 * waves), 0, 0, d, 1u);                                \
@@ -61,5 +75,7 @@ int main() {
   std::vector<u64> h(2);
   RUN(add_u32, 4) RUN(lshl_add_u32, 4) RUN(lshl_add_u64, 4) RUN(add_f32, 4) RUN(add_f64, 4) RUN(mul_f64, 4) RUN(fma_f64, 4) RUN(rcp_f64, 4)
   RUN(cvt_f64_u32, 4) RUN(cvt_u32_f64, 4) RUN(cvt_f32_u32, 4) RUN(mov_dpp, 4) RUN(add_dpp, 4)
+  printf("dependent chains (latency per instruction):\n");
+  RUN(dep_fma_f32, 4) RUN(dep_fma_f64, 4) RUN(dep_mul_f64, 4) RUN(dep_rsq_f64, 4) RUN(dep_cvt_f32_f64, 4)
   return 0;
 }
