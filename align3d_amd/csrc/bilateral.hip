@@ -593,18 +593,19 @@ __device__ __forceinline__ void load_window(uint32_t tile_id, const CELL* __rest
             z0 = (int)(tile_id % tz) * BT - 2;
   const int gh = (int)g.gh, gw = (int)g.gw, gd = (int)g.gd;
   const int t = (int)threadIdx.x, hi = t >> 4, lo = t & 15;
-  const int gc = c0 + hi, gz = z0 + lo;
-  const bool line_in = gc >= 0 && gc < gw && gz >= 0 && gz < gd;
-  // cell (gr, gc, gz) = first + i * row_stride: 32-bit arithmetic off the frame's (block-uniform) grid pointer — the
-  // fused kernels only see grids below 2^29 cells (grid_fits_idx32) — instead of a 64-bit multiply-add per load
-  const int row_stride = gw * gd * (int)sizeof(CELL);
-  int at_row = ((r0 * gw + gc) * gd + gz) * (int)sizeof(CELL);  // byte offset of (r0 + i, gc, gz), advanced by additions
+  // Sixteen UNCONDITIONAL loads at clamped coordinates (round 6; a load under `if (inside the grid)` is a branch of its
+  // own, sixteen of them per tile).  A cell outside the grid counts as zero — and the cell the clamp lands on IS zero:
+  // pixels splat into rows 2 .. gh - 2, columns 2 .. gw - 2 and channels 2 .. gd - 2 only (grid.rs:60-78: floor(t + 0.5) + 2
+  // against gd = floor(t_max) + 5), the rest of the packed grid keeps the zeros it starts with (a3d_context::grid_clean),
+  // so row 0 / gh - 1, column 0 / gw - 1 and channel 0 / gd - 1 are what "outside" reads.
+  const int gc = min(max(c0 + hi, 0), gw - 1), gz = min(max(z0 + lo, 0), gd - 1);
+  // cell (gr, gc, gz) = row part (block-uniform) + lane part: 32-bit arithmetic off the frame's (block-uniform) grid pointer —
+  // the fused kernels only see grids below 2^29 cells (grid_fits_idx32) — instead of a 64-bit multiply-add per load
+  const uint32_t row_stride = (uint32_t)(gw * gd) * (uint32_t)sizeof(CELL), lane_part = (uint32_t)(gc * gd + gz) * (uint32_t)sizeof(CELL);
 #pragma unroll
-  for (int i = 0; i < BR; ++i, at_row += row_stride) {
-    const int gr = r0 + i;
-    u[i] = 0;
-    if (line_in && gr >= 0 && gr < gh)
-      u[i] = *(const CELL __attribute__((address_space(1)))*)((a3d_gptr_c)packed + (uint32_t)at_row);
+  for (int i = 0; i < BR; ++i) {
+    const uint32_t gr = (uint32_t)min(max(r0 + i, 0), gh - 1);
+    u[i] = *(const CELL __attribute__((address_space(1)))*)((a3d_gptr_c)packed + (gr * row_stride + lane_part));
   }
 }
 
@@ -718,8 +719,32 @@ __device__ __forceinline__ void blur_tile(typename Pack<CELL>::EarlyValue* tile_
     stores = lo >= 2 && lo < BR - 2 && gr2 < gh && gz2 < gd;
     // normalised (grid.rs:90-104): value / weight — the common factor 4^6 cancels exactly — or, where the weight is zero,
     // the value itself (x 4^-6: the six divisions by four)
+    // Four quotients at a time, stage by stage and without a branch (round 6): written as `w > 0 ? value / w : value x 2^-12`
+    // per cell, each of the twelve became its own divergent if / else around a chain of nine dependent f64 operations —
+    // 2 700 cycles of a tile's 26 000 (profiles/round6_blur_tile_stamps.txt).  The quotient is taken for every lane over a
+    // denominator that is never zero and the result selected: the same values, the chains of four cells interleaved.
 #pragma unroll
-    for (int i = 2; i < BR - 2; ++i) o[i - 2] = vw[i] > (W)0 ? quotient_of_counts(vx[i], (double)vw[i]) : vx[i] * 0x1p-12;
+    for (int i0 = 2; i0 < BR - 2; i0 += 4) {
+      double wd[4], r[4], e[4], q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wd[k] = (double)(vw[i0 + k] > (W)0 ? vw[i0 + k] : (W)1), r[k] = __builtin_amdgcn_rcp(wd[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = __builtin_fma(-wd[k], r[k], 1.0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = __builtin_fma(r[k], e[k], r[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = __builtin_fma(-wd[k], r[k], 1.0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = __builtin_fma(r[k], e[k], r[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = vx[i0 + k] * r[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = __builtin_fma(-wd[k], q[k], vx[i0 + k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = __builtin_fma(e[k], r[k], q[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[i0 + k - 2] = vw[i0 + k] > (W)0 ? q[k] : vx[i0 + k] * 0x1p-12;
+    }
   }
   // THE ORDER OF WAITS (round 6).  Loads and stores share one in-order counter (vmcnt), and the compiler cannot know how many
   // of this tile's stores a wave issues (grid borders, the idle fourth wave), so a wait for the next window's loads placed
