@@ -601,7 +601,7 @@ def frame_build_roofline(ctx, W, H, levels=3):
     alg = 5 * W * H + out_bytes + grid_bytes
     us = float(np.median(live))
     prof_us, per_kernel, src = frame_build_kernel_us()
-    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "the 10 kernels of one batched build, per frame",
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "the 9 kernels of one batched build, per frame",
          "algorithmic_bytes_per_frame": alg, "input_bytes": 5 * W * H, "pyramid_bytes": out_bytes, "grid_bytes": grid_bytes,
          "grid_cells_per_frame": st["grid_cells"] / n, "marked_tiles_per_frame": st["marked_tiles"] / n,
          "kernel_us_per_frame": us, "kernel_us_per_frame_stats": stats(live),

@@ -2,7 +2,7 @@
 # frame build) (1) rocprofv3 --kernel-trace --stats, (2) a per-grid summary, (3) FETCH_SIZE / WRITE_SIZE passes ->
 # HBM bytes per launch of its dominant kernel.  Outputs under gpurun_out/profile_<round>/; copy them into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ROUND=${ROUND:-round5}
+ROUND=${ROUND:-round6}
 OUT=gpurun_out/profile_$ROUND
 rm -rf $OUT && mkdir -p $OUT
 trace() {  # NAME program args...
@@ -24,7 +24,7 @@ ROUND=$ROUND bash scripts/traffic_pmc.sh pcl_icp pcl_icp_head_kernel "source_poi
 rm -rf gpurun_out/traffic_fetch_fb gpurun_out/traffic_write_fb &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/traffic_fetch_fb -- python3 scripts/build_trace_probe.py 32 -1 > /dev/null 2> gpurun_out/traffic_fetch_fb.err &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/traffic_write_fb -- python3 scripts/build_trace_probe.py 32 -1 > /dev/null 2> gpurun_out/traffic_write_fb.err &&
-python3 scripts/summarize_traffic_sum.py gpurun_out/traffic_fetch_fb gpurun_out/traffic_write_fb "level0_kernel|blur_fused_kernel|blur_halve_words_kernel|splat_packed_kernel|resize_pick_kernel|luma_imap_kernel|unsplat_kernel|minmax_u16_kernel|dims_table_kernel" 320 frames_per_build=32 width=640 height=480 > gpurun_out/${ROUND}_frame_build_traffic.json &&
+python3 scripts/summarize_traffic_sum.py gpurun_out/traffic_fetch_fb gpurun_out/traffic_write_fb "level0_quad_kernel|level0_kernel|blur_fused_kernel|blur_halve_words_kernel|splat_packed_kernel|resize_pick_kernel|luma_imap_kernel|unsplat_kernel|minmax_u16_kernel|dims_table_kernel" 320 frames_per_build=32 width=640 height=480 > gpurun_out/${ROUND}_frame_build_traffic.json &&
 cp gpurun_out/${ROUND}_*_traffic*.json $OUT/ &&
 python3 bench.py > $OUT/${ROUND}_bench.json 2> $OUT/bench.err &&
 cp gpurun_out/bench_detail_n1.json $OUT/${ROUND}_bench_detail.json &&

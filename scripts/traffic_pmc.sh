@@ -3,7 +3,7 @@
 #   bash scripts/traffic_pmc.sh NAME KERNEL_SUBSTRING "key=value ..." python3 <program> [args]
 # Writes gpurun_out/<ROUND>_<NAME>_traffic.json (copy into profiles/: bench.py reads it for roofline.traffic).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ROUND=${ROUND:-round5}
+ROUND=${ROUND:-round6}
 NAME=$1; KERNEL=$2; KEYS=$3; shift 3
 rm -rf gpurun_out/traffic_fetch_$NAME gpurun_out/traffic_write_$NAME
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/traffic_fetch_$NAME -- "$@" > gpurun_out/traffic_fetch_$NAME.out 2> gpurun_out/traffic_fetch_$NAME.err &&
