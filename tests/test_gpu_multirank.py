@@ -189,3 +189,30 @@ def test_two_rank_line_carries_the_copy_ceiling():
         pytest.skip("scripts/copy_ceiling is not built")
     assert out["roofline"]["hbm_copy_ceiling_GBs"] > 1000 and 0 < out["roofline"]["frac_of_copy_ceiling"] < 1.5
     assert out["cpu_baseline"] is not None
+
+
+@pytest.mark.gpu
+def test_the_drivers_launch_form_with_one_rank_goes_through_rccl():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (one rank per GPU over RCCL).  With one GPU here: the same launcher, one rank,
+    `--rehearse-collective` = the N > 1 code path (process group on backend nccl = RCCL, the all-gather on the context's
+    stream through an ExternalStream, the device-count and context-device checks, the bounded cpu_baseline of a
+    collective run): what an 8-GPU node adds is the communicator's size."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-collective", "--pairs-per-gpu", "4",
+           "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-pairs", "1", "--cpu-orders", "2"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["ranks_in_collective"] == 1 and out["config"]["gathered_pairs"] == 4
+    assert out["config"]["gather_matches_local_poses"] is True and "RCCL" in out["config"]["collective"]
+    assert out["roofline"]["failed_pairs"] == 0 and out["cpu_baseline"] is not None
