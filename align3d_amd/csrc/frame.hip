@@ -954,8 +954,10 @@ a3d_status taps_for(a3d_context* ctx, uint32_t size, uint32_t count, float sigma
 // The work has two independent halves that meet in nobody's input: the DEPTH half (bilateral grid, level 0, picked
 // levels: `depth_part`) and the COLOUR half (blurred + halved colours, intensities and their maps: `color_part`); a
 // chunk whose grids outgrew the scratch region repeats the depth half only.  (Running the colour half on a second
-// stream under the depth half's VALU-bound kernels was measured in round 4: 15.3 against 15.4 us per frame — the blur
-// fills every CU's LDS, so the colour kernels only fit into the tails — and dropped.)
+// stream under the depth half was measured in round 4 (colour kernels enqueued last: 15.3 against 15.4 us per frame) and
+// again in round 6 (enqueued FIRST, to fill the ~55 us in which min / max, grid sizing, splat and unsplat leave the chip all
+// but idle: 11.6-12.2 against 11.8 us per frame resident, and streaming 17.1 -> 14.4-14.9 k pairs/s next to an aligning
+// context) — dropped both times.)
 a3d_status enqueue_chunk(a3d_context* ctx, const a3d_builder_params* prm, uint32_t F, const uint16_t* d_depth, uint32_t w,
                          uint32_t h, float fx, float fy, float cx, float cy, float depth_scale, const ArenaPlan& plan,
                          const FrameBases& bases, uint32_t* result, bool depth_part, bool color_part) {
