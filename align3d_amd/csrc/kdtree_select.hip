@@ -549,6 +549,19 @@ __device__ uint32_t g_sel_stamp_level = 2, g_sel_stamp_node = 0;
 #else
 #define A3D_SEL_STAMP(tag, cnt) do { } while (0)
 #endif
+#if defined(A3D_TAIL_STAMPS) && defined(A3D_NARROW_PHASE_STAMPS)  // scripts/narrow_stamps.py phases: block 0's network, phase by phase
+__device__ uint32_t g_nw_phase_n;
+#define A3D_PHASE_STAMP(tag, val)                                                                        \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && cap == SLOTS && g_nw_phase_n < 32) {                      \
+      g_sel_stamps[2 * g_nw_phase_n] = __builtin_amdgcn_s_memtime();                                     \
+      g_sel_stamps[2 * g_nw_phase_n + 1] = ((unsigned long long)(tag) << 32) | (val);                    \
+      ++g_nw_phase_n;                                                                                    \
+    }                                                                                                    \
+  } while (0)
+#else
+#define A3D_PHASE_STAMP(tag, val) do { } while (0)
+#endif
 
 // One block per node: finds the point of rank `t` under L_d among the node's median-bucket points and places them all.
 // The set is narrowed round by round — buckets over the actual [min, max] of one component of L_d at a time (a set
@@ -777,6 +790,76 @@ __global__ void __launch_bounds__(K2_THREADS)
 typedef unsigned long long Word;
 constexpr Word WORD_PADDING = ~0ull;
 
+// Compare-exchange of two 64-bit words WITHOUT a mask passing through the scalar unit.  `if ((hi < lo) == up) swap` compiles to
+// v_cmp_lt_u64 -> s_xor_b64 with the lanes' direction mask -> s_nop -> v_cndmask x 4, and the VALU -> SGPR -> SALU -> SGPR -> VALU
+// round trip costs a wave ~26 cycles each time (scripts/valu_rate.hip cmp: 39 cycles per compare + select through s_xor against 13
+// with the mask forwarded inside the VALU) — that, not the LDS, bound the network (round 6: the same 24 400 cycles for a 2048-word
+// sort with its words in LDS and with them in registers).  Here the direction is DATA: flip = 0 (ascending: lo keeps the smaller
+// word) or ~0 per lane, the compare's mask is consumed at once by one v_cndmask that turns it into the swap mask m, and the
+// words move by v_bfi_b32.
+// (the direction word goes through an empty asm first: knowing that it is 0 or ~0, hipcc folds all of this back into mask
+// arithmetic on the scalar unit)
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ uint32_t swap_mask(unsigned long long a, unsigned long long b, uint32_t flip, uint32_t nflip) { return a < b ? nflip : flip; }
+__device__ __forceinline__ unsigned long long bfi64(uint32_t m, unsigned long long take, unsigned long long keep) {
+  const uint32_t lo = ((uint32_t)take & m) | ((uint32_t)keep & ~m), hi = ((uint32_t)(take >> 32) & m) | ((uint32_t)(keep >> 32) & ~m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void compare_exchange(unsigned long long& lo, unsigned long long& hi, uint32_t flip, uint32_t nflip) {
+  const uint32_t m = swap_mask(hi, lo, flip, nflip);
+  const unsigned long long nl = bfi64(m, hi, lo), nh = bfi64(m, lo, hi);
+  lo = nl, hi = nh;
+}
+
+// The word of lane ^ M of the same wave, over the VALU's lane paths (checked lane by lane on the card: scripts/lane_xor_probe.hip).
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v) {
+  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  else if constexpr (M == 4) {  // row_shl:4 into banks 0 and 2 of every row, row_shr:4 into banks 1 and 3
+    const int r = __builtin_amdgcn_mov_dpp((int)v, 0x104, 0xF, 0x5, false);  // (the other banks: the next line)
+    return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)v, 0x114, 0xF, 0xA, false);
+  } else if constexpr (M == 8) {  // row_shl:8 into banks 0 and 1, row_shr:8 into banks 2 and 3
+    const int r = __builtin_amdgcn_mov_dpp((int)v, 0x108, 0xF, 0x3, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)v, 0x118, 0xF, 0xC, false);
+  } else if constexpr (M == 16) {  // odd rows of the first copy <-> even rows of the second (gfx950)
+    const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (threadIdx.x & 16u) ? p[0] : p[1];
+  } else {  // upper half of the first copy <-> lower half of the second (gfx950)
+    static_assert(M == 32, "lane distance");
+    const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32u) ? p[0] : p[1];
+  }
+}
+template <int M>
+__device__ __forceinline__ void lane_step(unsigned long long (&x)[4], uint32_t flip_raw) {  // flip = 0: this lane keeps the smaller word
+  const uint32_t flip = opaque(flip_raw), nflip = opaque(~flip_raw);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned long long y = ((unsigned long long)lane_xor32<M>((uint32_t)(x[e] >> 32)) << 32) | lane_xor32<M>((uint32_t)x[e]);
+    x[e] = bfi64(swap_mask(y, x[e], flip, nflip), y, x[e]);  // (equal words — padding — : either way the same word stays)
+  }
+}
+
+// The end of one merge phase of the network for a thread that holds the words i0 .. i0 + 3: distances J0, J0 / 2, .. 4 by
+// lane exchange, 2 and 1 inside the thread.
+template <int J0>
+__device__ __forceinline__ void merge_tail(unsigned long long (&x)[4], uint32_t i0, uint32_t fu) {  // fu = 0: the cell sorts upwards, ~0: downwards
+  // (the lower partner of an upward cell keeps the smaller word: flip = -(bit log2 J of i0) ^ fu, two VALU instructions)
+  if constexpr (J0 >= 128) lane_step<32>(x, (uint32_t)(((int)(i0 << 24)) >> 31) ^ fu);
+  if constexpr (J0 >= 64) lane_step<16>(x, (uint32_t)(((int)(i0 << 25)) >> 31) ^ fu);
+  if constexpr (J0 >= 32) lane_step<8>(x, (uint32_t)(((int)(i0 << 26)) >> 31) ^ fu);
+  if constexpr (J0 >= 16) lane_step<4>(x, (uint32_t)(((int)(i0 << 27)) >> 31) ^ fu);
+  if constexpr (J0 >= 8) lane_step<2>(x, (uint32_t)(((int)(i0 << 28)) >> 31) ^ fu);
+  lane_step<1>(x, (uint32_t)(((int)(i0 << 29)) >> 31) ^ fu);
+  const uint32_t f = opaque(fu), nf = opaque(~fu);
+  compare_exchange(x[0], x[2], f, nf), compare_exchange(x[1], x[3], f, nf);
+  compare_exchange(x[0], x[1], f, nf), compare_exchange(x[2], x[3], f, nf);
+}
+
 // Bitonic network over SLOTS words in cells of `cap` (a power of two, 32 <= cap <= SLOTS), four CONSECUTIVE words per
 // thread (word i = 4 * threadIdx.x + e) in registers on entry and exit.
 //   REGS: partner distances 1 and 2 stay inside the thread, 4 .. 128 are lane exchanges inside the wave (no barrier),
@@ -787,59 +870,81 @@ template <uint32_t SLOTS, bool REGS>
 __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* lds) {
   constexpr uint32_t THREADS = SLOTS / 4;
   const uint32_t i0 = 4u * threadIdx.x;
-  auto inside = [&](Word& lo, Word& hi, bool up) {  // compare-exchange of two words one thread holds
-    if ((hi < lo) == up) {
-      const Word t = lo;
-      lo = hi, hi = t;
-    }
-  };
+#ifdef A3D_NW_SKIP  // timing experiment (wrong trees): what the kernel costs without its networks
+  return;
+#endif
+  auto inside = [&](Word& lo, Word& hi, bool up) { compare_exchange(lo, hi, opaque(up ? 0u : ~0u), opaque(up ? ~0u : 0u)); };  // of two words one thread holds
+  // Word i lives at phys(i) = i ^ 5 * (bits 4-5 of i) ^ (bit 6 of i) << 4, a GF(2)-linear shuffle inside every 32 words: a
+  // stage pair of distances (j, j / 2) has quad q read the words base(q) | {0, j / 2, j, 3 j / 2}, i.e. the 32 lanes of a
+  // ds_read_b64 group put q's low five bits at the address bits below log2(j / 2) and from log2(j) + 1 up — for j = 4 .. 64
+  // two or more of them land on bits 5 and 6, outside the 32 8-byte slots of a bank row (the plain layout, and the one
+  // padded by a word per 32 of rounds 5-6: two- to four-way conflicts on the middle distances).  With this shuffle the 32
+  // lanes of every stage pair's reads and the 16 lanes of every ds_write_b64 group hit distinct slots
+  // (scripts/lds_shuffle_search.py enumerates the linear maps that do).
+  auto phys = [](uint32_t i) { return i ^ (((i >> 4) & 3u) * 5u) ^ ((i >> 2) & 16u); };
   if (REGS) {
-    auto keep = [&](Word& own, Word other, bool want_min) {
-      if ((other < own) == want_min) own = other;  // (equal words — padding — : either way the same word stays)
-    };
-    for (uint32_t kk = 2; kk <= cap; kk <<= 1) {
-      for (uint32_t j = kk >> 1; j >= 1; j >>= 1) {
-        if (j == 1) {
-          inside(x[0], x[1], ((i0 & (cap - 1u)) & kk) == 0u);
-          inside(x[2], x[3], (((i0 + 2u) & (cap - 1u)) & kk) == 0u);
-        } else if (j == 2) {
-          const bool up = ((i0 & (cap - 1u)) & kk) == 0u;  // (kk >= 4: one direction for the thread's four words)
-          inside(x[0], x[2], up), inside(x[1], x[3], up);
-        } else {
-          const bool up = ((i0 & (cap - 1u)) & kk) == 0u;
-          const bool lower = (i0 & j) == 0u;  // this thread holds the lower index of each pair
-          if (j <= 128u) {
-            const int m = (int)(j >> 2);
-            Word y[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (Word)__shfl_xor((long long)x[e], m, 64);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) keep(x[e], y[e], lower == up);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) lds[i0 + e] = x[e];
-            __syncthreads();
-            Word y[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = lds[(i0 ^ j) + e];
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) keep(x[e], y[e], lower == up);
-          }
-        }
-      }
+    // The thread keeps its four consecutive words in registers through the whole network.  Distances 1 and 2 are inside
+    // the thread; 4 .. 128 are the lanes l ^ 1 .. l ^ 32 of the same wave: the partner's word comes over the VALU's own
+    // lane paths (DPP quad_perm / row shifts, v_permlane16_swap, v_permlane32_swap: lane_xor32) — no LDS traffic, no
+    // waiting, both partners compare and each keeps its side.  Only distances >= 256 (other waves' words) go through LDS,
+    // two distances per round trip.  The network with its words in LDS (below) was bound by the LDS store path (ds_write_b64:
+    // ~85 B/clk per CU, MI355X_MICROARCH.md) and by one LDS round trip per stage pair: 24 400 cycles for the 2048-word sort.
+    const uint32_t cell_i0 = i0 & (cap - 1u);
+    inside(x[0], x[1], (cell_i0 & 2u) == 0u), inside(x[2], x[3], ((cell_i0 + 2u) & 2u) == 0u);
+    {
+      const bool up = (cell_i0 & 4u) == 0u;
+      inside(x[0], x[2], up), inside(x[1], x[3], up), inside(x[0], x[1], up), inside(x[2], x[3], up);
     }
+    const uint32_t p_own = phys(i0);  // (i0 = 4 t: the words i0 + e stand at p_own ^ e)
+    A3D_PHASE_STAMP(40, 4);
+    for (uint32_t kk = 8; kk <= cap; kk <<= 1) {
+      const uint32_t fu = (cell_i0 & kk) ? ~0u : 0u;  // (kk >= 8: one direction for the thread's four words; 0 = upwards)
+      uint32_t j = kk >> 1;
+      if (j >= 256u) {
+        __syncthreads();  // (the buffer's previous use may have been anyone's)
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) lds[p_own ^ e] = x[e];
+        while (j >= 256u) {
+          const uint32_t hh = j >> 1, lh = 31u - (uint32_t)__builtin_clz(hh);
+          const uint32_t q = threadIdx.x;
+          const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
+          const bool upq = ((base & (cap - 1u)) & kk) == 0u;
+          const uint32_t p0 = phys(base), dh = phys(hh), dj = phys(j);
+          __syncthreads();
+          Word a0 = lds[p0], a1 = lds[p0 ^ dh], a2 = lds[p0 ^ dj], a3 = lds[p0 ^ dj ^ dh];
+          inside(a0, a2, upq), inside(a1, a3, upq);
+          inside(a0, a1, upq), inside(a2, a3, upq);
+          lds[p0] = a0, lds[p0 ^ dh] = a1, lds[p0 ^ dj] = a2, lds[p0 ^ dj ^ dh] = a3;
+          j >>= 2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) x[e] = lds[p_own ^ e];
+        A3D_PHASE_STAMP(41, kk);
+      }
+      // (block-uniform) j <= 128 by now: the partners of the remaining distances j .. 4 are the lanes ^ (j / 4) .. ^ 1, then the
+      // thread's own words.  One straight-line tail per starting distance (a loop over j with a switch on the lane distance
+      // inside made hipcc keep three copies of every word alive across the cases).
+      switch (j) {
+        case 128u: merge_tail<128>(x, i0, fu); break;
+        case 64u: merge_tail<64>(x, i0, fu); break;
+        case 32u: merge_tail<32>(x, i0, fu); break;
+        case 16u: merge_tail<16>(x, i0, fu); break;
+        case 8u: merge_tail<8>(x, i0, fu); break;
+        default: merge_tail<4>(x, i0, fu); break;
+      }
+      A3D_PHASE_STAMP(42, kk);
+    }
+    __syncthreads();
     return;
   }
-  // the first phases (kk = 2, 4: distances 1 | 2, 1) stay inside the thread, then everything through LDS.  Word i lives
-  // at i + (i >> 5): one padding word per 32 keeps the quads of the short distances (8 .. 64 bytes apart in a plain
-  // layout: four-way bank conflicts on 64-bit accesses) on different banks.
+  // the first phases (kk = 2, 4: distances 1 | 2, 1) stay inside the thread, then everything through LDS (layout: phys).
   // Wave w's threads own the quads of words [256 w, 256 w + 256) in every stage pair of distances <= 128 (and the words
   // 4 t .. 4 t + 3 on entry, exit and in the distance-1 stage): such a stage reads only what its own wave wrote, the LDS
   // serves a wave's instructions in order, so between two of them no block barrier is needed — only the stage pairs of
   // distances >= 256 (5 of the 33 of a 2048-word sort, none below 512 words) exchange words between waves.  With two
   // waves per SIMD and a barrier per stage pair the network was bound by LDS round trips the barrier kept from overlapping.
-  auto at = [&](uint32_t i) -> Word& { return lds[i + (i >> 5)]; };
+  auto at = [&](uint32_t i) -> Word& { return lds[phys(i)]; };
   bool prev_cross = true;  // (the buffer's previous use may have been anyone's)
   auto stage_sync = [&](bool cross) {
     if (cross || prev_cross) __syncthreads();
@@ -862,18 +967,21 @@ __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* l
       const uint32_t base = ((q >> lh) << (lh + 2)) | (q & (hh - 1u));
       const bool up = ((base & (cap - 1u)) & kk) == 0u;
       stage_sync(j > 128u);
-      Word a0 = at(base), a1 = at(base + hh), a2 = at(base + j), a3 = at(base + j + hh);
+      // (phys is linear over xor and the bits of hh and j are clear in base: one shuffle per stage pair, the rest uniform)
+      const uint32_t p0 = phys(base), dh = phys(hh), dj = phys(j);
+      Word a0 = lds[p0], a1 = lds[p0 ^ dh], a2 = lds[p0 ^ dj], a3 = lds[p0 ^ dj ^ dh];
       inside(a0, a2, up), inside(a1, a3, up);
       inside(a0, a1, up), inside(a2, a3, up);
-      at(base) = a0, at(base + hh) = a1, at(base + j) = a2, at(base + j + hh) = a3;
+      lds[p0] = a0, lds[p0 ^ dh] = a1, lds[p0 ^ dj] = a2, lds[p0 ^ dj ^ dh] = a3;
       j >>= 2;
     }
     if (j == 1) {  // the thread's own four consecutive words
       const bool up = ((i0 & (cap - 1u)) & kk) == 0u;  // (kk >= 8: one direction for all four)
       stage_sync(false);
-      Word a0 = at(i0), a1 = at(i0 + 1), a2 = at(i0 + 2), a3 = at(i0 + 3);
+      const uint32_t p0 = phys(i0);  // (i0 = 4 t: the words i0 + e stand at p0 ^ e)
+      Word a0 = lds[p0], a1 = lds[p0 ^ 1u], a2 = lds[p0 ^ 2u], a3 = lds[p0 ^ 3u];
       inside(a0, a1, up), inside(a2, a3, up);
-      at(i0) = a0, at(i0 + 1) = a1, at(i0 + 2) = a2, at(i0 + 3) = a3;
+      lds[p0] = a0, lds[p0 ^ 1u] = a1, lds[p0 ^ 2u] = a2, lds[p0 ^ 3u] = a3;
     }
   }
   stage_sync(false);
@@ -956,7 +1064,7 @@ __global__ void __launch_bounds__(SLOTS / 4)
   // hipcc (ROCm 7.2) turns `axis == 0 ? r.x : axis == 1 ? r.y : r.z` with a wave-uniform axis inside a divergent
   // while-loop into a ladder of scalar branches around a strength-reduced pointer, and the axis-0 arm of that pointer is
   // left one record behind when the loop exits (observed: runs of equal x keys ranked over [lo - 1, hi - 1)).
-  __shared__ uint32_t long_runs;
+  __shared__ uint32_t long_runs, any_tie;
   const float* recf = (const float*)rec;
   auto coord = [&](uint32_t pos, uint32_t axis) { return recf[4u * pos + axis]; };
   auto lkey_at = [&](uint32_t pos, uint32_t level) {
@@ -965,13 +1073,37 @@ __global__ void __launch_bounds__(SLOTS / 4)
                 level >= 2 ? ord_bits(coord(pos, (ax + 1) % 3)) : 0u, __float_as_uint(coord(pos, 3))};
   };
   const uint32_t node0 = blockIdx.x;
+#if defined(A3D_TAIL_STAMPS) && defined(A3D_NARROW_PHASE_STAMPS)
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_nw_phase_n = 0;
+#endif
+#if defined(A3D_TAIL_STAMPS) && defined(A3D_NARROW_NET_STAMPS) && !defined(A3D_NARROW_PHASE_STAMPS)  // scripts/narrow_stamps.py: block 0's levels (s_memtime)
+  uint32_t n_stamp = 0;
+#define A3D_NW_STAMP(tag, val)                                                                 \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && n_stamp < 32) {                                 \
+      g_sel_stamps[2 * n_stamp] = __builtin_amdgcn_s_memtime();                                \
+      g_sel_stamps[2 * n_stamp + 1] = ((unsigned long long)(tag) << 32) | (val);               \
+      ++n_stamp;                                                                               \
+    }                                                                                          \
+  } while (0)
+#else
+#define A3D_NW_STAMP(tag, val) do { } while (0)
+#endif
+  A3D_NW_STAMP(30, 0);
   uint32_t s0, l0;
   bool exists0;
   sel_node_range(n, d0, node0, &s0, &l0, &exists0);
   uint32_t cap0 = 32;
   while (cap0 < l0) cap0 <<= 1;
+  // pm[i]: which record stands at position i.  The entry level moves the records themselves (its run handling reads them by
+  // position) and leaves pm the identity; every deeper level only permutes pm — 2 bytes per point and level instead of a
+  // 16-byte record gathered and written back (round 6: those moves were 37 000 of the kernel's 198 000 cycles,
+  // profiles/round6_kdtree_narrow_stamps.txt) — and the leaves are gathered through it once at the end.
+  uint16_t* pm = (uint16_t*)(xw + (SLOTS + SLOTS / 32u + 64u));  // behind the network's padded words
   for (uint32_t p = threadIdx.x; p < l0; p += THREADS) rec[p] = recs[s0 + p];
+  for (uint32_t p = threadIdx.x; p < SLOTS; p += THREADS) pm[p] = (uint16_t)p;
   __syncthreads();
+  A3D_NW_STAMP(31, l0);
   const uint32_t i0 = 4u * threadIdx.x;
   // The level a range enters at finds its points in arbitrary order and has to establish L_d itself: the network on
   // `key << 32 | current position` orders the keys, then every run of EQUAL keys (none, on ordinary data) is put into the
@@ -979,6 +1111,10 @@ __global__ void __launch_bounds__(SLOTS / 4)
   // wide / narrow border only: its points must stand in the order its parent's sort left them in.)  Every deeper level
   // finds L_{d-1} in the positions and needs the network only.
   const uint32_t first = (l0 <= 16 && d0 >= 1) ? d0 - 1 : d0;
+  // the thread's cell of the level before, carried down (kdtree.rs:46-52: mid = len / 2; a range of <= 16 points is a leaf
+  // and has no children): one step per level instead of sel_node_range's walk from the root (round 6)
+  uint32_t c_rs = 0, c_lc = l0;
+  bool c_ok = true;
   for (uint32_t d = first; d < D || d == first; ++d) {
     const bool entry = d <= d0;
     const uint32_t a = d % 3, rel = entry ? 0u : d - d0;
@@ -992,11 +1128,15 @@ __global__ void __launch_bounds__(SLOTS / 4)
         rs = 0, lc = l0;
         sorted = d < d0 ? true : l0 > 16;  // (d < d0: the leaf's own order, no split below)
       } else {
-        uint32_t sc;
-        bool ok;
-        sel_node_range(n, d, (node0 << rel) + cell, &sc, &lc, &ok);
-        rs = sc - s0;
-        sorted = ok && lc > 16;
+        if (c_ok && c_lc > 16) {
+          const uint32_t mid = c_lc >> 1;
+          if (cell & 1u) c_rs += mid, c_lc -= mid;
+          else c_lc = mid;
+        } else {
+          c_ok = false;
+        }
+        rs = c_rs, lc = c_lc;
+        sorted = c_ok && lc > 16;
       }
     }
     constexpr uint32_t SHORT_RUN = 8;  // a run no longer than this on either side of a point is ranked by counting
@@ -1018,7 +1158,7 @@ __global__ void __launch_bounds__(SLOTS / 4)
       heavy = long_runs != 0u;
       __syncthreads();
     }
-    float4 moved[4];
+    A3D_NW_STAMP(32, d);  // level set up (entry level: the long-run check done)
     bool mine[4];
     Word x[4];
 #pragma unroll
@@ -1026,41 +1166,87 @@ __global__ void __launch_bounds__(SLOTS / 4)
       mine[e] = sorted && pos0 + e < lc;
       x[e] = WORD_PADDING;
       if (mine[e]) {
-        const float v = coord(rs + pos0 + e, a);
+        // (at the entry level pm is the identity by definition — and its LDS words are the hash table's / the 128-bit network's
+        // until the level's end: read the position itself)
+        const float v = coord(entry ? rs + pos0 + e : (uint32_t)pm[rs + pos0 + e], a);
         if (d >= d0 && v != v) atomicOr(&flags[FLAG_NAN], 1u);  // partial_cmp().unwrap() would panic (kdtree.rs:43)
         x[e] = ((Word)ord_bits(v) << 32) | (pos0 + e);
       }
     }
     if (!heavy) {
       bitonic_sort<SLOTS, REGS>(x, cap, xw);
+      A3D_NW_STAMP(33, cap);  // network done
+      if (entry) {  // (block-uniform) the records themselves; pm stays the identity
+        // (four named values, loaded unconditionally: as an array, or behind `if (mine[e])`, hipcc keeps them in scratch memory
+        // across the barrier — 5 900 cycles of the kernel for this move alone)
+        const float4 m0 = rec[mine[0] ? rs + (uint32_t)x[0] : 0u], m1 = rec[mine[1] ? rs + (uint32_t)x[1] : 0u],
+                     m2 = rec[mine[2] ? rs + (uint32_t)x[2] : 0u], m3 = rec[mine[3] ? rs + (uint32_t)x[3] : 0u];
+        __syncthreads();
+        if (mine[0]) rec[rs + pos0] = m0;
+        if (mine[1]) rec[rs + pos0 + 1] = m1;
+        if (mine[2]) rec[rs + pos0 + 2] = m2;
+        if (mine[3]) rec[rs + pos0 + 3] = m3;
+      } else {
+        uint16_t np[4];
 #pragma unroll
-      for (uint32_t e = 0; e < 4; ++e)
-        if (mine[e]) moved[e] = rec[rs + (uint32_t)x[e]];
-      __syncthreads();
+        for (uint32_t e = 0; e < 4; ++e) np[e] = mine[e] ? pm[rs + (uint32_t)x[e]] : (uint16_t)0;
+        __syncthreads();
 #pragma unroll
-      for (uint32_t e = 0; e < 4; ++e)
-        if (mine[e]) rec[rs + pos0 + e] = moved[e];
-      __syncthreads();
-    }
-    if (entry) {  // runs of equal keys into the order of (previous axis' key, the one before, original index)
-      uint32_t* dest = (uint32_t*)xw;    // (the network's buffer is free between sorts)
-      if (threadIdx.x == 0) long_runs = heavy ? 1u : 0u;
-      __syncthreads();
-      for (uint32_t p = threadIdx.x; p < l0 && !heavy; p += THREADS) {
-        const uint32_t k = ord_bits(coord(p, a));
-        uint32_t lo = p, hi = p + 1;
-        while (lo > 0 && p - lo < SHORT_RUN && ord_bits(coord(lo - 1, a)) == k) --lo;
-        while (hi < l0 && hi - p <= SHORT_RUN && ord_bits(coord(hi, a)) == k) ++hi;
-        if (p - lo >= SHORT_RUN || hi - p > SHORT_RUN) long_runs = 1u;  // (benign race: every writer stores 1)
-        uint32_t rnk = p - lo;
-        if (hi - lo > 1) {
-          const LKey me = lkey_at(p, d);
-          rnk = 0;
-          for (uint32_t q = lo; q < hi; ++q) rnk += lkey_less(lkey_at(q, d), me) ? 1u : 0u;
-        }
-        dest[p] = lo + rnk;
+        for (uint32_t e = 0; e < 4; ++e)
+          if (mine[e]) pm[rs + pos0 + e] = np[e];
       }
       __syncthreads();
+    }
+    A3D_NW_STAMP(34, d);  // records moved
+    if (entry) {  // runs of equal keys into the order of (previous axis' key, the one before, original index)
+      uint32_t* dest = (uint32_t*)xw;    // (the network's buffer is free between sorts)
+      if (threadIdx.x == 0) long_runs = heavy ? 1u : 0u, any_tie = heavy ? 1u : 0u;
+      __syncthreads();
+      // ordinary data has no two equal keys in a range: one look at both neighbours of the thread's four points (all loads in
+      // flight at once) settles that, and nothing of the run handling below runs — not even `dest` is written (round 6: the loop
+      // below, with its dependent LDS reads per point, was 11 600 of the kernel's cycles on a cloud without a single tie)
+      uint32_t tied = 0u;  // bit e: the thread's e-th point has a neighbour with its key
+      if (!heavy) {
+        uint32_t kc[4], kl[4], kr[4];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+          const uint32_t p = threadIdx.x + e * THREADS, pc = p < l0 ? p : 0u;
+          kc[e] = ord_bits(coord(pc, a)), kl[e] = ord_bits(coord(pc > 0 ? pc - 1 : pc, a)), kr[e] = ord_bits(coord(pc + 1 < l0 ? pc + 1 : pc, a));
+        }
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+          const uint32_t p = threadIdx.x + e * THREADS;
+          tied |= (p < l0 && ((p > 0 && kl[e] == kc[e]) || (p + 1 < l0 && kr[e] == kc[e])) ? 1u : 0u) << e;
+        }
+        if (tied) any_tie = 1u;  // (benign race: every writer stores 1)
+      }
+      __syncthreads();
+      A3D_NW_STAMP(38, any_tie);  // neighbours compared
+      const bool ties = any_tie != 0u;  // (block-uniform)
+      if (!heavy && ties) {
+#pragma unroll 1
+        for (uint32_t e = 0; e < 4; ++e) {
+          const uint32_t p = threadIdx.x + e * THREADS;
+          if (p >= l0) continue;
+          if (!((tied >> e) & 1u)) {  // (nearly every point: it stays where it is)
+            dest[p] = p;
+            continue;
+          }
+          const uint32_t k = ord_bits(coord(p, a));
+          uint32_t lo = p, hi = p + 1;
+          while (lo > 0 && p - lo < SHORT_RUN && ord_bits(coord(lo - 1, a)) == k) --lo;
+          while (hi < l0 && hi - p <= SHORT_RUN && ord_bits(coord(hi, a)) == k) ++hi;
+          if (p - lo >= SHORT_RUN || hi - p > SHORT_RUN) long_runs = 1u;  // (benign race: every writer stores 1)
+          const LKey me = lkey_at(p, d);
+          uint32_t rnk = 0;
+          for (uint32_t q = lo; q < hi; ++q) rnk += lkey_less(lkey_at(q, d), me) ? 1u : 0u;
+          dest[p] = lo + rnk;
+        }
+      }
+      __syncthreads();
+      A3D_NW_STAMP(39, long_runs);  // short runs ranked
+      // (no two equal keys in the range — ordinary data —: every point already stands where L_d puts it, nothing to move)
+      const bool reorder = ties;
       if (long_runs) {
         // long runs of equal keys (a cloud from a depth image: thousands of points share a quantised z): the whole range
         // once more through the network, on the 128-bit words of L_d, instead of run-length-squared counting
@@ -1080,25 +1266,29 @@ __global__ void __launch_bounds__(SLOTS / 4)
         for (uint32_t q = threadIdx.x; q < l0; q += THREADS) dest[pay[q]] = q;  // the point that stood at pay[q] goes to q
         __syncthreads();
       }
-      float4 mv[4];
-#pragma unroll
-      for (uint32_t e = 0; e < 4; ++e) {
-        const uint32_t p = threadIdx.x + e * THREADS;
-        if (p < l0) mv[e] = rec[p];
+      if (reorder) {  // (block-uniform)
+        const uint32_t q0 = threadIdx.x, q1 = q0 + THREADS, q2 = q1 + THREADS, q3 = q2 + THREADS;
+        const float4 v0 = rec[q0 < l0 ? q0 : 0u], v1 = rec[q1 < l0 ? q1 : 0u], v2 = rec[q2 < l0 ? q2 : 0u], v3 = rec[q3 < l0 ? q3 : 0u];
+        __syncthreads();
+        if (q0 < l0) rec[dest[q0]] = v0;
+        if (q1 < l0) rec[dest[q1]] = v1;
+        if (q2 < l0) rec[dest[q2]] = v2;
+        if (q3 < l0) rec[dest[q3]] = v3;
+        __syncthreads();
       }
+      A3D_NW_STAMP(43, reorder);  // tied points in place
+    }
+    if (entry) {  // (the long-run path's 128-bit words lie over pm: the identity again before the first permuting level)
+      for (uint32_t p = threadIdx.x; p < SLOTS; p += THREADS) pm[p] = (uint16_t)p;
       __syncthreads();
-#pragma unroll
-      for (uint32_t e = 0; e < 4; ++e) {
-        const uint32_t p = threadIdx.x + e * THREADS;
-        if (p < l0) rec[dest[p]] = mv[e];
-      }
-      __syncthreads();
+      A3D_NW_STAMP(35, d);  // entry level: runs of equal keys ordered
     }
     if (d >= d0 && sorted) {
       const uint32_t mid = lc >> 1;
-      if (mid >= pos0 && mid < pos0 + 4) split[((1u << d) - 1u) + (node0 << rel) + cell] = coord(rs + mid, a);  // points[mid][k] (kdtree.rs:47-49)
+      if (mid >= pos0 && mid < pos0 + 4) split[((1u << d) - 1u) + (node0 << rel) + cell] = coord(pm[rs + mid], a);  // points[mid][k] (kdtree.rs:47-49)
     }
   }
+  A3D_NW_STAMP(36, 0);  // all levels done
   // leaves: slot r of the leaf reached by `path` at depth `depth` lives at (path << (D - depth)) * 16 + r (kdtree.hpp)
   for (uint32_t p = threadIdx.x; p < l0; p += THREADS) {
     uint32_t rs = 0, rl = l0, path = node0, depth = d0;
@@ -1109,26 +1299,35 @@ __global__ void __launch_bounds__(SLOTS / 4)
       ++depth;
     }
     const uint32_t slot = (path << (D - depth)) * 16u + (p - rs);
-    const float4 r = rec[p];
+    const float4 r = rec[pm[p]];
     leaves[slot] = r;
     slot_of_point[__float_as_uint(r.w)] = slot;
   }
   // +inf in the slots no point took, 0 in the split entries of this subtree's nodes that are leaves at depth D - 1
+  // (how many slots of each of the subtree's 2^sub leaf positions are taken: once per leaf position into the network's
+  // buffer, free by now, instead of a walk from the root for each of its sixteen slots)
   const uint32_t sub = D - d0, first_leaf = node0 << sub;
-  for (uint32_t q = threadIdx.x; q < (16u << sub); q += THREADS) {
-    const uint32_t P = first_leaf + (q >> 4), r = q & 15u;
-    bool used;
+  uint32_t* taken = (uint32_t*)xw;
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < (1u << sub); q += THREADS) {
+    const uint32_t P = first_leaf + q;
+    uint32_t cnt;
     if (D == 0) {
-      used = r < n;
+      cnt = n < 16u ? n : 16u;
     } else {
       uint32_t ps, pl;
       bool pe;
       sel_node_range(n, D - 1, P >> 1, &ps, &pl, &pe);  // (every node of depth D - 1 exists: leaves sit at D - 1 or D)
-      if (pl <= 16) used = (P & 1u) == 0u && r < pl;      // a leaf at depth D - 1 fills the even child's slots
-      else used = r < ((P & 1u) ? pl - (pl >> 1) : (pl >> 1));
+      if (pl <= 16) cnt = (P & 1u) == 0u ? pl : 0u;       // a leaf at depth D - 1 fills the even child's slots
+      else cnt = (P & 1u) ? pl - (pl >> 1) : (pl >> 1);
     }
-    if (!used) leaves[(size_t)first_leaf * 16u + q] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f);
+    taken[q] = cnt;
   }
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < (16u << sub); q += THREADS)
+    if ((q & 15u) >= taken[q >> 4])
+      leaves[(size_t)first_leaf * 16u + q] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f);
+  A3D_NW_STAMP(37, 0);  // leaves, slot_of_point and padding written
   if (D >= 1 && D - 1 >= d0) {
     const uint32_t subm = D - 1 - d0;
     for (uint32_t q = threadIdx.x; q < (1u << subm); q += THREADS) {
@@ -1648,10 +1847,10 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
                        recs[(d + 1) & 1], n, d, L.nb[d], nb_next, plans + off, boxes + off, plans + (2 * nodes - 1u),
                        boxes + (2 * nodes - 1u), hist[(d + 1) & 1], t->d_split, flags, cap_d, wide_d, whist);
   }
-  // the in-block levels by the sorting network with its words in LDS (measured fastest: DESIGN.md); diagnostics build:
-  // A3D_KDTREE_SORTNET=regs (its words in registers and lane exchanges) / =select (selection inside the block): the cross-checks
-  int net = 1;
-  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_SORTNET")) net = !strcmp(env, "regs") ? 2 : (!strcmp(env, "select") ? 0 : 1);
+  // the in-block levels by the sorting network with its words in registers (measured fastest: DESIGN.md §5); diagnostics build:
+  // A3D_KDTREE_SORTNET=lds (its words in LDS, the product of round 5) / =select (selection inside the block): the cross-checks
+  int net = 2;
+  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_SORTNET")) net = !strcmp(env, "lds") ? 1 : (!strcmp(env, "select") ? 0 : 2);
 #define A3D_NARROW_LAUNCH(SLOTS, REGS)                                                                                  \
   hipLaunchKernelGGL((sel_narrow_kernel<SLOTS, REGS>), dim3(1u << W), dim3(SLOTS / 4), nw_lds_bytes<SLOTS>(), s, recs[W & 1], n, \
                      W, D, t->d_split, t->d_leaves, t->d_slot_of_point, flags)

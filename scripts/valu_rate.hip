@@ -61,6 +61,32 @@ OPS(dep_fma_f32, float a0 = 1.0f + 1e-6f * (seed + threadIdx.x); float a1 = 1.00
     asm volatile("v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %0, %0, %1, %1" : "+v"(a0) : "v"(a1));)
 OPS(dep_cvt_f32_f64, double a0 = 1.0 + 1e-9 * (seed + threadIdx.x); float a1 = 0.f,
     asm volatile("v_cvt_f32_f64 %1, %0\n v_cvt_f64_f32 %0, %1\n v_cvt_f32_f64 %1, %0\n v_cvt_f64_f32 %0, %1" : "+v"(a0), "+v"(a1));)
+
+// ---- round 6, kd-tree network: what a 64-bit compare-exchange is made of -------------------------------------------------
+#undef SINK
+#define SINK out[1 + (threadIdx.x & 0)] += (u64)a0 + (u64)a1 + (u64)a2 + (u64)a3 + (u64)c0;
+OPS(cmp_lt_u64, u64 a0 = seed + threadIdx.x; u64 a1 = a0 * 3; u64 a2 = a0 * 5; u64 a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_cmp_lt_u64 vcc, %0, %1\n v_cmp_lt_u64 vcc, %1, %2\n v_cmp_lt_u64 vcc, %2, %3\n v_cmp_lt_u64 vcc, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");)
+OPS(cmp_lt_u32, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");)
+// compare -> select on the mask (VALU writes vcc, VALU reads it)
+OPS(cmp64_cnd, u64 a0 = seed + threadIdx.x; u64 a1 = a0 * 3; u64 a2 = a0 * 5; u64 a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_cmp_lt_u64 vcc, %0, %1\n v_cndmask_b32 %4, %4, %4, vcc\n v_cmp_lt_u64 vcc, %2, %3\n v_cndmask_b32 %4, %4, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0) : : "vcc");)
+// compare -> SALU xor with a direction mask -> select (what `if ((hi < lo) == up) swap` compiles to)
+OPS(cmp64_xor_cnd, u64 a0 = seed + threadIdx.x; u64 a1 = a0 * 3; u64 a2 = a0 * 5; u64 a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_cmp_lt_u64 vcc, %0, %1\n s_xor_b64 vcc, vcc, exec\n s_nop 0\n v_cndmask_b32 %4, %4, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0) : : "vcc", "scc");)  // (s_xor writes SCC: the loop's own s_cmp lives there)
+// the same decision from the borrow of a 64-bit subtraction (two full-rate instructions?)
+OPS(sub_borrow, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_sub_co_u32 %4, vcc, %0, %1\n v_subb_co_u32 %4, vcc, %2, %3, vcc\n v_sub_co_u32 %4, vcc, %1, %0\n v_subb_co_u32 %4, vcc, %3, %2, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0) : : "vcc");)
+OPS(cndmask, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");)
+OPS(permlane16_swap, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+OPS(permlane32_swap, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+// DPP read of a register a VALU instruction has just written (the hazard the compiler pads with s_nop 1)
+OPS(dpp_after_write, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned c0 = 0,
+    asm volatile("v_add_u32 %0, %0, %1\n s_nop 1\n v_mov_b32_dpp %2, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_u32 %1, %1, %2" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
 #define RUN(name, per)                                                                                   \
   for (int waves = 1; waves <= 4; waves *= 4) {                                                          \
     hipLaunchKernelGGL(k_##name, dim3(1), dim3(256 * waves), 0, 0, d, 1u);                                \
@@ -68,14 +94,20 @@ OPS(dep_cvt_f32_f64, double a0 = 1.0 + 1e-9 * (seed + threadIdx.x); float a1 = 0
     hipMemcpy(h.data(), d, 16, hipMemcpyDeviceToHost);                                                   \
     printf("%-14s %d wave(s)/SIMD: %.2f cycles per instruction per wave (shader clock counter)\n", #name, waves, (double)h[0] / (REP * 8.0 * per) * 1.0); \
   }
-int main() {
+int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  const bool only_new = argc > 1;  // ./valu_rate cmp: the round-6 kd-tree additions only
   u64* d;
   hipMalloc(&d, 1024);
   hipMemset(d, 0, 1024);
   std::vector<u64> h(2);
+  if (!only_new) {
   RUN(add_u32, 4) RUN(lshl_add_u32, 4) RUN(lshl_add_u64, 4) RUN(add_f32, 4) RUN(add_f64, 4) RUN(mul_f64, 4) RUN(fma_f64, 4) RUN(rcp_f64, 4)
   RUN(cvt_f64_u32, 4) RUN(cvt_u32_f64, 4) RUN(cvt_f32_u32, 4) RUN(mov_dpp, 4) RUN(add_dpp, 4)
   printf("dependent chains (latency per instruction):\n");
   RUN(dep_fma_f32, 4) RUN(dep_fma_f64, 4) RUN(dep_mul_f64, 4) RUN(dep_rsq_f64, 4) RUN(dep_cvt_f32_f64, 4)
+  }
+  printf("64-bit compare-exchange parts (kd-tree network):\n");
+  RUN(cmp_lt_u64, 4) RUN(cmp_lt_u32, 4) RUN(cmp64_cnd, 4) RUN(cmp64_xor_cnd, 4) RUN(sub_borrow, 4) RUN(cndmask, 4) RUN(permlane16_swap, 4) RUN(permlane32_swap, 4) RUN(dpp_after_write, 4)
   return 0;
 }

@@ -106,7 +106,7 @@ _KD_BUILDS = {
     "select_narrow32": {"A3D_KDTREE_NARROW_LEN": "32", "A3D_KDTREE_WIDE_PLACE": "0"},
     "select_narrow64": {"A3D_KDTREE_NARROW_LEN": "64", "A3D_KDTREE_WIDE_PLACE": "0"},
     "select_narrow512": {"A3D_KDTREE_NARROW_LEN": "512", "A3D_KDTREE_WIDE_PLACE": "0"},
-    "select_regs": {"A3D_KDTREE_SORTNET": "regs"},  # the in-block levels by the sorting network, its words in registers / lane exchanges
+    "select_lds": {"A3D_KDTREE_SORTNET": "lds"},  # the in-block levels by the sorting network with its words in LDS (the product keeps them in registers: round 6)
     "select_inblock": {"A3D_KDTREE_SORTNET": "select"},  # ... by selection inside the block (slower: a cross-check)
     "select_inblock_narrow64": {"A3D_KDTREE_SORTNET": "select", "A3D_KDTREE_NARROW_LEN": "64", "A3D_KDTREE_WIDE_PLACE": "0"},
     "select_place": {"A3D_KDTREE_WIDE_PLACE": "1"},
@@ -176,7 +176,7 @@ def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monke
     median under the closed-form order L_d + an unordered partition; the last levels sorted in LDS) against the sorting
     build (one stable sort per level) against rocPRIM's sorts against the host."""
     db = _kd_cases()[case]
-    if case == "n270213" and build not in ("select", "select_narrow512", "select_regs", "select_inblock", "select_place_cap64", "sorted", "sorted_rocprim"):
+    if case == "n270213" and build not in ("select", "select_narrow512", "select_lds", "select_inblock", "select_place_cap64", "sorted", "sorted_rocprim"):
         pytest.skip("the large case runs on the default borders only")
     host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
     dev = _build(diag_ctx, db, _KD_BUILDS[build], monkeypatch)
@@ -210,7 +210,7 @@ def test_kdtree_pairs_of_equal_coordinates_at_every_entry_axis(ctx, diag_ctx, mo
         db[2 * i + 1, axis] = db[2 * i, axis]
     host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
     hs, hl = host.download()
-    for c, env in ((ctx, {}), (diag_ctx, _KD_BUILDS["select_regs"]), (diag_ctx, _KD_BUILDS["select_inblock"]), (diag_ctx, _KD_BUILDS["select_narrow512"]),
+    for c, env in ((ctx, {}), (diag_ctx, _KD_BUILDS["select_lds"]), (diag_ctx, _KD_BUILDS["select_inblock"]), (diag_ctx, _KD_BUILDS["select_narrow512"]),
                    (diag_ctx, {"A3D_KDTREE_NARROW_LEN": "1024", "A3D_KDTREE_BUCKETS": "256"})):
         t = _build(c, db, env, monkeypatch)
         s_, l_ = t.download()
