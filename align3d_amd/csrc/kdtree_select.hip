@@ -66,6 +66,10 @@ constexpr uint32_t NSUB = 1024;        // finer buckets inside the median bucket
 constexpr uint32_t K1_THREADS = 512, K1_ROUNDS = 4, K1_TILE = K1_THREADS * K1_ROUNDS;
 constexpr uint32_t K2_THREADS = 1024;
 constexpr uint32_t PACK_THREADS = 256, PACK_ROUNDS = 4, PACK_TILE = PACK_THREADS * PACK_ROUNDS;
+#ifndef A3D_CURSOR_STRIDE
+#define A3D_CURSOR_STRIDE 32
+#endif
+constexpr uint32_t CURSOR_STRIDE = A3D_CURSOR_STRIDE;  // words between two of a level's place counters (node, class): each on its own 128-byte line
 
 enum : uint32_t { FLAG_NAN = 0, FLAG_OVERSIZED = 1 };  // words of the flag table the host reads back after the build
 
@@ -359,7 +363,7 @@ __global__ void __launch_bounds__(K1_THREADS)
       if (lane >= (uint32_t)off) incl += up;
     }
     if (lane < ENTRIES) wcnt[w][lane] = incl - v;
-    if (lane == 63 && incl) reserved = atomicAdd(&cursors[node * 4 + w], incl);
+    if (lane == 63 && incl) reserved = atomicAdd(&cursors[(node * 4 + w) * CURSOR_STRIDE], incl);
   }
   if (oversized) {  // the median bucket's points, one step finer (see SelWide)
     const uint32_t ap = (level + 2) % 3;
@@ -1752,7 +1756,7 @@ SelLayout sel_layout(uint32_t n, uint32_t narrow_len, uint32_t wide_cap) {
   L.partials = off, off += pad((size_t)L.pack_blocks * 6 * sizeof(float));
   L.zero_begin = off;
   L.flags = off, off += 256;
-  L.cursors = off, off += pad(nodes * 4 * sizeof(uint32_t));
+  L.cursors = off, off += pad(nodes * 4 * CURSOR_STRIDE * sizeof(uint32_t));
   L.hist_words = hist_words;
   L.hist = off, off += pad(2 * hist_words * sizeof(uint32_t));
   L.wide = off, off += pad(((size_t)1 << L.place_levels) * sizeof(SelWide));  // heap-indexed over the levels that can hold one
@@ -1837,7 +1841,7 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
     SelWide* wide_d = wide + (placing ? off : 0u);
     hipLaunchKernelGGL(sel_split_kernel, dim3(nodes * bpn), dim3(K1_THREADS),
                        (2 * nb_next + (placing ? 2 * NSUB : 0u)) * sizeof(uint32_t), s, recs[d & 1], recs[(d + 1) & 1], mid, n,
-                       d, bpn, L.nb[d], nb_next, plans + off, boxes + off, cursors + 4 * (size_t)off, hist[(d + 1) & 1], flags,
+                       d, bpn, L.nb[d], nb_next, plans + off, boxes + off, cursors + 4 * (size_t)off * CURSOR_STRIDE, hist[(d + 1) & 1], flags,
                        cap_d, wide_d, whist);
     if (placing)
       hipLaunchKernelGGL(sel_place_kernel, dim3(nodes * bpn), dim3(K1_THREADS), 2 * nb_next * sizeof(uint32_t), s, mid,
