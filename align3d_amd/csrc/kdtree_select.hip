@@ -157,15 +157,57 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
   return before + incl - v;
 }
 
-// Which of the `nb` <= 2 * THREADS buckets of `h` (LDS) holds rank `rank`: bucket b with  below(b) <= rank < below(b) + h[b].
-// Every thread of the block calls it; the one that owns the bucket writes *out.
+// Which of the `nb` <= NB_MAX buckets of `h` (LDS) holds rank `rank`: bucket b with  below(b) <= rank < below(b) + h[b].
+// Every thread of the block calls it (NB_MAX / THREADS consecutive buckets each); the one that owns the bucket writes *out.
 template <uint32_t THREADS>
 __device__ __forceinline__ void plan_from_hist(const uint32_t* h, uint32_t nb, uint32_t rank, SelPlan* out, uint32_t* tmp) {
-  const uint32_t b0 = 2 * threadIdx.x;
-  const uint32_t v0 = b0 < nb ? h[b0] : 0u, v1 = b0 + 1 < nb ? h[b0 + 1] : 0u;
-  const uint32_t ex = block_exclusive_scan<THREADS>(v0 + v1, tmp);
-  if (ex <= rank && rank < ex + v0) *out = SelPlan{b0, ex, v0, 0u};
-  else if (ex + v0 <= rank && rank < ex + v0 + v1) *out = SelPlan{b0 + 1, ex + v0, v1, 0u};
+  constexpr uint32_t PER = 2048 / THREADS;
+  static_assert(PER * THREADS == 2048 && PER >= 1, "NB_MAX buckets over the block");
+  const uint32_t b0 = PER * threadIdx.x;
+  uint32_t v[PER], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; ++k) v[k] = b0 + k < nb ? h[b0 + k] : 0u, sum += v[k];
+  uint32_t ex = block_exclusive_scan<THREADS>(sum, tmp);
+#pragma unroll
+  for (uint32_t k = 0; k < PER; ++k) {
+    if (ex <= rank && rank < ex + v[k]) *out = SelPlan{b0 + k, ex, v[k], 0u};
+    ex += v[k];
+  }
+}
+
+// The same for two tables at once (a node's two children): the two running sums travel as the halves of one 64-bit word
+// (each stays below 2^32: at most n points), one block scan instead of two.  `tmp64` >= 16 words of 64 bits.
+template <uint32_t THREADS>
+__device__ __forceinline__ void plans_from_two_hists(const uint32_t* h0, const uint32_t* h1, uint32_t nb, uint32_t rank0, uint32_t rank1,
+                                                     SelPlan* out0, SelPlan* out1, unsigned long long* tmp64) {
+  constexpr uint32_t PER = 2048 / THREADS;
+  const uint32_t b0 = PER * threadIdx.x, lane = lane_id(), w = threadIdx.x >> 6;
+  uint32_t v0[PER], v1[PER];
+  unsigned long long sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; ++k) {
+    v0[k] = b0 + k < nb ? h0[b0 + k] : 0u, v1[k] = b0 + k < nb ? h1[b0 + k] : 0u;
+    sum += ((unsigned long long)v1[k] << 32) | v0[k];
+  }
+  unsigned long long incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
+    if (lane >= (uint32_t)off) incl += up;
+  }
+  __syncthreads();  // tmp64 may still be read from a previous call
+  if (lane == 63) tmp64[w] = incl;
+  __syncthreads();
+  unsigned long long before = 0;
+  for (uint32_t ww = 0; ww < w; ++ww) before += tmp64[ww];
+  const unsigned long long ex = before + incl - sum;
+  uint32_t e0 = (uint32_t)ex, e1 = (uint32_t)(ex >> 32);
+#pragma unroll
+  for (uint32_t k = 0; k < PER; ++k) {
+    if (e0 <= rank0 && rank0 < e0 + v0[k]) *out0 = SelPlan{b0 + k, e0, v0[k], 0u};
+    if (e1 <= rank1 && rank1 < e1 + v1[k]) *out1 = SelPlan{b0 + k, e1, v1[k], 0u};
+    e0 += v0[k], e1 += v1[k];
+  }
 }
 
 // ---- records {x, y, z, index bits} + per-block bounds -------------------------------------------------------------
@@ -296,13 +338,33 @@ __device__ __forceinline__ uint32_t wide_sub_plan(const SelWide* wide, const uin
 }
 
 // ---- wide levels: route every point of a node below / into / above the bucket of its median -----------------------
+template <uint32_t THREADS, bool FOREIGN>
+__device__ __forceinline__ void resolve_node(unsigned char* smem, uint32_t node, float4* __restrict__ midbuf, float4* __restrict__ spare,
+                                             float4* __restrict__ rout, uint32_t n, uint32_t level, uint32_t nb, uint32_t nb_next,
+                                             const SelPlan plan, const SelBox box,
+                                             SelPlan* __restrict__ plans_next, SelBox* __restrict__ boxes_next, uint32_t* __restrict__ hist_next,
+                                             float* __restrict__ split, uint32_t* __restrict__ flags, uint32_t wide_cap, SelWide* __restrict__ wide,
+                                             uint32_t* __restrict__ whist);
+__device__ __forceinline__ void store_rec_agent(float4* p, const float4& r);
+
+// FUSED (round 6): the node's resolve step runs in the LAST of the node's blocks to finish instead of in a launch of its own —
+// a launch per level less (8 of the 21 of a 500 k build, ~4 us each of launch and first-touch latency for 3 us of work).  The
+// hand-over needs no L2 write-back: what the resolve step reads from other blocks — the side buffer's points, the children's
+// histograms — is written with agent-scope stores / memory-side atomics, every thread waits for its own to be acknowledged
+// (s_waitcnt), and only then the block takes its ticket (the fourth, otherwise unused, place counter of the node).
+#ifdef A3D_TAIL_STAMPS
+extern __device__ unsigned long long g_sel_stamps[64];
+extern __device__ uint32_t g_sel_stamp_level, g_sel_stamp_node;
+#endif
+template <bool FUSED>
 __global__ void __launch_bounds__(K1_THREADS)
-    sel_split_kernel(const float4* __restrict__ rin, float4* __restrict__ rout, float4* __restrict__ midbuf, uint32_t n,
+    sel_split_kernel(const float4* rin, float4* __restrict__ rout, float4* __restrict__ midbuf, uint32_t n,
                      uint32_t level, uint32_t blocks_per_node, uint32_t nb, uint32_t nb_next,
                      const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes, uint32_t* __restrict__ cursors,
                      uint32_t* __restrict__ hist_next, uint32_t* __restrict__ flags, uint32_t wide_cap,
-                     SelWide* __restrict__ wide, uint32_t* __restrict__ whist) {
-  extern __shared__ uint32_t h[];  // [2][nb_next]: the two children's histograms along the next axis; oversized: + [2][NSUB]
+                     SelWide* __restrict__ wide, uint32_t* __restrict__ whist, SelPlan* __restrict__ plans_next,
+                     SelBox* __restrict__ boxes_next, float* __restrict__ split) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t h[];  // [2][nb_next]: the two children's histograms along the next axis; oversized: + [2][NSUB]; FUSED: the resolve step's buffers afterwards
   __shared__ uint32_t w_mm[2];
   __shared__ uint32_t wcnt[3][K1_ROUNDS * (K1_THREADS / 64)];  // per class: (round, wave) counts, then exclusive prefixes
   __shared__ uint32_t base[3];
@@ -312,6 +374,9 @@ __global__ void __launch_bounds__(K1_THREADS)
   sel_node_range(n, level, node, &s, &l, &exists);
   const uint32_t tile_lo = part * K1_TILE;
   if (tile_lo >= l) return;
+#ifdef A3D_TAIL_STAMPS  // (scripts/sel_stamps.py: when the node's first block started, when its last block took the ticket)
+  if (FUSED && threadIdx.x == 0 && part == 0 && level == g_sel_stamp_level && node == g_sel_stamp_node) g_sel_stamps[60] = __builtin_amdgcn_s_memrealtime();
+#endif
   const SelPlan plan = plans[node];
   const SelBox box = boxes[node];
   const uint32_t a = level % 3, a2 = (level + 1) % 3;
@@ -414,7 +479,25 @@ __global__ void __launch_bounds__(K1_THREADS)
     const uint32_t off = base[cls[k]] + wcnt[cls[k]][k * (K1_THREADS / 64) + w] + rank[k];
     if (cls[k] == 0u) rout[s + off] = r[k];
     else if (cls[k] == 2u) rout[s + l - 1u - off] = r[k];
+    else if (FUSED) store_rec_agent(&midbuf[s + off], r[k]);
     else midbuf[s + off] = r[k];
+  }
+  if (FUSED) {
+    __shared__ uint32_t is_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this thread's stores and atomics have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t blocks_of_node = (l + K1_TILE - 1) / K1_TILE;  // (the launch's other blocks of the node left at once)
+      is_last = __hip_atomic_fetch_add(&cursors[(node * 4 + 3) * CURSOR_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == blocks_of_node - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+#ifdef A3D_TAIL_STAMPS
+    if (threadIdx.x == 0 && level == g_sel_stamp_level && node == g_sel_stamp_node) g_sel_stamps[61] = __builtin_amdgcn_s_memrealtime();
+#endif
+    resolve_node<K1_THREADS, true>((unsigned char*)h, node, midbuf, const_cast<float4*>(rin), rout, n, level, nb, nb_next, plan, box, plans_next,
+                                   boxes_next, hist_next, split, flags, wide_cap, wide, whist);
   }
 }
 
@@ -525,7 +608,13 @@ __device__ __forceinline__ bool lkey_less(const LKey& p, const LKey& q) {  // (b
   return (ph < qh) | ((ph == qh) & (pl < ql));
 }
 
-constexpr uint32_t RANK_SMALL = 64;  // a tied set this small is ranked by brute force (count the smaller ones)
+// (p, q as 128-bit numbers, x the most significant word; branch-free: a chain of `?:` compiles to a ladder of divergent branches)
+__device__ __forceinline__ bool lt128(const uint4& p, const uint4& q) {
+  const unsigned long long ph = ((unsigned long long)p.x << 32) | p.y, pl = ((unsigned long long)p.z << 32) | p.w;
+  const unsigned long long qh = ((unsigned long long)q.x << 32) | q.y, ql = ((unsigned long long)q.z << 32) | q.w;
+  return (ph < qh) | ((ph == qh) & (pl < ql));
+}
+constexpr uint32_t RANK_SMALL = 128;  // a set this small is ranked by brute force (count the smaller ones)
 constexpr size_t K2_LDS_BYTES = MIDDLE_CAP * sizeof(float4) + 2 * MIDDLE_CAP * sizeof(uint16_t) + (NSUB + 2 * NB_MAX) * sizeof(uint32_t);
 
 __device__ __forceinline__ uint32_t lkey_comp(const float4& r, uint32_t level, uint32_t c) {
@@ -572,23 +661,36 @@ __device__ uint32_t g_nw_phase_n;
 // whose points all agree in a component moves on to the next one; the original index, unique, ends it) — first from
 // global memory while it is larger than the block's LDS (a degenerate cloud: thousands of equal or nearly equal
 // coordinates), then in LDS; the last <= 64 candidates are ranked by brute force.  Exact for every input.
-__global__ void __launch_bounds__(K2_THREADS)
-    sel_resolve_kernel(float4* __restrict__ midbuf, float4* __restrict__ spare, float4* __restrict__ rout, uint32_t n,
-                       uint32_t level, uint32_t nb, uint32_t nb_next, const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes,
-                       SelPlan* __restrict__ plans_next, SelBox* __restrict__ boxes_next, uint32_t* __restrict__ hist_next,
-                       float* __restrict__ split, uint32_t* __restrict__ flags, uint32_t wide_cap, SelWide* __restrict__ wide,
-                       uint32_t* __restrict__ whist) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// FOREIGN: the caller is the LAST block of the node's split launch (sel_split_kernel<true>) — the side buffer and the children's
+// histograms were written by other blocks of the same launch, possibly through another XCD's L2: they are read with agent-scope
+// loads (the writers used agent-scope stores and memory-side atomics, and handed over through the node's ticket).
+__device__ __forceinline__ float4 load_rec_agent(const float4* p) {
+  const float* f = (const float*)p;
+  return make_float4(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                     __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void store_rec_agent(float4* p, const float4& r) {
+  float* f = (float*)p;
+  __hip_atomic_store(f, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(f + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(f + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_store(f + 3, r.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <uint32_t THREADS, bool FOREIGN>
+__device__ __forceinline__ void resolve_node(unsigned char* smem, uint32_t node, float4* __restrict__ midbuf, float4* __restrict__ spare,
+                                             float4* __restrict__ rout, uint32_t n, uint32_t level, uint32_t nb, uint32_t nb_next,
+                                             const SelPlan plan, const SelBox box,
+                                             SelPlan* __restrict__ plans_next, SelBox* __restrict__ boxes_next, uint32_t* __restrict__ hist_next,
+                                             float* __restrict__ split, uint32_t* __restrict__ flags, uint32_t wide_cap, SelWide* __restrict__ wide,
+                                             uint32_t* __restrict__ whist) {
   float4* rec = (float4*)smem;                         // [MIDDLE_CAP] the candidates once they fit
   uint16_t* list_a = (uint16_t*)(rec + MIDDLE_CAP);    // [MIDDLE_CAP] the current candidate set (indices into rec) ...
   uint16_t* list_b = list_a + MIDDLE_CAP;              // ... and the next
   uint32_t* hsub = (uint32_t*)(list_b + MIDDLE_CAP);   // [NSUB] histogram of a round
   uint32_t* hchild = hsub + NSUB;                      // [2][nb_next] the children's histograms along the next axis
   __shared__ uint32_t tmp[16];
+  __shared__ unsigned long long tmp64[16];
   __shared__ SelPlan sub_plan;
   __shared__ uint32_t n_left, n_right, n_keep, s_mn, s_mx;
   __shared__ float split_raw;
-  const uint32_t node = blockIdx.x;
 #ifdef A3D_TAIL_STAMPS
   uint32_t n_stamp = 0;
 #endif
@@ -596,13 +698,35 @@ __global__ void __launch_bounds__(K2_THREADS)
   bool exists;
   sel_node_range(n, level, node, &s, &l, &exists);
   const uint32_t mid = l >> 1;
-  const SelPlan plan = plans[node];
   A3D_SEL_STAMP(0, plan.count);
-  const SelBox box = boxes[node];
   const uint32_t a = level % 3, a2 = (level + 1) % 3;
   const float lo_a2 = pick3(box.lo, a2), hi_a2 = pick3(box.hi, a2);
   uint32_t* g = hist_next + (size_t)(2 * node) * nb_next;
-  for (uint32_t q = threadIdx.x; q < 2 * nb_next; q += K2_THREADS) hchild[q] = g[q], g[q] = 0u;  // (zeroed for level + 2)
+  // FOREIGN: the side buffer's first points (all of them, on ordinary data: a bucket holds a few hundred) are fetched next to
+  // the histograms instead of a memory round trip later
+  constexpr uint32_t PRE = 2;
+  float4 pre[PRE];
+  if (FOREIGN) {
+#pragma unroll
+    for (uint32_t k = 0; k < PRE; ++k) {
+      const uint32_t i = threadIdx.x + k * THREADS;
+      pre[k] = i < plan.count && plan.count <= MIDDLE_CAP ? load_rec_agent(midbuf + s + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  {  // (all of the thread's loads in flight at once: as a loop of load -> store pairs the agent-scope loads went one memory round trip at a time)
+    constexpr uint32_t PER = 2 * NB_MAX / THREADS;
+    uint32_t v[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t q = threadIdx.x + k * THREADS;
+      v[k] = q < 2 * nb_next ? (FOREIGN ? __hip_atomic_load(g + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g[q]) : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t q = threadIdx.x + k * THREADS;
+      if (q < 2 * nb_next) hchild[q] = v[k], g[q] = 0u;  // (zeroed for level + 2)
+    }
+  }
   if (threadIdx.x == 0) n_left = 0u, n_right = 0u;
   __syncthreads();
   float4* left_out = rout + s + plan.below;  // behind the points the split kernel put at the left end
@@ -618,7 +742,7 @@ __global__ void __launch_bounds__(K2_THREADS)
     if (threadIdx.x == 0) s_mn = ~0u, s_mx = 0u;
     __syncthreads();
     uint32_t mn = ~0u, mx = 0u;
-    for (uint32_t i = threadIdx.x; i < cnt; i += K2_THREADS) {
+    for (uint32_t i = threadIdx.x; i < cnt; i += THREADS) {
       const uint32_t k = lkey_comp(fetch(i), level, cmp);
       mn = min(mn, k), mx = max(mx, k);
     }
@@ -637,12 +761,12 @@ __global__ void __launch_bounds__(K2_THREADS)
     return [=](const float4& r) { return (lkey_comp(r, level, cmp) - mn) >> sh; };
   };
   auto round = [&](auto fetch, auto keep, uint32_t cnt, auto bucket, uint32_t t) {
-    for (uint32_t q = threadIdx.x; q < NSUB; q += K2_THREADS) hsub[q] = 0u;
+    for (uint32_t q = threadIdx.x; q < NSUB; q += THREADS) hsub[q] = 0u;
     if (threadIdx.x == 0) n_keep = 0u;
     __syncthreads();
     // (a set with few distinct keys — a quantised coordinate — puts whole waves into one bucket: an LDS atomic per lane
     // on one address is 64 serial operations; the lanes that share the first lane's bucket add as one)
-    for (uint32_t i0 = 0; i0 < cnt; i0 += K2_THREADS) {
+    for (uint32_t i0 = 0; i0 < cnt; i0 += THREADS) {
       const uint32_t i = i0 + threadIdx.x;
       const bool valid = i < cnt;
       const uint32_t b = valid ? bucket(fetch(i)) : 0u;
@@ -655,14 +779,14 @@ __global__ void __launch_bounds__(K2_THREADS)
       else if (valid && b != bl) atomicAdd(&hsub[b], 1u);
     }
     __syncthreads();
-    plan_from_hist<K2_THREADS>(hsub, NSUB, t, &sub_plan, tmp);
+    plan_from_hist<THREADS>(hsub, NSUB, t, &sub_plan, tmp);
     __syncthreads();
     const uint32_t star = sub_plan.bucket;
     // places are handed out per WAVE (three ballots, one LDS atomic per class and wave-iteration, the lane's rank from
     // the ballot) instead of one atomic per point on three shared counters
     const uint32_t lane = lane_id();
     const unsigned long long lower = (1ull << lane) - 1ull;
-    for (uint32_t i0 = 0; i0 < cnt; i0 += K2_THREADS) {  // (block-uniform trip count)
+    for (uint32_t i0 = 0; i0 < cnt; i0 += THREADS) {  // (block-uniform trip count)
       const uint32_t i = i0 + threadIdx.x;
       const bool valid = i < cnt;
       const float4 r = valid ? fetch(i) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -690,20 +814,22 @@ __global__ void __launch_bounds__(K2_THREADS)
   float4* src = midbuf + s;
   float4* dst = spare + s;
   bool fresh = true;  // nothing has narrowed the set yet
+  bool untouched = true;  // `src` still is the side buffer as the split launch's blocks wrote it
   if (c > wide_cap) {
     fresh = false;  // sel_place_kernel has placed all but one finer bucket of the set: that bucket is in `spare`
-    const uint32_t which = wide_sub_plan<K2_THREADS>(wide, whist, node, t, hsub, &sub_plan, tmp);
+    const uint32_t which = wide_sub_plan<THREADS>(wide, whist, node, t, hsub, &sub_plan, tmp);
     if (threadIdx.x == 0) n_left = sub_plan.below, n_right = c - sub_plan.below - sub_plan.count;
     t -= sub_plan.below, c = sub_plan.count, cmp = which;
     src = spare + s, dst = midbuf + s;
     uint32_t* g2 = whist + (size_t)node * 2 * NSUB;  // the tables serve the node of this index on the next level too
-    for (uint32_t q = threadIdx.x; q < 2 * NSUB; q += K2_THREADS) g2[q] = 0u;
+    for (uint32_t q = threadIdx.x; q < 2 * NSUB; q += THREADS) g2[q] = 0u;
     __syncthreads();
     A3D_SEL_STAMP(9, c);
   }
   if (c > MIDDLE_CAP && threadIdx.x == 0) atomicOr(&flags[FLAG_OVERSIZED], 1u);  // (the host's cue for sel_place_kernel)
   while (c > MIDDLE_CAP) {
-    auto fetch = [&](uint32_t i) { return src[i]; };
+    const bool foreign = FOREIGN && untouched;  // (the survivors of a round are this block's own stores)
+    auto fetch = [&](uint32_t i) { return foreign ? load_rec_agent(src + i) : src[i]; };
     min_max(fetch, c, cmp);
     A3D_SEL_STAMP(1, c);
     if (s_mn == s_mx) {  // all agree in this component of L_d: the next one decides
@@ -716,9 +842,19 @@ __global__ void __launch_bounds__(K2_THREADS)
     A3D_SEL_STAMP(2, c);
     float4* sw = src;
     src = dst, dst = sw;
+    untouched = false;
   }
   // ---- in LDS
-  for (uint32_t i = threadIdx.x; i < c; i += K2_THREADS) rec[i] = src[i], list_a[i] = (uint16_t)i;
+  if (FOREIGN && untouched) {  // (nothing narrowed from global memory: c = plan.count <= MIDDLE_CAP, the points as the split launch wrote them)
+#pragma unroll
+    for (uint32_t k = 0; k < PRE; ++k) {
+      const uint32_t i = threadIdx.x + k * THREADS;
+      if (i < c) rec[i] = pre[k], list_a[i] = (uint16_t)i;
+    }
+    for (uint32_t i = threadIdx.x + PRE * THREADS; i < c; i += THREADS) rec[i] = load_rec_agent(src + i), list_a[i] = (uint16_t)i;
+  } else {
+    for (uint32_t i = threadIdx.x; i < c; i += THREADS) rec[i] = src[i], list_a[i] = (uint16_t)i;
+  }
   __syncthreads();
   A3D_SEL_STAMP(3, c);
   uint16_t *cur = list_a, *nxt = list_b;
@@ -752,19 +888,31 @@ __global__ void __launch_bounds__(K2_THREADS)
     cur = nxt, nxt = sw;
   }
   A3D_SEL_STAMP(6, c);
-  // exact rank under L_d among the last <= 64 candidates: one wave, a candidate per lane, every other candidate's key
-  // by v_readlane (no LDS round trip per comparison)
-  if (threadIdx.x < 64) {
-    const uint32_t e = threadIdx.x;
-    const float4 r = e < c ? rec[cur[e]] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const LKey ke = lkey_of(r, level);
-    uint32_t rnk = 0;
-    for (uint32_t f = 0; f < c; ++f) {  // (c is block-uniform)
-      const LKey kf{(uint32_t)__builtin_amdgcn_readlane((int)ke.k0, (int)f), (uint32_t)__builtin_amdgcn_readlane((int)ke.k1, (int)f),
-                    (uint32_t)__builtin_amdgcn_readlane((int)ke.k2, (int)f), (uint32_t)__builtin_amdgcn_readlane((int)ke.idx, (int)f)};
-      rnk += lkey_less(kf, ke) ? 1u : 0u;
+  // exact rank under L_d among the last <= RANK_SMALL candidates, by the whole block: PARTS adjacent lanes share a candidate,
+  // each counts the smaller ones among every PARTS-th candidate (keys from LDS, the same address for the lanes of a part:
+  // broadcast reads), the partial counts meet by lane exchange.  (Rounds 5: one wave, a candidate per lane, the others' keys
+  // by v_readlane — 63 candidates took it 4.6 us; a set of 65 .. 128 went through a narrowing round of 2.6 us first.)
+  {
+    constexpr uint32_t PARTS = THREADS / RANK_SMALL;
+    static_assert(PARTS * RANK_SMALL == THREADS && PARTS <= 64 && (PARTS & (PARTS - 1)) == 0, "lanes of a candidate sit in one wave");
+    uint4* keys = (uint4*)hsub;  // (the rounds' table is free now: NSUB words = 256 keys)
+    static_assert(RANK_SMALL * sizeof(uint4) <= NSUB * sizeof(uint32_t), "keys fit the round's table");
+    if (threadIdx.x < c) {
+      const LKey lk = lkey_of(rec[cur[threadIdx.x]], level);
+      keys[threadIdx.x] = make_uint4(lk.k0, lk.k1, lk.k2, lk.idx);
     }
+    __syncthreads();
+    const uint32_t e = threadIdx.x / PARTS, part = threadIdx.x % PARTS;
+    uint32_t rnk = 0;
     if (e < c) {
+      const uint4 me = keys[e];
+      for (uint32_t f = part; f < c; f += PARTS) rnk += lt128(keys[f], me) ? 1u : 0u;
+    }
+#pragma unroll
+    for (uint32_t off = 1; off < PARTS; off <<= 1) rnk += (uint32_t)__shfl_xor((int)rnk, (int)off, 64);
+    // (places by one LDS atomic per candidate; per-wave ballots and an unrolled counting loop were measured slower here)
+    if (e < c && part == 0) {
+      const float4 r = rec[cur[e]];
       emit(r, rnk >= t);
       if (rnk == t) split_raw = comp(r, a);  // the point of rank len / 2: `points[mid][k]` (kdtree.rs:47-49)
     }
@@ -783,9 +931,19 @@ __global__ void __launch_bounds__(K2_THREADS)
     }
     boxes_next[2 * node + threadIdx.x] = cb;
   }
-  plan_from_hist<K2_THREADS>(hchild, nb_next, mid >> 1, &plans_next[2 * node], tmp);
-  plan_from_hist<K2_THREADS>(hchild + nb_next, nb_next, (l - mid) >> 1, &plans_next[2 * node + 1], tmp);
+  plans_from_two_hists<THREADS>(hchild, hchild + nb_next, nb_next, mid >> 1, (l - mid) >> 1, &plans_next[2 * node], &plans_next[2 * node + 1], tmp64);
   A3D_SEL_STAMP(8, c);
+}
+
+__global__ void __launch_bounds__(K2_THREADS)
+    sel_resolve_kernel(float4* __restrict__ midbuf, float4* __restrict__ spare, float4* __restrict__ rout, uint32_t n,
+                       uint32_t level, uint32_t nb, uint32_t nb_next, const SelPlan* __restrict__ plans, const SelBox* __restrict__ boxes,
+                       SelPlan* __restrict__ plans_next, SelBox* __restrict__ boxes_next, uint32_t* __restrict__ hist_next,
+                       float* __restrict__ split, uint32_t* __restrict__ flags, uint32_t wide_cap, SelWide* __restrict__ wide,
+                       uint32_t* __restrict__ whist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  resolve_node<K2_THREADS, false>(smem, blockIdx.x, midbuf, spare, rout, n, level, nb, nb_next, plans[blockIdx.x], boxes[blockIdx.x], plans_next, boxes_next, hist_next,
+                                  split, flags, wide_cap, wide, whist);
 }
 
 // ---- ranges of <= NARROW points: all remaining levels in one block ---------------------------------------------------
@@ -998,11 +1156,6 @@ __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* l
 // point's position as payload, words and payload in LDS: the entry level's order when the range holds long runs of equal
 // keys (a cloud from a depth image: thousands of points share a quantised z), where ranking every run by counting would
 // cost its length squared.  Branch-free comparison: a chain of `?:` compiles to a ladder of divergent branches.
-__device__ __forceinline__ bool lt128(const uint4& p, const uint4& q) {
-  const unsigned long long ph = ((unsigned long long)p.x << 32) | p.y, pl = ((unsigned long long)p.z << 32) | p.w;
-  const unsigned long long qh = ((unsigned long long)q.x << 32) | q.y, ql = ((unsigned long long)q.z << 32) | q.w;
-  return (ph < qh) | ((ph == qh) & (pl < ql));
-}
 template <uint32_t SLOTS>
 __device__ __forceinline__ void bitonic_lds128(uint4* w, uint32_t* pay, uint32_t cap) {
   constexpr uint32_t THREADS = SLOTS / 4;
@@ -1817,6 +1970,7 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   std::atomic<bool>& lds_allowed = lds_allowed_on[t->ctx->device & 63];
   if (!lds_allowed.load()) {
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS_BYTES));
+    A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS_BYTES));
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel<2048, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nw_lds_bytes<2048>()));
     A3D_HIP_TRY(hipFuncSetAttribute((const void*)sel_narrow_kernel<2048, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nw_lds_bytes<2048>()));
 #ifdef A3D_DIAGNOSTICS
@@ -1827,6 +1981,8 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   A3D_HIP_TRY(hipMemsetAsync(base + L.zero_begin, 0, L.zero_bytes, s));  // flags, cursors, both histogram tables
   hipLaunchKernelGGL(sel_pack_kernel, dim3(L.pack_blocks), dim3(PACK_THREADS), 0, s, d_points, n, recs[0], partials);
   const uint32_t W = L.wide_levels;
+  bool fuse = true;  // diagnostics build: A3D_KDTREE_FUSE=0 keeps the resolve step a launch of its own (the cross-check)
+  if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_FUSE")) fuse = atoi(env) != 0;
   if (W > 0) {
     hipLaunchKernelGGL(sel_hist0_kernel, dim3((n + K1_TILE - 1) / K1_TILE), dim3(K1_THREADS), L.nb[0] * sizeof(uint32_t), s,
                        recs[0], n, partials, L.pack_blocks, L.nb[0], boxes, hist[0]);
@@ -1839,10 +1995,18 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
     const bool placing = place && d < L.place_levels;
     const uint32_t cap_d = placing ? wide_cap : 0xffffffffu;
     SelWide* wide_d = wide + (placing ? off : 0u);
-    hipLaunchKernelGGL(sel_split_kernel, dim3(nodes * bpn), dim3(K1_THREADS),
+    // (a level that may place an oversized bucket with the whole chip keeps its three launches)
+    const bool fused = fuse && !placing;
+    if (fused) {
+      hipLaunchKernelGGL(sel_split_kernel<true>, dim3(nodes * bpn), dim3(K1_THREADS), K2_LDS_BYTES, s, recs[d & 1], recs[(d + 1) & 1], mid, n,
+                         d, bpn, L.nb[d], nb_next, plans + off, boxes + off, cursors + 4 * (size_t)off * CURSOR_STRIDE, hist[(d + 1) & 1], flags,
+                         cap_d, wide_d, whist, plans + (2 * nodes - 1u), boxes + (2 * nodes - 1u), t->d_split);
+      continue;
+    }
+    hipLaunchKernelGGL(sel_split_kernel<false>, dim3(nodes * bpn), dim3(K1_THREADS),
                        (2 * nb_next + (placing ? 2 * NSUB : 0u)) * sizeof(uint32_t), s, recs[d & 1], recs[(d + 1) & 1], mid, n,
                        d, bpn, L.nb[d], nb_next, plans + off, boxes + off, cursors + 4 * (size_t)off * CURSOR_STRIDE, hist[(d + 1) & 1], flags,
-                       cap_d, wide_d, whist);
+                       cap_d, wide_d, whist, plans + (2 * nodes - 1u), boxes + (2 * nodes - 1u), t->d_split);
     if (placing)
       hipLaunchKernelGGL(sel_place_kernel, dim3(nodes * bpn), dim3(K1_THREADS), 2 * nb_next * sizeof(uint32_t), s, mid,
                          recs[d & 1], recs[(d + 1) & 1], n, d, bpn, L.nb[d], nb_next, plans + off, boxes + off,

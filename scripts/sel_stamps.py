@@ -23,6 +23,9 @@ TAGS = {20: "narrow: entry", 21: "narrow: range in LDS", 22: "narrow: level set 
 def main():
     ctx = Context(0)
     (tgt, _), _ = bench.pcl_clouds(ctx, 500_000)
+    if os.environ.get("SEL_STAMPS_UNIFORM"):  # the uniform cloud of scripts/kd_probe.py instead
+        class _U: points = np.ascontiguousarray(bench.synth.uniform01_f32(10, 3 * 500_000).reshape(-1, 3))
+        tgt = _U
     lib = ctx.lib
     fn = lib.a3d_debug_sel_stamps
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_uint32, ctypes.c_uint32]
@@ -66,6 +69,8 @@ def main():
     for level, node, v in rows:
         print(f"level {level} node {node}")
         t0 = v[0]
+        if v[60] and v[61]:  # fused launch: the node's first split block started / its last block took the ticket (before the resolve step's entry)
+            print(f"   split launch: first block of the node started {(t0 - v[60]) / 100.0:.2f} us, last block took the ticket {(t0 - v[61]) / 100.0:.2f} us before the resolve step's entry")
         prev = t0
         for k in range(32):
             t, w = v[2 * k], v[2 * k + 1]

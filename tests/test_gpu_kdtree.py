@@ -94,7 +94,7 @@ def test_kdtree_full_size_500k_bit_exact(ctx):
 
 
 _KD_KNOBS = ("A3D_KDTREE_BUILD", "A3D_KDTREE_SORT", "A3D_KDTREE_WIDE_LEN", "A3D_KDTREE_NARROW_LEN", "A3D_KDTREE_SCAN",
-             "A3D_KDTREE_SORTNET", "A3D_KDTREE_BUCKETS", "A3D_KDTREE_WIDE_PLACE", "A3D_KDTREE_WIDE_CAP")
+             "A3D_KDTREE_SORTNET", "A3D_KDTREE_BUCKETS", "A3D_KDTREE_WIDE_PLACE", "A3D_KDTREE_WIDE_CAP", "A3D_KDTREE_FUSE")
 
 # The device builds (diagnostics build: knobs).  "select" is what the product library runs: the selection build
 # (kdtree_select.hip); NARROW_LEN makes its wide-level kernels run at test sizes; "sorted" is the sorting build (the
@@ -106,6 +106,9 @@ _KD_BUILDS = {
     "select_narrow32": {"A3D_KDTREE_NARROW_LEN": "32", "A3D_KDTREE_WIDE_PLACE": "0"},
     "select_narrow64": {"A3D_KDTREE_NARROW_LEN": "64", "A3D_KDTREE_WIDE_PLACE": "0"},
     "select_narrow512": {"A3D_KDTREE_NARROW_LEN": "512", "A3D_KDTREE_WIDE_PLACE": "0"},
+    # the resolve step as a launch of its own (the product runs it in the last block of the node's split launch: round 6)
+    "select_unfused": {"A3D_KDTREE_FUSE": "0", "A3D_KDTREE_WIDE_PLACE": "0"},
+    "select_unfused_narrow32": {"A3D_KDTREE_FUSE": "0", "A3D_KDTREE_NARROW_LEN": "32", "A3D_KDTREE_WIDE_PLACE": "0"},
     "select_lds": {"A3D_KDTREE_SORTNET": "lds"},  # the in-block levels by the sorting network with its words in LDS (the product keeps them in registers: round 6)
     "select_inblock": {"A3D_KDTREE_SORTNET": "select"},  # ... by selection inside the block (slower: a cross-check)
     "select_inblock_narrow64": {"A3D_KDTREE_SORTNET": "select", "A3D_KDTREE_NARROW_LEN": "64", "A3D_KDTREE_WIDE_PLACE": "0"},
@@ -176,7 +179,7 @@ def test_kdtree_device_build_is_bit_identical_to_host_build(ctx, diag_ctx, monke
     median under the closed-form order L_d + an unordered partition; the last levels sorted in LDS) against the sorting
     build (one stable sort per level) against rocPRIM's sorts against the host."""
     db = _kd_cases()[case]
-    if case == "n270213" and build not in ("select", "select_narrow512", "select_lds", "select_inblock", "select_place_cap64", "sorted", "sorted_rocprim"):
+    if case == "n270213" and build not in ("select", "select_narrow512", "select_unfused", "select_lds", "select_inblock", "select_place_cap64", "sorted", "sorted_rocprim"):
         pytest.skip("the large case runs on the default borders only")
     host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
     dev = _build(diag_ctx, db, _KD_BUILDS[build], monkeypatch)
@@ -210,7 +213,7 @@ def test_kdtree_pairs_of_equal_coordinates_at_every_entry_axis(ctx, diag_ctx, mo
         db[2 * i + 1, axis] = db[2 * i, axis]
     host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
     hs, hl = host.download()
-    for c, env in ((ctx, {}), (diag_ctx, _KD_BUILDS["select_lds"]), (diag_ctx, _KD_BUILDS["select_inblock"]), (diag_ctx, _KD_BUILDS["select_narrow512"]),
+    for c, env in ((ctx, {}), (diag_ctx, _KD_BUILDS["select_lds"]), (diag_ctx, _KD_BUILDS["select_unfused"]), (diag_ctx, _KD_BUILDS["select_inblock"]), (diag_ctx, _KD_BUILDS["select_narrow512"]),
                    (diag_ctx, {"A3D_KDTREE_NARROW_LEN": "1024", "A3D_KDTREE_BUCKETS": "256"})):
         t = _build(c, db, env, monkeypatch)
         s_, l_ = t.download()
