@@ -250,9 +250,13 @@ __global__ void __launch_bounds__(PACK_THREADS)
 }
 
 // The root's box (every block reduces the pack kernel's partials itself) and the root's histogram along x.
+// FUSED (round 6): the last block to finish derives the root's plan from the finished histogram (memory-side atomics, read
+// back with agent-scope loads) instead of sel_plan0_kernel in a launch of its own; `ticket` is a zeroed word.
+template <bool FUSED>
 __global__ void __launch_bounds__(K1_THREADS)
     sel_hist0_kernel(const float4* __restrict__ recs, uint32_t n, const float* __restrict__ partials, uint32_t n_partials,
-                     uint32_t nb, SelBox* __restrict__ boxes, uint32_t* __restrict__ hist) {
+                     uint32_t nb, SelBox* __restrict__ boxes, uint32_t* __restrict__ hist, uint32_t* __restrict__ ticket,
+                     SelPlan* __restrict__ plans) {
   extern __shared__ uint32_t h[];
   __shared__ float red[K1_THREADS / 64][6];
   __shared__ float box[6];
@@ -289,6 +293,30 @@ __global__ void __launch_bounds__(K1_THREADS)
   for (uint32_t q = threadIdx.x; q < nb; q += K1_THREADS) {
     const uint32_t v = h[q];
     if (v) atomicAdd(&hist[q], v);
+  }
+  if (FUSED) {
+    __shared__ uint32_t is_last;
+    __shared__ uint32_t tmp[16];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this thread's atomics have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!is_last) return;
+    constexpr uint32_t PER = NB_MAX / K1_THREADS;
+    uint32_t v[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t q = threadIdx.x + k * K1_THREADS;
+      v[k] = q < nb ? __hip_atomic_load(hist + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t q = threadIdx.x + k * K1_THREADS;
+      if (q < nb) h[q] = v[k], hist[q] = 0u;  // (zeroed for level 2)
+    }
+    __syncthreads();
+    plan_from_hist<K1_THREADS>(h, nb, n >> 1, &plans[0], tmp);
   }
 }
 
@@ -1984,9 +2012,15 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   bool fuse = true;  // diagnostics build: A3D_KDTREE_FUSE=0 keeps the resolve step a launch of its own (the cross-check)
   if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_FUSE")) fuse = atoi(env) != 0;
   if (W > 0) {
-    hipLaunchKernelGGL(sel_hist0_kernel, dim3((n + K1_TILE - 1) / K1_TILE), dim3(K1_THREADS), L.nb[0] * sizeof(uint32_t), s,
-                       recs[0], n, partials, L.pack_blocks, L.nb[0], boxes, hist[0]);
-    hipLaunchKernelGGL(sel_plan0_kernel, dim3(1), dim3(K2_THREADS), 0, s, n, L.nb[0], hist[0], plans);
+    uint32_t* ticket0 = flags + 8;  // (a word of the flag table's zeroed line)
+    if (fuse) {
+      hipLaunchKernelGGL(sel_hist0_kernel<true>, dim3((n + K1_TILE - 1) / K1_TILE), dim3(K1_THREADS), L.nb[0] * sizeof(uint32_t), s,
+                         recs[0], n, partials, L.pack_blocks, L.nb[0], boxes, hist[0], ticket0, plans);
+    } else {
+      hipLaunchKernelGGL(sel_hist0_kernel<false>, dim3((n + K1_TILE - 1) / K1_TILE), dim3(K1_THREADS), L.nb[0] * sizeof(uint32_t), s,
+                         recs[0], n, partials, L.pack_blocks, L.nb[0], boxes, hist[0], ticket0, plans);
+      hipLaunchKernelGGL(sel_plan0_kernel, dim3(1), dim3(K2_THREADS), 0, s, n, L.nb[0], hist[0], plans);
+    }
   }
   for (uint32_t d = 0; d < W; ++d) {
     const uint32_t nodes = 1u << d, off = nodes - 1u;  // heap offset of the level in the per-node tables

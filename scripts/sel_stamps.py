@@ -76,7 +76,7 @@ def main():
             t, w = v[2 * k], v[2 * k + 1]
             if t == 0:
                 break
-            print(f"   {TAGS.get(w >> 32, w >> 32):18s} c={w & 0xffffffff:7d}  +{(t - prev) / 100.0:7.2f} us   at {(t - t0) / 100.0:7.2f}")
+            print(f"   {str(TAGS.get(w >> 32, w >> 32)):18s} c={w & 0xffffffff:7d}  +{(t - prev) / 100.0:7.2f} us   at {(t - t0) / 100.0:7.2f}")
             prev = t
 
 
