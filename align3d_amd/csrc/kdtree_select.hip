@@ -14,38 +14,42 @@
 // So a level needs no sort: it needs, per node, the point of rank len / 2 under L_d and a partition around it, in any
 // order — and only the last few levels, where the leaves' order is fixed, need real sorts.
 //
-//   wide levels (ranges longer than 2048 points), TWO launches per level, nothing sorted:
+//   wide levels (ranges longer than 2048 points), ONE launch per level, nothing sorted:
 //     sel_split_kernel    every point's key falls into one of <= 2048 buckets, linear over the node's bounding box
 //                         along the axis (a monotone map: equal keys share a bucket).  The bucket that holds rank
 //                         len / 2 is known from the node's histogram (the `plan`); points below it go to the left end
 //                         of the range, points above it to the right end (block-wise reservations, any order), the
 //                         few in it to a side buffer.  The points routed left / right are at once counted into their
 //                         CHILD's histogram along the next axis (the child's box along that axis is the parent's).
-//     sel_resolve_kernel  one block per node: among the side buffer's points (a bucket: len / buckets points) the one
-//                         of rank len / 2 under L_d is found exactly — rounds of finer buckets over the set's actual
-//                         [min, max], component of L_d by component, then brute-force counting among the last <= 64 —
-//                         and all of them placed; the block writes the split value, the children's boxes, adds its
-//                         points to the children's histograms and derives the children's plans.
-//   ranges of <= 2048 points: sel_narrow_kernel, ONE launch, one block per range: a bitonic network on 128-bit words
-//     (L_d itself, + the point's position as payload) puts the range into L_d order; each further level is the network
-//     on 64-bit words `key bits << 32 | position in the range` (the position carries L_{d-1}); split values, leaf slots
-//     (+inf padding included) and slot_of_point are written from there.  The product runs the network with its words in
-//     LDS (sel_narrow_kernel<2048, false>: two stages per LDS round trip, block barriers only around the five stage pairs
-//     of a 2048-word sort that exchange words between waves); the form with four consecutive words per thread in registers
-//     and lane exchanges for partner distances 4 .. 128 (<2048, true>, A3D_KDTREE_SORTNET=regs) was measured slower
-//     (141 against 84 us) and is a cross-check of the diagnostics build.
+//     the resolve step    (resolve_node) one block per node: among the side buffer's points (a bucket: len / buckets
+//                         points) the one of rank len / 2 under L_d is found exactly — rounds of finer buckets over the
+//                         set's actual [min, max], component of L_d by component, then brute-force counting among the
+//                         last <= 128 — and all of them placed; the block writes the split value, the children's boxes,
+//                         adds its points to the children's histograms and derives the children's plans.  Round 6: it runs
+//                         in the LAST block of the node's split launch to finish (a ticket per node; what it reads from
+//                         the other blocks went out as agent-scope stores and memory-side atomics, so no L2 write-back is
+//                         needed) instead of in sel_resolve_kernel, a launch of its own — that one remains for levels with
+//                         a placement launch (below) and as the diagnostics build's cross-check (A3D_KDTREE_FUSE=0).
+//     sel_place_kernel    (a launch between the two on the levels whose ranges can hold more than 4096 points in one
+//                         bucket, only once a cloud of the context had such a bucket: a wall facing the camera is tens of
+//                         thousands of equal z.)  One resolve block narrows such a set at one CU's rate (30-60 GB/s:
+//                         133 us for 63 k points); instead the split kernel histograms the bucket's points one step finer
+//                         — by the key inside the bucket's bounds and, for a set of EQUAL keys, by the next component of
+//                         L_d — and this launch places all but one finer bucket of them with the whole chip (12 us then).
+//   ranges of <= 2048 points: sel_narrow_kernel, ONE launch, one block per range: a bitonic network on 64-bit words
+//     `key bits << 32 | position in the range` (the position carries L_{d-1}) per level — at the level a range enters at
+//     followed by ranking the (rare) runs of equal keys under L_d, or by the network on the 128-bit words of L_d itself when
+//     the range holds long runs —; split values, leaf slots (+inf padding included) and slot_of_point are written from there.
+//     The product keeps the network's words in REGISTERS (sel_narrow_kernel<2048, true>, round 6: four consecutive words per
+//     thread, partner distances 4 .. 128 over the VALU's lane paths — DPP, v_permlane16/32_swap —, only distances >= 256
+//     through LDS; compare-exchange with the direction as data: profiles/round6_kdtree_narrow_stamps.txt); the network with
+//     its words in LDS (<2048, false>, A3D_KDTREE_SORTNET=lds: round 5's product) and a selection inside the block (=select)
+//     are cross-checks of the diagnostics build.
 //
-//     sel_place_kernel    (a THIRD launch on the levels whose ranges can hold more than 4096 points in one bucket, only
-//                         once a cloud of the context had such a bucket: a wall facing the camera is tens of thousands
-//                         of equal z.)  One resolve block narrows such a set at one CU's rate (30-60 GB/s: 133 us for
-//                         63 k points); instead the split kernel histograms the bucket's points one step finer — by the
-//                         key inside the bucket's bounds and, for a set of EQUAL keys, by the next component of L_d —
-//                         and this launch places all but one finer bucket of them with the whole chip (12 us then).
-//   ranges of <= 2048 points: sel_narrow_kernel (below).
-//
-// 500 k points: 21 launches instead of ~110.  Exact for every input: a degenerate cloud (one coordinate
-// constant over a node, thousands of equal points) only costs the resolve block more narrowing rounds.  The sorting
-// build (kdtree_build.hip, diagnostics build) is the cross-check: same tree, bit for bit (tests/test_gpu_kdtree.py).
+// 500 k points: 11 launches (pack, root histogram + plan, 8 levels, in-block levels) instead of the sorting build's ~110
+// (DESIGN.md §5).  Exact for every input: a degenerate cloud (one coordinate constant over a node, thousands of equal points)
+// only costs the resolve step more narrowing rounds.  The sorting build (kdtree_build.hip, diagnostics build) is the
+// cross-check: same tree, bit for bit (tests/test_gpu_kdtree.py).
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>

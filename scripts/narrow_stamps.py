@@ -27,7 +27,7 @@ for rep in range(5):
     fn(out, 99, 0)
     runs.append(list(out))
 v = runs[-1]
-print("# sel_narrow_kernel<2048, false>, block 0, uniform 500 k cloud: shader-clock cycles (last of 5 builds)")
+print("# sel_narrow_kernel<2048, REGS>, block 0 (the product: words in registers; A3D_KDTREE_SORTNET=lds: in LDS), uniform 500 k cloud: shader-clock cycles (last of 5 builds)")
 prev = v[0]
 for k in range(32):
     if v[2 * k] == 0:
