@@ -218,9 +218,13 @@ __device__ __forceinline__ void plans_from_two_hists(const uint32_t* h0, const u
 typedef float sel_f32x3 __attribute__((ext_vector_type(3)));
 typedef sel_f32x3 __attribute__((aligned(4))) sel_f32x3_u;
 
+// (round 6: it also zeroes the build's flags, place counters and histogram tables — `zero`, in 16-byte words — which a memset
+// launch of 4.7 us did before it: nothing reads them before the next launch)
 __global__ void __launch_bounds__(PACK_THREADS)
-    sel_pack_kernel(const float* __restrict__ points, uint32_t n, float4* __restrict__ recs, float* __restrict__ partials) {
+    sel_pack_kernel(const float* __restrict__ points, uint32_t n, float4* __restrict__ recs, float* __restrict__ partials,
+                    uint4* __restrict__ zero, uint32_t zero_words) {
   __shared__ float red[PACK_THREADS / 64][6];
+  for (uint32_t i = blockIdx.x * PACK_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * PACK_THREADS) zero[i] = make_uint4(0u, 0u, 0u, 0u);
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
@@ -2010,8 +2014,10 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
 #endif
     lds_allowed.store(true);
   }
-  A3D_HIP_TRY(hipMemsetAsync(base + L.zero_begin, 0, L.zero_bytes, s));  // flags, cursors, both histogram tables
-  hipLaunchKernelGGL(sel_pack_kernel, dim3(L.pack_blocks), dim3(PACK_THREADS), 0, s, d_points, n, recs[0], partials);
+  // (flags, place counters, both histogram tables, the oversized buckets' tables: zeroed by the pack kernel)
+  static_assert(sizeof(uint4) == 16, "zero region in 16-byte words");
+  hipLaunchKernelGGL(sel_pack_kernel, dim3(L.pack_blocks), dim3(PACK_THREADS), 0, s, d_points, n, recs[0], partials,
+                     (uint4*)(base + L.zero_begin), (uint32_t)(L.zero_bytes / 16));
   const uint32_t W = L.wide_levels;
   bool fuse = true;  // diagnostics build: A3D_KDTREE_FUSE=0 keeps the resolve step a launch of its own (the cross-check)
   if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_FUSE")) fuse = atoi(env) != 0;

@@ -111,7 +111,7 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         builds.append((time.perf_counter() - t0) * 1e3)
         tree.free()
     # R3dTree::new over points that are already resident (a3d_kdtree_new_device): wall time of the call (allocation of the
-    # tree's arrays + 12 launches + the flag read-back) and the device time of its launches (events on the stream)
+    # tree's arrays + 11 launches + the flag read-back) and the device time of its launches (events on the stream)
     d_db = ctx.to_device(db)
     R3dTree.new_device(ctx, d_db, n).free()
     dev_wall, dev_kernels = [], []
@@ -150,10 +150,10 @@ def kdtree_bench(ctx, n=500_000, reps=20, groups=7):
         # coordinates read, a 4-byte index read and written: what a level-by-level build moves at least) x `depth` levels
         "build": {"device_ms": float(np.median(dev_wall)), "device_ms_stats": stats(dev_wall),
                   "kernel_ms": float(np.median(dev_kernels)), "kernel_ms_stats": stats(dev_kernels),
-                  # memset, pack, hist0 (+ the root's plan), one split launch per wide level (+ the node's resolve step), narrow —
+                  # pack (+ the workspace's zeroing), hist0 (+ the root's plan), one split launch per wide level (+ the node's resolve step), narrow —
                   # and, on build path 3 (a context that has seen an oversized median bucket), sel_place and sel_resolve as
                   # launches of their own on each of the first place_levels = 7 wide levels
-                  "launches": (lambda wide: 4 + wide + (2 * min(wide, 7) if int(path_seen) == 3 else 0))(
+                  "launches": (lambda wide: 3 + wide + (2 * min(wide, 7) if int(path_seen) == 3 else 0))(
                       max(0, int(np.ceil(np.log2(max(1, n / 2048)))))),
                   "build_path": int(path_seen),
                   "roofline": roofline(20 * n * depth, float(np.median(dev_kernels)), kernel="the selection build's launches (kdtree_select.hip), first to last",
