@@ -1,9 +1,10 @@
-# Per-launch durations of one kd-tree selection build (500 k uniform points): rocprofv3 --kernel-trace of scripts/kd_probe.py, the
+# Per-launch durations of one kd-tree selection build (500 k uniform points; KD_LEVELS_PROG=scripts/pcl_probe.py: the depth-image
+# cloud of configs[2]): rocprofv3 --kernel-trace of scripts/kd_probe.py, the
 # launches of the LAST build in stream order.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/kd_levels
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 scripts/kd_probe.py > $OUT/probe.out 2> $OUT/probe.err || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 ${KD_LEVELS_PROG:-scripts/kd_probe.py} > $OUT/probe.out 2> $OUT/probe.err || exit 1
 python3 - $(ls $OUT/t/*/*kernel_trace.csv | head -1) <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "sel_" in r["Kernel_Name"]]
