@@ -107,7 +107,11 @@ struct a3d_context {
   std::vector<SpareBlock> spare_blocks;
   // Set by a kd-tree build that met an oversized median bucket (a cloud with thousands of equal coordinates): later
   // builds of this context add the chip-wide placement launches for such buckets (kdtree_select.hip).
-  std::atomic<bool> kd_wide_place{false};
+  // kd-tree selection build: placement launches for oversized median buckets ON for a new context (its first depth-image cloud
+  // does not pay a lone block's streaming rounds), OFF after KD_QUIET_BUILDS builds in a row without such a bucket, ON again with
+  // the next one (kdtree_select.hip)
+  std::atomic<bool> kd_wide_place{true};
+  std::atomic<int> kd_quiet_builds{0};
   // Pyramid arenas handed back by a3d_range_image_free, kept for the next frame of the same size: a frame
   // stream then costs no hipMalloc / hipFree (each of which synchronises the whole device) per frame.
   // Guarded by a mutex because an image may be freed from another thread than the one building frames.

@@ -420,6 +420,7 @@ __global__ void __launch_bounds__(K1_THREADS)
   const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
   const unsigned long long lower = (1ull << lane) - 1ull;
   const bool oversized = plan.count > wide_cap;  // (block-uniform; the launch reserved the LDS for the finer tables)
+  if (oversized && part == 0 && threadIdx.x == 0) atomicOr(&flags[FLAG_OVERSIZED], 1u);  // (the host keeps the placement launches on)
   uint32_t* hw = h + 2 * nb_next;
   for (uint32_t q = threadIdx.x; q < 2 * nb_next + (oversized ? 2 * NSUB : 0u); q += K1_THREADS) h[q] = 0u;
   if (threadIdx.x < 2) w_mm[threadIdx.x] = 0u;
@@ -1981,10 +1982,14 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   hipStream_t s = t->ctx->stream;
   const uint32_t n = t->n, D = t->max_depth;
   const SelLayout L = sel_layout(n, narrow_len_setting(), wide_cap_setting());
-  // sel_place_kernel's launches (one more per level that can hold an oversized median bucket) only once a cloud of this
-  // context has had one: clouds without thousands of equal coordinates never pay for them, a stream of depth-image
-  // clouds pays the lone resolve block's slow rounds on its first build only.  The tree is the same either way.
-  bool place = t->ctx->kd_wide_place.load();
+  // sel_place_kernel's launches (one more, and the resolve step a launch of its own, per level that can hold an oversized
+  // median bucket): a context starts with them (round 6: its first depth-image cloud paid a lone resolve block's streaming
+  // rounds, 0.70 instead of 0.34 ms), drops them after KD_QUIET_BUILDS builds in a row that met no such bucket (clouds without
+  // thousands of equal coordinates pay ~35 us more on a context's first builds only) and takes them up again when one shows.
+  // The tree is the same either way.
+  constexpr int KD_QUIET_BUILDS = 4;
+  const bool place_by_context = t->ctx->kd_wide_place.load();
+  bool place = place_by_context;
   if (const char* env = A3D_DIAG_ENV("A3D_KDTREE_WIDE_PLACE"))
     if (*env) place = atoi(env) != 0;
   const uint32_t wide_cap = place ? L.wide_cap : 0xffffffffu;
@@ -2090,7 +2095,11 @@ a3d_status kdtree_build_device_select(a3d_kdtree* t, const float* d_points, void
   volatile uint32_t* h_flags = t->ctx->pinned_words + a3d_context::PINNED_WORDS;
   A3D_HIP_TRY(hipMemcpyAsync((void*)h_flags, flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   A3D_HIP_TRY(hipStreamSynchronize(s));
-  if (h_flags[FLAG_OVERSIZED]) t->ctx->kd_wide_place.store(true);
+  if (h_flags[FLAG_OVERSIZED]) {
+    t->ctx->kd_wide_place.store(true), t->ctx->kd_quiet_builds.store(0);
+  } else if (place_by_context && L.place_levels > 0) {  // (a cloud too small to hold such a bucket says nothing)
+    if (t->ctx->kd_quiet_builds.fetch_add(1) + 1 >= KD_QUIET_BUILDS) t->ctx->kd_wide_place.store(false), t->ctx->kd_quiet_builds.store(0);
+  }
   A3D_REQUIRE(!h_flags[FLAG_NAN], A3D_NAN_IN_INPUT,
               "NaN coordinate in kd-tree input (the reference panics in partial_cmp().unwrap())");
   return A3D_OK;

@@ -441,8 +441,9 @@ a3d_status a3d_kdtree_new(a3d_context* ctx, const float* points, uint64_t n, a3d
 a3d_status a3d_kdtree_new_device(a3d_context* ctx, const void* d_points, uint64_t n, a3d_kdtree** out);
 /* Instrumentation: which build made the tree: 1 selection build (kdtree_select.hip: the product's), 3 the same with one
  * more launch per upper level that places oversized median buckets chip-wide (a cloud from a depth image: a wall of
- * tens of thousands of equal coordinates; a context's builds add it once one of its clouds had such a bucket — the tree
- * is the same either way); diagnostics build only: 0 host build, 2 sorting build (the cross-checks). */
+ * tens of thousands of equal coordinates; a new context's builds have it, drop it after four builds in a row without such a
+ * bucket and take it up again with the next one — the tree is the same either way); diagnostics build only: 0 host build,
+ * 2 sorting build (the cross-checks). */
 a3d_status a3d_kdtree_build_path(a3d_kdtree* tree, int32_t* out_path);
 /* Instrumentation: device time (ms) of the build's launches (first kernel to last, hipEvents on the context's stream;
  * without the upload of host points and without the allocation of the tree's arrays). */

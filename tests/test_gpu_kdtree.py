@@ -286,8 +286,9 @@ def test_kdtree_selection_build_finishes_degenerate_clouds(ctx, diag_ctx, monkey
 
 
 def test_kdtree_context_switches_to_wide_placement_after_an_oversized_bucket(diag_ctx, monkeypatch):
-    """The product's policy: a context's builds add sel_place_kernel's launches once one of its clouds had a median bucket
-    larger than the resolve block's LDS.  Same tree before and after; a cloud without such buckets never switches."""
+    """The product's policy (round 6): a new context's builds have sel_place_kernel's launches (its first depth-image cloud
+    does not pay a lone block's streaming rounds), drop them after four builds in a row without a median bucket larger than
+    the resolve block's LDS, and take them up again once a cloud had one.  Same tree whatever the path."""
     from align3d_amd import Context
 
     for k in _KD_KNOBS:
@@ -299,13 +300,13 @@ def test_kdtree_context_switches_to_wide_placement_after_an_oversized_bucket(dia
     host_b = _build(diag_ctx, benign, {"A3D_KDTREE_BUILD": "host"}, monkeypatch).download()
     host_w = _build(diag_ctx, wall, {"A3D_KDTREE_BUILD": "host"}, monkeypatch).download()
     paths = []
-    for db, want in ((benign, host_b), (benign, host_b), (wall, host_w), (wall, host_w), (benign, host_b)):
+    for db, want in ((benign, host_b),) * 5 + ((wall, host_w), (wall, host_w), (benign, host_b)):
         t = R3dTree.new(fresh, db)
         got = t.download()
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
         paths.append(t.build_path())
         t.free()
-    assert paths == [1, 1, 1, 3, 3]
+    assert paths == [3, 3, 3, 3, 1, 1, 3, 3]  # on for a new context, off after four quiet builds, on again after the wall
     fresh.close()
 
 
