@@ -87,6 +87,52 @@ OPS(permlane32_swap, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; uns
 // DPP read of a register a VALU instruction has just written (the hazard the compiler pads with s_nop 1)
 OPS(dpp_after_write, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned c0 = 0,
     asm volatile("v_add_u32 %0, %0, %1\n s_nop 1\n v_mov_b32_dpp %2, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_u32 %1, %1, %2" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+
+// ---- v_cndmask and where its mask comes from (round 6) ---------------------------------------------------------------------------
+#undef SINK
+#define SINK out[1 + (threadIdx.x & 0)] += (u64)a0 + (u64)a1 + (u64)a2 + (u64)a3;
+#define CND4 "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc"
+#define CND4S "v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_cndmask_b32_e64 %2, %2, %3, s[20:21]\n v_cndmask_b32_e64 %3, %3, %0, s[20:21]"
+// the mask written once by a VALU compare before the loop
+OPS(cnd_vcc_valu_once, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a1) : "vcc"),
+    asm volatile(CND4 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+// ... once by the scalar unit before the loop
+OPS(cnd_vcc_salu_once, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; asm volatile("s_mov_b64 vcc, 0x55555555" : : : "vcc"),
+    asm volatile(CND4 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+// ... in an SGPR pair other than vcc (VOP3 encoding), written by the scalar unit before the loop
+OPS(cnd_sgpr_salu_once, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; asm volatile("s_mov_b64 s[20:21], 0x55555555" : : : "s20", "s21"),
+    asm volatile(CND4S : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s20", "s21");)
+// ... rewritten by a VALU compare in front of every four selects
+OPS(cnd_vcc_valu_each, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7,
+    asm volatile("v_cmp_lt_u32 vcc, %0, %1\n" CND4 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");)
+// ... rewritten by the scalar unit in front of every four selects
+OPS(cnd_vcc_salu_each, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7,
+    asm volatile("s_not_b64 vcc, vcc\n s_nop 0\n" CND4 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc", "scc");)
+// the same selects as v_bfi_b32 with the mask as data (no SGPR operand at all)
+OPS(bfi_mask_data, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned m = threadIdx.x & 1 ? ~0u : 0u,
+    asm volatile("v_bfi_b32 %0, %4, %0, %1\n v_bfi_b32 %1, %4, %1, %2\n v_bfi_b32 %2, %4, %2, %3\n v_bfi_b32 %3, %4, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));)
+
+// eight of them in ONE asm statement (no scalar instruction of the loop between them) / with an unrelated scalar add between each two
+#define CND8 CND4 "\n" CND4
+OPS(cnd_vcc_block8, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a1) : "vcc"),
+    asm volatile(CND8 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+#define CND4_SALU "v_cndmask_b32 %0, %0, %1, vcc\n s_add_u32 s20, s20, 1\n v_cndmask_b32 %1, %1, %2, vcc\n s_add_u32 s20, s20, 1\n v_cndmask_b32 %2, %2, %3, vcc\n s_add_u32 s20, s20, 1\n v_cndmask_b32 %3, %3, %0, vcc\n s_add_u32 s20, s20, 1"
+OPS(cnd_vcc_salu_between, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a1) : "vcc"),
+    asm volatile(CND4_SALU : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s20", "scc");)
+#define ADD4_SALU "v_add_u32 %0, %0, %1\n s_add_u32 s20, s20, 1\n v_add_u32 %1, %1, %2\n s_add_u32 s20, s20, 1\n v_add_u32 %2, %2, %3\n s_add_u32 s20, s20, 1\n v_add_u32 %3, %3, %0\n s_add_u32 s20, s20, 1"
+OPS(add_salu_between, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7,
+    asm volatile(ADD4_SALU : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s20", "scc");)
+
+// VOP3 encoding with vcc named as the mask operand / VOP2 selects with an unrelated VALU add between each two
+#define CND4E64V "v_cndmask_b32_e64 %0, %0, %1, vcc\n v_cndmask_b32_e64 %1, %1, %2, vcc\n v_cndmask_b32_e64 %2, %2, %3, vcc\n v_cndmask_b32_e64 %3, %3, %0, vcc"
+OPS(cnd_e64_vcc, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a1) : "vcc"),
+    asm volatile(CND4E64V : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+#define CND4_VADD "v_cndmask_b32 %0, %0, %1, vcc\n v_add_u32 %4, %4, %4\n v_cndmask_b32 %1, %1, %2, vcc\n v_add_u32 %4, %4, %4\n v_cndmask_b32 %2, %2, %3, vcc\n v_add_u32 %4, %4, %4\n v_cndmask_b32 %3, %3, %0, vcc\n v_add_u32 %4, %4, %4"
+OPS(cnd_vcc_vadd_between, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned m = a0; asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a1) : "vcc"),
+    asm volatile(CND4_VADD : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(m));)
+// independent selects (no register of one is another's source)
+OPS(cnd_vcc_independent, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; unsigned b0 = 1; unsigned b1 = 2; asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a1) : "vcc"),
+    asm volatile("v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %4, %5, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %4, %5, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
 #define RUN(name, per)                                                                                   \
   for (int waves = 1; waves <= 4; waves *= 4) {                                                          \
     hipLaunchKernelGGL(k_##name, dim3(1), dim3(256 * waves), 0, 0, d, 1u);                                \
@@ -109,5 +155,8 @@ int main(int argc, char** argv) {
   }
   printf("64-bit compare-exchange parts (kd-tree network):\n");
   RUN(cmp_lt_u64, 4) RUN(cmp_lt_u32, 4) RUN(cmp64_cnd, 4) RUN(cmp64_xor_cnd, 4) RUN(sub_borrow, 4) RUN(cndmask, 4) RUN(permlane16_swap, 4) RUN(permlane32_swap, 4) RUN(dpp_after_write, 4)
+  printf("v_cndmask by the origin of its mask (4 selects per statement; the *_each forms: 5 / 6 instructions):\n");
+  RUN(cnd_vcc_valu_once, 4) RUN(cnd_vcc_salu_once, 4) RUN(cnd_sgpr_salu_once, 4) RUN(cnd_vcc_valu_each, 5) RUN(cnd_vcc_salu_each, 6) RUN(bfi_mask_data, 4)
+  RUN(cnd_vcc_block8, 8) RUN(cnd_vcc_salu_between, 8) RUN(add_salu_between, 8) RUN(cnd_e64_vcc, 4) RUN(cnd_vcc_vadd_between, 8) RUN(cnd_vcc_independent, 4)
   return 0;
 }

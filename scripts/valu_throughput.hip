@@ -38,6 +38,14 @@ KERNEL(lane_4words, unsigned f = threadIdx.x & 1 ? ~0u : 0u; unsigned nf = ~f; u
                     : "+v"(f), "+v"(nf), "+v"(xl), "+v"(xh), "+v"(yl), "+v"(yh), "+v"(m), "+v"(xl1), "+v"(xh1), "+v"(yl1), "+v"(yh1), "+v"(m1),
                       "+v"(xl2), "+v"(xh2), "+v"(yl2), "+v"(yh2), "+v"(m2), "+v"(xl3), "+v"(xh3), "+v"(yl3), "+v"(yh3), "+v"(m3) : : "vcc");,
        (u64)xl + xh + xl1 + xh1 + xl2 + xh2 + xl3 + xh3)
+// selects: VOP2 v_cndmask_b32 (implicit vcc) back to back, and the same selects in the VOP3 encoding (scripts/valu_rate.hip cmp:
+// a lone wave needs ~22 cycles for each VOP2 select that follows another one, 6 in VOP3)
+KERNEL(cnd_vop2, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a1) : "vcc"),
+       asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));,
+       (u64)a0 + a1 + a2 + a3)
+KERNEL(cnd_vop3, unsigned a0 = seed + threadIdx.x; unsigned a1 = a0 * 3; unsigned a2 = a0 * 5; unsigned a3 = a0 * 7; asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a0), "v"(a1) : "vcc"),
+       asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc\n v_cndmask_b32_e64 %1, %1, %2, vcc\n v_cndmask_b32_e64 %2, %2, %3, vcc\n v_cndmask_b32_e64 %3, %3, %0, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));,
+       (u64)a0 + a1 + a2 + a3)
 int main() {
   setvbuf(stdout, nullptr, _IONBF, 0);
   u64* d;
@@ -55,6 +63,6 @@ int main() {
     printf("%-10s %d wave(s)/SIMD: span %7llu cycles, %.2f cycles per wave-instruction per SIMD (a wave's own loop: %.0f cycles)\n", #name, waves, \
            (unsigned long long)(last - first), (double)(last - first) / instr_per_simd, (double)own / (4 * waves)); \
   }
-  RUN(add_u32, 4) RUN(fma_f32, 4) RUN(lane_1word, 6) RUN(lane_4words, 24)
+  RUN(add_u32, 4) RUN(fma_f32, 4) RUN(lane_1word, 6) RUN(lane_4words, 24) RUN(cnd_vop2, 4) RUN(cnd_vop3, 4)
   return 0;
 }
