@@ -1196,13 +1196,23 @@ __device__ __forceinline__ void bitonic_sort(Word (&x)[4], uint32_t cap, Word* l
 template <uint32_t SLOTS>
 __device__ __forceinline__ void bitonic_lds128(uint4* w, uint32_t* pay, uint32_t cap) {
   constexpr uint32_t THREADS = SLOTS / 4;
+  // (compare-exchange as in bitonic_sort: the direction as data, the 128-bit comparison as the borrow of hi - lo through four
+  // VALU subtractions, one v_cndmask into the swap mask, the ten words moved by v_bfi — as `if (lt128(hi, lo) == up) swap` it
+  // was three 64-bit compares joined on the scalar unit and ten VOP2 selects in a row: profiles/round6_valu_rate.txt)
   auto inside = [&](uint4& lo, uint4& hi, uint32_t& plo, uint32_t& phi, bool up) {
-    if (lt128(hi, lo) == up) {
-      const uint4 t = lo;
-      lo = hi, hi = t;
-      const uint32_t tp = plo;
-      plo = phi, phi = tp;
-    }
+    const uint32_t flip = opaque(up ? 0u : ~0u), nflip = opaque(up ? ~0u : 0u);
+    uint32_t m, t;
+    asm volatile(
+        "v_sub_co_u32 %1, vcc, %2, %6\n v_subb_co_u32 %1, vcc, %3, %7, vcc\n v_subb_co_u32 %1, vcc, %4, %8, vcc\n"
+        "v_subb_co_u32 %1, vcc, %5, %9, vcc\n v_cndmask_b32 %0, %10, %11, vcc"
+        : "=&v"(m), "=&v"(t)
+        : "v"(hi.w), "v"(hi.z), "v"(hi.y), "v"(hi.x), "v"(lo.w), "v"(lo.z), "v"(lo.y), "v"(lo.x), "v"(flip), "v"(nflip)
+        : "vcc");  // m = hi < lo (x the most significant word) ? nflip : flip
+    auto bfi = [&](uint32_t take, uint32_t keep) { return (take & m) | (keep & ~m); };
+    const uint4 nl = make_uint4(bfi(hi.x, lo.x), bfi(hi.y, lo.y), bfi(hi.z, lo.z), bfi(hi.w, lo.w));
+    const uint4 nh = make_uint4(bfi(lo.x, hi.x), bfi(lo.y, hi.y), bfi(lo.z, hi.z), bfi(lo.w, hi.w));
+    const uint32_t npl = bfi(phi, plo), nph = bfi(plo, phi);
+    lo = nl, hi = nh, plo = npl, phi = nph;
   };
   // (block barriers only around the stage pairs that exchange words between waves: see bitonic_sort)
   bool prev_cross = true;

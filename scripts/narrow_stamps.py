@@ -19,6 +19,9 @@ fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_uint32, ctypes.c_uin
 fn.restype = ctypes.c_int
 out = (ctypes.c_ulonglong * 64)()
 uni = np.ascontiguousarray(bench.synth.uniform01_f32(10, 3 * 500_000).reshape(-1, 3))
+if os.environ.get("NARROW_STAMPS_PCL"):  # the depth-image cloud of configs[2] instead (long runs of equal z: the 128-bit network)
+    (tgt, _), _ = bench.pcl_clouds(ctx, 500_000)
+    uni = np.ascontiguousarray(tgt.points)
 R3dTree.new(ctx, uni).free()
 runs = []
 for rep in range(5):
