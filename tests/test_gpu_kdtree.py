@@ -361,3 +361,33 @@ def test_icp_from_resident_clouds_gives_the_same_bits(ctx):
     for T in (got, again):
         assert np.array_equal(np.concatenate([T.t, T.q]).view(np.uint32), np.concatenate([ref.t, ref.q]).view(np.uint32))
     ds.free()
+
+
+@pytest.mark.gpu
+def test_kdtree_product_build_on_random_sizes_and_distributions(ctx, diag_ctx, monkeypatch):
+    """The product's build (round 6: resolve step and root plan inside the split / histogram launches' last blocks, in-block
+    network in registers) against the host build over sizes that put the wide / in-block border, the last block of a node
+    and the placement switch everywhere: uniform, quantised (a depth image's z) and clustered clouds, twice on the same
+    context (the second build reuses the first one's workspace: tickets and counters must have been left clean)."""
+    rng = np.random.default_rng(2026)
+    sizes = [2048, 2049, 4095, 4096, 4097, 6143, 8193, 12289] + [int(v) for v in rng.integers(3000, 400000, size=25)]
+    for k in _KD_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for i, n in enumerate(sizes):
+        kind = i % 3
+        if kind == 0:
+            db = rng.random((n, 3), dtype=np.float32)
+        elif kind == 1:  # quantised z with a wall, x / y on a lattice scaled by z
+            z = np.where(rng.random(n) < 0.4, 2.0, np.round(rng.uniform(1.0, 4.0, n) * 500) / 500).astype(np.float32)
+            db = np.stack([rng.integers(-300, 300, n) * z / 300, rng.integers(-200, 200, n) * z / 300, z], axis=-1).astype(np.float32)
+        else:
+            db = np.concatenate([rng.normal(c, 0.02, size=(n // 3 + 1, 3)) for c in ((0, 0, 0), (1, 1, 1), (1.01, 1, 1))])[:n].astype(np.float32)
+            rng.shuffle(db)
+        host = _build(diag_ctx, db, {"A3D_KDTREE_BUILD": "host"}, monkeypatch)
+        hs, hl = host.download()
+        for _ in range(2):
+            t = R3dTree.new(ctx, db)
+            s_, l_ = t.download()
+            assert t.stats() == host.stats() and np.array_equal(s_, hs) and np.array_equal(l_, hl), (n, kind)
+            t.free()
+        host.free()
