@@ -269,6 +269,13 @@ __global__ void __launch_bounds__(K1_THREADS)
   __shared__ float red[K1_THREADS / 64][6];
   __shared__ float box[6];
   for (uint32_t q = threadIdx.x; q < nb; q += K1_THREADS) h[q] = 0u;
+  // (the thread's keys are requested first: their round trip runs under the reduction of the partial bounds)
+  float xk[K1_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
+    const uint32_t i = blockIdx.x * K1_TILE + k * K1_THREADS + threadIdx.x;
+    xk[k] = i < n ? recs[i].x : 0.0f;
+  }
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   for (uint32_t b = threadIdx.x; b < n_partials; b += K1_THREADS)
@@ -295,7 +302,7 @@ __global__ void __launch_bounds__(K1_THREADS)
 #pragma unroll
   for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
     const uint32_t i = blockIdx.x * K1_TILE + k * K1_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&h[bucket_of(canon(recs[i].x), blo, bhi, nb)], 1u);
+    if (i < n) atomicAdd(&h[bucket_of(canon(xk[k]), blo, bhi, nb)], 1u);
   }
   __syncthreads();
   for (uint32_t q = threadIdx.x; q < nb; q += K1_THREADS) {
