@@ -227,11 +227,22 @@ __global__ void __launch_bounds__(PACK_THREADS)
   for (uint32_t i = blockIdx.x * PACK_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * PACK_THREADS) zero[i] = make_uint4(0u, 0u, 0u, 0u);
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  // (all of the thread's loads first, from clamped indices: a load behind `if (i < n)` is followed by s_waitcnt vmcnt(0) at the
+  // branch's join, and four of them are four memory round trips one after the other — round 6 found every kernel of this file
+  // loading that way: 3-4 us per launch)
+  sel_f32x3 pk[PACK_ROUNDS];
+#pragma unroll
+  for (uint32_t k = 0; k < PACK_ROUNDS; ++k) {
+    const uint32_t i = blockIdx.x * PACK_TILE + k * PACK_THREADS + threadIdx.x;
+    pk[k] = *(const sel_f32x3_u*)(points + 3 * (size_t)(i < n ? i : n - 1u));
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < PACK_ROUNDS; ++k) asm volatile("" : "+v"(pk[k].x), "+v"(pk[k].y), "+v"(pk[k].z));  // (keeps the loads up here)
 #pragma unroll
   for (uint32_t k = 0; k < PACK_ROUNDS; ++k) {
     const uint32_t i = blockIdx.x * PACK_TILE + k * PACK_THREADS + threadIdx.x;
     if (i < n) {
-      const sel_f32x3 p = *(const sel_f32x3_u*)(points + 3 * (size_t)i);
+      const sel_f32x3 p = pk[k];
       recs[i] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
       const float c[3] = {canon(p.x), canon(p.y), canon(p.z)};
 #pragma unroll
@@ -274,7 +285,7 @@ __global__ void __launch_bounds__(K1_THREADS)
 #pragma unroll
   for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
     const uint32_t i = blockIdx.x * K1_TILE + k * K1_THREADS + threadIdx.x;
-    xk[k] = i < n ? recs[i].x : 0.0f;
+    xk[k] = recs[i < n ? i : n - 1u].x;  // (unconditional: see sel_pack_kernel)
   }
   float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
   float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -436,8 +447,7 @@ __global__ void __launch_bounds__(K1_THREADS)
 #pragma unroll
   for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
     const uint32_t i = tile_lo + k * K1_THREADS + threadIdx.x;
-    const bool valid = i < l;
-    r[k] = valid ? rin[s + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[k] = rin[s + (i < l ? i : l - 1u)];  // (unconditional, all four in flight: see sel_pack_kernel)
   }
 #pragma unroll
   for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
@@ -579,7 +589,7 @@ __global__ void __launch_bounds__(K1_THREADS)
 #pragma unroll
   for (uint32_t k = 0; k < K1_ROUNDS; ++k) {
     const uint32_t i = tile_lo + k * K1_THREADS + threadIdx.x;
-    r[k] = i < c ? midbuf[s + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[k] = midbuf[s + (i < c ? i : c - 1u)];  // (unconditional, all four in flight: see sel_pack_kernel)
   }
   const uint32_t which = wide_sub_plan<K1_THREADS>(wide, whist, node, mid - plan.below, hs, &sub_plan, tmp);
   const uint32_t star = sub_plan.bucket;
@@ -754,7 +764,7 @@ __device__ __forceinline__ void resolve_node(unsigned char* smem, uint32_t node,
 #pragma unroll
     for (uint32_t k = 0; k < PRE; ++k) {
       const uint32_t i = threadIdx.x + k * THREADS;
-      pre[k] = i < plan.count && plan.count <= MIDDLE_CAP ? load_rec_agent(midbuf + s + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pre[k] = load_rec_agent(midbuf + s + (i < plan.count ? i : (plan.count ? plan.count - 1u : 0u)));  // (unconditional; used only if the set was not narrowed from global memory)
     }
   }
   {  // (all of the thread's loads in flight at once: as a loop of load -> store pairs the agent-scope loads went one memory round trip at a time)
@@ -1311,7 +1321,22 @@ __global__ void __launch_bounds__(SLOTS / 4)
   // 16-byte record gathered and written back (round 6: those moves were 37 000 of the kernel's 198 000 cycles,
   // profiles/round6_kdtree_narrow_stamps.txt) — and the leaves are gathered through it once at the end.
   uint16_t* pm = (uint16_t*)(xw + (SLOTS + SLOTS / 32u + 64u));  // behind the network's padded words
-  for (uint32_t p = threadIdx.x; p < l0; p += THREADS) rec[p] = recs[s0 + p];
+  {  // (SLOTS / THREADS = 4 loads per thread, unconditional and all in flight: see sel_pack_kernel)
+    float4 got[SLOTS / THREADS];
+#pragma unroll
+    for (uint32_t k = 0; k < SLOTS / THREADS; ++k) {
+      const uint32_t p = threadIdx.x + k * THREADS;
+      got[k] = recs[s0 + (p < l0 ? p : l0 - 1u)];
+    }
+    // (an empty asm that reads them: otherwise hipcc sinks every load into the `if` that stores its value, one round trip each)
+#pragma unroll
+    for (uint32_t k = 0; k < SLOTS / THREADS; ++k) asm volatile("" : "+v"(got[k].x), "+v"(got[k].y), "+v"(got[k].z), "+v"(got[k].w));
+#pragma unroll
+    for (uint32_t k = 0; k < SLOTS / THREADS; ++k) {
+      const uint32_t p = threadIdx.x + k * THREADS;
+      if (p < l0) rec[p] = got[k];
+    }
+  }
   for (uint32_t p = threadIdx.x; p < SLOTS; p += THREADS) pm[p] = (uint16_t)p;
   __syncthreads();
   A3D_NW_STAMP(31, l0);
