@@ -773,7 +773,8 @@ __device__ __forceinline__ void resolve_node(unsigned char* smem, uint32_t node,
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
       const uint32_t q = threadIdx.x + k * THREADS;
-      v[k] = q < 2 * nb_next ? (FOREIGN ? __hip_atomic_load(g + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g[q]) : 0u;
+      const uint32_t qc = q < 2 * nb_next ? q : 0u;  // (unconditional loads: see sel_pack_kernel)
+      v[k] = FOREIGN ? __hip_atomic_load(g + qc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g[qc];
     }
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
@@ -906,8 +907,22 @@ __device__ __forceinline__ void resolve_node(unsigned char* smem, uint32_t node,
       if (i < c) rec[i] = pre[k], list_a[i] = (uint16_t)i;
     }
     for (uint32_t i = threadIdx.x + PRE * THREADS; i < c; i += THREADS) rec[i] = load_rec_agent(src + i), list_a[i] = (uint16_t)i;
-  } else {
-    for (uint32_t i = threadIdx.x; i < c; i += THREADS) rec[i] = src[i], list_a[i] = (uint16_t)i;
+  } else {  // (all of the thread's loads in flight together: see sel_pack_kernel)
+    constexpr uint32_t PER_FILL = MIDDLE_CAP / THREADS;
+    float4 got[PER_FILL];
+    const uint32_t last = c ? c - 1u : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < PER_FILL; ++k) {
+      const uint32_t i = threadIdx.x + k * THREADS;
+      got[k] = src[i < c ? i : last];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER_FILL; ++k) asm volatile("" : "+v"(got[k].x), "+v"(got[k].y), "+v"(got[k].z), "+v"(got[k].w));
+#pragma unroll
+    for (uint32_t k = 0; k < PER_FILL; ++k) {
+      const uint32_t i = threadIdx.x + k * THREADS;
+      if (i < c) rec[i] = got[k], list_a[i] = (uint16_t)i;
+    }
   }
   __syncthreads();
   A3D_SEL_STAMP(3, c);
